@@ -1,0 +1,141 @@
+"""Synthetic tokenised-drawing batches that follow the reference batch contract.
+
+The layout mirrors what the reference's CPU dataloader hands the model
+(reference plankassembly/datasets/line_data.py:34-109, sideface_data.py:137-213):
+
+* every ``input_*`` row has length ``MAX_INPUT_LENGTH - 1``: 4 tokens per line,
+  then END (512), then PAD (513); the id tensors are 0 at END/PAD;
+* ``input_mask = input_value == PAD``;
+* ``output_value`` has length ``MAX_OUTPUT_LENGTH``: 6 tokens per plank (plank 0 is
+  the overall bounding box), END, PAD;
+* ``output_label = 514 + attach`` where a pointer is attached, else the value;
+* ``output_mask = output_value == PAD``.
+
+Only the *distribution* is synthetic (there is no network for the real dataset);
+the recipe is the one written down in SURVEY.md section 8(d).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+END = 512
+PAD = 513
+VOCAB = 514
+
+
+def pointer_mask_row(i: int, sz: int) -> np.ndarray:
+    """Closed form of the reference's ``_generate_pointer_mask`` row ``i`` (models.py:91-101)."""
+    row = np.zeros(sz, dtype=bool)
+    if i < 6:
+        return row
+    for j in range(sz):
+        if j < 6:
+            row[j] = j == i % 6
+        else:
+            row[j] = (j % 6) == ((i % 6) + 3) % 6
+    return row
+
+
+@dataclass
+class SynthSpec:
+    max_input_length: int = 1200
+    max_output_length: int = 128
+    n_lines: tuple = (8, 299)     # inclusive range of line (or side-face) count per sample
+    n_planks: tuple = (2, 21)     # inclusive range of planks (incl. the bbox plank)
+    with_type: bool = True        # sideface batches carry no ``input_type``
+    attach_prob: float = 0.5
+    valid_pointers: bool = True   # draw pointer targets from the reference's pointer mask
+
+
+def synth_sample(rng: np.random.Generator, spec: SynthSpec):
+    S = spec.max_input_length - 1
+    T = spec.max_output_length
+    lo, hi = spec.n_lines
+    n = int(rng.integers(lo, hi + 1))
+    n = min(n, (S - 1) // 4)
+    views = np.sort(rng.integers(0, 3, size=n))
+    values = rng.integers(0, 512, size=(n, 4))
+    types = rng.integers(0, 2, size=n)
+    if n:
+        _, counts = np.unique(views, return_counts=True)
+        pos = np.concatenate([np.arange(c) for c in counts])
+    else:
+        pos = np.zeros(0, dtype=np.int64)
+
+    def padded(body, fill):
+        out = np.full(S, fill, dtype=np.int64)
+        out[: len(body)] = body
+        return out
+
+    value = padded(np.append(values.reshape(-1), END), PAD)
+    sample = {
+        "input_value": value,
+        "input_pos": padded(np.repeat(pos, 4), 0),
+        "input_coord": padded(np.arange(4 * n) % 4, 0),
+        "input_view": padded(np.repeat(views, 4), 0),
+    }
+    if spec.with_type:
+        sample["input_type"] = padded(np.repeat(types, 4), 0)
+    sample["input_mask"] = value == PAD
+
+    plo, phi = spec.n_planks
+    p = int(rng.integers(plo, phi + 1))
+    p = min(p, (T - 1) // 6)
+    seq = rng.integers(0, 512, size=6 * p)
+    attach = np.full(6 * p, -1, dtype=np.int64)
+    for i in range(6, 6 * p):
+        if rng.random() < spec.attach_prob:
+            if spec.valid_pointers:
+                cand = np.nonzero(pointer_mask_row(i, i))[0]
+            else:
+                cand = np.arange(i)
+            if len(cand):
+                j = int(rng.choice(cand))
+                attach[i] = j
+                seq[i] = seq[j]
+    out_value = np.full(T, PAD, dtype=np.int64)
+    out_value[: 6 * p] = seq
+    out_value[6 * p] = END
+    label = np.full(T, -1, dtype=np.int64)
+    label[: 6 * p] = attach
+    lab = np.where(label != -1, label + VOCAB, out_value)
+    sample["output_value"] = out_value
+    sample["output_label"] = lab
+    sample["output_mask"] = out_value == PAD
+    return sample
+
+
+def synth_batch(batch_size: int, spec: SynthSpec, seed: int = 2022, device=None):
+    """A collated batch (dict of LongTensor/BoolTensor [B, L]) plus ``name``."""
+    rng = np.random.default_rng(seed)
+    samples = [synth_sample(rng, spec) for _ in range(batch_size)]
+    batch = {"name": [f"synth_{seed}_{i:04d}" for i in range(batch_size)]}
+    for key in samples[0]:
+        arr = np.stack([s[key] for s in samples])
+        t = torch.from_numpy(arr)
+        batch[key] = t.to(device) if device is not None else t
+    return batch
+
+
+def spec_for(kind: str, max_input_length=None, max_output_length=None) -> SynthSpec:
+    """Named workloads of SURVEY.md section 8(d) / BASELINE.json ``configs``."""
+    if kind == "complete":
+        s = SynthSpec(1200, 128, (8, 299), (2, 21), True)
+    elif kind == "visible":
+        s = SynthSpec(1000, 128, (8, 249), (2, 21), True)
+    elif kind == "sideface":
+        s = SynthSpec(300, 128, (0, 74), (2, 21), False)
+    elif kind == "headline":          # d_model=512, seq=1024 (BASELINE.json metric)
+        s = SynthSpec(1025, 128, (8, 255), (2, 21), True)
+    elif kind == "decode":            # batch 256, max_len 1024
+        s = SynthSpec(1025, 1024, (255, 255), (2, 21), True)
+    else:
+        raise ValueError(kind)
+    if max_input_length is not None:
+        s.max_input_length = max_input_length
+    if max_output_length is not None:
+        s.max_output_length = max_output_length
+    return s

@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_fixture(name):
+    """npz -> (state_dict, batch, rest) with torch tensors."""
+    z = np.load(os.path.join(GOLDEN, name))
+    sd, batch, rest = {}, {}, {}
+    for k in z.files:
+        v = z[k]
+        if k.startswith("sd::"):
+            sd[k[4:]] = torch.from_numpy(v.copy())
+        elif k.startswith("batch::"):
+            batch[k[7:]] = torch.from_numpy(v.copy())
+        else:
+            rest[k] = v
+    # batch-dict order matters for the embedding sum (reference models.py:107): value,pos,coord,view,type
+    order = ["input_value", "input_pos", "input_coord", "input_view", "input_type", "input_mask",
+             "output_value", "output_label", "output_mask"]
+    batch = {k: batch[k] for k in order if k in batch}
+    return sd, batch, rest
+
+
+@pytest.fixture(scope="session")
+def small_fixture():
+    return load_fixture("fixture_small.npz")
+
+
+@pytest.fixture(scope="session")
+def ragged_fixture():
+    return load_fixture("fixture_ragged.npz")
+
+
+@pytest.fixture(scope="session")
+def tiny_fixture():
+    return load_fixture("fixture_tiny.npz")
+
+
+def has_gpu():
+    return torch.cuda.is_available()
