@@ -1,0 +1,193 @@
+/*
+ * plank_hip.h -- C ABI of libplank_hip.so, the MI355X (gfx950) implementation of the
+ * PlankAssembly encoder-decoder hot path.
+ *
+ * The reference has no FFI: its hot path (reference plankassembly/models.py) is Python glue
+ * over torch.nn modules.  The drop-in boundary towards the reference's callers is therefore
+ * the Python surface in plankassembly_amd/models.py (build_model / forward / state_dict,
+ * SURVEY.md section 8b); THIS header is the boundary between that host code and the device
+ * code.  Each entry point names the reference lines (and the torch op behind them) it
+ * replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a device pointer owned by the caller (PyTorch's caching allocator);
+ *     the library never allocates, frees or synchronises; scratch is passed in explicitly;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work on it (capturable
+ *     in a hipGraph);
+ *   - return value: 0 on success, a hipError_t (>0) from the launch, or a negative
+ *     PA_E* code for a bad argument.  No exceptions cross the ABI;
+ *   - dtypes: PA_F32 (parity path, exact-f32 MFMA) and PA_BF16 (throughput path, bf16 MFMA,
+ *     f32 accumulate).  Parameters, LayerNorm statistics, losses and gradients of
+ *     parameters are always f32.
+ *   - one process per GPU; calls are made from that process' host thread.
+ */
+#ifndef PLANK_HIP_H
+#define PLANK_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_F32 0
+#define PA_BF16 1
+
+#define PA_EINVAL (-1)   /* bad argument (null pointer, unsupported size/dtype) */
+#define PA_EALIGN (-2)   /* pointer / leading dimension not 16-byte aligned where required */
+#define PA_ESHAPE (-3)   /* unsupported shape (e.g. head dim) */
+
+int pa_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C[b] = epi( alpha * A[b] x B[b] ),  A: M x K, B: K x N.
+ * Replaces every nn.Linear / torch.bmm on the path: MHA in_proj / out_proj
+ * (torch F.multi_head_attention_forward), FFN linear1/linear2 (torch transformer.py
+ * _ff_block), vocab_head / pointer_head (reference models.py:145-149) and their backward
+ * GEMMs (dX = dY W, dW = dY^T X).
+ *   a_kcontig: 1 -> A stored [M][K] (lda = row stride); 0 -> stored [K][M]
+ *   b_kcontig: 1 -> B stored [N][K] (torch Linear weight layout); 0 -> stored [K][N]
+ * epilogue order: *alpha, +bias[n], relu, relu-backward gate (aux[m][n] > 0 ? v*aux_scale : 0),
+ * dropout(drop_p, drop_seed; element index = (b*M+m)*N+n), +R[m][n].
+ * splitk > 1: contraction split into `splitk` slices, partial products go through `ws`
+ * (f32, splitk*batch*M*N elements) and a reduce pass applies the epilogue.
+ */
+typedef struct {
+    const void* A; const void* B; void* C;
+    const float* bias;          /* [N] f32 or NULL */
+    const void* R;              /* residual [M][ldr], dtype = out_dtype, or NULL (may alias C) */
+    const void* aux;            /* relu-backward gate [M][ldaux], dtype = in_dtype, or NULL */
+    void* ws;                   /* split-K workspace or NULL */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldr, ldaux;
+    int64_t sA, sB, sC, sR, sAux;   /* batch strides in elements */
+    int32_t batch;
+    int32_t a_kcontig, b_kcontig;
+    int32_t in_dtype, out_dtype;
+    float alpha;
+    int32_t relu;
+    float aux_scale;
+    float drop_p; uint32_t drop_seed;
+    int32_t splitk;
+} pa_gemm_args;
+int pa_gemm(const pa_gemm_args* a, void* stream);
+
+/* column sums: out[n] (+)= sum_m X[m][n]  (bias gradients).  f32 out. `partial` is scratch of
+ * pa_colsum_ws_floats(M,N) floats. */
+int64_t pa_colsum_ws_floats(int32_t M, int32_t N);
+int pa_colsum(const void* X, int32_t dtype, int32_t M, int32_t N, int32_t ldx, float* out,
+              int32_t accumulate, float* partial, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embeddings.
+ * pa_embed_input_fwd: reference models.py:103-112 (_embed_input): out[t] = sum_k table_k[idx_k[t]].
+ *   tables: up to 5 f32 tables [rows_k][d]; idx: int64 [n_tok] each; a NULL idx skips the table
+ *   (sideface batches have no input_type).
+ * pa_embed_output_fwd: reference models.py:114-138 (_embed_output): out[b][0] = 0,
+ *   out[b][t] = value[tok[b][t-1]] + coord[(t-1) % dof] + pos[(t-1) / dof], t in [1, T).
+ *   tok has row stride tok_ld (the reference passes output_value[:, :-1]).
+ * pa_embed_*_bwd: scatter-add of d_out into the f32 table gradients (atomic).
+ */
+int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* const* tables, const int64_t* const* idx,
+                       int32_t n_tables, int64_t n_tok, int32_t d, void* stream);
+int pa_embed_input_bwd(const void* dout, int32_t dtype, float* const* dtables, const int64_t* const* idx,
+                       int32_t n_tables, int64_t n_tok, int32_t d, void* stream);
+int pa_embed_output_fwd(void* out, int32_t out_dtype, const float* value, const float* coord, const float* pos,
+                        const int64_t* tok, int32_t tok_ld, int32_t B, int32_t T, int32_t d, int32_t dof,
+                        void* stream);
+int pa_embed_output_bwd(const void* dout, int32_t dtype, float* dvalue, float* dcoord, float* dpos,
+                        const int64_t* tok, int32_t tok_ld, int32_t B, int32_t T, int32_t d, int32_t dof,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (biased variance), torch nn.LayerNorm as used by
+ * TransformerEncoderLayer/DecoderLayer post-norm branch (torch nn/modules/transformer.py) with
+ * eps = 1.0 per layer (reference models.py:60-61,66-67: normalize_before lands in the eps slot)
+ * and 1e-5 for encoder.norm / decoder.norm (models.py:62,68).
+ * fwd: y = (z - mean) * rstd * gamma + beta; saves mean/rstd (f32 [rows]).
+ * bwd: dz from dy; dgamma/dbeta are ACCUMULATED into f32 outputs through `partial` scratch
+ *      (pa_layernorm_ws_floats(rows, d) floats).  If drop_p > 0, also writes
+ *      ddrop = dz * dropout_mask(seed, row*d+col) / (1-p)  (gradient of the sub-layer output
+ *      that went through dropout before the residual add).  dzsum (optional) accumulates the
+ *      column sums of that sub-layer-output gradient (ddrop if drop_p > 0, else dz) = the bias
+ *      gradient of the Linear that produced it.
+ */
+int64_t pa_layernorm_ws_floats(int64_t rows, int32_t d);
+int pa_layernorm_fwd(void* y, const void* z, const float* gamma, const float* beta, float* mean, float* rstd,
+                     int64_t rows, int32_t d, float eps, int32_t dtype, void* stream);
+int pa_layernorm_bwd(void* dz, void* ddrop, const void* dy, const void* z, const float* gamma,
+                     const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dzsum,
+                     float* partial, int64_t rows, int32_t d, int32_t dtype,
+                     float drop_p, uint32_t drop_seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head attention core: softmax(Q K^T * scale + mask) V per (batch, head), flash-style
+ * (scores never reach HBM).  Replaces torch F.multi_head_attention_forward's
+ * bmm/softmax/dropout/bmm (torch 1.10) resp. scaled_dot_product_attention (torch 2.x) for the
+ * encoder self-attention (key padding mask), decoder self-attention (causal + key padding,
+ * reference models.py:85-89,209-214) and decoder cross-attention (memory key padding).
+ *   Q/K/V/O: element (b, l, h, c) at ptr[(b*L + l)*ld + h*dh + c]  (head = contiguous dh slice,
+ *   so Q/K/V may be views into the packed in_proj output);
+ *   kpm: uint8 [B][Lk], 1 = masked key (PAD), or NULL;  causal: key j allowed iff j <= i;
+ *   lse: f32 [B][H][Lq] log-sum-exp of the scaled, masked scores (saved for backward);
+ *   dropout on the attention probabilities (torch MHA `dropout`): element index
+ *   ((b*H+h)*Lq+i)*Lk+j hashed with drop_seed.
+ * bwd: dq/dk/dv have the layouts of q/k/v; delta is f32 scratch [B][H][Lq].
+ */
+typedef struct {
+    const void* q; const void* k; const void* v; void* o;
+    float* lse;
+    const uint8_t* kpm;
+    int32_t B, H, Lq, Lk, dh;
+    int32_t ldq, ldk, ldv, ldo;
+    int32_t causal;
+    float scale;
+    float drop_p; uint32_t drop_seed;
+    int32_t dtype;
+    /* backward only */
+    const void* dout; void* dq; void* dk; void* dv; float* delta;
+    int32_t lddo, lddq, lddk, lddv;
+} pa_attn_args;
+int pa_attn_fwd(const pa_attn_args* a, void* stream);
+int pa_attn_bwd(const pa_attn_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Output heads + mixture NLL (training): reference models.py:140-166,186 (_create_dist training
+ * branch) and 219-227 (nll_loss(ignore_index=PAD), argmax accuracy).
+ * Inputs: vocab logits [rows][ldv] f32 (rows = B*T), pointer logits [B][T][T] f32 (already
+ * scaled by 1/d_model), switch logit [rows] f32, labels int64 [rows] in [0, V+T).
+ * fwd accumulates stats[0] += sum of -logp(label) over non-PAD rows, stats[1] += #non-PAD rows,
+ * stats[2] += #correct argmax; saves per-row (lse_vocab, lse_ptr) for backward.
+ * The training mask quirk is reproduced: pointer logits j >= i are REPLACED by the value 1e-6
+ * and stay in the softmax.
+ * bwd writes d(vocab logits), d(pointer logits) (zero where j >= i) in `out_dtype` (they feed the
+ * backward GEMMs) and d(switch logit) in f32, for loss = stats[0] / stats[1]  (upstream gradient
+ * `gscale`, normally 1).
+ * pa_switch_fwd: s[row] = h[row] . w + b (reference models.py:153), pa_switch_bwd its gradient
+ * (dh += ds * w fused into the caller's GEMM epilogue is not possible, so dh_out is written
+ * and dw/db accumulated).
+ */
+int pa_switch_fwd(float* s, const void* h, int32_t dtype, const float* w, const float* b, int64_t rows,
+                  int32_t d, void* stream);
+int pa_switch_bwd(void* dh, int32_t accumulate, float* dw, float* db, const float* ds, const void* h,
+                  int32_t dtype, const float* w, float* partial, int64_t rows, int32_t d, void* stream);
+int pa_mixture_nll_fwd(float* stats, float* row_lse, const float* vocab, int32_t ldv, const float* ptr,
+                       const float* sw, const int64_t* label, int32_t B, int32_t T, int32_t V, int32_t pad,
+                       void* stream);
+int pa_mixture_nll_bwd(void* dvocab, void* dptr, int32_t out_dtype, float* dsw, const float* stats,
+                       const float* row_lse, const float* vocab, int32_t ldv, const float* ptr, const float* sw,
+                       const int64_t* label, int32_t B, int32_t T, int32_t V, int32_t pad, float gscale,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Adam (torch.optim.Adam defaults; reference trainer_complete.py:127-129), fused over one flat
+ * parameter buffer.  Optionally refreshes the bf16 shadow copy of the parameters.
+ * `gscale` multiplies the gradient first (1/world_size for a summed all-reduce).
+ */
+int pa_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float b1,
+                 float b2, float eps, int32_t step, float gscale, void* stream);
+int pa_cast(void* dst, int32_t dst_dtype, const void* src, int32_t src_dtype, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,109 @@
+"""ctypes binding of libplank_hip.so (the C ABI declared in include/plank_hip.h).
+
+The library is REQUIRED: there is no CPU / eager fallback anywhere in plankassembly_amd.  If the
+shared object is missing or fails to load, importing the ops raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libplank_hip.so")
+
+PA_F32, PA_BF16 = 0, 1
+_ERR = {-1: "PA_EINVAL (bad argument)", -2: "PA_EALIGN (misaligned pointer / leading dimension)",
+        -3: "PA_ESHAPE (unsupported shape)", -4: "PA_ESTATE (bad model/workspace state)"}
+
+
+class PlankHipError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+                ("R", C.c_void_p), ("aux", C.c_void_p), ("ws", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
+                ("ldaux", C.c_int32),
+                ("sA", C.c_int64), ("sB", C.c_int64), ("sC", C.c_int64), ("sR", C.c_int64), ("sAux", C.c_int64),
+                ("batch", C.c_int32), ("a_kcontig", C.c_int32), ("b_kcontig", C.c_int32),
+                ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("alpha", C.c_float), ("relu", C.c_int32),
+                ("aux_scale", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
+                ("splitk", C.c_int32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
+                ("lse", C.c_void_p), ("kpm", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32), ("dh", C.c_int32),
+                ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
+                ("causal", C.c_int32), ("scale", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
+                ("dtype", C.c_int32),
+                ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
+                ("delta", C.c_void_p),
+                ("lddo", C.c_int32), ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PlankHipError(
+                f"{LIB_PATH} is missing: build it with `python -m plankassembly_amd.build` "
+                "(hipcc, gfx950).  plankassembly_amd has no fallback path.")
+        _lib = C.CDLL(LIB_PATH)
+        P, I, I64, F, U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
+        sig = {
+            "pa_version": (I, []),
+            "pa_gemm": (I, [P, P]),
+            "pa_colsum_ws_floats": (I64, [I, I]),
+            "pa_colsum": (I, [P, I, I, I, I, P, I, P, P]),
+            "pa_embed_input_fwd": (I, [P, I, P, P, I, I64, I, P]),
+            "pa_embed_input_bwd": (I, [P, I, P, P, I, I64, I, P]),
+            "pa_embed_output_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
+            "pa_embed_output_bwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
+            "pa_layernorm_ws_floats": (I64, [I64, I]),
+            "pa_layernorm_fwd": (I, [P, P, P, P, P, P, I64, I, F, I, P]),
+            "pa_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I64, I, I, F, U, P]),
+            "pa_attn_fwd": (I, [P, P]),
+            "pa_attn_bwd": (I, [P, P]),
+            "pa_switch_fwd": (I, [P, P, I, P, P, I64, I, P]),
+            "pa_switch_bwd": (I, [P, I, P, P, P, P, I, P, P, I64, I, P]),
+            "pa_mixture_nll_fwd": (I, [P, P, P, I, P, P, P, I, I, I, I, P]),
+            "pa_mixture_nll_bwd": (I, [P, P, I, P, P, P, P, I, P, P, P, I, I, I, I, F, P]),
+            "pa_adam_step": (I, [P, P, P, P, P, I64, F, F, F, F, I, F, P]),
+            "pa_cast": (I, [P, I, P, I, I64, P]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = res, args
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = _ERR.get(rc, f"hipError {rc}")
+        raise PlankHipError(f"{what} failed: {msg}")
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return PA_F32
+    if t.dtype == torch.bfloat16:
+        return PA_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

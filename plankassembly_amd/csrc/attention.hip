@@ -1,0 +1,692 @@
+// Flash-style multi-head attention for gfx950 (forward, backward dK/dV, backward dQ).
+// See include/plank_hip.h (pa_attn_fwd / pa_attn_bwd).
+//
+// Formulation.  Every product is computed "transposed" so that per-query softmax statistics are
+// lane-local in the 32x32 MFMA C/D layout (col = lane & 31):
+//   forward   S^T[key][q] = K Q^T          (A = K rows from LDS, B = this lane's Q row, registers)
+//             O^T[d][q]  += V^T P^T        (A = V^T rows from a TRANSPOSED LDS image, B = P^T straight
+//                                           from the S^T accumulator registers - no cross-lane moves:
+//                                           the 8 contraction slots of a lane are the 8 keys it already
+//                                           holds, and V^T is read with the same key labelling)
+//   bwd dQ    dP^T = V dO^T, dS^T = P^T o (dP^T - D),  dQ^T += K^T dS^T   (same shapes as forward)
+//   bwd dK/dV S = Q K^T, dP = dO V^T (lane = key), dV^T += dO^T P, dK^T += Q^T dS
+// Tiles: 128 rows of the "owned" side per block (4 waves x 32), 64 rows of the streamed side per
+// step, staged global -> registers -> LDS (double buffered, one barrier per step) as a natural
+// [row][dh] image and/or a transposed [dh][row] image (4 x EB register blocks transposed in
+// flight).  LDS images are XOR-swizzled in 16-byte chunks.  Scores never touch HBM.
+// Softmax runs in the log2 domain (exp2), f32 statistics.
+#include "common.cuh"
+#include "../../include/plank_hip.h"
+
+namespace {
+
+constexpr int NTH = 256;
+constexpr int BOWN = 128;   // rows owned by a block (32 per wave)
+constexpr int BSTR = 64;    // rows streamed per step
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnP {
+    const void* q; const void* k; const void* v; void* o; float* lse; const uint8_t* kpm;
+    int B, H, Lq, Lk;
+    int ldq, ldk, ldv, ldo;
+    int causal; float scale;
+    uint32_t drop_thr; float drop_scale; uint32_t drop_seed;
+    const void* dout; void* dq; void* dk; void* dv; float* delta;
+    int lddo, lddq, lddk, lddv;
+};
+
+template <typename T, int DH> struct AT {
+    static constexpr int EB = ET<T>::EB, KC = ET<T>::KC;
+    static constexpr int NS = DH / KC;                 // mma16B steps over dh
+    static constexpr int NDT = (DH + 31) / 32;         // 32-row d tiles of a transposed product
+    static constexpr int NCHR = DH / EB;               // 16-byte chunks per natural row
+    static constexpr int RBN = DH * sizeof(T);         // natural row bytes
+    static constexpr int RBT = BSTR * sizeof(T);       // transposed row bytes (64 columns)
+    static constexpr int NCHT = RBT / 16;
+    static constexpr int NAT_BYTES = BSTR * RBN;
+    static constexpr int TR_BYTES = DH * RBT;          // == NAT_BYTES
+    static constexpr int NSB = 16 * NCHR;              // 4-row sub-blocks per streamed tile
+    static constexpr int NITEM = (2 * NSB + NTH - 1) / NTH;   // sub-blocks per thread for two tiles
+};
+
+template <int RB> __device__ __forceinline__ int swz_off(int row, int chunk) {
+    constexpr int NCH = RB / 16;
+    constexpr int RPB = (RB >= 256) ? 1 : 256 / RB;
+    return row * RB + (((chunk ^ (row / RPB)) & (NCH - 1)) << 4);
+}
+
+// ---- staging: a thread owns 4 consecutive rows x one 16-byte chunk of the streamed tile ----------
+template <typename T, int DH>
+__device__ __forceinline__ void load_sub(u32x4* regs, const T* base, int ld, int row0, int nrows, int sb) {
+    using A = AT<T, DH>;
+    const int cb = sb % A::NCHR, rb = sb / A::NCHR;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + rb * 4 + i;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r < nrows) v = *reinterpret_cast<const u32x4*>(base + (size_t)r * ld + cb * A::EB);
+        regs[i] = v;
+    }
+}
+template <typename T, int DH>
+__device__ __forceinline__ void store_nat(const u32x4* regs, char* lds, int sb) {
+    using A = AT<T, DH>;
+    const int cb = sb % A::NCHR, rb = sb / A::NCHR;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<u32x4*>(lds + swz_off<A::RBN>(rb * 4 + i, cb)) = regs[i];
+}
+// transposed image: [d][row]; this thread contributes rows rb*4..+3 for d = cb*EB .. +EB-1
+template <typename T, int DH> struct StoreTr;
+template <int DH> struct StoreTr<float, DH> {
+    static __device__ __forceinline__ void run(const u32x4* regs, char* lds, int sb) {
+        using A = AT<float, DH>;
+        const int cb = sb % A::NCHR, rb = sb / A::NCHR;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u32x4 o; o[0] = regs[0][e]; o[1] = regs[1][e]; o[2] = regs[2][e]; o[3] = regs[3][e];
+            // row d = cb*4+e, columns rb*4..rb*4+3 = 16 bytes = chunk rb
+            *reinterpret_cast<u32x4*>(lds + swz_off<A::RBT>(cb * 4 + e, rb)) = o;
+        }
+    }
+};
+template <int DH> struct StoreTr<bf16, DH> {
+    static __device__ __forceinline__ void run(const u32x4* regs, char* lds, int sb) {
+        using A = AT<bf16, DH>;
+        const int cb = sb % A::NCHR, rb = sb / A::NCHR;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            u32x2 o;
+#pragma unroll
+            for (int qd = 0; qd < 2; ++qd) {
+                const uint32_t lo = regs[2 * qd][e >> 1], hi = regs[2 * qd + 1][e >> 1];
+                o[qd] = (e & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+            }
+            // row d = cb*8+e, columns rb*4..+3 = 8 bytes at byte rb*8: chunk rb>>1, sub (rb&1)*8
+            *reinterpret_cast<u32x2*>(lds + swz_off<A::RBT>(cb * 8 + e, rb >> 1) + (rb & 1) * 8) = o;
+        }
+    }
+};
+
+// ---- MFMA helpers ------------------------------------------------------------------------------------
+// acc(32 x 32) += NAT[row0 + (lane&31)][:] (A operand, contraction over dh) x regs (B operand)
+template <typename T, int DH>
+__device__ __forceinline__ void mma_nat(f32x16& acc, const char* nat, int row0, const u32x4* regs, int lane) {
+    using A = AT<T, DH>;
+    const int row = row0 + (lane & 31), half = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < A::NS; ++s) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(nat + swz_off<A::RBN>(row, 2 * s + half));
+        mma16B<T>(acc, a, regs[s]);
+    }
+}
+// acc[dt](32 d x 32) += TR[dt*32 + (lane&31)][col0 + slots] (A operand) x P (B operand = this lane's 16
+// accumulator values of a 32-slot sub-tile; slot labelling: value r <-> column 8*(r>>2) + 4*half + (r&3))
+template <typename T, int DH> struct MmaTr;
+template <int DH> struct MmaTr<float, DH> {
+    static __device__ __forceinline__ void run(f32x16* acc, const char* tr, int col0, const f32x16& pv, int lane) {
+        using A = AT<float, DH>;
+        const int half = lane >> 5;
+#pragma unroll
+        for (int dt = 0; dt < A::NDT; ++dt) {
+            const int d = dt * 32 + (lane & 31);
+            const bool ok = d < DH;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = col0 + 8 * g + 4 * half;            // 4 consecutive f32 = one 16-byte chunk
+                u32x4 a = {0u, 0u, 0u, 0u};
+                if (ok) a = *reinterpret_cast<const u32x4*>(tr + swz_off<A::RBT>(d, col >> 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), pv[4 * g + e], acc[dt], 0, 0, 0);
+            }
+        }
+    }
+};
+template <int DH> struct MmaTr<bf16, DH> {
+    static __device__ __forceinline__ void run(f32x16* acc, const char* tr, int col0, const f32x16& pv, int lane) {
+        using A = AT<bf16, DH>;
+        const int half = lane >> 5;
+        u32x4 pb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) pb[u][w] = pack_bf16(pv[8 * u + 2 * w], pv[8 * u + 2 * w + 1]);
+#pragma unroll
+        for (int dt = 0; dt < A::NDT; ++dt) {
+            const int d = dt * 32 + (lane & 31);
+            const bool ok = d < DH;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int col = col0 + 16 * u + 4 * half;           // bytes col*2: chunk (col>>3), sub (col&7)*2
+                u32x4 a = {0u, 0u, 0u, 0u};
+                if (ok) {
+                    const u32x2 a0 = *reinterpret_cast<const u32x2*>(tr + swz_off<A::RBT>(d, col >> 3) + (col & 7) * 2);
+                    const u32x2 a1 = *reinterpret_cast<const u32x2*>(tr + swz_off<A::RBT>(d, (col + 8) >> 3) + (col & 7) * 2);
+                    a[0] = a0[0]; a[1] = a0[1]; a[2] = a1[0]; a[3] = a1[1];
+                }
+                mma16B<bf16>(acc[dt], a, pb[u]);
+            }
+        }
+    }
+};
+
+// this lane's row (q or key) operand for mma_nat's B side: NS 16-byte vectors
+template <typename T, int DH>
+__device__ __forceinline__ void load_row_regs(u32x4* regs, const T* base, int ld, int row, int nrows, int lane) {
+    using A = AT<T, DH>;
+    const int half = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < A::NS; ++s) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < nrows) v = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + A::KC * s + A::EB * half);
+        regs[s] = v;
+    }
+}
+
+// store a transposed-product accumulator (lane = row, registers = d) as rows of [row][d]
+template <typename T, int DH>
+__device__ __forceinline__ void store_rows(T* base, int ld, int row, int nrows, const f32x16* acc, float mul, int lane) {
+    using A = AT<T, DH>;
+    if (row >= nrows) return;
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = dt * 32 + 8 * g + 4 * (lane >> 5);
+            if (d < DH) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[dt][4 * g + e] * mul;
+                st4<T>(base + (size_t)row * ld + d, o);
+            }
+        }
+}
+
+template <typename T, int DH> struct Smem {
+    using A = AT<T, DH>;
+    // [buf][X tile | Y tile | Z tile | W tile | 64 mask bytes + 64 lse + 64 delta]
+    static constexpr int AUX_BYTES = 64 + 2 * 64 * 4;
+    static constexpr int BUF_FWD = 2 * A::NAT_BYTES + 64;
+    static constexpr int BUF_DQ = 3 * A::NAT_BYTES + 64;
+    static constexpr int BUF_DKV = 4 * A::NAT_BYTES + 2 * 64 * 4;
+};
+
+// =====================================================================================================
+// forward
+template <typename T, int DH>
+__global__ __launch_bounds__(NTH) void attn_fwd_kernel(AttnP p) {
+    using A = AT<T, DH>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
+    const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
+    const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
+    const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * p.Lk : nullptr;
+    const int qrow = q0 + wave * 32 + (lane & 31);
+
+    u32x4 qreg[A::NS];
+    load_row_regs<T, DH>(qreg, Qp, p.ldq, qrow, p.Lq, lane);
+
+    int nsteps = (p.Lk + BSTR - 1) / BSTR;
+    if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+
+    f32x16 oacc[A::NDT];
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl = p.scale * LOG2E;
+
+    u32x4 st[A::NITEM][4];
+    uint8_t mreg = 0;
+    auto gload = [&](int step) {
+        const int k0 = step * BSTR;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) {
+                const int sb = item % A::NSB;
+                if (item < A::NSB) load_sub<T, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
+                else load_sub<T, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
+            }
+        }
+        if (tid < BSTR) {
+            const int key = k0 + tid;
+            mreg = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * Smem<T, DH>::BUF_FWD;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) {
+                const int sb = item % A::NSB;
+                if (item < A::NSB) store_nat<T, DH>(st[j], base, sb);
+                else StoreTr<T, DH>::run(st[j], base + A::NAT_BYTES, sb);
+            }
+        }
+        if (tid < BSTR) reinterpret_cast<uint8_t*>(base + 2 * A::NAT_BYTES)[tid] = mreg;
+    };
+
+    if (nsteps > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) gload(step + 1);
+        const char* knat = smem + buf * Smem<T, DH>::BUF_FWD;
+        const char* vtr = knat + A::NAT_BYTES;
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(knat + 2 * A::NAT_BYTES);
+        const int k0 = step * BSTR;
+
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+            mma_nat<T, DH>(sacc[kt], knat, kt * 32, qreg, lane);
+        }
+        // scores -> log2 domain, masks
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int koff = kt * 32 + 8 * g + 4 * half;
+                const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + koff + e;
+                    float x = sacc[kt][4 * g + e] * sl;
+                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
+                    x = masked ? -INFINITY : x;
+                    sacc[kt][4 * g + e] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_safe);
+        m_run = m_new;
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pe = exp2f(sacc[kt][r] - m_safe);
+                lsum += pe;
+                if (p.drop_thr) {
+                    const int key = k0 + kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                    const uint32_t idx = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.Lk + key);
+                    pe = drop_keep(p.drop_seed, idx, p.drop_thr) ? pe * p.drop_scale : 0.f;
+                }
+                sacc[kt][r] = pe;
+            }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) MmaTr<T, DH>::run(oacc, vtr, kt * 32, sacc[kt], lane);
+
+        if (step + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    T* Op = reinterpret_cast<T*>(p.o) + (size_t)b * p.Lq * p.ldo + h * DH;
+    store_rows<T, DH>(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);
+    if (half == 0 && qrow < p.Lq && p.lse)
+        p.lse[((size_t)b * p.H + h) * p.Lq + qrow] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : 0.f;
+}
+
+// =====================================================================================================
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
+    const int64_t total = (int64_t)p.B * p.H * p.Lq;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i % p.Lq);
+    const int h = (int)((i / p.Lq) % p.H);
+    const int b = (int)(i / ((int64_t)p.Lq * p.H));
+    const T* o = reinterpret_cast<const T*>(p.o) + ((size_t)b * p.Lq + q) * p.ldo + h * DH;
+    const T* g = reinterpret_cast<const T*>(p.dout) + ((size_t)b * p.Lq + q) * p.lddo + h * DH;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH; c += 4) {
+        const f32x4 a = ld4<T>(o + c), d4 = ld4<T>(g + c);
+        s += a[0] * d4[0] + a[1] * d4[1] + a[2] * d4[2] + a[3] * d4[3];
+    }
+    p.delta[i] = s;
+}
+
+// =====================================================================================================
+// backward, dQ: block owns 128 queries, streams keys
+template <typename T, int DH>
+__global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP p) {
+    using A = AT<T, DH>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
+    const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
+    const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
+    const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
+    const T* dOp = reinterpret_cast<const T*>(p.dout) + (size_t)b * p.Lq * p.lddo + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * p.Lk : nullptr;
+    const int qrow = q0 + wave * 32 + (lane & 31);
+
+    u32x4 qreg[A::NS], doreg[A::NS];
+    load_row_regs<T, DH>(qreg, Qp, p.ldq, qrow, p.Lq, lane);
+    load_row_regs<T, DH>(doreg, dOp, p.lddo, qrow, p.Lq, lane);
+    const size_t srow = ((size_t)b * p.H + h) * p.Lq + qrow;
+    const float lse2 = (qrow < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
+    const float dlt = (qrow < p.Lq) ? p.delta[srow] : 0.f;
+
+    int nsteps = (p.Lk + BSTR - 1) / BSTR;
+    if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+
+    f32x16 dqacc[A::NDT];
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
+    const float sl = p.scale * LOG2E;
+
+    u32x4 st[A::NITEM][4];
+    uint8_t mreg = 0;
+    auto gload = [&](int step) {
+        const int k0 = step * BSTR;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) {
+                const int sb = item % A::NSB;
+                if (item < A::NSB) load_sub<T, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
+                else load_sub<T, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
+            }
+        }
+        if (tid < BSTR) {
+            const int key = k0 + tid;
+            mreg = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * Smem<T, DH>::BUF_DQ;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) {
+                const int sb = item % A::NSB;
+                if (item < A::NSB) {
+                    store_nat<T, DH>(st[j], base, sb);                              // K natural
+                    StoreTr<T, DH>::run(st[j], base + A::NAT_BYTES, sb);            // K transposed
+                } else {
+                    store_nat<T, DH>(st[j], base + 2 * A::NAT_BYTES, sb);           // V natural
+                }
+            }
+        }
+        if (tid < BSTR) reinterpret_cast<uint8_t*>(base + 3 * A::NAT_BYTES)[tid] = mreg;
+    };
+
+    if (nsteps > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) gload(step + 1);
+        const char* knat = smem + buf * Smem<T, DH>::BUF_DQ;
+        const char* ktr = knat + A::NAT_BYTES;
+        const char* vnat = knat + 2 * A::NAT_BYTES;
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(knat + 3 * A::NAT_BYTES);
+        const int k0 = step * BSTR;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+            mma_nat<T, DH>(sacc, knat, kt * 32, qreg, lane);
+            mma_nat<T, DH>(dpacc, vnat, kt * 32, doreg, lane);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int koff = kt * 32 + 8 * g + 4 * half;
+                const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + koff + e;
+                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
+                    const float pe = masked ? 0.f : exp2f(sacc[4 * g + e] * sl - lse2);
+                    float dp = dpacc[4 * g + e];
+                    if (p.drop_thr) {
+                        const uint32_t idx = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.Lk + key);
+                        dp = drop_keep(p.drop_seed, idx, p.drop_thr) ? dp * p.drop_scale : 0.f;
+                    }
+                    sacc[4 * g + e] = pe * (dp - dlt) * p.scale;          // dS^T
+                }
+            }
+            MmaTr<T, DH>::run(dqacc, ktr, kt * 32, sacc, lane);
+        }
+        if (step + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    T* dQp = reinterpret_cast<T*>(p.dq) + (size_t)b * p.Lq * p.lddq + h * DH;
+    store_rows<T, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, 1.0f, lane);
+}
+
+// =====================================================================================================
+// backward, dK/dV: block owns 128 keys, streams queries
+template <typename T, int DH>
+__global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP p) {
+    using A = AT<T, DH>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * BOWN;
+    const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
+    const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
+    const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
+    const T* dOp = reinterpret_cast<const T*>(p.dout) + (size_t)b * p.Lq * p.lddo + h * DH;
+    const int krow = key0 + wave * 32 + (lane & 31);
+    const bool kmasked = (krow >= p.Lk) || (p.kpm && p.kpm[(size_t)b * p.Lk + krow]);
+
+    u32x4 kreg[A::NS], vreg[A::NS];
+    load_row_regs<T, DH>(kreg, Kp, p.ldk, krow, p.Lk, lane);
+    load_row_regs<T, DH>(vreg, Vp, p.ldv, krow, p.Lk, lane);
+
+    const int nsteps = (p.Lq + BSTR - 1) / BSTR;
+    const int step0 = p.causal ? (key0 / BSTR) : 0;       // queries before the first owned key see none of them
+
+    f32x16 dkacc[A::NDT], dvacc[A::NDT];
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkacc[dt][r] = 0.f; dvacc[dt][r] = 0.f; }
+    const float sl = p.scale * LOG2E;
+
+    u32x4 st[A::NITEM][4];
+    float lreg = 0.f, dreg = 0.f;
+    auto gload = [&](int step) {
+        const int r0 = step * BSTR;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) {
+                const int sb = item % A::NSB;
+                if (item < A::NSB) load_sub<T, DH>(st[j], Qp, p.ldq, r0, p.Lq, sb);
+                else load_sub<T, DH>(st[j], dOp, p.lddo, r0, p.Lq, sb);
+            }
+        }
+        if (tid < BSTR) {
+            const int qr = r0 + tid;
+            const size_t srow = ((size_t)b * p.H + h) * p.Lq + qr;
+            lreg = (qr < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
+            dreg = (qr < p.Lq) ? p.delta[srow] : 0.f;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * Smem<T, DH>::BUF_DKV;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) {
+                const int sb = item % A::NSB;
+                char* t0 = base + (item < A::NSB ? 0 : 2 * A::NAT_BYTES);
+                store_nat<T, DH>(st[j], t0, sb);
+                StoreTr<T, DH>::run(st[j], t0 + A::NAT_BYTES, sb);
+            }
+        }
+        if (tid < BSTR) {
+            float* aux = reinterpret_cast<float*>(base + 4 * A::NAT_BYTES);
+            aux[tid] = lreg; aux[64 + tid] = dreg;
+        }
+    };
+
+    if (step0 < nsteps) { gload(step0); lstore(0); }
+    __syncthreads();
+
+    for (int step = step0; step < nsteps; ++step) {
+        const int buf = (step - step0) & 1;
+        if (step + 1 < nsteps) gload(step + 1);
+        const char* qnat = smem + buf * Smem<T, DH>::BUF_DKV;
+        const char* qtr = qnat + A::NAT_BYTES;
+        const char* donat = qnat + 2 * A::NAT_BYTES;
+        const char* dotr = qnat + 3 * A::NAT_BYTES;
+        const float* aux = reinterpret_cast<const float*>(qnat + 4 * A::NAT_BYTES);
+        const int r0 = step * BSTR;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+            mma_nat<T, DH>(sacc, qnat, qt * 32, kreg, lane);       // S[q][key]: rows q (regs), col key (lane)
+            mma_nat<T, DH>(dpacc, donat, qt * 32, vreg, lane);     // dP[q][key]
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qoff = qt * 32 + 8 * g + 4 * half;
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(aux + qoff);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(aux + 64 + qoff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qr = r0 + qoff + e;
+                    const bool masked = kmasked || (p.causal && krow > qr);
+                    float pe = masked ? 0.f : exp2f(sacc[4 * g + e] * sl - l4[e]);
+                    float dp = dpacc[4 * g + e];
+                    float pd = pe;
+                    if (p.drop_thr) {
+                        const uint32_t idx = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qr) * p.Lk + krow);
+                        const bool keep = drop_keep(p.drop_seed, idx, p.drop_thr);
+                        dp = keep ? dp * p.drop_scale : 0.f;
+                        pd = keep ? pe * p.drop_scale : 0.f;
+                    }
+                    sacc[4 * g + e] = pd;                                   // dropped P  -> dV
+                    dpacc[4 * g + e] = pe * (dp - d4[e]) * p.scale;         // dS         -> dK
+                }
+            }
+            MmaTr<T, DH>::run(dvacc, dotr, qt * 32, sacc, lane);
+            MmaTr<T, DH>::run(dkacc, qtr, qt * 32, dpacc, lane);
+        }
+        if (step + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    T* dKp = reinterpret_cast<T*>(p.dk) + (size_t)b * p.Lk * p.lddk + h * DH;
+    T* dVp = reinterpret_cast<T*>(p.dv) + (size_t)b * p.Lk * p.lddv + h * DH;
+    store_rows<T, DH>(dKp, p.lddk, krow, p.Lk, dkacc, 1.0f, lane);
+    store_rows<T, DH>(dVp, p.lddv, krow, p.Lk, dvacc, 1.0f, lane);
+}
+
+// =====================================================================================================
+AttnP make_params(const pa_attn_args* a) {
+    AttnP p;
+    p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o; p.lse = a->lse; p.kpm = a->kpm;
+    p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk;
+    p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+    p.causal = a->causal; p.scale = a->scale;
+    p.drop_thr = (uint32_t)(a->drop_p * 65536.0f + 0.5f);
+    p.drop_scale = 1.0f / (1.0f - a->drop_p);
+    p.drop_seed = a->drop_seed;
+    p.dout = a->dout; p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.delta = a->delta;
+    p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
+    return p;
+}
+
+template <typename K> int set_lds(K kern, int bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+template <typename T, int DH> int run_fwd(const AttnP& p, hipStream_t st) {
+    const int shm = 2 * Smem<T, DH>::BUF_FWD;
+    int rc = set_lds(attn_fwd_kernel<T, DH>, shm);
+    if (rc) return rc;
+    dim3 grid((p.Lq + BOWN - 1) / BOWN, p.H, p.B);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(NTH), shm, st, p);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+template <typename T, int DH> int run_bwd(const AttnP& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.B * p.H * p.Lq;
+    hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    PA_CHECK_LAUNCH();
+    int shm = 2 * Smem<T, DH>::BUF_DKV;
+    int rc = set_lds(attn_bwd_dkv_kernel<T, DH>, shm);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DH>), dim3((p.Lk + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
+    PA_CHECK_LAUNCH();
+    shm = 2 * Smem<T, DH>::BUF_DQ;
+    rc = set_lds(attn_bwd_dq_kernel<T, DH>, shm);
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), dim3((p.Lq + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T> int dispatch(const pa_attn_args* a, bool bwd, hipStream_t st) {
+    const AttnP p = make_params(a);
+    switch (a->dh) {
+        case 16: return bwd ? run_bwd<T, 16>(p, st) : run_fwd<T, 16>(p, st);
+        case 32: return bwd ? run_bwd<T, 32>(p, st) : run_fwd<T, 32>(p, st);
+        case 64: return bwd ? run_bwd<T, 64>(p, st) : run_fwd<T, 64>(p, st);
+        default: return PA_ESHAPE;
+    }
+}
+
+int check_args(const pa_attn_args* a, bool bwd) {
+    if (!a || !a->q || !a->k || !a->v || !a->o || !a->lse) return PA_EINVAL;
+    if (a->B <= 0 || a->H <= 0 || a->Lq <= 0 || a->Lk <= 0) return PA_EINVAL;
+    if (a->dtype != PA_F32 && a->dtype != PA_BF16) return PA_EINVAL;
+    if (a->drop_p < 0.f || a->drop_p >= 1.f) return PA_EINVAL;
+    const int EB = a->dtype == PA_BF16 ? 8 : 4;
+    auto al = [&](const void* ptr, int ld) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && ld % EB == 0; };
+    if (!al(a->q, a->ldq) || !al(a->k, a->ldk) || !al(a->v, a->ldv) || !al(a->o, a->ldo)) return PA_EALIGN;
+    if (bwd) {
+        if (!a->dout || !a->dq || !a->dk || !a->dv || !a->delta) return PA_EINVAL;
+        if (!al(a->dout, a->lddo) || !al(a->dq, a->lddq) || !al(a->dk, a->lddk) || !al(a->dv, a->lddv)) return PA_EALIGN;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pa_attn_fwd(const pa_attn_args* a, void* stream) {
+    int rc = check_args(a, false);
+    if (rc) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return a->dtype == PA_BF16 ? dispatch<bf16>(a, false, st) : dispatch<float>(a, false, st);
+}
+
+extern "C" int pa_attn_bwd(const pa_attn_args* a, void* stream) {
+    int rc = check_args(a, true);
+    if (rc) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return a->dtype == PA_BF16 ? dispatch<bf16>(a, true, st) : dispatch<float>(a, true, st);
+}

@@ -1,0 +1,117 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the PlankAssembly hot path.
+// Everything here is written for MI355X only: 64-lane waves, 32x32 MFMA tiles, 16-byte LDS vectors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define PA_F32 0
+#define PA_BF16 1
+
+// ---------------------------------------------------------------------------------------------
+// element traits: EB = elements per 16-byte vector; KC = contraction elements one mma16B() covers
+template <typename T> struct ET;
+template <> struct ET<float> { static constexpr int EB = 4; static constexpr int KC = 8; static constexpr int DT = PA_F32; };
+template <> struct ET<bf16>  { static constexpr int EB = 8; static constexpr int KC = 16; static constexpr int DT = PA_BF16; };
+
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    bf16x2 p; p[0] = (bf16)lo; p[1] = (bf16)hi;          // v_cvt_pk_bf16_f32 (RNE)
+    return *reinterpret_cast<uint32_t*>(&p);
+}
+
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16>(const bf16* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<bf16>(bf16* p, float v) { *p = (bf16)v; }
+
+// 4 consecutive elements <-> float4 (8 B for bf16, 16 B for f32); pointer must be suitably aligned
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld4<bf16>(const bf16* p) {
+    u32x2 u = *reinterpret_cast<const u32x2*>(p);
+    f32x4 r; r[0] = bf16_lo(u[0]); r[1] = bf16_hi(u[0]); r[2] = bf16_lo(u[1]); r[3] = bf16_hi(u[1]);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16>(bf16* p, f32x4 v) {
+    u32x2 u; u[0] = pack_bf16(v[0], v[1]); u[1] = pack_bf16(v[2], v[3]);
+    *reinterpret_cast<u32x2*>(p) = u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One "16-byte step" of a 32x32 MFMA tile.  Lane l = (i = l & 31, h = l >> 5) supplies for the A
+// operand row i and for the B operand column i the EB contraction elements [EB*h, EB*h+EB) of
+// the step's KC = 2*EB elements.  bf16: one v_mfma_f32_32x32x16_bf16.  f32: four
+// v_mfma_f32_32x32x2_f32 (exact f32; MFMA e pairs element e of both half-waves, which is a
+// consistent relabelling of the contraction index for A and B alike).
+// C/D layout (dtype independent): col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5), r in [0,16).
+template <typename T> __device__ __forceinline__ void mma16B(f32x16& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma16B<bf16>(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                  *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16B<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[e]), __uint_as_float(b[e]), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// transpose an EB x EB element block held as EB 16-byte vectors (vector i = row i) in registers
+template <typename T> __device__ __forceinline__ void transpose_block(const u32x4* in, u32x4* out);
+template <> __device__ __forceinline__ void transpose_block<float>(const u32x4* in, u32x4* out) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        out[e][0] = in[0][e]; out[e][1] = in[1][e]; out[e][2] = in[2][e]; out[e][3] = in[3][e];
+    }
+}
+template <> __device__ __forceinline__ void transpose_block<bf16>(const u32x4* in, u32x4* out) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t lo = in[2 * q][e >> 1], hi = in[2 * q + 1][e >> 1];
+            out[e][q] = (e & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based dropout RNG: 32-bit avalanche hash of (seed, element index); 16 bits per decision.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// keep-decision for element idx; thr16 = round(p * 65536).  P(keep) = 1 - thr16/65536.
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t thr16) {
+    uint32_t h = mix32(idx * 0x9e3779b9u + seed);
+    return (h >> 16) >= thr16;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+#define PA_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

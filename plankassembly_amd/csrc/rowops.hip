@@ -1,0 +1,590 @@
+// HBM-bound row kernels of the PlankAssembly hot path for gfx950: embedding gathers (+ scatter-add
+// backward), LayerNorm fwd/bwd, switch head, fused mixture-NLL fwd/bwd, Adam, casts.
+// One 64-lane wave per row with 16-byte (4 x f32 / 4 x bf16 = 8-byte) vector accesses and
+// shuffle reductions; parameter-gradient column sums go through per-block partials (deterministic).
+#include "common.cuh"
+#include "../../include/plank_hip.h"
+
+namespace {
+
+constexpr int MAXV = 8;   // vectors of 4 per lane per row -> d <= 2048
+
+// ================================================================================ embeddings
+struct EmbTabs { const float* t[5]; const int64_t* idx[5]; int n; };
+struct EmbGrads { float* t[5]; const int64_t* idx[5]; int n; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_input_fwd_kernel(T* out, EmbTabs tb, int64_t n_tok, int d) {
+    const int vec_per_row = d >> 2;
+    const int64_t total = n_tok * vec_per_row;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t tok = e / vec_per_row;
+        const int c = (int)(e % vec_per_row) << 2;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (k < tb.n && tb.idx[k]) {
+                const int64_t r = tb.idx[k][tok];
+                acc += *reinterpret_cast<const f32x4*>(tb.t[k] + r * d + c);
+            }
+        }
+        st4<T>(out + tok * d + c, acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_input_bwd_kernel(const T* dout, EmbGrads tb, int64_t n_tok, int d) {
+    const int vec_per_row = d >> 2;
+    const int64_t total = n_tok * vec_per_row;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t tok = e / vec_per_row;
+        const int c = (int)(e % vec_per_row) << 2;
+        const f32x4 g = ld4<T>(dout + tok * d + c);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (k < tb.n && tb.idx[k]) {
+                float* dst = tb.t[k] + tb.idx[k][tok] * d + c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dst + j, g[j]);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_output_fwd_kernel(T* out, const float* value, const float* coord,
+                                                               const float* pos, const int64_t* tok, int tok_ld,
+                                                               int B, int Tn, int d, int dof) {
+    const int vec_per_row = d >> 2;
+    const int64_t total = (int64_t)B * Tn * vec_per_row;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / vec_per_row;
+        const int c = (int)(e % vec_per_row) << 2;
+        const int b = (int)(row / Tn), t = (int)(row % Tn);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            const int64_t v = tok[(int64_t)b * tok_ld + (t - 1)];
+            acc = *reinterpret_cast<const f32x4*>(value + v * d + c);
+            acc += *reinterpret_cast<const f32x4*>(coord + (int64_t)((t - 1) % dof) * d + c);
+            acc += *reinterpret_cast<const f32x4*>(pos + (int64_t)((t - 1) / dof) * d + c);
+        }
+        st4<T>(out + row * d + c, acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_output_bwd_kernel(const T* dout, float* dvalue, float* dcoord, float* dpos,
+                                                               const int64_t* tok, int tok_ld, int B, int Tn, int d, int dof) {
+    const int vec_per_row = d >> 2;
+    const int64_t total = (int64_t)B * Tn * vec_per_row;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / vec_per_row;
+        const int c = (int)(e % vec_per_row) << 2;
+        const int b = (int)(row / Tn), t = (int)(row % Tn);
+        if (t == 0) continue;
+        const f32x4 g = ld4<T>(dout + row * d + c);
+        const int64_t v = tok[(int64_t)b * tok_ld + (t - 1)];
+        float* p0 = dvalue + v * d + c;
+        float* p1 = dcoord + (int64_t)((t - 1) % dof) * d + c;
+        float* p2 = dpos + (int64_t)((t - 1) / dof) * d + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { unsafeAtomicAdd(p0 + j, g[j]); unsafeAtomicAdd(p1 + j, g[j]); unsafeAtomicAdd(p2 + j, g[j]); }
+    }
+}
+
+// ================================================================================ LayerNorm
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(T* y, const T* z, const float* gamma, const float* beta,
+                                                            float* mean, float* rstd, int64_t rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* zr = z + row * d;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + i * 64) << 2;
+        if (c < d) { v[i] = ld4<T>(zr + c); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
+    }
+    const float mu = wave_sum(s) / d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + i * 64) << 2;
+        if (c < d) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float t = v[i][j] - mu; q += t * t; }
+        }
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(q) / d + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    T* yr = y + row * d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + i * 64) << 2;
+        if (c < d) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+            st4<T>(yr + c, o);
+        }
+    }
+}
+
+constexpr int LNB_ROWS = 32;   // rows per block in backward (8 per wave)
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(T* dz, T* ddrop, const T* dy, const T* z, const float* gamma,
+                                                            const float* mean, const float* rstd, float* partial,
+                                                            int64_t rows, int d, uint32_t drop_thr, float drop_scale,
+                                                            uint32_t drop_seed, int want_dzsum) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][3][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 ag[MAXV], ab[MAXV], as[MAXV];
+    f32x4 gm[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = ag[i]; as[i] = ag[i];
+        const int c = (lane + i * 64) << 2;
+        if (c < d) gm[i] = *reinterpret_cast<const f32x4*>(gamma + c);
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * LNB_ROWS;
+    for (int rr = wave; rr < LNB_ROWS; rr += 4) {
+        const int64_t row = r0 + rr;
+        if (row >= rows) break;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[MAXV], g[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (lane + i * 64) << 2;
+            if (c < d) {
+                const f32x4 zz = ld4<T>(z + row * d + c);
+                const f32x4 dd = ld4<T>(dy + row * d + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[i][j] = (zz[j] - mu) * rs;
+                    g[i][j] = dd[j] * gm[i][j];
+                    s1 += g[i][j];
+                    s2 += g[i][j] * xh[i][j];
+                    ag[i][j] += dd[j] * xh[i][j];
+                    ab[i][j] += dd[j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / d;
+        s2 = wave_sum(s2) / d;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (lane + i * 64) << 2;
+            if (c < d) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = rs * (g[i][j] - s1 - xh[i][j] * s2);
+                st4<T>(dz + row * d + c, o);
+                if (drop_thr) {
+                    f32x4 od;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        od[j] = drop_keep(drop_seed, (uint32_t)(row * d + c + j), drop_thr) ? o[j] * drop_scale : 0.f;
+                    st4<T>(ddrop + row * d + c, od);
+                    as[i] += od;
+                } else {
+                    as[i] += o;
+                }
+            }
+        }
+    }
+    // cross-wave reduction of the column sums, then one partial row per block
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + i * 64) << 2;
+        if (c < d) {
+            *reinterpret_cast<f32x4*>(red + (wave * 3 + 0) * d + c) = ag[i];
+            *reinterpret_cast<f32x4*>(red + (wave * 3 + 1) * d + c) = ab[i];
+            *reinterpret_cast<f32x4*>(red + (wave * 3 + 2) * d + c) = as[i];
+        }
+    }
+    __syncthreads();
+    const int nq = want_dzsum ? 3 : 2;
+    for (int e = threadIdx.x; e < nq * d; e += 256) {
+        const int qn = e / d, c = e % d;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(w * 3 + qn) * d + c];
+        partial[((size_t)blockIdx.x * 3 + qn) * d + c] = s;
+    }
+}
+
+// sums `nparts` partial rows of `nq` quantities and ACCUMULATES into up to three outputs
+__global__ __launch_bounds__(256) void partial_finish_kernel(const float* partial, int nparts, int part_stride, int q_stride,
+                                                             int ncols, float* o0, float* o1, float* o2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int qn = blockIdx.y;
+    float* o = qn == 0 ? o0 : (qn == 1 ? o1 : o2);
+    if (c >= ncols || !o) return;
+    float s = 0.f;
+    for (int i = 0; i < nparts; ++i) s += partial[(size_t)i * part_stride + (size_t)qn * q_stride + c];
+    o[c] += s;
+}
+
+// ================================================================================ switch head
+template <typename T>
+__global__ __launch_bounds__(256) void switch_fwd_kernel(float* s, const T* h, const float* w, const float* b,
+                                                         int64_t rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float acc = 0.f;
+    for (int c = lane << 2; c < d; c += 256) {
+        const f32x4 hv = ld4<T>(h + row * d + c);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+        acc += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) s[row] = acc + b[0];
+}
+
+// dh (+)= ds * w ; partial[blk][0][d] = sum_rows ds*h ; partial[blk][1][0] = sum_rows ds
+template <typename T>
+__global__ __launch_bounds__(256) void switch_bwd_kernel(T* dh, int accumulate, const float* ds, const T* h,
+                                                         const float* w, float* partial, int64_t rows, int d) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4][d] + [4]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 aw[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) aw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float adb = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * LNB_ROWS;
+    for (int rr = wave; rr < LNB_ROWS; rr += 4) {
+        const int64_t row = r0 + rr;
+        if (row >= rows) break;
+        const float g = ds[row];
+        adb += g;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (lane + i * 64) << 2;
+            if (c < d) {
+                const f32x4 hv = ld4<T>(h + row * d + c);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { aw[i][j] += g * hv[j]; o[j] = g * wv[j]; }
+                if (accumulate) o += ld4<T>(dh + row * d + c);
+                st4<T>(dh + row * d + c, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (lane + i * 64) << 2;
+        if (c < d) *reinterpret_cast<f32x4*>(red + wave * d + c) = aw[i];
+    }
+    if (lane == 0) red[4 * d + wave] = adb;
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256)
+        partial[((size_t)blockIdx.x * 2 + 0) * d + c] = red[c] + red[d + c] + red[2 * d + c] + red[3 * d + c];
+    if (threadIdx.x == 0)
+        partial[((size_t)blockIdx.x * 2 + 1) * d] = red[4 * d] + red[4 * d + 1] + red[4 * d + 2] + red[4 * d + 3];
+}
+
+// ================================================================================ mixture NLL
+// One wave per (b, i) row.  Row = [vocab logits (V)] ++ [pointer logits (T), j >= i replaced by 1e-6].
+struct RowStat { float m, s; int arg; };
+__device__ __forceinline__ void online(RowStat& st, float x, int idx) {
+    if (x > st.m) { st.s = st.s * expf(st.m - x) + 1.f; st.m = x; st.arg = idx; }
+    else st.s += expf(x - st.m);
+}
+__device__ __forceinline__ RowStat wave_merge(RowStat a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(a.m, o), s2 = __shfl_xor(a.s, o);
+        const int g2 = __shfl_xor(a.arg, o);
+        const float mn = fmaxf(a.m, m2);
+        const float sa = (a.m == -INFINITY) ? 0.f : a.s * expf(a.m - mn);
+        const float sb = (m2 == -INFINITY) ? 0.f : s2 * expf(m2 - mn);
+        // first-max tie break: smaller index wins on equal value
+        if (m2 > a.m || (m2 == a.m && g2 < a.arg)) a.arg = g2;
+        a.m = mn; a.s = sa + sb;
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void mixture_nll_fwd_kernel(float* stats, float* row_lse, const float* vocab, int ldv,
+                                                              const float* ptr, const float* sw, const int64_t* label,
+                                                              int B, int Tn, int V, int pad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * Tn) return;
+    const int i = (int)(row % Tn);
+    const float* vr = vocab + row * ldv;
+    const float* pr = ptr + row * Tn;
+    RowStat sv{-INFINITY, 0.f, 0x7fffffff}, sp{-INFINITY, 0.f, 0x7fffffff};
+    for (int k = lane; k < V; k += 64) online(sv, vr[k], k);
+    for (int j = lane; j < Tn; j += 64) online(sp, (j >= i) ? 1e-6f : pr[j], j);
+    sv = wave_merge(sv);
+    sp = wave_merge(sp);
+    const float lse_v = sv.m + logf(sv.s), lse_p = sp.m + logf(sp.s);
+    const float prob = 1.0f / (1.0f + expf(-sw[row]));
+    const float lv = logf(fmaxf(1.0f - prob, 1e-6f)), lp = logf(fmaxf(prob, 1e-6f));
+    if (lane == 0) {
+        row_lse[row * 2] = lse_v; row_lse[row * 2 + 1] = lse_p;
+        const int64_t lab = label[row];
+        if (lab != pad) {
+            float logp;
+            if (lab < V) logp = vr[lab] - lse_v + lv;
+            else { const int j = (int)(lab - V); logp = ((j >= i) ? 1e-6f : pr[j]) - lse_p + lp; }
+            const float best_v = sv.m - lse_v + lv, best_p = sp.m - lse_p + lp;
+            const int64_t pred = (best_p > best_v) ? (int64_t)V + sp.arg : (int64_t)sv.arg;
+            atomicAdd(stats + 0, -logp);
+            atomicAdd(stats + 1, 1.0f);
+            if (pred == lab) atomicAdd(stats + 2, 1.0f);
+        }
+    }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void mixture_nll_bwd_kernel(TO* dvocab, TO* dptr, float* dsw, const float* stats,
+                                                              const float* row_lse, const float* vocab, int ldv,
+                                                              const float* ptr, const float* sw, const int64_t* label,
+                                                              int B, int Tn, int V, int pad, float gscale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * Tn) return;
+    const int i = (int)(row % Tn);
+    const int64_t lab = label[row];
+    TO* dv = dvocab + row * ldv;
+    TO* dp = dptr + row * Tn;
+    if (lab == pad) {
+        for (int k = lane; k < ldv; k += 64) st1<TO>(dv + k, 0.f);
+        for (int j = lane; j < Tn; j += 64) st1<TO>(dp + j, 0.f);
+        if (lane == 0) dsw[row] = 0.f;
+        return;
+    }
+    const float g = gscale / stats[1];
+    const float prob = 1.0f / (1.0f + expf(-sw[row]));
+    if (lab < V) {
+        const float lse_v = row_lse[row * 2];
+        const float* vr = vocab + row * ldv;
+        for (int k = lane; k < ldv; k += 64)
+            st1<TO>(dv + k, (k < V) ? g * (expf(vr[k] - lse_v) - (k == lab ? 1.f : 0.f)) : 0.f);
+        for (int j = lane; j < Tn; j += 64) st1<TO>(dp + j, 0.f);
+        if (lane == 0) dsw[row] = (1.0f - prob >= 1e-6f) ? g * prob : 0.f;
+    } else {
+        const float lse_p = row_lse[row * 2 + 1];
+        const float* pr = ptr + row * Tn;
+        const int js = (int)(lab - V);
+        for (int k = lane; k < ldv; k += 64) st1<TO>(dv + k, 0.f);
+        for (int j = lane; j < Tn; j += 64)
+            st1<TO>(dp + j, (j < i) ? g * (expf(pr[j] - lse_p) - (j == js ? 1.f : 0.f)) : 0.f);
+        if (lane == 0) dsw[row] = (prob >= 1e-6f) ? -g * (1.0f - prob) : 0.f;
+    }
+}
+
+// ================================================================================ Adam / cast
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, bf16* pb, int64_t n,
+                                                   float step_size, float b1, float b2, float eps, float inv_sqrt_bc2,
+                                                   float gscale) {
+    const int64_t n4 = n >> 2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 pp = *reinterpret_cast<f32x4*>(p + e * 4);
+        f32x4 gg = *reinterpret_cast<const f32x4*>(g + e * 4);
+        f32x4 mm = *reinterpret_cast<f32x4*>(m + e * 4);
+        f32x4 vv = *reinterpret_cast<f32x4*>(v + e * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gj = gg[j] * gscale;
+            mm[j] = b1 * mm[j] + (1.f - b1) * gj;
+            vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
+            pp[j] -= step_size * mm[j] / (sqrtf(vv[j]) * inv_sqrt_bc2 + eps);
+        }
+        *reinterpret_cast<f32x4*>(p + e * 4) = pp;
+        *reinterpret_cast<f32x4*>(m + e * 4) = mm;
+        *reinterpret_cast<f32x4*>(v + e * 4) = vv;
+        if (pb) st4<bf16>(pb + e * 4, pp);
+    }
+    // tail (n % 4)
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t e = (n4 << 2) + threadIdx.x;
+        const float gj = g[e] * gscale;
+        const float mj = b1 * m[e] + (1.f - b1) * gj;
+        const float vj = b2 * v[e] + (1.f - b2) * gj * gj;
+        m[e] = mj; v[e] = vj;
+        p[e] -= step_size * mj / (sqrtf(vj) * inv_sqrt_bc2 + eps);
+        if (pb) pb[e] = (bf16)p[e];
+    }
+}
+
+template <typename TD, typename TS>
+__global__ __launch_bounds__(256) void cast_kernel(TD* dst, const TS* src, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        st1<TD>(dst + e, ld1<TS>(src + e));
+}
+
+inline int grid_for(int64_t work_items, int per_block = 256, int cap = 4096) {
+    int64_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int pa_version(void) { return 1; }
+
+extern "C" int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* const* tables, const int64_t* const* idx,
+                                  int32_t n_tables, int64_t n_tok, int32_t d, void* stream) {
+    if (!out || !tables || !idx || n_tables < 1 || n_tables > 5 || (d & 3) || n_tok <= 0) return PA_EINVAL;
+    EmbTabs tb; tb.n = n_tables;
+    for (int k = 0; k < 5; ++k) { tb.t[k] = k < n_tables ? tables[k] : nullptr; tb.idx[k] = k < n_tables ? idx[k] : nullptr; }
+    const int grid = grid_for(n_tok * (d >> 2));
+    if (out_dtype == PA_BF16) hipLaunchKernelGGL(embed_input_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)out, tb, n_tok, d);
+    else hipLaunchKernelGGL(embed_input_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)out, tb, n_tok, d);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pa_embed_input_bwd(const void* dout, int32_t dtype, float* const* dtables, const int64_t* const* idx,
+                                  int32_t n_tables, int64_t n_tok, int32_t d, void* stream) {
+    if (!dout || !dtables || !idx || n_tables < 1 || n_tables > 5 || (d & 3) || n_tok <= 0) return PA_EINVAL;
+    EmbGrads tb; tb.n = n_tables;
+    for (int k = 0; k < 5; ++k) { tb.t[k] = k < n_tables ? dtables[k] : nullptr; tb.idx[k] = k < n_tables ? idx[k] : nullptr; }
+    const int grid = grid_for(n_tok * (d >> 2));
+    if (dtype == PA_BF16) hipLaunchKernelGGL(embed_input_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dout, tb, n_tok, d);
+    else hipLaunchKernelGGL(embed_input_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)dout, tb, n_tok, d);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pa_embed_output_fwd(void* out, int32_t out_dtype, const float* value, const float* coord, const float* pos,
+                                   const int64_t* tok, int32_t tok_ld, int32_t B, int32_t T, int32_t d, int32_t dof,
+                                   void* stream) {
+    if (!out || !value || !coord || !pos || !tok || (d & 3) || B <= 0 || T <= 0 || dof <= 0) return PA_EINVAL;
+    const int grid = grid_for((int64_t)B * T * (d >> 2));
+    if (out_dtype == PA_BF16) hipLaunchKernelGGL(embed_output_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)out, value, coord, pos, tok, tok_ld, B, T, d, dof);
+    else hipLaunchKernelGGL(embed_output_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)out, value, coord, pos, tok, tok_ld, B, T, d, dof);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pa_embed_output_bwd(const void* dout, int32_t dtype, float* dvalue, float* dcoord, float* dpos,
+                                   const int64_t* tok, int32_t tok_ld, int32_t B, int32_t T, int32_t d, int32_t dof,
+                                   void* stream) {
+    if (!dout || !dvalue || !dcoord || !dpos || !tok || (d & 3) || B <= 0 || T <= 0 || dof <= 0) return PA_EINVAL;
+    const int grid = grid_for((int64_t)B * T * (d >> 2));
+    if (dtype == PA_BF16) hipLaunchKernelGGL(embed_output_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dout, dvalue, dcoord, dpos, tok, tok_ld, B, T, d, dof);
+    else hipLaunchKernelGGL(embed_output_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)dout, dvalue, dcoord, dpos, tok, tok_ld, B, T, d, dof);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int64_t pa_layernorm_ws_floats(int64_t rows, int32_t d) {
+    return ((rows + LNB_ROWS - 1) / LNB_ROWS) * 3 * (int64_t)d;
+}
+
+extern "C" int pa_layernorm_fwd(void* y, const void* z, const float* gamma, const float* beta, float* mean, float* rstd,
+                                int64_t rows, int32_t d, float eps, int32_t dtype, void* stream) {
+    if (!y || !z || !gamma || !beta || !mean || !rstd || rows <= 0 || (d & 3) || d > 256 * MAXV) return PA_EINVAL;
+    const int grid = (int)((rows + 3) / 4);
+    if (dtype == PA_BF16) hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)y, (const bf16*)z, gamma, beta, mean, rstd, rows, d, eps);
+    else hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)y, (const float*)z, gamma, beta, mean, rstd, rows, d, eps);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pa_layernorm_bwd(void* dz, void* ddrop, const void* dy, const void* z, const float* gamma,
+                                const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dzsum,
+                                float* partial, int64_t rows, int32_t d, int32_t dtype,
+                                float drop_p, uint32_t drop_seed, void* stream) {
+    if (!dz || !dy || !z || !gamma || !mean || !rstd || !dgamma || !dbeta || !partial) return PA_EINVAL;
+    if (rows <= 0 || (d & 3) || d > 256 * MAXV || drop_p < 0.f || drop_p >= 1.f) return PA_EINVAL;
+    const uint32_t thr = (uint32_t)(drop_p * 65536.0f + 0.5f);
+    if (thr && !ddrop) return PA_EINVAL;
+    const float scale = 1.0f / (1.0f - drop_p);
+    const int grid = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
+    const size_t shm = (size_t)4 * 3 * d * sizeof(float);
+    if (dtype == PA_BF16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), shm, ST(stream), (bf16*)dz, (bf16*)ddrop, (const bf16*)dy, (const bf16*)z, gamma, mean, rstd, partial, rows, d, thr, scale, drop_seed, dzsum ? 1 : 0);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), shm, ST(stream), (float*)dz, (float*)ddrop, (const float*)dy, (const float*)z, gamma, mean, rstd, partial, rows, d, thr, scale, drop_seed, dzsum ? 1 : 0);
+    PA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(partial_finish_kernel, dim3((d + 255) / 256, dzsum ? 3 : 2), dim3(256), 0, ST(stream), partial, grid, 3 * d, d, d, dgamma, dbeta, dzsum);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pa_switch_fwd(float* s, const void* h, int32_t dtype, const float* w, const float* b, int64_t rows,
+                             int32_t d, void* stream) {
+    if (!s || !h || !w || !b || rows <= 0 || (d & 3)) return PA_EINVAL;
+    const int grid = (int)((rows + 3) / 4);
+    if (dtype == PA_BF16) hipLaunchKernelGGL(switch_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), s, (const bf16*)h, w, b, rows, d);
+    else hipLaunchKernelGGL(switch_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), s, (const float*)h, w, b, rows, d);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pa_switch_bwd(void* dh, int32_t accumulate, float* dw, float* db, const float* ds, const void* h,
+                             int32_t dtype, const float* w, float* partial, int64_t rows, int32_t d, void* stream) {
+    if (!dh || !dw || !db || !ds || !h || !w || !partial || rows <= 0 || (d & 3) || d > 256 * MAXV) return PA_EINVAL;
+    const int grid = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
+    const size_t shm = (size_t)(4 * d + 4) * sizeof(float);
+    if (dtype == PA_BF16) hipLaunchKernelGGL(switch_bwd_kernel<bf16>, dim3(grid), dim3(256), shm, ST(stream), (bf16*)dh, accumulate, ds, (const bf16*)h, w, partial, rows, d);
+    else hipLaunchKernelGGL(switch_bwd_kernel<float>, dim3(grid), dim3(256), shm, ST(stream), (float*)dh, accumulate, ds, (const float*)h, w, partial, rows, d);
+    PA_CHECK_LAUNCH();
+    // partial rows: [blk][0][d] = dw, [blk][1][0] = db
+    hipLaunchKernelGGL(partial_finish_kernel, dim3((d + 255) / 256, 1), dim3(256), 0, ST(stream), partial, grid, 2 * d, d, d, dw, (float*)nullptr, (float*)nullptr);
+    PA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(partial_finish_kernel, dim3(1, 1), dim3(256), 0, ST(stream), partial + d, grid, 2 * d, d, 1, db, (float*)nullptr, (float*)nullptr);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pa_mixture_nll_fwd(float* stats, float* row_lse, const float* vocab, int32_t ldv, const float* ptr,
+                                  const float* sw, const int64_t* label, int32_t B, int32_t T, int32_t V, int32_t pad,
+                                  void* stream) {
+    if (!stats || !row_lse || !vocab || !ptr || !sw || !label || B <= 0 || T <= 0 || V <= 0 || ldv < V) return PA_EINVAL;
+    const int grid = (int)(((int64_t)B * T + 3) / 4);
+    hipLaunchKernelGGL(mixture_nll_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pa_mixture_nll_bwd(void* dvocab, void* dptr, int32_t out_dtype, float* dsw, const float* stats,
+                                  const float* row_lse, const float* vocab, int32_t ldv, const float* ptr,
+                                  const float* sw, const int64_t* label, int32_t B, int32_t T, int32_t V, int32_t pad,
+                                  float gscale, void* stream) {
+    if (!dvocab || !dptr || !dsw || !stats || !row_lse || !vocab || !ptr || !sw || !label) return PA_EINVAL;
+    if (B <= 0 || T <= 0 || V <= 0 || ldv < V) return PA_EINVAL;
+    const int grid = (int)(((int64_t)B * T + 3) / 4);
+    if (out_dtype == PA_BF16) hipLaunchKernelGGL(mixture_nll_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)dvocab, (bf16*)dptr, dsw, stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, gscale);
+    else hipLaunchKernelGGL(mixture_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)dvocab, (float*)dptr, dsw, stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, gscale);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pa_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float b1,
+                            float b2, float eps, int32_t step, float gscale, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return PA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+         reinterpret_cast<uintptr_t>(v)) & 15) return PA_EALIGN;
+    const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, (bf16*)p_bf16, n,
+                       step_size, b1, b2, eps, inv_sqrt_bc2, gscale);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pa_cast(void* dst, int32_t dst_dtype, const void* src, int32_t src_dtype, int64_t n, void* stream) {
+    if (!dst || !src || n <= 0) return PA_EINVAL;
+    const int grid = grid_for(n, 256, 2048);
+    if (dst_dtype == PA_BF16 && src_dtype == PA_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, ST(stream), (bf16*)dst, (const float*)src, n);
+    else if (dst_dtype == PA_F32 && src_dtype == PA_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, ST(stream), (float*)dst, (const bf16*)src, n);
+    else if (dst_dtype == PA_F32 && src_dtype == PA_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, ST(stream), (float*)dst, (const float*)src, n);
+    else return PA_EINVAL;
+    PA_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,227 @@
+"""Thin torch-tensor wrappers over the op-level C ABI (include/plank_hip.h).
+
+Used by the kernel parity tests and by host code that needs a single op.  The model-level
+path (plankassembly_amd.models) drives the same kernels through the C++ runtime entry points.
+All tensors must live on the GPU; everything enqueues on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _f32(*shape, device):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, residual=None, aux=None, aux_scale=1.0,
+         relu=False, alpha=1.0, drop_p=0.0, drop_seed=0, out_dtype=None, splitk=1, out=None):
+    """C[b] = epi(alpha * A[b] @ B[b]).  a: [batch?, M, K] (or [K, M] if not a_kcontig);
+    b: [batch?, N, K] if b_kcontig (Linear weight layout) else [K, N]."""
+    batched = a.dim() == 3
+    A3 = a if batched else a[None]
+    B3 = b if b.dim() == 3 else b[None]
+    batch = A3.shape[0]
+    M, K = (A3.shape[1], A3.shape[2]) if a_kcontig else (A3.shape[2], A3.shape[1])
+    N = B3.shape[1] if b_kcontig else B3.shape[2]
+    assert (B3.shape[2] if b_kcontig else B3.shape[1]) == K
+    assert A3.stride(2) == 1 and B3.stride(2) == 1
+    out_dtype = out_dtype or a.dtype
+    if out is None:
+        out = torch.empty((batch, M, N) if batched else (M, N), dtype=out_dtype, device=a.device)
+    O3 = out if out.dim() == 3 else out[None]
+    g = L.GemmArgs()
+    g.A, g.B, g.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.R = residual.data_ptr() if residual is not None else None
+    g.aux = aux.data_ptr() if aux is not None else None
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = A3.stride(1), B3.stride(1), O3.stride(1)
+    g.ldr = (residual if residual is not None else O3).stride(-2)
+    g.ldaux = aux.stride(-2) if aux is not None else 0
+    g.sA = A3.stride(0) if batch > 1 else 0
+    g.sB = B3.stride(0) if (b.dim() == 3 and B3.shape[0] > 1) else 0
+    g.sC = O3.stride(0) if batch > 1 else 0
+    g.sR = residual.stride(0) if (residual is not None and residual.dim() == 3 and batch > 1) else 0
+    g.sAux = aux.stride(0) if (aux is not None and aux.dim() == 3 and batch > 1) else 0
+    g.batch = batch
+    g.a_kcontig, g.b_kcontig = int(a_kcontig), int(b_kcontig)
+    g.in_dtype, g.out_dtype = L.dt(a), L.dt(out)
+    g.alpha, g.relu, g.aux_scale = alpha, int(relu), aux_scale
+    g.drop_p, g.drop_seed = drop_p, drop_seed
+    g.splitk = splitk
+    ws = None
+    if splitk > 1:
+        ws = _f32(splitk * batch * M * N, device=a.device)
+        g.ws = ws.data_ptr()
+    L.check(L.lib().pa_gemm(C.byref(g), L.stream()), "pa_gemm")
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    M, N = x.shape
+    if out is None:
+        out = torch.zeros(N, dtype=torch.float32, device=x.device)
+    part = _f32(int(L.lib().pa_colsum_ws_floats(M, N)), device=x.device)
+    L.check(L.lib().pa_colsum(L.ptr(x), L.dt(x), M, N, x.stride(0), L.ptr(out), int(accumulate), L.ptr(part),
+                              L.stream()), "pa_colsum")
+    return out
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def embed_input_fwd(tables, idx, dtype=torch.float32):
+    n_tok = next(i for i in idx if i is not None).numel()
+    d = tables[0].shape[1]
+    out = torch.empty(n_tok, d, dtype=dtype, device=tables[0].device)
+    L.check(L.lib().pa_embed_input_fwd(L.ptr(out), L.dt(out), _ptr_array(tables), _ptr_array(idx), len(tables),
+                                       C.c_int64(n_tok), d, L.stream()), "pa_embed_input_fwd")
+    return out
+
+
+def embed_input_bwd(dout, dtables, idx):
+    n_tok, d = dout.shape
+    L.check(L.lib().pa_embed_input_bwd(L.ptr(dout), L.dt(dout), _ptr_array(dtables), _ptr_array(idx), len(dtables),
+                                       C.c_int64(n_tok), d, L.stream()), "pa_embed_input_bwd")
+
+
+def embed_output_fwd(value, coord, pos, tok, T, dof=6, dtype=torch.float32):
+    B = tok.shape[0]
+    d = value.shape[1]
+    out = torch.empty(B, T, d, dtype=dtype, device=value.device)
+    L.check(L.lib().pa_embed_output_fwd(L.ptr(out), L.dt(out), L.ptr(value), L.ptr(coord), L.ptr(pos), L.ptr(tok),
+                                        tok.stride(0), B, T, d, dof, L.stream()), "pa_embed_output_fwd")
+    return out
+
+
+def embed_output_bwd(dout, dvalue, dcoord, dpos, tok, dof=6):
+    B, T, d = dout.shape
+    L.check(L.lib().pa_embed_output_bwd(L.ptr(dout), L.dt(dout), L.ptr(dvalue), L.ptr(dcoord), L.ptr(dpos),
+                                        L.ptr(tok), tok.stride(0), B, T, d, dof, L.stream()), "pa_embed_output_bwd")
+
+
+def layernorm_fwd(z, gamma, beta, eps):
+    rows, d = z.numel() // z.shape[-1], z.shape[-1]
+    y = torch.empty_like(z)
+    mean, rstd = _f32(rows, device=z.device), _f32(rows, device=z.device)
+    L.check(L.lib().pa_layernorm_fwd(L.ptr(y), L.ptr(z), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd),
+                                     C.c_int64(rows), d, C.c_float(eps), L.dt(z), L.stream()), "pa_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, z, gamma, mean, rstd, dgamma, dbeta, dzsum=None, drop_p=0.0, drop_seed=0):
+    rows, d = z.numel() // z.shape[-1], z.shape[-1]
+    dz = torch.empty_like(z)
+    ddrop = torch.empty_like(z) if drop_p > 0 else None
+    part = _f32(int(L.lib().pa_layernorm_ws_floats(rows, d)), device=z.device)
+    L.check(L.lib().pa_layernorm_bwd(L.ptr(dz), L.ptr(ddrop), L.ptr(dy), L.ptr(z), L.ptr(gamma), L.ptr(mean),
+                                     L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dzsum), L.ptr(part),
+                                     C.c_int64(rows), d, L.dt(z), C.c_float(drop_p), C.c_uint32(drop_seed),
+                                     L.stream()), "pa_layernorm_bwd")
+    return dz, ddrop
+
+
+def _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H):
+    B, Lq = q.shape[0], q.shape[1]
+    Lk = k.shape[1]
+    dh = q.shape[2] // H
+    a = L.AttnArgs()
+    a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+    a.kpm = kpm.data_ptr() if kpm is not None else None
+    a.B, a.H, a.Lq, a.Lk, a.dh = B, H, Lq, Lk, dh
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1), k.stride(1), v.stride(1), o.stride(1)
+    a.causal = int(causal)
+    a.scale = scale if scale is not None else 1.0 / math.sqrt(dh)
+    a.drop_p, a.drop_seed = drop_p, drop_seed
+    a.dtype = L.dt(q)
+    return a
+
+
+def attn_fwd(q, k, v, H, kpm=None, causal=False, scale=None, drop_p=0.0, drop_seed=0):
+    """q: [B, Lq, H*dh] (may be a strided view of a packed projection), k/v: [B, Lk, H*dh];
+    kpm: uint8/bool [B, Lk] (1 = PAD).  Returns (o [B, Lq, H*dh], lse [B, H, Lq])."""
+    B, Lq, dm = q.shape
+    o = torch.empty(B, Lq, dm, dtype=q.dtype, device=q.device)
+    lse = _f32(B, H, Lq, device=q.device)
+    if kpm is not None:
+        kpm = kpm.to(torch.uint8).contiguous()
+    a = _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H)
+    L.check(L.lib().pa_attn_fwd(C.byref(a), L.stream()), "pa_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(dout, q, k, v, o, lse, H, kpm=None, causal=False, scale=None, drop_p=0.0, drop_seed=0):
+    if kpm is not None:
+        kpm = kpm.to(torch.uint8).contiguous()
+    a = _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H)
+    dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
+    dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+    delta = _f32(lse.shape, device=q.device)
+    a.dout, a.dq, a.dk, a.dv, a.delta = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
+    a.lddo, a.lddq, a.lddk, a.lddv = dout.stride(1), dq.stride(1), dk.stride(1), dv.stride(1)
+    L.check(L.lib().pa_attn_bwd(C.byref(a), L.stream()), "pa_attn_bwd")
+    return dq, dk, dv
+
+
+def switch_fwd(h, w, b):
+    rows, d = h.numel() // h.shape[-1], h.shape[-1]
+    s = _f32(rows, device=h.device)
+    L.check(L.lib().pa_switch_fwd(L.ptr(s), L.ptr(h), L.dt(h), L.ptr(w), L.ptr(b), C.c_int64(rows), d, L.stream()),
+            "pa_switch_fwd")
+    return s
+
+
+def switch_bwd(ds, h, w, dw, db, dh=None):
+    rows, d = h.numel() // h.shape[-1], h.shape[-1]
+    acc = dh is not None
+    if dh is None:
+        dh = torch.empty_like(h)
+    part = _f32(((rows + 31) // 32) * 2 * d, device=h.device)
+    L.check(L.lib().pa_switch_bwd(L.ptr(dh), int(acc), L.ptr(dw), L.ptr(db), L.ptr(ds), L.ptr(h), L.dt(h), L.ptr(w),
+                                  L.ptr(part), C.c_int64(rows), d, L.stream()), "pa_switch_bwd")
+    return dh
+
+
+def mixture_nll_fwd(vocab, ptr, sw, label, V, pad):
+    """vocab [B,T,ldv] f32, ptr [B,T,T] f32 (scaled), sw [B*T] f32, label int64 [B,T].
+    Returns stats (sum_nll, n_valid, n_correct) and per-row lse."""
+    B, T = label.shape
+    stats = torch.zeros(4, dtype=torch.float32, device=vocab.device)
+    row_lse = _f32(B * T, 2, device=vocab.device)
+    L.check(L.lib().pa_mixture_nll_fwd(L.ptr(stats), L.ptr(row_lse), L.ptr(vocab), vocab.stride(-2), L.ptr(ptr),
+                                       L.ptr(sw), L.ptr(label), B, T, V, pad, L.stream()), "pa_mixture_nll_fwd")
+    return stats, row_lse
+
+
+def mixture_nll_bwd(stats, row_lse, vocab, ptr, sw, label, V, pad, gscale=1.0, out_dtype=torch.float32):
+    B, T = label.shape
+    dvocab = torch.empty(vocab.shape, dtype=out_dtype, device=vocab.device)
+    dptr = torch.empty(ptr.shape, dtype=out_dtype, device=vocab.device)
+    dsw = torch.empty_like(sw)
+    L.check(L.lib().pa_mixture_nll_bwd(L.ptr(dvocab), L.ptr(dptr), L.dt(dvocab), L.ptr(dsw), L.ptr(stats), L.ptr(row_lse),
+                                       L.ptr(vocab), vocab.stride(-2), L.ptr(ptr), L.ptr(sw), L.ptr(label), B, T, V,
+                                       pad, C.c_float(gscale), L.stream()), "pa_mixture_nll_bwd")
+    return dvocab, dptr, dsw
+
+
+def adam_step(p, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8, gscale=1.0, p_bf16=None):
+    L.check(L.lib().pa_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(p_bf16), C.c_int64(p.numel()),
+                                 C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps), int(step),
+                                 C.c_float(gscale), L.stream()), "pa_adam_step")
+
+
+def cast(src, dtype):
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    L.check(L.lib().pa_cast(L.ptr(dst), L.dt(dst), L.ptr(src), L.dt(src), C.c_int64(src.numel()), L.stream()),
+            "pa_cast")
+    return dst
