@@ -160,8 +160,9 @@ int pa_attn_bwd(const pa_attn_args* a, void* stream);
  * The training mask quirk is reproduced: pointer logits j >= i are REPLACED by the value 1e-6
  * and stay in the softmax.
  * bwd writes d(vocab logits), d(pointer logits) (zero where j >= i) in `out_dtype` (they feed the
- * backward GEMMs) and d(switch logit) in f32, for loss = stats[0] / stats[1]  (upstream gradient
- * `gscale`, normally 1).
+ * backward GEMMs) and d(switch logit) in f32, for loss = stats[0] / stats[1]; the upstream
+ * gradient is gscale * stats[3] (stats[3] is device resident so autograd's grad_output never
+ * needs a host sync).
  * pa_switch_fwd: s[row] = h[row] . w + b (reference models.py:153), pa_switch_bwd its gradient
  * (dh += ds * w fused into the caller's GEMM epilogue is not possible, so dh_out is written
  * and dw/db accumulated).
@@ -186,6 +187,69 @@ int pa_mixture_nll_bwd(void* dvocab, void* dptr, int32_t out_dtype, float* dsw, 
 int pa_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float b1,
                  float b2, float eps, int32_t step, float gscale, void* stream);
 int pa_cast(void* dst, int32_t dst_dtype, const void* src, int32_t src_dtype, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Model-level runtime: one call enqueues the whole training forward of reference
+ * plankassembly/models.py:190-233 (train_step: _embed_input, encoder, _embed_output, decoder,
+ * _create_dist, nll_loss, accuracy) resp. its backward, on the caller's stream, using only the
+ * caller's workspace.  `pa_model` is a small HOST-side object (configuration, parameter pointer
+ * tables, workspace layout); it owns no device memory.
+ *
+ * Parameters are bound as three pointer tables in the canonical order of the reference
+ * state_dict (plankassembly_amd/models.py PARAM_ORDER):
+ *   params_f32 : f32 master parameters (embedding tables, biases, LayerNorm affine are read here)
+ *   params_lp  : the same tensors in the compute dtype (GEMM B operands); = params_f32 for PA_F32
+ *   grads      : f32 gradients (may be NULL for inference).  Gradients that are produced by
+ *                accumulation (embedding tables, LayerNorm affine, out_proj/linear2 biases, switch
+ *                head) are ADDED to: the caller zeroes the gradient buffer before backward.
+ * The torch argument-order slip of the reference is explicit here: eps_layer = float(NORMALIZE_BEFORE)
+ * (1.0), eps_final = 1e-5, has_enc_norm = bool(NORMALIZE_BEFORE), layers are post-norm.
+ */
+typedef struct pa_model pa_model;
+typedef struct {
+    int32_t d_model, n_head, d_ff, n_enc, n_dec, vocab;
+    int32_t out_dof;
+    float eps_layer, eps_final;
+    int32_t has_enc_norm;
+    float dropout;
+    int32_t pad, end;
+    int32_t dtype;
+} pa_model_cfg;
+typedef struct {
+    const int64_t* input_idx[5];   /* input_value, input_pos, input_coord, input_view, input_type (NULL ok) : [B][S] */
+    const uint8_t* input_mask;     /* [B][S], 1 = PAD */
+    const int64_t* output_value;   /* [B][T]  (NULL: run the encoder only) */
+    const int64_t* output_label;   /* [B][T] */
+    const uint8_t* output_mask;    /* [B][T] */
+    int32_t B, S, T;
+} pa_batch;
+
+#define PA_T_MEMORY 0
+#define PA_T_HIDDENS 1
+#define PA_T_VOCAB_LOGITS 2
+#define PA_T_PTR_LOGITS 3
+
+int pa_model_create(const pa_model_cfg* cfg, pa_model** out);
+void pa_model_destroy(pa_model* m);
+int pa_model_num_params(const pa_model* m);
+int pa_model_bind(pa_model* m, void* const* params_f32, void* const* params_lp, void* const* grads);
+int64_t pa_model_train_ws_bytes(pa_model* m, int32_t B, int32_t S, int32_t T);
+/* stats (device, f32[4]): [0] sum of -log p(label) over non-PAD labels, [1] #non-PAD, [2] #correct.
+ * loss = stats[0]/stats[1] (reference models.py:221), accuracy = stats[2]/(stats[1]+1e-10) (:227);
+ * [3] upstream gradient d(objective)/d(loss), initialised to 1 by the forward and read (on the
+ * device, no host sync) by the backward.
+ * `seed` keys this step's dropout masks (training != 0 and cfg.dropout > 0). */
+int pa_model_train_fwd(pa_model* m, const pa_batch* batch, void* ws, int64_t ws_bytes, uint32_t seed,
+                       int32_t training, float* stats, void* stream);
+/* Backward in execution-ordered segments [seg_lo, seg_hi): 0 = heads + decoder.norm,
+ * 1..n_dec = decoder layers (last layer first), then output embedding, encoder.norm, encoder
+ * layers (last first), input embedding.  After segment s returns, the gradients of that
+ * segment's parameters are final on `stream` (the shared value-embedding table only after the
+ * last segment) - the host can launch their all-reduce on a side stream. */
+int pa_model_train_num_segments(const pa_model* m);
+int pa_model_train_bwd(pa_model* m, int32_t seg_lo, int32_t seg_hi, float gscale, void* stream);
+/* introspection for parity tests: device pointer + element count of an activation of the last forward */
+int pa_model_tensor(pa_model* m, int32_t which, void** ptr, int64_t* numel);
 
 #ifdef __cplusplus
 }

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void mixture_nll_bwd_kernel(TO* dvocab, TO* dp
         if (lane == 0) dsw[row] = 0.f;
         return;
     }
-    const float g = gscale / stats[1];
+    const float g = gscale * stats[3] / stats[1];      // stats[3] = upstream d(loss), device resident
     const float prob = 1.0f / (1.0f + expf(-sw[row]));
     if (lab < V) {
         const float lse_v = row_lse[row * 2];

@@ -1,0 +1,457 @@
+// Model-level runtime for the PlankAssembly hot path on MI355X: sequences the gfx950 kernels of
+// gemm.hip / attention.hip / rowops.hip for a full training forward (reference
+// plankassembly/models.py:190-233, train_step) and a hand-derived backward, over one caller-owned
+// workspace ("arena").  Host-only logic: no device allocation, no synchronisation, enqueue-only
+// (hipGraph capturable).  See include/plank_hip.h (pa_model_*).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <new>
+#include <string.h>
+#include <vector>
+#include "../../include/plank_hip.h"
+
+#include "model.h"
+
+namespace {
+
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
+    pa_model* m; void* st;
+    int dt() const { return m->cfg.dtype; }
+
+    // C[M,N] = epi(A[M,K] x W^T) with W a torch Linear weight [N][K]
+    int linear(const void* A, int lda, const void* W, const float* bias, void* Cout, int ldc, int M, int N, int K,
+               int relu = 0, float drop_p = 0.f, uint32_t seed = 0, const void* R = nullptr, int ldr = 0,
+               int out_dtype = -1) const {
+        pa_gemm_args g; memset(&g, 0, sizeof(g));
+        g.A = A; g.B = W; g.C = Cout; g.bias = bias; g.R = R;
+        g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = K; g.ldc = ldc; g.ldr = ldr;
+        g.batch = 1; g.a_kcontig = 1; g.b_kcontig = 1;
+        g.in_dtype = dt(); g.out_dtype = out_dtype < 0 ? dt() : out_dtype;
+        g.alpha = 1.f; g.relu = relu; g.aux_scale = 1.f; g.drop_p = drop_p; g.drop_seed = seed; g.splitk = 1;
+        return pa_gemm(&g, st);
+    }
+    // dX[M,K] = dY[M,N] x W[N][K]  (+ R)   (optionally relu-backward gated by aux)
+    int linear_dx(const void* dY, int lddy, const void* W, int ldw, void* dX, int lddx, int M, int N, int K,
+                  const void* R = nullptr, int ldr = 0, const void* aux = nullptr, int ldaux = 0,
+                  float aux_scale = 1.f) const {
+        pa_gemm_args g; memset(&g, 0, sizeof(g));
+        g.A = dY; g.B = W; g.C = dX; g.R = R; g.aux = aux;
+        g.M = M; g.N = K; g.K = N; g.lda = lddy; g.ldb = ldw; g.ldc = lddx; g.ldr = ldr; g.ldaux = ldaux;
+        g.batch = 1; g.a_kcontig = 1; g.b_kcontig = 0;
+        g.in_dtype = dt(); g.out_dtype = dt();
+        g.alpha = 1.f; g.aux_scale = aux_scale; g.splitk = 1;
+        return pa_gemm(&g, st);
+    }
+    // dW[N][K] = dY[M,N]^T x X[M,K] (f32 out, split-K over the rows), db[N] = colsum(dY) unless db == NULL
+    int linear_dw(const void* dY, int lddy, const void* Xin, int ldx, float* dW, float* db, int M, int N, int K) const {
+        pa_gemm_args g; memset(&g, 0, sizeof(g));
+        g.A = dY; g.B = Xin; g.C = dW;
+        g.M = N; g.N = K; g.K = M; g.lda = lddy; g.ldb = ldx; g.ldc = K;
+        g.batch = 1; g.a_kcontig = 0; g.b_kcontig = 0;
+        g.in_dtype = dt(); g.out_dtype = PA_F32;
+        g.alpha = 1.f; g.aux_scale = 1.f;
+        const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+        const int ktile = dt() == PA_BF16 ? 64 : 16;
+        const int nkt = (M + ktile - 1) / ktile;
+        int sk = 1;
+        if (tiles < 256) {
+            sk = (512 + tiles - 1) / tiles;
+            if (sk > 16) sk = 16;
+            if (sk > nkt / 4) sk = nkt / 4 > 0 ? nkt / 4 : 1;
+            while (sk > 1 && (size_t)sk * N * K > m->splitws_floats) --sk;
+        }
+        g.splitk = sk; g.ws = m->splitws;
+        RC(pa_gemm(&g, st));
+        if (db) RC(pa_colsum(dY, dt(), M, N, lddy, db, 0, m->partial, st));
+        return 0;
+    }
+    int ln_fwd(void* y, const void* z, const float* g, const float* b, float* mean, float* rstd, int64_t rows, float eps) const {
+        return pa_layernorm_fwd(y, z, g, b, mean, rstd, rows, m->cfg.d_model, eps, dt(), st);
+    }
+    int ln_bwd(void* dz, void* ddrop, const void* dy, const void* z, const float* g, const float* mean, const float* rstd,
+               float* dg, float* db, float* dzsum, int64_t rows, float drop_p, uint32_t seed) const {
+        return pa_layernorm_bwd(dz, ddrop, dy, z, g, mean, rstd, dg, db, dzsum, m->partial, rows, m->cfg.d_model, dt(),
+                                drop_p, seed, st);
+    }
+    int attn(bool bwd, const void* q, int ldq, const void* k, const void* v, int ldkv, void* o, float* lse,
+             const uint8_t* kpm, int Lq, int Lk, int causal, float drop_p, uint32_t seed,
+             const void* dout = nullptr, void* dq = nullptr, int lddq = 0, void* dk = nullptr, void* dv = nullptr,
+             int lddkv = 0) const {
+        pa_attn_args a; memset(&a, 0, sizeof(a));
+        const int d = m->cfg.d_model, H = m->cfg.n_head;
+        a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.kpm = kpm;
+        a.B = m->B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = d / H;
+        a.ldq = ldq; a.ldk = ldkv; a.ldv = ldkv; a.ldo = d;
+        a.causal = causal; a.scale = 1.0f / sqrtf((float)(d / H));
+        a.drop_p = drop_p; a.drop_seed = seed; a.dtype = dt();
+        if (!bwd) return pa_attn_fwd(&a, st);
+        a.dout = dout; a.dq = dq; a.dk = dk; a.dv = dv; a.delta = m->delta;
+        a.lddo = d; a.lddq = lddq; a.lddk = lddkv; a.lddv = lddkv;
+        return pa_attn_bwd(&a, st);
+    }
+};
+
+}  // namespace
+size_t pa_train_layout(pa_model* m, char* base, int B, int S, int T) {
+    const pa_model_cfg& c = m->cfg;
+    const size_t e = c.dtype == PA_BF16 ? 2 : 4;
+    const size_t d = c.d_model, ff = c.d_ff, H = c.n_head;
+    const size_t BS = (size_t)B * S, BT = (size_t)B * T, R = BS > BT ? BS : BT;
+    Arena a{base, 0};
+    m->esz = e;
+    m->X.resize(c.n_enc + 1); m->Y.resize(c.n_dec + 1); m->ea.resize(c.n_enc); m->da.resize(c.n_dec);
+    for (int i = 0; i <= c.n_enc; ++i) m->X[i] = a.take(BS * d * e);
+    for (int i = 0; i < c.n_enc; ++i) {
+        EncAct& t = m->ea[i];
+        t.qkv = a.take(BS * 3 * d * e); t.o = a.take(BS * d * e); t.z1 = a.take(BS * d * e); t.y1 = a.take(BS * d * e);
+        t.hff = a.take(BS * ff * e); t.z2 = a.take(BS * d * e);
+        t.lse = (float*)a.take((size_t)B * H * S * 4);
+        t.m1 = (float*)a.take(BS * 4); t.r1 = (float*)a.take(BS * 4); t.m2 = (float*)a.take(BS * 4); t.r2 = (float*)a.take(BS * 4);
+    }
+    m->memory = a.take(BS * d * e); m->mem_m = (float*)a.take(BS * 4); m->mem_r = (float*)a.take(BS * 4);
+    for (int i = 0; i <= c.n_dec; ++i) m->Y[i] = a.take(BT * d * e);
+    for (int i = 0; i < c.n_dec; ++i) {
+        DecAct& t = m->da[i];
+        t.qkv = a.take(BT * 3 * d * e); t.o_sa = a.take(BT * d * e); t.z1 = a.take(BT * d * e); t.y1 = a.take(BT * d * e);
+        t.q_ca = a.take(BT * d * e); t.kv_ca = a.take(BS * 2 * d * e); t.o_ca = a.take(BT * d * e);
+        t.z2 = a.take(BT * d * e); t.y2 = a.take(BT * d * e); t.hff = a.take(BT * ff * e); t.z3 = a.take(BT * d * e);
+        t.lse_sa = (float*)a.take((size_t)B * H * T * 4); t.lse_ca = (float*)a.take((size_t)B * H * T * 4);
+        t.m1 = (float*)a.take(BT * 4); t.r1 = (float*)a.take(BT * 4); t.m2 = (float*)a.take(BT * 4);
+        t.r2 = (float*)a.take(BT * 4); t.m3 = (float*)a.take(BT * 4); t.r3 = (float*)a.take(BT * 4);
+    }
+    m->hid = a.take(BT * d * e); m->hid_m = (float*)a.take(BT * 4); m->hid_r = (float*)a.take(BT * 4);
+    m->ldv = (c.vocab + 7) / 8 * 8;
+    m->vlog = (float*)a.take(BT * m->ldv * 4); m->pfeat = a.take(BT * d * e);
+    m->plog = (float*)a.take(BT * T * 4); m->sw = (float*)a.take(BT * 4); m->row_lse = (float*)a.take(BT * 2 * 4);
+    // backward temporaries
+    m->gA = a.take(R * d * e); m->gB = a.take(R * d * e); m->gC = a.take(R * d * e); m->gD = a.take(R * d * e);
+    m->gE = a.take(R * d * e); m->gF = a.take(R * ff * e); m->gQ3 = a.take(R * 3 * d * e);
+    m->gKV = a.take(BS * 2 * d * e); m->dmem = a.take(BS * d * e);
+    m->dvlog = a.take(BT * m->ldv * e); m->dplog = a.take(BT * T * e); m->dsw = (float*)a.take(BT * 4);
+    m->delta = (float*)a.take((size_t)B * H * R * 4);
+    size_t part = (size_t)pa_layernorm_ws_floats((int64_t)R, (int)d);
+    const size_t wide = 3 * d > ff ? 3 * d : ff;
+    const size_t cs = (size_t)pa_colsum_ws_floats((int)R, (int)(wide > (size_t)m->ldv ? wide : m->ldv));
+    if (cs > part) part = cs;
+    m->partial = (float*)a.take(part * 4);
+    const size_t wmax = (3 * d * d > d * ff ? 3 * d * d : d * ff);
+    m->splitws_floats = 16 * wmax;
+    m->splitws = (float*)a.take(m->splitws_floats * 4);
+    return a.off;
+}
+namespace {
+
+}  // namespace
+// --------------------------------------------------------------------------------------------------
+int pa_train_forward_impl(pa_model* m, void* st) {
+    const pa_model_cfg& c = m->cfg;
+    Ctx k{m, st};
+    const int d = c.d_model, ff = c.d_ff, B = m->B, S = m->S, T = m->T;
+    const int BS = B * S, BT = B * T;
+    const float p = m->p_drop;
+    auto PF = [&](int i) { return (const float*)m->pf[i]; };
+    auto PL = [&](int i) { return (const void*)m->pl[i]; };
+    // ---- encoder (reference models.py:103-112, 206) ----
+    {
+        const float* tabs[5] = {PF(P_IN_VALUE), PF(P_IN_POS), PF(P_IN_COORD), PF(P_IN_VIEW), PF(P_IN_TYPE)};
+        RC(pa_embed_input_fwd(m->X[0], c.dtype, tabs, m->batch.input_idx, 5, (int64_t)BS, d, st));
+    }
+    for (int i = 0; i < c.n_enc; ++i) {
+        const int pb = m->enc_base(i);
+        EncAct& t = m->ea[i];
+        const size_t e = m->esz;
+        RC(k.linear(m->X[i], d, PL(pb + E_IN_W), PF(pb + E_IN_B), t.qkv, 3 * d, BS, 3 * d, d));
+        RC(k.attn(false, t.qkv, 3 * d, (char*)t.qkv + d * e, (char*)t.qkv + 2 * d * e, 3 * d, t.o, t.lse,
+                  m->batch.input_mask, S, S, 0, p, site_seed(m->seed, 8 * i + 0)));
+        RC(k.linear(t.o, d, PL(pb + E_OUT_W), PF(pb + E_OUT_B), t.z1, d, BS, d, d, 0, p, site_seed(m->seed, 8 * i + 1), m->X[i], d));
+        RC(k.ln_fwd(t.y1, t.z1, PF(pb + E_N1_W), PF(pb + E_N1_B), t.m1, t.r1, BS, c.eps_layer));
+        RC(k.linear(t.y1, d, PL(pb + E_L1_W), PF(pb + E_L1_B), t.hff, ff, BS, ff, d, 1, p, site_seed(m->seed, 8 * i + 2)));
+        RC(k.linear(t.hff, ff, PL(pb + E_L2_W), PF(pb + E_L2_B), t.z2, d, BS, d, ff, 0, p, site_seed(m->seed, 8 * i + 3), t.y1, d));
+        RC(k.ln_fwd(m->X[i + 1], t.z2, PF(pb + E_N2_W), PF(pb + E_N2_B), t.m2, t.r2, BS, c.eps_layer));
+    }
+    const void* memory = m->X[c.n_enc];
+    if (c.has_enc_norm) {
+        RC(k.ln_fwd(m->memory, m->X[c.n_enc], PF(m->enc_norm()), PF(m->enc_norm() + 1), m->mem_m, m->mem_r, BS, c.eps_final));
+        memory = m->memory;
+    }
+    if (!m->batch.output_value) return 0;      // encoder-only call (greedy decode prologue)
+    // ---- decoder (reference models.py:114-138, 204, 209-214) ----
+    RC(pa_embed_output_fwd(m->Y[0], c.dtype, PF(P_IN_VALUE), PF(P_Q_COORD), PF(P_Q_POS), m->batch.output_value, T, B, T, d,
+                           c.out_dof, st));
+    for (int i = 0; i < c.n_dec; ++i) {
+        const int pb = m->dec_base(i);
+        DecAct& t = m->da[i];
+        const size_t e = m->esz;
+        const uint32_t sb = 1000 + 8 * i;
+        RC(k.linear(m->Y[i], d, PL(pb + D_SA_IN_W), PF(pb + D_SA_IN_B), t.qkv, 3 * d, BT, 3 * d, d));
+        RC(k.attn(false, t.qkv, 3 * d, (char*)t.qkv + d * e, (char*)t.qkv + 2 * d * e, 3 * d, t.o_sa, t.lse_sa,
+                  m->batch.output_mask, T, T, 1, p, site_seed(m->seed, sb + 0)));
+        RC(k.linear(t.o_sa, d, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), t.z1, d, BT, d, d, 0, p, site_seed(m->seed, sb + 1), m->Y[i], d));
+        RC(k.ln_fwd(t.y1, t.z1, PF(pb + D_N1_W), PF(pb + D_N1_B), t.m1, t.r1, BT, c.eps_layer));
+        // cross attention: q from y1 (rows 0..d of in_proj), k/v from memory (rows d..3d)
+        RC(k.linear(t.y1, d, PL(pb + D_CA_IN_W), PF(pb + D_CA_IN_B), t.q_ca, d, BT, d, d));
+        RC(k.linear(memory, d, (const char*)PL(pb + D_CA_IN_W) + (size_t)d * d * e, PF(pb + D_CA_IN_B) + d, t.kv_ca, 2 * d, BS, 2 * d, d));
+        RC(k.attn(false, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, 2 * d, t.o_ca, t.lse_ca, m->batch.input_mask, T, S, 0, p,
+                  site_seed(m->seed, sb + 2)));
+        RC(k.linear(t.o_ca, d, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), t.z2, d, BT, d, d, 0, p, site_seed(m->seed, sb + 3), t.y1, d));
+        RC(k.ln_fwd(t.y2, t.z2, PF(pb + D_N2_W), PF(pb + D_N2_B), t.m2, t.r2, BT, c.eps_layer));
+        RC(k.linear(t.y2, d, PL(pb + D_L1_W), PF(pb + D_L1_B), t.hff, ff, BT, ff, d, 1, p, site_seed(m->seed, sb + 4)));
+        RC(k.linear(t.hff, ff, PL(pb + D_L2_W), PF(pb + D_L2_B), t.z3, d, BT, d, ff, 0, p, site_seed(m->seed, sb + 5), t.y2, d));
+        RC(k.ln_fwd(m->Y[i + 1], t.z3, PF(pb + D_N3_W), PF(pb + D_N3_B), t.m3, t.r3, BT, c.eps_layer));
+    }
+    RC(k.ln_fwd(m->hid, m->Y[c.n_dec], PF(m->dec_norm()), PF(m->dec_norm() + 1), m->hid_m, m->hid_r, BT, c.eps_final));
+    // ---- heads + mixture NLL (reference models.py:140-166, 219-227) ----
+    const int tl = m->tail();
+    RC(k.linear(m->hid, d, PL(tl + T_VOCAB_W), PF(tl + T_VOCAB_B), m->vlog, m->ldv, BT, c.vocab, d, 0, 0.f, 0, nullptr, 0, PA_F32));
+    RC(k.linear(m->hid, d, PL(tl + T_PTR_W), PF(tl + T_PTR_B), m->pfeat, d, BT, d, d));
+    {
+        pa_gemm_args g; memset(&g, 0, sizeof(g));
+        g.A = m->pfeat; g.B = m->hid; g.C = m->plog;
+        g.M = T; g.N = T; g.K = d; g.lda = d; g.ldb = d; g.ldc = T;
+        g.sA = (int64_t)T * d; g.sB = (int64_t)T * d; g.sC = (int64_t)T * T; g.batch = B;
+        g.a_kcontig = 1; g.b_kcontig = 1; g.in_dtype = c.dtype; g.out_dtype = PA_F32;
+        g.alpha = 1.0f / (float)d; g.aux_scale = 1.f; g.splitk = 1;
+        RC(pa_gemm(&g, st));
+    }
+    RC(pa_switch_fwd(m->sw, m->hid, c.dtype, PF(tl + T_SW_W), PF(tl + T_SW_B), (int64_t)BT, d, st));
+    hipError_t he = hipMemsetAsync(m->stats, 0, 3 * sizeof(float), (hipStream_t)st);
+    if (he != hipSuccess) return (int)he;
+    he = hipMemsetD32Async((hipDeviceptr_t)(m->stats + 3), 0x3f800000, 1, (hipStream_t)st);   // upstream grad = 1.0f
+    if (he != hipSuccess) return (int)he;
+    RC(pa_mixture_nll_fwd(m->stats, m->row_lse, m->vlog, m->ldv, m->plog, m->sw, m->batch.output_label, B, T, c.vocab, c.pad, st));
+    return 0;
+}
+namespace {
+
+// --------------------------------------------------------------------------------------------------
+// backward segments (execution order): 0 heads+decoder.norm | 1..n_dec decoder layers (last first)
+// | n_dec+1 output embedding | n_dec+2 encoder.norm | then encoder layers (last first) | input embedding
+int bwd_heads(pa_model* m, float gscale, void* st) {
+    const pa_model_cfg& c = m->cfg;
+    Ctx k{m, st};
+    const int d = c.d_model, B = m->B, T = m->T, BT = B * T, tl = m->tail();
+    auto G = [&](int i) { return (float*)m->gr[i]; };
+    RC(pa_mixture_nll_bwd(m->dvlog, m->dplog, c.dtype, m->dsw, m->stats, m->row_lse, m->vlog, m->ldv, m->plog, m->sw,
+                          m->batch.output_label, B, T, c.vocab, c.pad, gscale, st));
+    // vocab head
+    RC(k.linear_dx(m->dvlog, m->ldv, m->pl[tl + T_VOCAB_W], d, m->gA, d, BT, c.vocab, d));
+    RC(k.linear_dw(m->dvlog, m->ldv, m->hid, d, G(tl + T_VOCAB_W), G(tl + T_VOCAB_B), BT, c.vocab, d));
+    // pointer head: plog[b] = pfeat[b] hid[b]^T / d
+    {
+        pa_gemm_args g; memset(&g, 0, sizeof(g));
+        g.A = m->dplog; g.B = m->hid; g.C = m->gB;                 // dpfeat = dplog x hid / d
+        g.M = T; g.N = d; g.K = T; g.lda = T; g.ldb = d; g.ldc = d;
+        g.sA = (int64_t)T * T; g.sB = (int64_t)T * d; g.sC = (int64_t)T * d; g.batch = B;
+        g.a_kcontig = 1; g.b_kcontig = 0; g.in_dtype = c.dtype; g.out_dtype = c.dtype;
+        g.alpha = 1.0f / (float)d; g.aux_scale = 1.f; g.splitk = 1;
+        RC(pa_gemm(&g, st));
+        g.A = m->dplog; g.B = m->pfeat; g.C = m->gA; g.R = m->gA;   // dhid += dplog^T x pfeat / d
+        g.a_kcontig = 0; g.ldr = d; g.sR = (int64_t)T * d;
+        RC(pa_gemm(&g, st));
+    }
+    RC(k.linear_dx(m->gB, d, m->pl[tl + T_PTR_W], d, m->gA, d, BT, d, d, m->gA, d));
+    RC(k.linear_dw(m->gB, d, m->hid, d, G(tl + T_PTR_W), G(tl + T_PTR_B), BT, d, d));
+    RC(pa_switch_bwd(m->gA, 1, G(tl + T_SW_W), G(tl + T_SW_B), m->dsw, m->hid, c.dtype, (const float*)m->pf[tl + T_SW_W],
+                     m->partial, (int64_t)BT, d, st));
+    // decoder.norm
+    const int dn = m->dec_norm();
+    // (dz may alias dy: a wave holds its whole row in registers before it stores)
+    return k.ln_bwd(m->gA, nullptr, m->gA, m->Y[c.n_dec], (const float*)m->pf[dn], m->hid_m, m->hid_r, G(dn), G(dn + 1), nullptr,
+                    BT, 0.f, 0);
+}
+
+// FFN block backward shared by encoder/decoder layers.  In: gA = d(layer output).  Out: gA = d(FFN input y).
+int bwd_ffn(pa_model* m, Ctx& k, int rows, const void* z, const float* mean, const float* rstd, const void* hff,
+            const void* yin, int w1, int w2, int nw, uint32_t seed_inner, uint32_t seed_out) {
+    const pa_model_cfg& c = m->cfg;
+    const int d = c.d_model, ff = c.d_ff;
+    const float p = m->p_drop;
+    auto G = [&](int i) { return (float*)m->gr[i]; };
+    (void)seed_inner;
+    void* ddrop = p > 0.f ? m->gC : m->gB;
+    RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, z, (const float*)m->pf[nw], mean, rstd, G(nw), G(nw + 1),
+                G(w2 + 1), rows, p, seed_out));
+    RC(k.linear_dw(ddrop, d, hff, ff, G(w2), nullptr, rows, d, ff));
+    RC(k.linear_dx(ddrop, d, m->pl[w2], ff, m->gF, ff, rows, d, ff, nullptr, 0, hff, ff, 1.0f / (1.0f - p)));
+    RC(k.linear_dw(m->gF, ff, yin, d, G(w1), G(w1 + 1), rows, ff, d));
+    RC(k.linear_dx(m->gF, ff, m->pl[w1], d, m->gA, d, rows, ff, d, m->gB, d));
+    return 0;
+}
+
+int bwd_dec_layer(pa_model* m, int i, void* st) {
+    const pa_model_cfg& c = m->cfg;
+    Ctx k{m, st};
+    const int d = c.d_model, B = m->B, S = m->S, T = m->T, BS = B * S, BT = B * T;
+    const float p = m->p_drop;
+    const size_t e = m->esz;
+    const int pb = m->dec_base(i);
+    DecAct& t = m->da[i];
+    const uint32_t sb = 1000 + 8 * i;
+    auto G = [&](int j) { return (float*)m->gr[j]; };
+    const void* memory = c.has_enc_norm ? m->memory : m->X[c.n_enc];
+    RC(bwd_ffn(m, k, BT, t.z3, t.m3, t.r3, t.hff, t.y2, pb + D_L1_W, pb + D_L2_W, pb + D_N3_W,
+               site_seed(m->seed, sb + 4), site_seed(m->seed, sb + 5)));
+    // cross attention block: z2 = y1 + drop(out_proj(attn(q(y1), kv(memory))))
+    void* ddrop = p > 0.f ? m->gC : m->gB;
+    RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, t.z2, (const float*)m->pf[pb + D_N2_W], t.m2, t.r2, G(pb + D_N2_W),
+                G(pb + D_N2_B), G(pb + D_CA_OUT_B), BT, p, site_seed(m->seed, sb + 3)));
+    RC(k.linear_dw(ddrop, d, t.o_ca, d, G(pb + D_CA_OUT_W), nullptr, BT, d, d));
+    RC(k.linear_dx(ddrop, d, m->pl[pb + D_CA_OUT_W], d, m->gD, d, BT, d, d));
+    RC(k.attn(true, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, 2 * d, t.o_ca, t.lse_ca, m->batch.input_mask, T, S, 0, p,
+              site_seed(m->seed, sb + 2), m->gD, m->gE, d, m->gKV, (char*)m->gKV + d * e, 2 * d));
+    float* dWin = G(pb + D_CA_IN_W); float* dbin = G(pb + D_CA_IN_B);
+    RC(k.linear_dw(m->gE, d, t.y1, d, dWin, dbin, BT, d, d));
+    RC(k.linear_dw(m->gKV, 2 * d, memory, d, dWin + (size_t)d * d, dbin + d, BS, 2 * d, d));
+    RC(k.linear_dx(m->gKV, 2 * d, (const char*)m->pl[pb + D_CA_IN_W] + (size_t)d * d * e, d, m->dmem, d, BS, 2 * d, d,
+                   m->dmem_written ? m->dmem : nullptr, d));
+    m->dmem_written = true;
+    RC(k.linear_dx(m->gE, d, m->pl[pb + D_CA_IN_W], d, m->gA, d, BT, d, d, m->gB, d));
+    // self attention block: z1 = Y[i] + drop(out_proj(attn(qkv(Y[i]))))
+    RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, t.z1, (const float*)m->pf[pb + D_N1_W], t.m1, t.r1, G(pb + D_N1_W),
+                G(pb + D_N1_B), G(pb + D_SA_OUT_B), BT, p, site_seed(m->seed, sb + 1)));
+    RC(k.linear_dw(ddrop, d, t.o_sa, d, G(pb + D_SA_OUT_W), nullptr, BT, d, d));
+    RC(k.linear_dx(ddrop, d, m->pl[pb + D_SA_OUT_W], d, m->gD, d, BT, d, d));
+    RC(k.attn(true, t.qkv, 3 * d, (char*)t.qkv + d * e, (char*)t.qkv + 2 * d * e, 3 * d, t.o_sa, t.lse_sa,
+              m->batch.output_mask, T, T, 1, p, site_seed(m->seed, sb + 0), m->gD, m->gQ3, 3 * d,
+              (char*)m->gQ3 + d * e, (char*)m->gQ3 + 2 * d * e, 3 * d));
+    RC(k.linear_dw(m->gQ3, 3 * d, m->Y[i], d, G(pb + D_SA_IN_W), G(pb + D_SA_IN_B), BT, 3 * d, d));
+    RC(k.linear_dx(m->gQ3, 3 * d, m->pl[pb + D_SA_IN_W], d, m->gA, d, BT, 3 * d, d, m->gB, d));
+    return 0;
+}
+
+int bwd_enc_layer(pa_model* m, int i, void* st) {
+    const pa_model_cfg& c = m->cfg;
+    Ctx k{m, st};
+    const int d = c.d_model, B = m->B, S = m->S, BS = B * S;
+    const float p = m->p_drop;
+    const size_t e = m->esz;
+    const int pb = m->enc_base(i);
+    EncAct& t = m->ea[i];
+    auto G = [&](int j) { return (float*)m->gr[j]; };
+    RC(bwd_ffn(m, k, BS, t.z2, t.m2, t.r2, t.hff, t.y1, pb + E_L1_W, pb + E_L2_W, pb + E_N2_W,
+               site_seed(m->seed, 8 * i + 2), site_seed(m->seed, 8 * i + 3)));
+    void* ddrop = p > 0.f ? m->gC : m->gB;
+    RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, t.z1, (const float*)m->pf[pb + E_N1_W], t.m1, t.r1, G(pb + E_N1_W),
+                G(pb + E_N1_B), G(pb + E_OUT_B), BS, p, site_seed(m->seed, 8 * i + 1)));
+    RC(k.linear_dw(ddrop, d, t.o, d, G(pb + E_OUT_W), nullptr, BS, d, d));
+    RC(k.linear_dx(ddrop, d, m->pl[pb + E_OUT_W], d, m->gD, d, BS, d, d));
+    RC(k.attn(true, t.qkv, 3 * d, (char*)t.qkv + d * e, (char*)t.qkv + 2 * d * e, 3 * d, t.o, t.lse, m->batch.input_mask, S, S, 0,
+              p, site_seed(m->seed, 8 * i + 0), m->gD, m->gQ3, 3 * d, (char*)m->gQ3 + d * e, (char*)m->gQ3 + 2 * d * e, 3 * d));
+    RC(k.linear_dw(m->gQ3, 3 * d, m->X[i], d, G(pb + E_IN_W), G(pb + E_IN_B), BS, 3 * d, d));
+    RC(k.linear_dx(m->gQ3, 3 * d, m->pl[pb + E_IN_W], d, m->gA, d, BS, 3 * d, d, m->gB, d));
+    return 0;
+}
+
+int backward_segment(pa_model* m, int seg, float gscale, void* st) {
+    const pa_model_cfg& c = m->cfg;
+    Ctx k{m, st};
+    const int d = c.d_model, B = m->B, S = m->S, T = m->T, BS = B * S;
+    auto G = [&](int j) { return (float*)m->gr[j]; };
+    if (seg == 0) { m->dmem_written = false; return bwd_heads(m, gscale, st); }
+    if (seg <= c.n_dec) return bwd_dec_layer(m, c.n_dec - seg, st);
+    if (seg == c.n_dec + 1)
+        return pa_embed_output_bwd(m->gA, c.dtype, G(P_IN_VALUE), G(P_Q_COORD), G(P_Q_POS), m->batch.output_value, T, B, T, d,
+                                   c.out_dof, st);
+    if (seg == c.n_dec + 2) {
+        if (!m->dmem_written) {       // no decoder layers: memory got no gradient
+            hipError_t he = hipMemsetAsync(m->dmem, 0, (size_t)BS * d * m->esz, (hipStream_t)st);
+            if (he != hipSuccess) return (int)he;
+        }
+        if (c.has_enc_norm) {
+            const int en = m->enc_norm();
+            return k.ln_bwd(m->gA, nullptr, m->dmem, m->X[c.n_enc], (const float*)m->pf[en], m->mem_m, m->mem_r, G(en), G(en + 1),
+                            nullptr, BS, 0.f, 0);
+        }
+        hipError_t he = hipMemcpyAsync(m->gA, m->dmem, (size_t)BS * d * m->esz, hipMemcpyDeviceToDevice, (hipStream_t)st);
+        return he == hipSuccess ? 0 : (int)he;
+    }
+    const int es = seg - (c.n_dec + 3);
+    if (es < c.n_enc) return bwd_enc_layer(m, c.n_enc - 1 - es, st);
+    if (es == c.n_enc) {
+        float* dt[5] = {G(P_IN_VALUE), G(P_IN_POS), G(P_IN_COORD), G(P_IN_VIEW), G(P_IN_TYPE)};
+        return pa_embed_input_bwd(m->gA, c.dtype, dt, m->batch.input_idx, 5, (int64_t)BS, d, st);
+    }
+    return PA_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int pa_model_create(const pa_model_cfg* cfg, pa_model** out) {
+    if (!cfg || !out) return PA_EINVAL;
+    if (cfg->d_model <= 0 || cfg->n_head <= 0 || cfg->d_model % cfg->n_head) return PA_EINVAL;
+    const int dh = cfg->d_model / cfg->n_head;
+    if (dh != 16 && dh != 32 && dh != 64) return PA_ESHAPE;
+    if (cfg->d_model % 8 || cfg->d_ff % 8) return PA_ESHAPE;
+    if (cfg->dtype != PA_F32 && cfg->dtype != PA_BF16) return PA_EINVAL;
+    if (cfg->dropout < 0.f || cfg->dropout >= 1.f) return PA_EINVAL;
+    pa_model* m = new (std::nothrow) pa_model();
+    if (!m) return PA_EINVAL;
+    m->cfg = *cfg;
+    m->n_params = P_FIXED_HEAD + cfg->n_enc * E_COUNT + 2 + cfg->n_dec * D_COUNT + 2 + T_COUNT;
+    m->pf.assign(m->n_params, nullptr); m->pl.assign(m->n_params, nullptr); m->gr.assign(m->n_params, nullptr);
+    *out = m;
+    return 0;
+}
+
+void pa_decode_free_layout(pa_model* m);   // decode.hip
+extern "C" void pa_model_destroy(pa_model* m) { if (m) { pa_decode_free_layout(m); delete m; } }
+
+extern "C" int pa_model_num_params(const pa_model* m) { return m ? m->n_params : PA_EINVAL; }
+
+extern "C" int pa_model_bind(pa_model* m, void* const* params_f32, void* const* params_lp, void* const* grads) {
+    if (!m || !params_f32 || !params_lp) return PA_EINVAL;
+    for (int i = 0; i < m->n_params; ++i) {
+        m->pf[i] = params_f32[i]; m->pl[i] = params_lp[i]; m->gr[i] = grads ? grads[i] : nullptr;
+    }
+    m->bound = true;
+    return 0;
+}
+
+extern "C" int64_t pa_model_train_ws_bytes(pa_model* m, int32_t B, int32_t S, int32_t T) {
+    if (!m || B <= 0 || S <= 0 || T <= 0) return PA_EINVAL;
+    return (int64_t)pa_train_layout(m, nullptr, B, S, T) + 256;
+}
+
+extern "C" int pa_model_train_fwd(pa_model* m, const pa_batch* batch, void* ws, int64_t ws_bytes, uint32_t seed,
+                                  int32_t training, float* stats, void* stream) {
+    if (!m || !m->bound || !batch || !ws || !stats) return PA_EINVAL;
+    if (batch->B <= 0 || batch->S <= 0 || batch->T <= 0 || !batch->input_idx[0] || !batch->input_mask) return PA_EINVAL;
+    if (batch->output_value && (!batch->output_label || !batch->output_mask)) return PA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) return PA_EALIGN;
+    const size_t need = pa_train_layout(m, (char*)ws, batch->B, batch->S, batch->T);
+    if ((int64_t)need > ws_bytes) return PA_EINVAL;
+    m->batch = *batch; m->B = batch->B; m->S = batch->S; m->T = batch->T;
+    m->seed = seed; m->p_drop = training ? m->cfg.dropout : 0.f;
+    m->stats = stats;
+    m->have_fwd = false;
+    int rc = pa_train_forward_impl(m, stream);
+    if (rc == 0) m->have_fwd = batch->output_value != nullptr;
+    return rc;
+}
+
+extern "C" int pa_model_train_num_segments(const pa_model* m) {
+    return m ? m->cfg.n_dec + m->cfg.n_enc + 4 : PA_EINVAL;
+}
+
+extern "C" int pa_model_train_bwd(pa_model* m, int32_t seg_lo, int32_t seg_hi, float gscale, void* stream) {
+    if (!m || !m->have_fwd) return PA_EINVAL;
+    for (int i = 0; i < m->n_params; ++i) if (!m->gr[i]) return PA_EINVAL;
+    const int nseg = m->cfg.n_dec + m->cfg.n_enc + 4;
+    if (seg_lo < 0 || seg_hi > nseg || seg_lo > seg_hi) return PA_EINVAL;
+    for (int s = seg_lo; s < seg_hi; ++s) RC(backward_segment(m, s, gscale, stream));
+    return 0;
+}
+
+extern "C" int pa_model_tensor(pa_model* m, int32_t which, void** ptr, int64_t* numel) {
+    if (!m || !ptr || !numel || m->B == 0) return PA_EINVAL;
+    const int64_t d = m->cfg.d_model;
+    switch (which) {
+        case PA_T_MEMORY: *ptr = m->cfg.has_enc_norm ? m->memory : m->X[m->cfg.n_enc]; *numel = (int64_t)m->B * m->S * d; return 0;
+        case PA_T_HIDDENS: *ptr = m->hid; *numel = (int64_t)m->B * m->T * d; return 0;
+        case PA_T_VOCAB_LOGITS: *ptr = m->vlog; *numel = (int64_t)m->B * m->T * m->ldv; return 0;
+        case PA_T_PTR_LOGITS: *ptr = m->plog; *numel = (int64_t)m->B * m->T * m->T; return 0;
+        default: return PA_EINVAL;
+    }
+}

@@ -1,0 +1,508 @@
+"""MI355X-native drop-in for the reference's ``plankassembly/models.py``.
+
+Same surface as the reference (reference models.py:11-76, 325-343):
+
+* ``build_model(cfg)`` -> ``nn.Module``; ``cfg.MODEL.* / cfg.DATA.* / cfg.TOKEN`` as in the reference;
+* ``module.forward(batch)``: training -> ``{'loss', 'accuracy'}``, eval -> ``{'samples', 'attach',
+  'predicts', 'groundtruths'}``;
+* ``state_dict()`` keys and shapes identical to the reference's torch modules (SURVEY.md appendix
+  A), so reference / published checkpoints load unchanged; parameters are real ``nn.Parameter`` s
+  whose ``.grad`` is populated by ``loss.backward()``.
+
+Behind that surface nothing of torch.nn is used: the whole train step (embeddings, 6+6 post-norm
+transformer layers, heads, mixture NLL) and its backward run as hand-written HIP kernels sequenced
+by the C++ runtime in ``csrc/runtime.hip`` through the C ABI in ``include/plank_hip.h``; greedy
+decoding runs the KV-cached decode kernels.  There is no CPU or eager fallback: the module only
+works on a ROCm device with ``libplank_hip.so`` built.
+
+MI355X-first layout: all parameters are views into ONE flat f32 buffer (and gradients into one
+flat f32 buffer, bf16 GEMM operands into one flat shadow buffer) so that Adam is a single fused
+kernel and the data-parallel gradient exchange is a handful of large contiguous RCCL all-reduces
+issued per backward segment (see ``plankassembly_amd/distributed.py``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+# ------------------------------------------------------------------------------------------------
+class _ModelCfg(C.Structure):
+    _fields_ = [("d_model", C.c_int32), ("n_head", C.c_int32), ("d_ff", C.c_int32), ("n_enc", C.c_int32),
+                ("n_dec", C.c_int32), ("vocab", C.c_int32), ("out_dof", C.c_int32),
+                ("eps_layer", C.c_float), ("eps_final", C.c_float), ("has_enc_norm", C.c_int32),
+                ("dropout", C.c_float), ("pad", C.c_int32), ("end", C.c_int32), ("dtype", C.c_int32)]
+
+
+class _Batch(C.Structure):
+    _fields_ = [("input_idx", C.c_void_p * 5), ("input_mask", C.c_void_p), ("output_value", C.c_void_p),
+                ("output_label", C.c_void_p), ("output_mask", C.c_void_p),
+                ("B", C.c_int32), ("S", C.c_int32), ("T", C.c_int32)]
+
+
+INPUT_KEYS = ("input_value", "input_pos", "input_coord", "input_view", "input_type")
+
+
+def param_order(n_enc: int, n_dec: int):
+    """Canonical parameter order = the reference's state_dict order (csrc/runtime.hip enums)."""
+    keys = [f"input_embeddings.{k}.weight" for k in INPUT_KEYS]
+    keys += ["query_coord_embedding.weight", "query_pos_embedding.weight"]
+    for i in range(n_enc):
+        p = f"encoder.layers.{i}."
+        keys += [p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias", p + "self_attn.out_proj.weight",
+                 p + "self_attn.out_proj.bias", p + "linear1.weight", p + "linear1.bias", p + "linear2.weight",
+                 p + "linear2.bias", p + "norm1.weight", p + "norm1.bias", p + "norm2.weight", p + "norm2.bias"]
+    keys += ["encoder.norm.weight", "encoder.norm.bias"]
+    for i in range(n_dec):
+        p = f"decoder.layers.{i}."
+        keys += [p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias", p + "self_attn.out_proj.weight",
+                 p + "self_attn.out_proj.bias", p + "multihead_attn.in_proj_weight", p + "multihead_attn.in_proj_bias",
+                 p + "multihead_attn.out_proj.weight", p + "multihead_attn.out_proj.bias", p + "linear1.weight",
+                 p + "linear1.bias", p + "linear2.weight", p + "linear2.bias", p + "norm1.weight", p + "norm1.bias",
+                 p + "norm2.weight", p + "norm2.bias", p + "norm3.weight", p + "norm3.bias"]
+    keys += ["decoder.norm.weight", "decoder.norm.bias"]
+    keys += ["vocab_head.weight", "vocab_head.bias", "pointer_head.weight", "pointer_head.bias",
+             "switch_head.weight", "switch_head.bias"]
+    return keys
+
+
+class _Holder(nn.Module):
+    """Pure parameter container (gives the reference's dotted state_dict names)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container; the fused HIP path does the arithmetic")
+
+
+def _xavier_(t):
+    if t.dim() > 1:
+        nn.init.xavier_uniform_(t)
+
+
+class _TrainStepFn(torch.autograd.Function):
+    """loss = stats[0] / stats[1]; backward drives the HIP backward segments and fills the flat
+    gradient buffer (parameter .grad tensors are views of it)."""
+
+    @staticmethod
+    def forward(ctx, hook, model, stats):
+        ctx.model = model
+        loss = stats[0] / stats[1]
+        return loss + 0.0 * hook
+
+    @staticmethod
+    def backward(ctx, gloss):
+        ctx.model._run_backward(gloss)
+        return None, None, None
+
+
+class PlankModel(nn.Module):
+    """See module docstring.  Constructor signature = reference models.py:13-29 plus
+    ``compute_dtype`` ('f32' parity path / 'bf16' throughput path)."""
+
+    def __init__(self, num_model=512, num_head=8, num_feedforward=1024, dropout=0.1, activation="relu",
+                 normalize_before=True, num_encoder_layers=6, num_decoder_layers=6, num_view=3, num_type=2,
+                 num_input_dof=4, num_output_dof=6, max_input_length=400, max_output_length=128, vocab_size=514,
+                 token=None, compute_dtype=None):
+        super().__init__()
+        if activation != "relu":
+            raise ValueError("only ACTIVATION: relu is implemented (all reference configs use it)")
+        if num_input_dof != 4 or num_view < 1:
+            pass
+        compute_dtype = compute_dtype or os.environ.get("PLANK_COMPUTE_DTYPE", "f32")
+        if compute_dtype not in ("f32", "bf16"):
+            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
+        self.compute_dtype = compute_dtype
+        self.num_model, self.num_head, self.num_feedforward = num_model, num_head, num_feedforward
+        self.dropout = float(dropout)
+        # the reference passes normalize_before in torch's layer_norm_eps slot (models.py:60-61,66-67)
+        self.eps_layer = float(normalize_before)
+        self.has_enc_norm = bool(normalize_before)
+        self.num_encoder_layers, self.num_decoder_layers = num_encoder_layers, num_decoder_layers
+        self.max_num_input = math.ceil(max_input_length / num_input_dof)
+        self.max_num_output = math.ceil(max_output_length / num_output_dof)
+        self.max_input_length, self.max_output_length = max_input_length, max_output_length
+        self.num_input_dof, self.num_output_dof = num_input_dof, num_output_dof
+        self.vocab_size = vocab_size
+        self.token = token
+
+        d, ff = num_model, num_feedforward
+        shapes = OrderedDict()
+        tab_rows = dict(input_value=vocab_size, input_pos=self.max_num_input, input_coord=num_input_dof,
+                        input_view=num_view, input_type=num_type)
+        for k in INPUT_KEYS:
+            shapes[f"input_embeddings.{k}.weight"] = (tab_rows[k], d)
+        shapes["query_coord_embedding.weight"] = (num_output_dof, d)
+        shapes["query_pos_embedding.weight"] = (self.max_num_output, d)
+
+        def attn(p):
+            shapes[p + "in_proj_weight"] = (3 * d, d); shapes[p + "in_proj_bias"] = (3 * d,)
+            shapes[p + "out_proj.weight"] = (d, d); shapes[p + "out_proj.bias"] = (d,)
+
+        def ffn(p):
+            shapes[p + "linear1.weight"] = (ff, d); shapes[p + "linear1.bias"] = (ff,)
+            shapes[p + "linear2.weight"] = (d, ff); shapes[p + "linear2.bias"] = (d,)
+
+        def norm(p):
+            shapes[p + "weight"] = (d,); shapes[p + "bias"] = (d,)
+
+        for i in range(num_encoder_layers):
+            p = f"encoder.layers.{i}."
+            attn(p + "self_attn."); ffn(p); norm(p + "norm1."); norm(p + "norm2.")
+        norm("encoder.norm.")
+        for i in range(num_decoder_layers):
+            p = f"decoder.layers.{i}."
+            attn(p + "self_attn."); attn(p + "multihead_attn."); ffn(p)
+            norm(p + "norm1."); norm(p + "norm2."); norm(p + "norm3.")
+        norm("decoder.norm.")
+        shapes["vocab_head.weight"] = (vocab_size, d); shapes["vocab_head.bias"] = (vocab_size,)
+        shapes["pointer_head.weight"] = (d, d); shapes["pointer_head.bias"] = (d,)
+        shapes["switch_head.weight"] = (1, d); shapes["switch_head.bias"] = (1,)
+
+        self._order = param_order(num_encoder_layers, num_decoder_layers)
+        assert list(shapes) == self._order
+        self._shapes = shapes
+        self._offsets, off = {}, 0
+        for k, s in shapes.items():
+            self._offsets[k] = off
+            off += (math.prod(s) + 63) // 64 * 64            # 256-byte aligned sub-buffers
+        self._numel = off
+
+        # module tree with the reference's names; parameters are created as views of one flat buffer
+        flat = torch.zeros(self._numel, dtype=torch.float32)
+        self._params = OrderedDict()
+        for k, s in shapes.items():
+            parts = k.split(".")
+            mod = self
+            for name in parts[:-1]:
+                if not hasattr(mod, name):
+                    mod.add_module(name, _Holder())
+                mod = getattr(mod, name)
+            n = math.prod(s)
+            view = flat[self._offsets[k]: self._offsets[k] + n].view(s)
+            prm = nn.Parameter(view)
+            mod.register_parameter(parts[-1], prm)
+            self._params[k] = prm
+        if not self.has_enc_norm:
+            # the reference builds no encoder.norm in this case (models.py:62); keep the slots out of state_dict
+            del self.encoder._modules["norm"]
+            for k in ("encoder.norm.weight", "encoder.norm.bias"):
+                self._params[k].requires_grad_(False)
+        self._flat = flat
+        self._gflat = None
+        self._gtmp = None
+        self._shadow = None
+        self._shadow_version = -1
+        self._handle = None
+        self._ws = None
+        self._stats = None
+        self._step_seed = 0
+        self._grad_hook = None
+        self._hook_leaf = None
+        self._decoder = None
+        self._reset_parameters()
+
+    # ---------------------------------------------------------------------------------- init / layout
+    def _reset_parameters(self):
+        """reference models.py:78-83 (xavier on dim>1) + torch defaults for 1-D parameters."""
+        with torch.no_grad():
+            for k, p in self._params.items():
+                if p.dim() > 1:
+                    _xavier_(p)
+                elif "norm" in k and k.endswith("weight"):
+                    p.fill_(1.0)
+                elif k.endswith("linear1.bias") or k.endswith("linear2.bias") or k in (
+                        "vocab_head.bias", "pointer_head.bias", "switch_head.bias"):
+                    fan_in = self._shapes[k.replace("bias", "weight")][1]
+                    bound = 1.0 / math.sqrt(fan_in)
+                    p.uniform_(-bound, bound)
+                else:
+                    p.zero_()
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._reflatten()
+        return out
+
+    def _reflatten(self):
+        """Re-establish the single flat buffer after .to()/.cuda()/load_state_dict re-created tensors."""
+        first = next(iter(self._params.values()))
+        dev = first.device
+        need = any(p.data.untyped_storage().data_ptr() != self._flat.untyped_storage().data_ptr()
+                   or p.device != self._flat.device or p.dtype != torch.float32 for p in self._params.values())
+        if not need:
+            return
+        flat = torch.zeros(self._numel, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for k, p in self._params.items():
+                n = p.numel()
+                view = flat[self._offsets[k]: self._offsets[k] + n].view(self._shapes[k])
+                view.copy_(p.data.to(torch.float32))
+                p.data = view
+                p.grad = None
+        self._flat = flat
+        self._gflat = self._gtmp = self._shadow = None
+        self._shadow_version = -1
+        self._drop_handle()
+
+    def _drop_handle(self):
+        if self._handle is not None:
+            L.lib().pa_model_destroy(self._handle)
+            self._handle = None
+        self._ws = None
+        self._decoder = None
+
+    def __del__(self):
+        try:
+            self._drop_handle()
+        except Exception:
+            pass
+
+    # state_dict without encoder.norm when the reference would not have it
+    def state_dict(self, *args, **kwargs):
+        return super().state_dict(*args, **kwargs)
+
+    # ---------------------------------------------------------------------------------- runtime binding
+    @property
+    def flat_params(self):
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        self._ensure_grads()
+        return self._gflat
+
+    def segment_slices(self):
+        """[(lo, hi)] element ranges of the flat gradient buffer that become final after each backward
+        segment, in execution order (heads, decoder layers last->first, output embedding, encoder.norm,
+        encoder layers last->first, input embedding).  The shared value table lives in the last range."""
+        o = self._offsets
+        ne, nd = self.num_encoder_layers, self.num_decoder_layers
+        end = self._numel
+        out = [(o["decoder.norm.weight"], end)]
+        for i in range(nd - 1, -1, -1):
+            lo = o[f"decoder.layers.{i}.self_attn.in_proj_weight"]
+            hi = o[f"decoder.layers.{i + 1}.self_attn.in_proj_weight"] if i + 1 < nd else o["decoder.norm.weight"]
+            out.append((lo, hi))
+        first_dec = o["decoder.layers.0.self_attn.in_proj_weight"] if nd else o["decoder.norm.weight"]
+        out.append((o["query_coord_embedding.weight"], o["encoder.layers.0.self_attn.in_proj_weight"] if ne
+                    else o["encoder.norm.weight"]))
+        out.append((o["encoder.norm.weight"], first_dec))
+        for i in range(ne - 1, -1, -1):
+            lo = o[f"encoder.layers.{i}.self_attn.in_proj_weight"]
+            hi = o[f"encoder.layers.{i + 1}.self_attn.in_proj_weight"] if i + 1 < ne else o["encoder.norm.weight"]
+            out.append((lo, hi))
+        out.append((0, o["query_coord_embedding.weight"]))
+        return out
+
+    def register_grad_ready_hook(self, fn):
+        """fn(seg_index, lo, hi) is called right after backward segment ``seg_index`` was enqueued."""
+        self._grad_hook = fn
+
+    def _require_gpu(self):
+        if self._flat.device.type != "cuda":
+            raise L.PlankHipError(
+                "plankassembly_amd.PlankModel runs only on a ROCm GPU (module is on "
+                f"'{self._flat.device}'): move it with .cuda(); there is no CPU fallback path.")
+        L.lib()
+
+    def _pa_dtype(self):
+        return L.PA_BF16 if self.compute_dtype == "bf16" else L.PA_F32
+
+    def _ensure_handle(self):
+        self._require_gpu()
+        if self._handle is not None:
+            return
+        cfg = _ModelCfg(self.num_model, self.num_head, self.num_feedforward, self.num_encoder_layers,
+                        self.num_decoder_layers, self.vocab_size, self.num_output_dof, self.eps_layer, 1e-5,
+                        int(self.has_enc_norm), self.dropout, int(self.token.PAD), int(self.token.END),
+                        self._pa_dtype())
+        h = C.c_void_p()
+        L.check(L.lib().pa_model_create(C.byref(cfg), C.byref(h)), "pa_model_create")
+        self._handle = h
+        self._rebind()
+
+    def _ptr_table(self, flat, esz):
+        n = len(self._order)
+        arr = (C.c_void_p * n)()
+        base = flat.data_ptr()
+        for i, k in enumerate(self._order):
+            arr[i] = base + self._offsets[k] * esz
+        return arr
+
+    def _rebind(self, grads=None):
+        pf = self._ptr_table(self._flat, 4)
+        if self.compute_dtype == "bf16":
+            if self._shadow is None:
+                self._shadow = torch.empty(self._numel, dtype=torch.bfloat16, device=self._flat.device)
+                self._shadow_version = -1
+            pl = self._ptr_table(self._shadow, 2)
+        else:
+            pl = pf
+        g = grads if grads is not None else self._gflat
+        gr = self._ptr_table(g, 4) if g is not None else None
+        L.check(L.lib().pa_model_bind(self._handle, pf, pl, gr), "pa_model_bind")
+        self._bound_grads = g
+
+    def _ensure_grads(self):
+        if self._gflat is None:
+            self._gflat = torch.zeros(self._numel, dtype=torch.float32, device=self._flat.device)
+
+    def _refresh_shadow(self):
+        if self.compute_dtype != "bf16":
+            return
+        v = self._flat._version
+        if v != self._shadow_version:
+            L.check(L.lib().pa_cast(L.ptr(self._shadow), L.PA_BF16, L.ptr(self._flat), L.PA_F32,
+                                    C.c_int64(self._numel), L.stream()), "pa_cast")
+            self._shadow_version = v
+
+    def mark_shadow_fresh(self):
+        """Called by the fused optimizer, which refreshes the bf16 shadow inside its own kernel."""
+        self._shadow_version = self._flat._version
+
+    # ---------------------------------------------------------------------------------- batches
+    def _make_batch(self, batch, with_output=True):
+        iv = batch["input_value"]
+        B, S = iv.shape
+        keep = []
+        b = _Batch()
+        for i, k in enumerate(INPUT_KEYS):
+            t = batch.get(k)
+            if t is None:
+                b.input_idx[i] = None
+                continue
+            t = t.to(device=self._flat.device, dtype=torch.int64).contiguous()
+            keep.append(t)
+            b.input_idx[i] = t.data_ptr()
+        m = batch["input_mask"].to(self._flat.device).contiguous()
+        m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+        keep.append(m)
+        b.input_mask = m.data_ptr()
+        T = self.max_output_length
+        if with_output:
+            ov = batch["output_value"].to(device=self._flat.device, dtype=torch.int64).contiguous()
+            ol = batch["output_label"].to(device=self._flat.device, dtype=torch.int64).contiguous()
+            om = batch["output_mask"].to(self._flat.device).contiguous()
+            om = om.view(torch.uint8) if om.dtype == torch.bool else om.to(torch.uint8)
+            keep += [ov, ol, om]
+            T = ov.shape[1]
+            b.output_value, b.output_label, b.output_mask = ov.data_ptr(), ol.data_ptr(), om.data_ptr()
+        b.B, b.S, b.T = B, S, T
+        return b, keep
+
+    def _workspace(self, B, S, T):
+        need = int(L.lib().pa_model_train_ws_bytes(self._handle, B, S, T))
+        if need < 0:
+            L.check(need, "pa_model_train_ws_bytes")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self._flat.device)
+        return self._ws
+
+    # ---------------------------------------------------------------------------------- train step
+    def train_step(self, batch):
+        """reference models.py:190-233."""
+        self._ensure_handle()
+        self._refresh_shadow()
+        b, keep = self._make_batch(batch, True)
+        ws = self._workspace(b.B, b.S, b.T)
+        base = (ws.data_ptr() + 255) // 256 * 256
+        stats = torch.empty(4, dtype=torch.float32, device=self._flat.device)
+        self._step_seed = (self._step_seed * 1664525 + 1013904223 + int(torch.initial_seed())) & 0xFFFFFFFF
+        L.check(L.lib().pa_model_train_fwd(self._handle, C.byref(b), C.c_void_p(base),
+                                           C.c_int64(ws.numel() - (base - ws.data_ptr())),
+                                           C.c_uint32(self._step_seed), 1 if self.training else 0,
+                                           L.ptr(stats), L.stream()), "pa_model_train_fwd")
+        self._live = (b, keep, stats)
+        if self._hook_leaf is None or self._hook_leaf.device != stats.device:
+            self._hook_leaf = torch.zeros((), device=stats.device, requires_grad=True)
+        if torch.is_grad_enabled():
+            loss = _TrainStepFn.apply(self._hook_leaf, self, stats)
+        else:
+            loss = stats[0] / stats[1]
+        accuracy = stats[2] / (stats[1] + 1e-10)
+        return {"loss": loss, "accuracy": accuracy}
+
+    def _run_backward(self, gloss):
+        self._ensure_grads()
+        accumulate = any(p.grad is not None for p in self._params.values())
+        target = self._gflat
+        if accumulate:
+            if self._gtmp is None:
+                self._gtmp = torch.empty_like(self._gflat)
+            target = self._gtmp
+        target.zero_()
+        if self._bound_grads is not target:
+            self._rebind(target)
+        nseg = int(L.lib().pa_model_train_num_segments(self._handle))
+        stats = self._live[2]
+        stats[3:4].copy_(gloss.reshape(1).to(torch.float32), non_blocking=True)   # upstream grad, no host sync
+        slices = self.segment_slices()
+        hook = self._grad_hook if not accumulate else None
+        for s in range(nseg):
+            L.check(L.lib().pa_model_train_bwd(self._handle, s, s + 1, C.c_float(1.0), L.stream()),
+                    "pa_model_train_bwd")
+            if hook is not None:
+                hook(s, *slices[s])
+        if accumulate:
+            self._gflat.add_(self._gtmp)
+            if self._grad_hook is not None:
+                for s in range(nseg):
+                    self._grad_hook(s, *slices[s])
+        for k, p in self._params.items():
+            if p.grad is None and p.requires_grad:
+                n = p.numel()
+                p.grad = self._gflat[self._offsets[k]: self._offsets[k] + n].view(self._shapes[k])
+
+    # ---------------------------------------------------------------------------------- eval (greedy decode)
+    def parse_sequence(self, sequence):
+        """reference models.py:258-265."""
+        valid_mask = torch.cumsum(sequence == self.token.END, 0) == 0
+        valid_seq = sequence[valid_mask]
+        num_plank = len(valid_seq) // self.num_output_dof
+        return valid_seq[:num_plank * self.num_output_dof].reshape(-1, self.num_output_dof)
+
+    def eval_step(self, batch):
+        """reference models.py:267-323: greedy autoregressive sampling (KV-cached HIP decode)."""
+        from .decode import GreedyDecoder
+        self._ensure_handle()
+        self._refresh_shadow()
+        if self._decoder is None:
+            self._decoder = GreedyDecoder(self)
+        output, attach = self._decoder.run(batch)
+        predicts, groundtruths = [], []
+        for i in range(output.shape[0]):
+            predicts.append(self.parse_sequence(output[i]))
+            groundtruths.append(self.parse_sequence(batch["output_value"][i].to(output.device)))
+        return {"samples": output, "attach": attach, "predicts": predicts, "groundtruths": groundtruths}
+
+    def forward(self, batch):
+        """reference models.py:325-330."""
+        return self.train_step(batch) if self.training else self.eval_step(batch)
+
+    # ---------------------------------------------------------------------------------- introspection
+    def debug_tensor(self, which):
+        names = {"memory": 0, "hiddens": 1, "vocab_logits": 2, "ptr_logits": 3}
+        p, n = C.c_void_p(), C.c_int64()
+        L.check(L.lib().pa_model_tensor(self._handle, names[which], C.byref(p), C.byref(n)), "pa_model_tensor")
+        dt = torch.float32 if (which in ("vocab_logits", "ptr_logits") or self.compute_dtype == "f32") else torch.bfloat16
+        esz = 4 if dt == torch.float32 else 2
+        off = p.value - self._ws.data_ptr()
+        return self._ws[off: off + n.value * esz].view(dt).clone()
+
+
+def build_model(cfg):
+    """reference models.py:333-343.  Optional ``cfg.MODEL.COMPUTE_DTYPE`` ('f32' | 'bf16')."""
+    model_cfg = cfg.MODEL
+    dtype = getattr(model_cfg, "COMPUTE_DTYPE", None) if not isinstance(model_cfg, dict) else model_cfg.get("COMPUTE_DTYPE")
+    return PlankModel(
+        cfg.MODEL.NUM_MODEL, cfg.MODEL.NUM_HEAD, cfg.MODEL.NUM_FEEDFORWARD, cfg.MODEL.DROPOUT,
+        cfg.MODEL.ACTIVATION, cfg.MODEL.NORMALIZE_BEFORE, cfg.MODEL.NUM_ENCODER_LAYERS,
+        cfg.MODEL.NUM_DECODER_LAYERS, cfg.DATA.NUM_VIEW, cfg.DATA.NUM_TYPE, cfg.DATA.NUM_INPUT_DOF,
+        cfg.DATA.NUM_OUTPUT_DOF, cfg.DATA.MAX_INPUT_LENGTH, cfg.DATA.MAX_OUTPUT_LENGTH, cfg.DATA.VOCAB_SIZE,
+        cfg.TOKEN, compute_dtype=dtype)

@@ -1,0 +1,59 @@
+"""Fused Adam over the model's flat parameter buffer (one HIP kernel per step).
+
+Same update rule and defaults as ``torch.optim.Adam(model.parameters(), lr=cfg.LR)`` used by the
+reference (trainer_complete.py:127-129): betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad.
+Also refreshes the model's bf16 GEMM-operand shadow in the same pass.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        params = [p for p in model.parameters() if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.model = model
+        self.grad_scale = grad_scale
+        self._step = 0
+        self._m = None
+        self._v = None
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.model._params.values():
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        m = self.model
+        flat, g = m.flat_params, m.flat_grads
+        if self._m is None or self._m.device != flat.device:
+            self._m = torch.zeros_like(flat)
+            self._v = torch.zeros_like(flat)
+        self._step += 1
+        grp = self.param_groups[0]
+        shadow = m._shadow if m.compute_dtype == "bf16" else None
+        L.check(L.lib().pa_adam_step(L.ptr(flat), L.ptr(g), L.ptr(self._m), L.ptr(self._v), L.ptr(shadow),
+                                     C.c_int64(flat.numel()), C.c_float(grp["lr"]), C.c_float(grp["betas"][0]),
+                                     C.c_float(grp["betas"][1]), C.c_float(grp["eps"]), self._step,
+                                     C.c_float(self.grad_scale), L.stream()), "pa_adam_step")
+        flat._version  # (in-place update through the C ABI does not bump torch's version counter)
+        if shadow is not None:
+            m.mark_shadow_fresh()
+        else:
+            m._shadow_version = -1
+        return loss
+
+    def state_dict(self):
+        return {"step": self._step, "m": self._m, "v": self._v, "param_groups": self.param_groups}
+
+    def load_state_dict(self, sd):
+        self._step, self._m, self._v = sd["step"], sd["m"], sd["v"]

@@ -1,0 +1,164 @@
+"""Model-level parity on the GPU: plankassembly_amd.PlankModel (HIP path through the C ABI) against
+the golden vectors produced by the reference model (tests/golden) and the CPU oracle."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOKEN = types.SimpleNamespace(END=512, PAD=513)
+
+
+def make(sd, dtype="f32", d=64, h=4, ff=128, ne=2, nd=2, max_in=65, max_out=36, dropout=0.0):
+    from plankassembly_amd.models import PlankModel
+    m = PlankModel(d, h, ff, dropout, "relu", True, ne, nd, 3, 2, 4, 6, max_in, max_out, 514, TOKEN,
+                   compute_dtype=dtype)
+    m.load_state_dict(sd)
+    return m.cuda()
+
+
+def to_dev(batch):
+    return {k: v.cuda() for k, v in batch.items()}
+
+
+def test_g1_g2_train_forward_backward_f32(small_fixture):
+    sd, batch, g = small_fixture
+    m = make(sd).train()
+    out = m(to_dev(batch))
+    assert abs(out["loss"].item() - float(g["g1::loss"])) < 1e-4
+    assert abs(out["accuracy"].item() - float(g["g1::accuracy"])) < 1e-6
+    B, S = batch["input_value"].shape
+    mem = m.debug_tensor("memory").view(B, S, -1).cpu()
+    valid = ~batch["input_mask"]
+    assert float((mem[valid] - torch.from_numpy(g["g1::memory"])[valid]).abs().max()) < 1e-4
+    hid = m.debug_tensor("hiddens").view(B, -1, 64).cpu()
+    assert float((hid - torch.from_numpy(g["g1::hiddens"])).abs().max()) < 1e-4
+    out["loss"].backward()
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        ref = torch.from_numpy(g["g2::" + k])
+        assert p.grad is not None, k
+        err = float((p.grad.cpu() - ref).abs().max())
+        scale = float(ref.abs().max())
+        rel = err / max(scale, 1e-3)
+        if rel > worst[1]:
+            worst = (k, rel)
+        assert err <= 1e-5 + 1e-4 * scale, (k, err, scale)
+    print("worst relative grad error", worst)
+
+
+def test_g3_fused_adam_step(small_fixture):
+    from plankassembly_amd.optim import FusedAdam
+    sd, batch, g = small_fixture
+    m = make(sd).train()
+    opt = FusedAdam(m, lr=1e-4)
+    opt.zero_grad()
+    m(to_dev(batch))["loss"].backward()
+    opt.step()
+    # on step 1 the update is lr * g/(|g|+eps): entries with |g| ~ eps are noise-dominated, so
+    # compare where the reference gradient is well above eps and bound the rest by lr
+    for k, v in m.state_dict().items():
+        ref = torch.from_numpy(g["g3::" + k])
+        gref = torch.from_numpy(g["g2::" + k]).abs()
+        diff = (v.cpu() - ref).abs()
+        assert float(diff.max()) <= 2.0001e-4, k
+        solid = gref > 1e-5
+        if solid.any():
+            assert float(diff[solid].max()) < 2e-6, (k, float(diff[solid].max()))
+
+
+def test_g7_ragged_sideface_f32(ragged_fixture):
+    sd, batch, g = ragged_fixture
+    m = make(sd).train()
+    out = m(to_dev(batch))
+    assert abs(out["loss"].item() - float(g["g1::loss"])) < 1e-4
+    hid = m.debug_tensor("hiddens").view(batch["output_value"].shape[0], -1, 64).cpu()
+    assert float((hid - torch.from_numpy(g["g1::hiddens"])).abs().max()) < 1e-4
+    out["loss"].backward()
+    for k in ("input_embeddings.input_value.weight", "input_embeddings.input_view.weight",
+              "decoder.layers.1.multihead_attn.in_proj_weight"):
+        ref = torch.from_numpy(g["g2::" + k])
+        err = float((dict(m.named_parameters())[k].grad.cpu() - ref).abs().max())
+        assert err <= 1e-5 + 1e-4 * float(ref.abs().max()), (k, err)
+    gt = dict(m.named_parameters())["input_embeddings.input_type.weight"].grad
+    assert gt is not None and not gt.any()                  # unused table: zero gradient, no error
+
+
+def test_train_bf16_close_to_oracle(tiny_fixture):
+    """bf16 throughput path vs the f32 CPU oracle on the (untrained) tiny BASELINE config, where the
+    gradients carry signal (the briefly-trained small fixture sits at loss 0.01: noise-level grads)."""
+    from oracle import plank_oracle as O
+    from plankassembly_amd.data import SynthSpec, synth_batch
+    sd, _, g = tiny_fixture
+    batch = synth_batch(4, SynthSpec(1200, 128, (8, 299), (2, 21), True), seed=int(g["g8::seed"]))
+    batch.pop("name")
+    cfg = O.OracleCfg(d_model=128, n_head=8, d_ff=256, n_enc=2, n_dec=2, max_input_length=1200, max_output_length=128)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.train_forward(p, cfg, batch)
+    ref["loss"].backward()
+    m = make(sd, "bf16", 128, 8, 256, 2, 2, 1200, 128).train()
+    out = m(to_dev(batch))
+    assert abs(out["loss"].item() - float(ref["loss"])) < 2e-2 * float(ref["loss"])
+    out["loss"].backward()
+    num = den1 = den2 = 0.0
+    worst = 1.0
+    for k, prm in m.named_parameters():
+        r = p[k].grad.double().flatten()
+        got = prm.grad.cpu().double().flatten()
+        num += float(got @ r); den1 += float(got @ got); den2 += float(r @ r)
+        if float(r @ r) > 0:
+            worst = min(worst, float(got @ r) / (float(got @ got) ** 0.5 * float(r @ r) ** 0.5 + 1e-30))
+    cos = num / (den1 ** 0.5 * den2 ** 0.5)
+    print("bf16 grad cosine total", cos, "worst tensor", worst)
+    assert cos > 0.995, cos
+    assert worst > 0.95, worst
+
+
+def test_g8_tiny_config_loss_curve(tiny_fixture):
+    from plankassembly_amd.data import SynthSpec, synth_batch
+    from plankassembly_amd.optim import FusedAdam
+    sd, _, g = tiny_fixture
+    batch = synth_batch(4, SynthSpec(1200, 128, (8, 299), (2, 21), True), seed=int(g["g8::seed"]))
+    batch.pop("name")
+    m = make(sd, "f32", 128, 8, 256, 2, 2, 1200, 128).train()
+    opt = FusedAdam(m, lr=1e-4)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        out = m(to_dev(batch))
+        out["loss"].backward()
+        opt.step()
+        losses.append(out["loss"].item())
+    assert np.allclose(losses, g["g8::losses"], atol=2e-4), (losses, g["g8::losses"])
+
+
+def test_gradient_accumulation_and_torch_adam(small_fixture):
+    """Drop-in semantics: .grad accumulates across backward calls unless zeroed; torch.optim.Adam works."""
+    sd, batch, g = small_fixture
+    m = make(sd).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    opt.zero_grad()
+    m(to_dev(batch))["loss"].backward()
+    g1 = m.vocab_head.weight.grad.clone()
+    m(to_dev(batch))["loss"].backward()
+    assert float((m.vocab_head.weight.grad - 2 * g1).abs().max()) < 1e-6 * max(1.0, float(g1.abs().max()))
+    opt.zero_grad()
+    m(to_dev(batch))["loss"].backward()
+    assert float((m.vocab_head.weight.grad - g1).abs().max()) < 1e-6
+    opt.step()
+    ref = torch.from_numpy(g["g3::vocab_head.weight"])
+    solid = torch.from_numpy(g["g2::vocab_head.weight"]).abs() > 1e-5
+    assert float((m.vocab_head.weight.detach().cpu() - ref)[solid].abs().max()) < 2e-6
+
+
+def test_dropout_training_runs_and_is_stochastic(small_fixture):
+    sd, batch, _ = small_fixture
+    m = make(sd, dropout=0.2).train()
+    l1 = m(to_dev(batch))["loss"]
+    l1.backward()
+    l2 = m(to_dev(batch))["loss"]
+    assert torch.isfinite(l1) and torch.isfinite(l2) and abs(l1.item() - l2.item()) > 1e-6
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    m.eval()
