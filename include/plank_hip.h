@@ -251,6 +251,26 @@ int pa_model_train_bwd(pa_model* m, int32_t seg_lo, int32_t seg_hi, float gscale
 /* introspection for parity tests: device pointer + element count of an activation of the last forward */
 int pa_model_tensor(pa_model* m, int32_t which, void** ptr, int64_t* numel);
 
+/* ------------------------------------------------------------------------------------------
+ * Greedy decode: reference plankassembly/models.py:267-307 (eval_step loop), 168-186 (_create_dist
+ * eval branch, last row only), 235-256 (_sample).  K/V-cached (the reference recomputes the whole
+ * prefix and the cross-attention K/V projection of `memory` every step); token-exact w.r.t. the
+ * reference in PA_F32.
+ *   1. run the encoder: pa_model_train_fwd with batch.output_value == NULL (T = 1);
+ *   2. pa_decode_begin: lays out `ws` (pa_decode_ws_bytes), projects the cross-attention K/V of
+ *      `memory` for every decoder layer once, resets the device-side step counter / outputs;
+ *   3. pa_decode_step x Tmax: one token for every sequence.  All step kernels read the step index
+ *      from device memory, so ONE captured hipGraph of a step can be replayed Tmax times;
+ *   4. pa_decode_buffers: device pointers of tokens int64 [B][Tmax], attach int64 [B][Tmax]
+ *      (-1 = no pointer), first_end int32 [B] (step at which END was first emitted, -1 = never),
+ *      t_dev int32 (steps done).  The reference's early stop (all rows contain END) is the
+ *      host checking first_end between replays and truncating to max(first_end)+1 columns.
+ */
+int64_t pa_decode_ws_bytes(pa_model* m, int32_t B, int32_t S, int32_t Tmax);
+int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t Tmax, void* stream);
+int pa_decode_step(pa_model* m, void* stream);
+int pa_decode_buffers(pa_model* m, void** tokens, void** attach, void** first_end, void** t_dev);
+
 #ifdef __cplusplus
 }
 #endif

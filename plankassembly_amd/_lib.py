@@ -80,6 +80,19 @@ def lib():
             "pa_mixture_nll_bwd": (I, [P, P, I, P, P, P, P, I, P, P, P, I, I, I, I, F, P]),
             "pa_adam_step": (I, [P, P, P, P, P, I64, F, F, F, F, I, F, P]),
             "pa_cast": (I, [P, I, P, I, I64, P]),
+            "pa_model_create": (I, [P, P]),
+            "pa_model_destroy": (None, [P]),
+            "pa_model_num_params": (I, [P]),
+            "pa_model_bind": (I, [P, P, P, P]),
+            "pa_model_train_ws_bytes": (I64, [P, I, I, I]),
+            "pa_model_train_fwd": (I, [P, P, P, I64, U, I, P, P]),
+            "pa_model_train_num_segments": (I, [P]),
+            "pa_model_train_bwd": (I, [P, I, I, F, P]),
+            "pa_model_tensor": (I, [P, I, P, P]),
+            "pa_decode_ws_bytes": (I64, [P, I, I, I]),
+            "pa_decode_begin": (I, [P, P, I64, I, P]),
+            "pa_decode_step": (I, [P, P]),
+            "pa_decode_buffers": (I, [P, P, P, P, P]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)

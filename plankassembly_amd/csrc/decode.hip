@@ -1,0 +1,396 @@
+// Greedy autoregressive decode for gfx950: reference plankassembly/models.py:267-307 (eval_step) with a
+// K/V cache instead of the reference's O(T^2) prefix recompute (mathematically identical for a causal
+// decoder in eval mode).  One decode step = a fixed sequence of kernels that
+// read the step index from DEVICE memory, so the host can capture the step once in a hipGraph and
+// replay it max_output_length times.
+//   * single-query attention (HBM-bound batched GEMV): 16-byte K/V row chunks per lane, score
+//     reduction across the lanes of a row with wave shuffles, online softmax per lane group,
+//     partial (m, l, acc) merge through LDS.
+//   * sampling kernel fuses: pointer logits against the hidden-state cache, switch head, vocab /
+//     pointer softmax, gating, the 1e-6 pointer-mask fill, first-max argmax, pointer copy, END tracking
+//     (reference models.py:168-186 eval branch of _create_dist and 235-256 _sample).
+#include <math.h>
+#include <new>
+#include <string.h>
+#include "common.cuh"
+#include "model.h"
+
+struct DecodeLayout {
+    int B = 0, S = 0, Tmax = 0;
+    std::vector<void*> cross_kv, self_kv;      // per decoder layer: [B*S][2d], [B][Tmax][2d]
+    void *hid_cache, *x, *qkv, *ao, *z, *y, *q, *ff, *pfeat, *h;
+    float *vlog, *mean, *rstd;
+    int64_t *tokens, *attach; int32_t *first_end, *t_dev;
+    uint8_t* kpm;                              // copy of input_mask: the captured step must not depend on batch tensors
+};
+
+namespace {
+
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+constexpr float LOG2E_F = 1.4426950408889634f;
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dec_embed_kernel(T* x, const float* value, const float* coord, const float* pos,
+                                                        const int64_t* tokens, int Tmax, const int32_t* t_dev, int B, int d, int dof) {
+    const int t = *t_dev;
+    const int vec = d >> 2;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < B * vec; e += gridDim.x * 256) {
+        const int b = e / vec, c = (e % vec) << 2;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            const int64_t v = tokens[(int64_t)b * Tmax + (t - 1)];
+            acc = *reinterpret_cast<const f32x4*>(value + v * d + c);
+            acc += *reinterpret_cast<const f32x4*>(coord + (int64_t)((t - 1) % dof) * d + c);
+            acc += *reinterpret_cast<const f32x4*>(pos + (int64_t)((t - 1) / dof) * d + c);
+        }
+        st4<T>(x + (int64_t)b * d + c, acc);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dec_append_kv_kernel(T* cache, const T* qkv, const int32_t* t_dev, int B, int Tmax, int d) {
+    const int t = *t_dev;
+    const int vec = (2 * d) >> 2;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < B * vec; e += gridDim.x * 256) {
+        const int b = e / vec, c = (e % vec) << 2;
+        st4<T>(cache + ((int64_t)b * Tmax + t) * 2 * d + c, ld4<T>(qkv + (int64_t)b * 3 * d + d + c));
+    }
+}
+
+// single-query attention; grid (H, B), 4 waves.  Lk = fixed_lk or *t_dev + 1.
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int ldq, const T* kv, int64_t kv_bstride, int ldkv,
+                                                       int voff, const uint8_t* kpm, int fixed_lk, const int32_t* t_dev,
+                                                       int d, float scale) {
+    constexpr int EB = ET<T>::EB;
+    constexpr int LPR = DH / EB;             // lanes per key row
+    constexpr int KPW = 64 / LPR;            // keys per wave step
+    constexpr int NG = 4 * KPW;              // partial groups per block
+    __shared__ float part[NG * (DH + 2)];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane % LPR, slot = lane / LPR;
+    const int Lk = fixed_lk > 0 ? fixed_lk : (*t_dev + 1);
+    const T* kb = kv + (int64_t)b * kv_bstride + h * DH + c * EB;
+    const T* vb = kb + voff;
+    const uint8_t* mk = kpm ? kpm + (int64_t)b * Lk : nullptr;
+    float qv[EB];
+    {
+        const T* qp = q + (int64_t)b * ldq + h * DH + c * EB;
+#pragma unroll
+        for (int e = 0; e < EB; e += 4) { const f32x4 t4 = ld4<T>(qp + e); qv[e] = t4[0]; qv[e + 1] = t4[1]; qv[e + 2] = t4[2]; qv[e + 3] = t4[3]; }
+    }
+    const float sl = scale * LOG2E_F;
+    float m = -INFINITY, l = 0.f, acc[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) acc[e] = 0.f;
+    for (int base = wave * KPW; base < Lk; base += 4 * KPW) {
+        const int key = base + slot;
+        const bool in = key < Lk;
+        float kx[EB], vx[EB];
+#pragma unroll
+        for (int e = 0; e < EB; e += 4) {
+            f32x4 k4 = {0.f, 0.f, 0.f, 0.f}, v4 = k4;
+            if (in) { k4 = ld4<T>(kb + (int64_t)key * ldkv + e); v4 = ld4<T>(vb + (int64_t)key * ldkv + e); }
+            kx[e] = k4[0]; kx[e + 1] = k4[1]; kx[e + 2] = k4[2]; kx[e + 3] = k4[3];
+            vx[e] = v4[0]; vx[e + 1] = v4[1]; vx[e + 2] = v4[2]; vx[e + 3] = v4[3];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EB; ++e) s += qv[e] * kx[e];
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+        const bool ok = in && !(mk && mk[key]);
+        if (ok) {
+            s *= sl;
+            const float mn = fmaxf(m, s);
+            const float alpha = exp2f(m - mn), p = exp2f(s - mn);
+            l = l * alpha + p;
+#pragma unroll
+            for (int e = 0; e < EB; ++e) acc[e] = acc[e] * alpha + p * vx[e];
+            m = mn;
+        }
+    }
+    const int g = wave * KPW + slot;
+    if (c == 0) { part[g * (DH + 2)] = m; part[g * (DH + 2) + 1] = l; }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) part[g * (DH + 2) + 2 + c * EB + e] = acc[e];
+    __syncthreads();
+    if (tid < DH) {
+        float M = -INFINITY;
+        for (int i = 0; i < NG; ++i) M = fmaxf(M, part[i * (DH + 2)]);
+        float num = 0.f, den = 0.f;
+        for (int i = 0; i < NG; ++i) {
+            const float mi = part[i * (DH + 2)];
+            if (mi == -INFINITY) continue;
+            const float w = exp2f(mi - M);
+            den += part[i * (DH + 2) + 1] * w;
+            num += part[i * (DH + 2) + 2 + tid] * w;
+        }
+        st1<T>(out + (int64_t)b * d + h * DH + tid, den > 0.f ? num / den : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct ArgMax { float v; int i; };
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {   // first-max: larger value, then smaller index
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    return v;
+}
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return v;
+}
+__device__ __forceinline__ bool ptr_allowed(int i, int j) {      // reference models.py:91-101, closed form
+    if (i < 6) return false;
+    return j < 6 ? (j == i % 6) : ((j % 6) == ((i % 6) + 3) % 6);
+}
+
+constexpr int MAX_T = 2048;
+
+template <typename T>
+__global__ __launch_bounds__(256) void dec_sample_kernel(const float* vlog, int ldv, const T* pfeat, const T* h, T* hid_cache,
+                                                         const float* sw_w, const float* sw_b, int64_t* tokens,
+                                                         int64_t* attach, int32_t* first_end, const int32_t* t_dev,
+                                                         int Tmax, int d, int V, int end_tok) {
+    __shared__ float plog[MAX_T];
+    __shared__ float sh[4];
+    __shared__ ArgMax sha[4];
+    __shared__ float s_sw;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = *t_dev, sz = t + 1, i = t;
+    const T* hb = h + (int64_t)b * d;
+    T* cache = hid_cache + (int64_t)b * Tmax * d;
+    for (int c = tid; c < d; c += 256) cache[(int64_t)t * d + c] = hb[c];
+    const float* vr = vlog + (int64_t)b * ldv;
+    // vocab softmax statistics
+    float vmax = -INFINITY;
+    for (int k = tid; k < V; k += 256) vmax = fmaxf(vmax, vr[k]);
+    vmax = block_max(vmax, sh);
+    float vsum = 0.f;
+    for (int k = tid; k < V; k += 256) vsum += expf(vr[k] - vmax);
+    vsum = block_sum(vsum, sh);
+    ArgMax best{-INFINITY, 0x7fffffff};
+    if (sz < 6) {                                                     // models.py:172-173: un-gated vocab softmax
+        for (int k = tid; k < V; k += 256) best = better(best, ArgMax{expf(vr[k] - vmax) / vsum, k});
+    } else {
+        // pointer logits over the hidden prefix (row j = t is written above but masked: j >= i)
+        const T* pf = pfeat + (int64_t)b * d;
+        for (int j = wave; j < t; j += 4) {
+            float s = 0.f;
+            for (int c = lane << 2; c < d; c += 256) {
+                const f32x4 a = ld4<T>(pf + c), hh = ld4<T>(cache + (int64_t)j * d + c);
+                s += a[0] * hh[0] + a[1] * hh[1] + a[2] * hh[2] + a[3] * hh[3];
+            }
+            s = wave_sum(s);
+            if (lane == 0) plog[j] = s / (float)d;
+        }
+        if (wave == 0) {
+            float s = 0.f;
+            for (int c = lane << 2; c < d; c += 256) {
+                const f32x4 hh = ld4<T>(hb + c); const f32x4 w = *reinterpret_cast<const f32x4*>(sw_w + c);
+                s += hh[0] * w[0] + hh[1] * w[1] + hh[2] * w[2] + hh[3] * w[3];
+            }
+            s = wave_sum(s);
+            if (lane == 0) s_sw = s + sw_b[0];
+        }
+        __syncthreads();
+        const float prob = 1.0f / (1.0f + expf(-s_sw));
+        float pmax = -INFINITY;
+        for (int j = tid; j < t; j += 256) pmax = fmaxf(pmax, plog[j]);
+        pmax = block_max(pmax, sh);
+        float psum = 0.f;
+        for (int j = tid; j < t; j += 256) psum += expf(plog[j] - pmax);
+        psum = block_sum(psum, sh);
+        const float gate_v = 1.0f - prob;
+        for (int k = tid; k < V; k += 256) best = better(best, ArgMax{(expf(vr[k] - vmax) / vsum) * gate_v, k});
+        for (int j = tid; j < sz; j += 256) {
+            float val = 1e-6f;                                        // models.py:183-184 fill after gating
+            if (ptr_allowed(i, j)) val = (j < i) ? (expf(plog[j] - pmax) / psum) * prob : 0.f;
+            best = better(best, ArgMax{val, V + j});
+        }
+    }
+    // block arg-max (first maximum)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax other{__shfl_xor(best.v, o), __shfl_xor(best.i, o)};
+        best = better(best, other);
+    }
+    if (lane == 0) sha[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        best = better(better(sha[0], sha[1]), better(sha[2], sha[3]));
+        int64_t tok = best.i, ptr = -1;
+        if (best.i >= V) { ptr = best.i - V; tok = tokens[(int64_t)b * Tmax + ptr]; }   // models.py:248-251
+        tokens[(int64_t)b * Tmax + t] = tok;
+        attach[(int64_t)b * Tmax + t] = ptr;
+        if (tok == end_tok && first_end[b] < 0) first_end[b] = t;
+    }
+}
+
+__global__ void dec_advance_kernel(int32_t* t_dev) { if (threadIdx.x == 0) *t_dev += 1; }
+
+// ------------------------------------------------------------------------------------------------
+int linear(pa_model* m, const void* A, const void* W, const float* bias, void* Cout, int ldc, int M, int N, int K,
+           int relu, const void* R, int out_dtype, void* st) {
+    pa_gemm_args g; memset(&g, 0, sizeof(g));
+    g.A = A; g.B = W; g.C = Cout; g.bias = bias; g.R = R;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = ldc; g.ldr = ldc;
+    g.batch = 1; g.a_kcontig = 1; g.b_kcontig = 1;
+    g.in_dtype = m->cfg.dtype; g.out_dtype = out_dtype < 0 ? m->cfg.dtype : out_dtype;
+    g.alpha = 1.f; g.relu = relu; g.aux_scale = 1.f; g.splitk = 1;
+    return pa_gemm(&g, st);
+}
+
+size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tmax) {
+    const pa_model_cfg& c = m->cfg;
+    const size_t e = c.dtype == PA_BF16 ? 2 : 4, d = c.d_model, ff = c.d_ff;
+    Arena a{base, 0};
+    L->B = B; L->S = S; L->Tmax = Tmax;
+    L->cross_kv.resize(c.n_dec); L->self_kv.resize(c.n_dec);
+    for (int i = 0; i < c.n_dec; ++i) {
+        L->cross_kv[i] = a.take((size_t)B * S * 2 * d * e);
+        L->self_kv[i] = a.take((size_t)B * Tmax * 2 * d * e);
+    }
+    L->hid_cache = a.take((size_t)B * Tmax * d * e);
+    L->x = a.take(B * d * e); L->qkv = a.take(B * 3 * d * e); L->ao = a.take(B * d * e); L->z = a.take(B * d * e);
+    L->y = a.take(B * d * e); L->q = a.take(B * d * e); L->ff = a.take(B * ff * e); L->pfeat = a.take(B * d * e);
+    L->h = a.take(B * d * e);
+    L->vlog = (float*)a.take((size_t)B * ((c.vocab + 7) / 8 * 8) * 4);
+    L->mean = (float*)a.take(B * 4); L->rstd = (float*)a.take(B * 4);
+    L->tokens = (int64_t*)a.take((size_t)B * Tmax * 8); L->attach = (int64_t*)a.take((size_t)B * Tmax * 8);
+    L->first_end = (int32_t*)a.take(B * 4); L->t_dev = (int32_t*)a.take(256);
+    L->kpm = (uint8_t*)a.take((size_t)B * S);
+    return a.off;
+}
+
+template <typename T>
+int launch_attn(pa_model* m, T* out, const T* q, int ldq, const T* kv, int64_t bstride, int ldkv, int voff, const uint8_t* kpm,
+                int fixed_lk, const int32_t* t_dev, int B, void* st) {
+    const int d = m->cfg.d_model, H = m->cfg.n_head, dh = d / H;
+    const float scale = 1.0f / sqrtf((float)dh);
+    dim3 grid(H, B);
+    hipStream_t s = (hipStream_t)st;
+    switch (dh) {
+        case 16: hipLaunchKernelGGL((dec_attn_kernel<T, 16>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
+        case 32: hipLaunchKernelGGL((dec_attn_kernel<T, 32>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
+        case 64: hipLaunchKernelGGL((dec_attn_kernel<T, 64>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
+        default: return PA_ESHAPE;
+    }
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int step_impl(pa_model* m, void* st) {
+    const pa_model_cfg& c = m->cfg;
+    DecodeLayout* L = m->dec;
+    const int d = c.d_model, ff = c.d_ff, B = L->B, S = L->S, Tmax = L->Tmax;
+    hipStream_t s = (hipStream_t)st;
+    auto PF = [&](int i) { return (const float*)m->pf[i]; };
+    auto PL = [&](int i) { return (const void*)m->pl[i]; };
+    const size_t e = sizeof(T);
+    const int g1 = (B * (d / 4) + 255) / 256;
+    hipLaunchKernelGGL(dec_embed_kernel<T>, dim3(g1), dim3(256), 0, s, (T*)L->x, PF(P_IN_VALUE), PF(P_Q_COORD), PF(P_Q_POS),
+                       L->tokens, Tmax, L->t_dev, B, d, c.out_dof);
+    PA_CHECK_LAUNCH();
+    void* x = L->x;
+    for (int i = 0; i < c.n_dec; ++i) {
+        const int pb = m->dec_base(i);
+        RC(linear(m, x, PL(pb + D_SA_IN_W), PF(pb + D_SA_IN_B), L->qkv, 3 * d, B, 3 * d, d, 0, nullptr, -1, st));
+        hipLaunchKernelGGL(dec_append_kv_kernel<T>, dim3((B * (2 * d / 4) + 255) / 256), dim3(256), 0, s, (T*)L->self_kv[i],
+                           (const T*)L->qkv, L->t_dev, B, Tmax, d);
+        PA_CHECK_LAUNCH();
+        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->qkv, 3 * d, (const T*)L->self_kv[i], (int64_t)Tmax * 2 * d, 2 * d, d, nullptr, 0,
+                          L->t_dev, B, st));
+        RC(linear(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), L->z, d, B, d, d, 0, x, -1, st));
+        RC(pa_layernorm_fwd(L->y, L->z, PF(pb + D_N1_W), PF(pb + D_N1_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
+        RC(linear(m, L->y, PL(pb + D_CA_IN_W), PF(pb + D_CA_IN_B), L->q, d, B, d, d, 0, nullptr, -1, st));
+        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->q, d, (const T*)L->cross_kv[i], (int64_t)S * 2 * d, 2 * d, d, L->kpm, S,
+                          L->t_dev, B, st));
+        RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z, d, B, d, d, 0, L->y, -1, st));
+        RC(pa_layernorm_fwd(L->x, L->z, PF(pb + D_N2_W), PF(pb + D_N2_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
+        RC(linear(m, L->x, PL(pb + D_L1_W), PF(pb + D_L1_B), L->ff, ff, B, ff, d, 1, nullptr, -1, st));
+        RC(linear(m, L->ff, PL(pb + D_L2_W), PF(pb + D_L2_B), L->z, d, B, d, ff, 0, L->x, -1, st));
+        RC(pa_layernorm_fwd(L->x, L->z, PF(pb + D_N3_W), PF(pb + D_N3_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
+        (void)e;
+    }
+    RC(pa_layernorm_fwd(L->h, L->x, PF(m->dec_norm()), PF(m->dec_norm() + 1), L->mean, L->rstd, B, d, c.eps_final, c.dtype, st));
+    const int tl = m->tail(), ldv = (c.vocab + 7) / 8 * 8;
+    RC(linear(m, L->h, PL(tl + T_VOCAB_W), PF(tl + T_VOCAB_B), L->vlog, ldv, B, c.vocab, d, 0, nullptr, PA_F32, st));
+    RC(linear(m, L->h, PL(tl + T_PTR_W), PF(tl + T_PTR_B), L->pfeat, d, B, d, d, 0, nullptr, -1, st));
+    hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(B), dim3(256), 0, s, L->vlog, ldv, (const T*)L->pfeat, (const T*)L->h,
+                       (T*)L->hid_cache, PF(tl + T_SW_W), PF(tl + T_SW_B), L->tokens, L->attach, L->first_end, L->t_dev, Tmax, d,
+                       c.vocab, c.end);
+    PA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(64), 0, s, L->t_dev);
+    PA_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+void pa_decode_free_layout(pa_model* m) {
+    if (m && m->dec) { delete m->dec; m->dec = nullptr; }
+}
+
+extern "C" int64_t pa_decode_ws_bytes(pa_model* m, int32_t B, int32_t S, int32_t Tmax) {
+    if (!m || B <= 0 || S <= 0 || Tmax <= 0 || Tmax > MAX_T) return PA_EINVAL;
+    DecodeLayout tmp;
+    return (int64_t)dec_layout(m, &tmp, nullptr, B, S, Tmax) + 256;
+}
+
+// Requires a preceding encoder-only pa_model_train_fwd (batch.output_value == NULL) on the same stream:
+// uses its memory, batch size, sequence length and input_mask.
+extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t Tmax, void* stream) {
+    if (!m || !m->bound || !ws || m->B <= 0 || Tmax <= 0 || Tmax > MAX_T) return PA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) return PA_EALIGN;
+    if (!m->dec) m->dec = new (std::nothrow) DecodeLayout();
+    if (!m->dec) return PA_EINVAL;
+    DecodeLayout* L = m->dec;
+    const size_t need = dec_layout(m, L, (char*)ws, m->B, m->S, Tmax);
+    if ((int64_t)need > ws_bytes) return PA_EINVAL;
+    const pa_model_cfg& c = m->cfg;
+    const int d = c.d_model, B = m->B, S = m->S;
+    const size_t e = c.dtype == PA_BF16 ? 2 : 4;
+    const void* memory = c.has_enc_norm ? m->memory : m->X[c.n_enc];
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < c.n_dec; ++i) {       // cross-attention K/V of the memory: once per sequence, not per step
+        const int pb = m->dec_base(i);
+        RC(linear(m, memory, (const char*)m->pl[pb + D_CA_IN_W] + (size_t)d * d * e, (const float*)m->pf[pb + D_CA_IN_B] + d,
+                  L->cross_kv[i], 2 * d, B * S, 2 * d, d, 0, nullptr, -1, stream));
+    }
+    hipError_t he = hipMemcpyAsync(L->kpm, m->batch.input_mask, (size_t)B * S, hipMemcpyDeviceToDevice, s);
+    if (he != hipSuccess) return (int)he;
+    he = hipMemsetAsync(L->first_end, 0xFF, (size_t)B * 4, s);
+    if (he != hipSuccess) return (int)he;
+    he = hipMemsetAsync(L->t_dev, 0, 4, s);
+    if (he != hipSuccess) return (int)he;
+    he = hipMemsetAsync(L->tokens, 0, (size_t)B * Tmax * 8, s);
+    if (he != hipSuccess) return (int)he;
+    he = hipMemsetAsync(L->attach, 0xFF, (size_t)B * Tmax * 8, s);
+    return he == hipSuccess ? 0 : (int)he;
+}
+
+extern "C" int pa_decode_step(pa_model* m, void* stream) {
+    if (!m || !m->dec || m->dec->B <= 0) return PA_EINVAL;
+    return m->cfg.dtype == PA_BF16 ? step_impl<bf16>(m, stream) : step_impl<float>(m, stream);
+}
+
+extern "C" int pa_decode_buffers(pa_model* m, void** tokens, void** attach, void** first_end, void** t_dev) {
+    if (!m || !m->dec || !tokens || !attach || !first_end || !t_dev) return PA_EINVAL;
+    *tokens = m->dec->tokens; *attach = m->dec->attach; *first_end = m->dec->first_end; *t_dev = m->dec->t_dev;
+    return 0;
+}

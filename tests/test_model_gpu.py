@@ -162,3 +162,61 @@ def test_dropout_training_runs_and_is_stochastic(small_fixture):
     assert torch.isfinite(l1) and torch.isfinite(l2) and abs(l1.item() - l2.item()) > 1e-6
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
     m.eval()
+
+
+# ------------------------------------------------------------------------------------------ greedy decode
+@pytest.mark.parametrize("graph", [False, True])
+def test_g4_greedy_decode_token_exact(small_fixture, graph):
+    import plankassembly_amd.decode as D
+    sd, batch, g = small_fixture
+    m = make(sd).eval()
+    m._ensure_handle()
+    m._decoder = D.GreedyDecoder(m, use_graph=graph, check_every=5)
+    with torch.no_grad():
+        out = m(to_dev(batch))
+    assert np.array_equal(out["samples"].cpu().numpy(), g["g4::samples"])       # bit-exact tokens
+    assert np.array_equal(out["attach"].cpu().numpy(), g["g4::attach"])
+    assert (out["attach"] >= 0).any()
+    for i, (p, q) in enumerate(zip(out["predicts"], out["groundtruths"])):
+        assert np.array_equal(p.cpu().numpy(), g[f"g4::predict{i}"])
+        assert np.array_equal(q.cpu().numpy(), g[f"g4::groundtruth{i}"])
+    # a second call (graph reuse, new batch tensors) gives the same answer
+    with torch.no_grad():
+        out2 = m(to_dev(batch))
+    assert torch.equal(out2["samples"], out["samples"]) and torch.equal(out2["attach"], out["attach"])
+
+
+def test_g7_greedy_decode_ragged_sideface(ragged_fixture):
+    sd, batch, g = ragged_fixture
+    m = make(sd).eval()
+    with torch.no_grad():
+        out = m(to_dev(batch))
+    assert np.array_equal(out["samples"].cpu().numpy(), g["g4::samples"])
+    assert np.array_equal(out["attach"].cpu().numpy(), g["g4::attach"])
+
+
+def test_greedy_decode_no_early_stop_matches_oracle(small_fixture):
+    """Run all max_output_length steps (the decode benchmark mode) and compare with the oracle."""
+    from oracle import plank_oracle as O
+    import plankassembly_amd.decode as D
+    sd, batch, _ = small_fixture
+    cfg = O.OracleCfg(d_model=64, n_head=4, d_ff=128, n_enc=2, n_dec=2, max_input_length=65, max_output_length=36)
+    with torch.no_grad():
+        s_ref, a_ref = O.greedy_decode_cached(sd, cfg, batch, early_stop=False)
+    m = make(sd).eval()
+    m._ensure_handle()
+    dec = D.GreedyDecoder(m)
+    s, a = dec.run(to_dev(batch), early_stop=False)
+    assert s.shape == (4, 36)
+    assert torch.equal(s.cpu(), s_ref) and torch.equal(a.cpu(), a_ref)
+
+
+def test_greedy_decode_bf16_mostly_agrees(small_fixture):
+    sd, batch, g = small_fixture
+    m = make(sd, "bf16").eval()
+    with torch.no_grad():
+        out = m(to_dev(batch))
+    ref = torch.from_numpy(g["g4::samples"])
+    n = min(ref.shape[1], out["samples"].shape[1])
+    agree = (out["samples"].cpu()[:, :n] == ref[:, :n]).float().mean().item()
+    assert agree > 0.9, agree
