@@ -129,8 +129,10 @@ int pa_layernorm_bwd(void* dz, void* ddrop, const void* dy, const void* z, const
  *   so Q/K/V may be views into the packed in_proj output);
  *   kpm: uint8 [B][Lk], 1 = masked key (PAD), or NULL;  causal: key j allowed iff j <= i;
  *   lse: f32 [B][H][Lq] log-sum-exp of the scaled, masked scores (saved for backward);
- *   dropout on the attention probabilities (torch MHA `dropout`): element index
- *   ((b*H+h)*Lq+i)*Lk+j hashed with drop_seed.
+ *   dropout on the attention probabilities (torch MHA `dropout`): counter-based, one hash of
+ *   (drop_seed, ((b*H+h)*Lq+i)*ceil(Lk/4) + j/4) decides 4 consecutive keys with 8 bits each, i.e. the
+ *   drop probability is quantised to round(256 p)/256 (0.2 -> 51/256) and survivors are scaled by
+ *   256/(256 - round(256 p)) so the expectation is exact; backward regenerates the same mask.
  * bwd: dq/dk/dv have the layouts of q/k/v; delta is f32 scratch [B][H][Lq].
  */
 typedef struct {

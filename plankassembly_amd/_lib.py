@@ -50,6 +50,20 @@ class AttnArgs(C.Structure):
 _lib = None
 
 
+def _check_single_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64; our library must bind to THAT copy (it does when torch was
+    imported first, which this module guarantees) - two HIP runtimes in one process do not share streams."""
+    try:
+        maps = open("/proc/self/maps").read()
+    except OSError:                                            # pragma: no cover
+        return
+    libs = {ln.split()[-1] for ln in maps.splitlines() if "libamdhip64" in ln}
+    if len(libs) > 1:
+        raise PlankHipError(
+            "two HIP runtimes are mapped into this process (" + ", ".join(sorted(libs)) + "): libplank_hip.so was "
+            "loaded before torch. Import torch (or plankassembly_amd) before dlopen-ing libplank_hip.so.")
+
+
 def lib():
     """Load (once) and return the shared library; raises if it is not built."""
     global _lib
@@ -59,6 +73,7 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -m plankassembly_amd.build` "
                 "(hipcc, gfx950).  plankassembly_amd has no fallback path.")
         _lib = C.CDLL(LIB_PATH)
+        _check_single_hip_runtime()
         P, I, I64, F, U = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
         sig = {
             "pa_version": (I, []),

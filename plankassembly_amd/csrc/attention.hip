@@ -25,13 +25,16 @@ constexpr int BOWN = 128;   // rows owned by a block (32 per wave)
 constexpr int BSTR = 64;    // rows streamed per step
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
+constexpr float RESCALE_THR = 8.0f;   // log2 units: running max is only raised when it grows by more than 2^8
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct AttnP {
     const void* q; const void* k; const void* v; void* o; float* lse; const uint8_t* kpm;
     int B, H, Lq, Lk;
     int ldq, ldk, ldv, ldo;
     int causal; float scale;
-    uint32_t drop_thr; float drop_scale; uint32_t drop_seed;
+    uint32_t drop_thr; float drop_scale; uint32_t drop_seed; int nk4;
     const void* dout; void* dq; void* dk; void* dv; float* delta;
     int lddo, lddq, lddk, lddv;
 };
@@ -310,29 +313,39 @@ __global__ __launch_bounds__(NTH) void attn_fwd_kernel(AttnP p) {
                 }
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_safe);
-        m_run = m_new;
+        // Deferred rescale: the running max (any upper-bound-ish reference works for softmax) is raised only
+        // when some row of this wave outgrew it by more than 2^RESCALE_THR; then O and l are rescaled once.
+        // Scaling by a power-of-two-ish factor does not change floating-point relative error, and l, O and the
+        // LSE all use the same reference, so the result is exact up to rounding.
+        if (__any(mx > m_run + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float ms = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2(m_run - ms);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            m_run = m_new;
+        }
+        const float m_safe = (m_run == -INFINITY) ? 0.f : m_run;
         float lsum = 0.f;
+        const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.nk4);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pe = exp2f(sacc[kt][r] - m_safe);
-                lsum += pe;
-                if (p.drop_thr) {
-                    const int key = k0 + kt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                    const uint32_t idx = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.Lk + key);
-                    pe = drop_keep(p.drop_seed, idx, p.drop_thr) ? pe * p.drop_scale : 0.f;
+            for (int g = 0; g < 4; ++g) {
+                uint32_t hsh = 0;
+                if (p.drop_thr) hsh = drop_hash4(p.drop_seed, drow + ((k0 + kt * 32 + 8 * g + 4 * half) >> 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pe = fast_exp2(sacc[kt][4 * g + e] - m_safe);
+                    lsum += pe;
+                    if (p.drop_thr) pe = drop_keep4(hsh, e, p.drop_thr) ? pe * p.drop_scale : 0.f;
+                    sacc[kt][4 * g + e] = pe;
                 }
-                sacc[kt][r] = pe;
             }
-        l_run = l_run * alpha + lsum;
-#pragma unroll
-        for (int dt = 0; dt < A::NDT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        l_run += lsum;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) MmaTr<T, DH>::run(oacc, vtr, kt * 32, sacc[kt], lane);
 
@@ -400,6 +413,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
     const float sl = p.scale * LOG2E;
+    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.nk4);
 
     u32x4 st[A::NITEM][4];
     uint8_t mreg = 0;
@@ -459,16 +473,15 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP p) {
             for (int g = 0; g < 4; ++g) {
                 const int koff = kt * 32 + 8 * g + 4 * half;
                 const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
+                uint32_t hsh = 0;
+                if (p.drop_thr) hsh = drop_hash4(p.drop_seed, drow + ((k0 + koff) >> 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int key = k0 + koff + e;
                     const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
-                    const float pe = masked ? 0.f : exp2f(sacc[4 * g + e] * sl - lse2);
+                    const float pe = masked ? 0.f : fast_exp2(sacc[4 * g + e] * sl - lse2);
                     float dp = dpacc[4 * g + e];
-                    if (p.drop_thr) {
-                        const uint32_t idx = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.Lk + key);
-                        dp = drop_keep(p.drop_seed, idx, p.drop_thr) ? dp * p.drop_scale : 0.f;
-                    }
+                    if (p.drop_thr) dp = drop_keep4(hsh, e, p.drop_thr) ? dp * p.drop_scale : 0.f;
                     sacc[4 * g + e] = pe * (dp - dlt) * p.scale;          // dS^T
                 }
             }
@@ -576,12 +589,12 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP p) {
                 for (int e = 0; e < 4; ++e) {
                     const int qr = r0 + qoff + e;
                     const bool masked = kmasked || (p.causal && krow > qr);
-                    float pe = masked ? 0.f : exp2f(sacc[4 * g + e] * sl - l4[e]);
+                    float pe = masked ? 0.f : fast_exp2(sacc[4 * g + e] * sl - l4[e]);
                     float dp = dpacc[4 * g + e];
                     float pd = pe;
                     if (p.drop_thr) {
-                        const uint32_t idx = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qr) * p.Lk + krow);
-                        const bool keep = drop_keep(p.drop_seed, idx, p.drop_thr);
+                        const uint32_t idx4 = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qr) * p.nk4 + (krow >> 2));
+                        const bool keep = drop_keep4(drop_hash4(p.drop_seed, idx4), krow & 3, p.drop_thr);
                         dp = keep ? dp * p.drop_scale : 0.f;
                         pd = keep ? pe * p.drop_scale : 0.f;
                     }
@@ -608,8 +621,9 @@ AttnP make_params(const pa_attn_args* a) {
     p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk;
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
     p.causal = a->causal; p.scale = a->scale;
-    p.drop_thr = (uint32_t)(a->drop_p * 65536.0f + 0.5f);
-    p.drop_scale = 1.0f / (1.0f - a->drop_p);
+    p.drop_thr = (uint32_t)(a->drop_p * 256.0f + 0.5f);            // 8-bit resolution (see drop_hash4)
+    p.drop_scale = 256.0f / (256.0f - (float)p.drop_thr);
+    p.nk4 = (a->Lk + 3) / 4;
     p.drop_seed = a->drop_seed;
     p.dout = a->dout; p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.delta = a->delta;
     p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
@@ -629,24 +643,20 @@ template <typename T, int DH> int run_fwd(const AttnP& p, hipStream_t st) {
     int rc = set_lds(attn_fwd_kernel<T, DH>, shm);
     if (rc) return rc;
     dim3 grid((p.Lq + BOWN - 1) / BOWN, p.H, p.B);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(NTH), shm, st, p);
-    PA_CHECK_LAUNCH();
+    PA_LAUNCH((attn_fwd_kernel<T, DH>), grid, dim3(NTH), shm, st, p);
     return 0;
 }
 template <typename T, int DH> int run_bwd(const AttnP& p, hipStream_t st) {
     const int64_t total = (int64_t)p.B * p.H * p.Lq;
-    hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
-    PA_CHECK_LAUNCH();
+    PA_LAUNCH((attn_delta_kernel<T, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
     int shm = 2 * Smem<T, DH>::BUF_DKV;
     int rc = set_lds(attn_bwd_dkv_kernel<T, DH>, shm);
     if (rc) return rc;
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DH>), dim3((p.Lk + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
-    PA_CHECK_LAUNCH();
+    PA_LAUNCH((attn_bwd_dkv_kernel<T, DH>), dim3((p.Lk + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
     shm = 2 * Smem<T, DH>::BUF_DQ;
     rc = set_lds(attn_bwd_dq_kernel<T, DH>, shm);
     if (rc) return rc;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), dim3((p.Lq + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
-    PA_CHECK_LAUNCH();
+    PA_LAUNCH((attn_bwd_dq_kernel<T, DH>), dim3((p.Lq + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
     return 0;
 }
 

@@ -103,6 +103,12 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t 
     return (h >> 16) >= thr16;
 }
 
+// Attention-probability dropout: ONE hash yields the keep decisions of 4 consecutive keys of a query row
+// (8 bits each; the drop probability is quantised to thr8/256 and the survivors are scaled by 256/(256-thr8),
+// so the expectation is exact).  idx4 = row * ceil(Lk/4) + key/4, decision j = key & 3.
+__device__ __forceinline__ uint32_t drop_hash4(uint32_t seed, uint32_t idx4) { return mix32(idx4 * 0x9e3779b9u + seed); }
+__device__ __forceinline__ bool drop_keep4(uint32_t h, int j, uint32_t thr8) { return ((h >> (8 * j)) & 0xffu) >= thr8; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -114,4 +120,8 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-#define PA_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+// Launch + error check.  hipGetLastError() is sticky per thread: a stale error left behind by some unrelated
+// earlier runtime call (e.g. the host framework probing devices) must not be blamed on this launch, so it is
+// cleared first.
+#define PA_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); \
+        hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -284,12 +284,11 @@ int launch_attn(pa_model* m, T* out, const T* q, int ldq, const T* kv, int64_t b
     dim3 grid(H, B);
     hipStream_t s = (hipStream_t)st;
     switch (dh) {
-        case 16: hipLaunchKernelGGL((dec_attn_kernel<T, 16>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
-        case 32: hipLaunchKernelGGL((dec_attn_kernel<T, 32>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
-        case 64: hipLaunchKernelGGL((dec_attn_kernel<T, 64>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
+        case 16: PA_LAUNCH((dec_attn_kernel<T, 16>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
+        case 32: PA_LAUNCH((dec_attn_kernel<T, 32>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
+        case 64: PA_LAUNCH((dec_attn_kernel<T, 64>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
         default: return PA_ESHAPE;
     }
-    PA_CHECK_LAUNCH();
     return 0;
 }
 
@@ -303,16 +302,14 @@ int step_impl(pa_model* m, void* st) {
     auto PL = [&](int i) { return (const void*)m->pl[i]; };
     const size_t e = sizeof(T);
     const int g1 = (B * (d / 4) + 255) / 256;
-    hipLaunchKernelGGL(dec_embed_kernel<T>, dim3(g1), dim3(256), 0, s, (T*)L->x, PF(P_IN_VALUE), PF(P_Q_COORD), PF(P_Q_POS),
+    PA_LAUNCH(dec_embed_kernel<T>, dim3(g1), dim3(256), 0, s, (T*)L->x, PF(P_IN_VALUE), PF(P_Q_COORD), PF(P_Q_POS),
                        L->tokens, Tmax, L->t_dev, B, d, c.out_dof);
-    PA_CHECK_LAUNCH();
     void* x = L->x;
     for (int i = 0; i < c.n_dec; ++i) {
         const int pb = m->dec_base(i);
         RC(linear(m, x, PL(pb + D_SA_IN_W), PF(pb + D_SA_IN_B), L->qkv, 3 * d, B, 3 * d, d, 0, nullptr, -1, st));
-        hipLaunchKernelGGL(dec_append_kv_kernel<T>, dim3((B * (2 * d / 4) + 255) / 256), dim3(256), 0, s, (T*)L->self_kv[i],
+        PA_LAUNCH(dec_append_kv_kernel<T>, dim3((B * (2 * d / 4) + 255) / 256), dim3(256), 0, s, (T*)L->self_kv[i],
                            (const T*)L->qkv, L->t_dev, B, Tmax, d);
-        PA_CHECK_LAUNCH();
         RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->qkv, 3 * d, (const T*)L->self_kv[i], (int64_t)Tmax * 2 * d, 2 * d, d, nullptr, 0,
                           L->t_dev, B, st));
         RC(linear(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), L->z, d, B, d, d, 0, x, -1, st));
@@ -331,12 +328,10 @@ int step_impl(pa_model* m, void* st) {
     const int tl = m->tail(), ldv = (c.vocab + 7) / 8 * 8;
     RC(linear(m, L->h, PL(tl + T_VOCAB_W), PF(tl + T_VOCAB_B), L->vlog, ldv, B, c.vocab, d, 0, nullptr, PA_F32, st));
     RC(linear(m, L->h, PL(tl + T_PTR_W), PF(tl + T_PTR_B), L->pfeat, d, B, d, d, 0, nullptr, -1, st));
-    hipLaunchKernelGGL(dec_sample_kernel<T>, dim3(B), dim3(256), 0, s, L->vlog, ldv, (const T*)L->pfeat, (const T*)L->h,
+    PA_LAUNCH(dec_sample_kernel<T>, dim3(B), dim3(256), 0, s, L->vlog, ldv, (const T*)L->pfeat, (const T*)L->h,
                        (T*)L->hid_cache, PF(tl + T_SW_W), PF(tl + T_SW_B), L->tokens, L->attach, L->first_end, L->t_dev, Tmax, d,
                        c.vocab, c.end);
-    PA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dec_advance_kernel, dim3(1), dim3(64), 0, s, L->t_dev);
-    PA_CHECK_LAUNCH();
+    PA_LAUNCH(dec_advance_kernel, dim3(1), dim3(64), 0, s, L->t_dev);
     return 0;
 }
 

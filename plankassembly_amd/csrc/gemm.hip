@@ -269,9 +269,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
 
 template <typename T, bool A_KC, bool B_KC>
 int launch_t(const GemmP& p, bool aligned, dim3 grid, hipStream_t st) {
-    if (aligned) hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, true>), grid, dim3(NT), 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<T, A_KC, B_KC, false>), grid, dim3(NT), 0, st, p);
-    PA_CHECK_LAUNCH();
+    if (aligned) PA_LAUNCH((gemm_kernel<T, A_KC, B_KC, true>), grid, dim3(NT), 0, st, p);
+    else PA_LAUNCH((gemm_kernel<T, A_KC, B_KC, false>), grid, dim3(NT), 0, st, p);
     return 0;
 }
 template <typename T>
@@ -336,10 +335,9 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         if (a->in_dtype == PA_BF16)
-            hipLaunchKernelGGL(splitk_reduce_kernel<bf16>, dim3(blocks), dim3(256), 0, st, p, (const float*)a->ws);
+            PA_LAUNCH(splitk_reduce_kernel<bf16>, dim3(blocks), dim3(256), 0, st, p, (const float*)a->ws);
         else
-            hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, p, (const float*)a->ws);
-        PA_CHECK_LAUNCH();
+            PA_LAUNCH(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, p, (const float*)a->ws);
     }
     return 0;
 }
@@ -378,11 +376,9 @@ extern "C" int pa_colsum(const void* X, int32_t dtype, int32_t M, int32_t N, int
     const int nparts = (M + CS_ROWS - 1) / CS_ROWS;
     dim3 grid((N + 255) / 256, nparts);
     if (dtype == PA_BF16)
-        hipLaunchKernelGGL(colsum_partial_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)X, M, N, ldx, partial);
+        PA_LAUNCH(colsum_partial_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)X, M, N, ldx, partial);
     else
-        hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)X, M, N, ldx, partial);
-    PA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partial, nparts, N, out, accumulate);
-    PA_CHECK_LAUNCH();
+        PA_LAUNCH(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)X, M, N, ldx, partial);
+    PA_LAUNCH(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partial, nparts, N, out, accumulate);
     return 0;
 }

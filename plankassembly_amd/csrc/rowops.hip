@@ -442,9 +442,8 @@ extern "C" int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* con
     EmbTabs tb; tb.n = n_tables;
     for (int k = 0; k < 5; ++k) { tb.t[k] = k < n_tables ? tables[k] : nullptr; tb.idx[k] = k < n_tables ? idx[k] : nullptr; }
     const int grid = grid_for(n_tok * (d >> 2));
-    if (out_dtype == PA_BF16) hipLaunchKernelGGL(embed_input_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)out, tb, n_tok, d);
-    else hipLaunchKernelGGL(embed_input_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)out, tb, n_tok, d);
-    PA_CHECK_LAUNCH();
+    if (out_dtype == PA_BF16) PA_LAUNCH(embed_input_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)out, tb, n_tok, d);
+    else PA_LAUNCH(embed_input_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)out, tb, n_tok, d);
     return 0;
 }
 
@@ -454,9 +453,8 @@ extern "C" int pa_embed_input_bwd(const void* dout, int32_t dtype, float* const*
     EmbGrads tb; tb.n = n_tables;
     for (int k = 0; k < 5; ++k) { tb.t[k] = k < n_tables ? dtables[k] : nullptr; tb.idx[k] = k < n_tables ? idx[k] : nullptr; }
     const int grid = grid_for(n_tok * (d >> 2));
-    if (dtype == PA_BF16) hipLaunchKernelGGL(embed_input_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dout, tb, n_tok, d);
-    else hipLaunchKernelGGL(embed_input_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)dout, tb, n_tok, d);
-    PA_CHECK_LAUNCH();
+    if (dtype == PA_BF16) PA_LAUNCH(embed_input_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dout, tb, n_tok, d);
+    else PA_LAUNCH(embed_input_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)dout, tb, n_tok, d);
     return 0;
 }
 
@@ -465,9 +463,8 @@ extern "C" int pa_embed_output_fwd(void* out, int32_t out_dtype, const float* va
                                    void* stream) {
     if (!out || !value || !coord || !pos || !tok || (d & 3) || B <= 0 || T <= 0 || dof <= 0) return PA_EINVAL;
     const int grid = grid_for((int64_t)B * T * (d >> 2));
-    if (out_dtype == PA_BF16) hipLaunchKernelGGL(embed_output_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)out, value, coord, pos, tok, tok_ld, B, T, d, dof);
-    else hipLaunchKernelGGL(embed_output_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)out, value, coord, pos, tok, tok_ld, B, T, d, dof);
-    PA_CHECK_LAUNCH();
+    if (out_dtype == PA_BF16) PA_LAUNCH(embed_output_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)out, value, coord, pos, tok, tok_ld, B, T, d, dof);
+    else PA_LAUNCH(embed_output_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)out, value, coord, pos, tok, tok_ld, B, T, d, dof);
     return 0;
 }
 
@@ -476,9 +473,8 @@ extern "C" int pa_embed_output_bwd(const void* dout, int32_t dtype, float* dvalu
                                    void* stream) {
     if (!dout || !dvalue || !dcoord || !dpos || !tok || (d & 3) || B <= 0 || T <= 0 || dof <= 0) return PA_EINVAL;
     const int grid = grid_for((int64_t)B * T * (d >> 2));
-    if (dtype == PA_BF16) hipLaunchKernelGGL(embed_output_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dout, dvalue, dcoord, dpos, tok, tok_ld, B, T, d, dof);
-    else hipLaunchKernelGGL(embed_output_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)dout, dvalue, dcoord, dpos, tok, tok_ld, B, T, d, dof);
-    PA_CHECK_LAUNCH();
+    if (dtype == PA_BF16) PA_LAUNCH(embed_output_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dout, dvalue, dcoord, dpos, tok, tok_ld, B, T, d, dof);
+    else PA_LAUNCH(embed_output_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)dout, dvalue, dcoord, dpos, tok, tok_ld, B, T, d, dof);
     return 0;
 }
 
@@ -490,9 +486,8 @@ extern "C" int pa_layernorm_fwd(void* y, const void* z, const float* gamma, cons
                                 int64_t rows, int32_t d, float eps, int32_t dtype, void* stream) {
     if (!y || !z || !gamma || !beta || !mean || !rstd || rows <= 0 || (d & 3) || d > 256 * MAXV) return PA_EINVAL;
     const int grid = (int)((rows + 3) / 4);
-    if (dtype == PA_BF16) hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)y, (const bf16*)z, gamma, beta, mean, rstd, rows, d, eps);
-    else hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)y, (const float*)z, gamma, beta, mean, rstd, rows, d, eps);
-    PA_CHECK_LAUNCH();
+    if (dtype == PA_BF16) PA_LAUNCH(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)y, (const bf16*)z, gamma, beta, mean, rstd, rows, d, eps);
+    else PA_LAUNCH(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)y, (const float*)z, gamma, beta, mean, rstd, rows, d, eps);
     return 0;
 }
 
@@ -507,11 +502,9 @@ extern "C" int pa_layernorm_bwd(void* dz, void* ddrop, const void* dy, const voi
     const float scale = 1.0f / (1.0f - drop_p);
     const int grid = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
     const size_t shm = (size_t)4 * 3 * d * sizeof(float);
-    if (dtype == PA_BF16) hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), shm, ST(stream), (bf16*)dz, (bf16*)ddrop, (const bf16*)dy, (const bf16*)z, gamma, mean, rstd, partial, rows, d, thr, scale, drop_seed, dzsum ? 1 : 0);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), shm, ST(stream), (float*)dz, (float*)ddrop, (const float*)dy, (const float*)z, gamma, mean, rstd, partial, rows, d, thr, scale, drop_seed, dzsum ? 1 : 0);
-    PA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(partial_finish_kernel, dim3((d + 255) / 256, dzsum ? 3 : 2), dim3(256), 0, ST(stream), partial, grid, 3 * d, d, d, dgamma, dbeta, dzsum);
-    PA_CHECK_LAUNCH();
+    if (dtype == PA_BF16) PA_LAUNCH(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), shm, ST(stream), (bf16*)dz, (bf16*)ddrop, (const bf16*)dy, (const bf16*)z, gamma, mean, rstd, partial, rows, d, thr, scale, drop_seed, dzsum ? 1 : 0);
+    else PA_LAUNCH(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), shm, ST(stream), (float*)dz, (float*)ddrop, (const float*)dy, (const float*)z, gamma, mean, rstd, partial, rows, d, thr, scale, drop_seed, dzsum ? 1 : 0);
+    PA_LAUNCH(partial_finish_kernel, dim3((d + 255) / 256, dzsum ? 3 : 2), dim3(256), 0, ST(stream), partial, grid, 3 * d, d, d, dgamma, dbeta, dzsum);
     return 0;
 }
 
@@ -519,9 +512,8 @@ extern "C" int pa_switch_fwd(float* s, const void* h, int32_t dtype, const float
                              int32_t d, void* stream) {
     if (!s || !h || !w || !b || rows <= 0 || (d & 3)) return PA_EINVAL;
     const int grid = (int)((rows + 3) / 4);
-    if (dtype == PA_BF16) hipLaunchKernelGGL(switch_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), s, (const bf16*)h, w, b, rows, d);
-    else hipLaunchKernelGGL(switch_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), s, (const float*)h, w, b, rows, d);
-    PA_CHECK_LAUNCH();
+    if (dtype == PA_BF16) PA_LAUNCH(switch_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), s, (const bf16*)h, w, b, rows, d);
+    else PA_LAUNCH(switch_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), s, (const float*)h, w, b, rows, d);
     return 0;
 }
 
@@ -530,14 +522,11 @@ extern "C" int pa_switch_bwd(void* dh, int32_t accumulate, float* dw, float* db,
     if (!dh || !dw || !db || !ds || !h || !w || !partial || rows <= 0 || (d & 3) || d > 256 * MAXV) return PA_EINVAL;
     const int grid = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
     const size_t shm = (size_t)(4 * d + 4) * sizeof(float);
-    if (dtype == PA_BF16) hipLaunchKernelGGL(switch_bwd_kernel<bf16>, dim3(grid), dim3(256), shm, ST(stream), (bf16*)dh, accumulate, ds, (const bf16*)h, w, partial, rows, d);
-    else hipLaunchKernelGGL(switch_bwd_kernel<float>, dim3(grid), dim3(256), shm, ST(stream), (float*)dh, accumulate, ds, (const float*)h, w, partial, rows, d);
-    PA_CHECK_LAUNCH();
+    if (dtype == PA_BF16) PA_LAUNCH(switch_bwd_kernel<bf16>, dim3(grid), dim3(256), shm, ST(stream), (bf16*)dh, accumulate, ds, (const bf16*)h, w, partial, rows, d);
+    else PA_LAUNCH(switch_bwd_kernel<float>, dim3(grid), dim3(256), shm, ST(stream), (float*)dh, accumulate, ds, (const float*)h, w, partial, rows, d);
     // partial rows: [blk][0][d] = dw, [blk][1][0] = db
-    hipLaunchKernelGGL(partial_finish_kernel, dim3((d + 255) / 256, 1), dim3(256), 0, ST(stream), partial, grid, 2 * d, d, d, dw, (float*)nullptr, (float*)nullptr);
-    PA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(partial_finish_kernel, dim3(1, 1), dim3(256), 0, ST(stream), partial + d, grid, 2 * d, d, 1, db, (float*)nullptr, (float*)nullptr);
-    PA_CHECK_LAUNCH();
+    PA_LAUNCH(partial_finish_kernel, dim3((d + 255) / 256, 1), dim3(256), 0, ST(stream), partial, grid, 2 * d, d, d, dw, (float*)nullptr, (float*)nullptr);
+    PA_LAUNCH(partial_finish_kernel, dim3(1, 1), dim3(256), 0, ST(stream), partial + d, grid, 2 * d, d, 1, db, (float*)nullptr, (float*)nullptr);
     return 0;
 }
 
@@ -546,8 +535,7 @@ extern "C" int pa_mixture_nll_fwd(float* stats, float* row_lse, const float* voc
                                   void* stream) {
     if (!stats || !row_lse || !vocab || !ptr || !sw || !label || B <= 0 || T <= 0 || V <= 0 || ldv < V) return PA_EINVAL;
     const int grid = (int)(((int64_t)B * T + 3) / 4);
-    hipLaunchKernelGGL(mixture_nll_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad);
-    PA_CHECK_LAUNCH();
+    PA_LAUNCH(mixture_nll_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad);
     return 0;
 }
 
@@ -558,9 +546,8 @@ extern "C" int pa_mixture_nll_bwd(void* dvocab, void* dptr, int32_t out_dtype, f
     if (!dvocab || !dptr || !dsw || !stats || !row_lse || !vocab || !ptr || !sw || !label) return PA_EINVAL;
     if (B <= 0 || T <= 0 || V <= 0 || ldv < V) return PA_EINVAL;
     const int grid = (int)(((int64_t)B * T + 3) / 4);
-    if (out_dtype == PA_BF16) hipLaunchKernelGGL(mixture_nll_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)dvocab, (bf16*)dptr, dsw, stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, gscale);
-    else hipLaunchKernelGGL(mixture_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)dvocab, (float*)dptr, dsw, stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, gscale);
-    PA_CHECK_LAUNCH();
+    if (out_dtype == PA_BF16) PA_LAUNCH(mixture_nll_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)dvocab, (bf16*)dptr, dsw, stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, gscale);
+    else PA_LAUNCH(mixture_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)dvocab, (float*)dptr, dsw, stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, gscale);
     return 0;
 }
 
@@ -572,19 +559,17 @@ extern "C" int pa_adam_step(float* p, const float* g, float* m, float* v, void* 
     const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, (bf16*)p_bf16, n,
+    PA_LAUNCH(adam_kernel, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, ST(stream), p, g, m, v, (bf16*)p_bf16, n,
                        step_size, b1, b2, eps, inv_sqrt_bc2, gscale);
-    PA_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int pa_cast(void* dst, int32_t dst_dtype, const void* src, int32_t src_dtype, int64_t n, void* stream) {
     if (!dst || !src || n <= 0) return PA_EINVAL;
     const int grid = grid_for(n, 256, 2048);
-    if (dst_dtype == PA_BF16 && src_dtype == PA_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, ST(stream), (bf16*)dst, (const float*)src, n);
-    else if (dst_dtype == PA_F32 && src_dtype == PA_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, ST(stream), (float*)dst, (const bf16*)src, n);
-    else if (dst_dtype == PA_F32 && src_dtype == PA_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, ST(stream), (float*)dst, (const float*)src, n);
+    if (dst_dtype == PA_BF16 && src_dtype == PA_F32) PA_LAUNCH((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, ST(stream), (bf16*)dst, (const float*)src, n);
+    else if (dst_dtype == PA_F32 && src_dtype == PA_BF16) PA_LAUNCH((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, ST(stream), (float*)dst, (const bf16*)src, n);
+    else if (dst_dtype == PA_F32 && src_dtype == PA_F32) PA_LAUNCH((cast_kernel<float, float>), dim3(grid), dim3(256), 0, ST(stream), (float*)dst, (const float*)src, n);
     else return PA_EINVAL;
-    PA_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,87 @@
+"""Data-parallel gradient exchange for PlankModel: one process per GPU, RCCL over xGMI.
+
+The reference gets data parallelism implicitly from Lightning's ``strategy: ddp``
+(configs/train_complete.yaml:18 -> torch DistributedDataParallel: 25 MB buckets of per-parameter
+gradients, NCCL all-reduce).  Here the gradients already live in ONE flat f32 buffer ordered
+[embeddings | encoder layers | encoder.norm | decoder layers | decoder.norm | heads], and the HIP
+backward runs in segments that finish contiguous slices of it (heads first).  After each segment
+the slice is handed to RCCL as a single large all-reduce that overlaps with the remaining
+backward kernels - a few contiguous 8-13 MB collectives per step instead of hundreds of
+per-parameter ones, sized for xGMI's per-link bound rather than for NVSwitch.
+
+The sum is left un-averaged; FusedAdam applies 1/world_size inside its kernel (``grad_scale``).
+Works on CPU tensors with the gloo backend too (that is how the CPU test-suite covers it).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, model, process_group=None, coalesce_below=2 * 1024 * 1024):
+        """``coalesce_below``: segments smaller than this many elements are merged with the next one
+        (encoder.norm / output-embedding slices are a few KB)."""
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.model = model
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.slices = model.segment_slices()
+        self.nseg = len(self.slices)
+        self.coalesce_below = coalesce_below
+        self._works = []
+        self._pending = None          # (lo, hi) run of contiguous finished-but-unsent slices
+        self.launched = []            # [(lo, hi)] of the last backward, for tests / introspection
+        model.register_grad_ready_hook(self._on_segment)
+
+    # the flat-buffer order is the reverse of the backward order, so finished slices extend DOWNWARDS
+    def _on_segment(self, seg, lo, hi):
+        if seg == 0:
+            self._works, self.launched, self._pending = [], [], None
+        if self._pending is None:
+            self._pending = (lo, hi)
+        elif hi == self._pending[0]:
+            self._pending = (lo, self._pending[1])
+        elif lo == self._pending[1]:
+            self._pending = (self._pending[0], hi)
+        else:                               # not adjacent: flush what we have, start a new run
+            self._flush()
+            self._pending = (lo, hi)
+        last = seg == self.nseg - 1
+        if last or (self._pending[1] - self._pending[0]) >= self.coalesce_below:
+            self._flush()
+        if last:
+            self.wait()
+
+    def _flush(self):
+        if self._pending is None:
+            return
+        lo, hi = self._pending
+        self._pending = None
+        if hi <= lo:
+            return
+        g = self.model.flat_grads
+        # ProcessGroupNCCL (= RCCL on ROCm) orders the collective after the work already enqueued on
+        # the current stream and runs it on its own stream: the remaining backward kernels overlap.
+        self._works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched.append((lo, hi))
+
+    def wait(self):
+        for w in self._works:
+            w.wait()                        # stream-level wait on GPU, blocking on gloo
+        self._works = []
+
+    def broadcast_parameters(self, src=0):
+        """DDP constructor semantics: every rank starts from rank ``src``'s parameters."""
+        dist.broadcast(self.model.flat_params, src=src, group=self.group)
+        if getattr(self.model, "_shadow_version", None) is not None:
+            self.model._shadow_version = -1
+
+
+def allreduce_metric_sums(values, group=None):
+    """Sum a small vector of metric accumulators over ranks (reference plankassembly/metric.py:13-16,
+    ``dist_reduce_fx='sum'``; trainer_complete.py:87-89 ``sync_dist=True``)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
+    return values

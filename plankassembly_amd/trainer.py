@@ -1,0 +1,334 @@
+"""Trainer surface of the reference (trainer_complete.py / trainer_visible.py / trainer_sideface.py)
+for the MI355X hot path, without Lightning / detectron2 / torchmetrics / jsonargparse (none of
+them is installed in this image): same class, same hook names (Lightning 1.7: ``training_step``,
+``validation_step``, ``validation_epoch_end``, ``test_step``, ``test_epoch_end``,
+``configure_optimizers``, ``*_dataloader``), same YAML config files, same CLI shape
+(``fit`` / ``test``, ``--config``, ``--ckpt_path``, ``--trainer.<key> value``).
+
+What differs is underneath: ``self.model`` is the HIP-backed PlankModel, the optimizer is the fused
+Adam over the flat parameter buffer, and the ``ddp`` strategy is one process per GPU with the
+segmented RCCL gradient exchange of ``plankassembly_amd.distributed`` (launch with
+``python -m torch.distributed.run --nproc-per-node N trainer_complete.py fit --config ...``).
+Checkpoints are Lightning-shaped (``state_dict`` with the ``model.`` prefix + ``hyper_parameters``),
+so the reference's published checkpoints load and ours load in the reference.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .config import CfgNode, load_cli_config
+from .data import SynthSpec, synth_sample
+from .metric import build_criterion, build_matcher
+from .models import build_model
+
+
+class SyntheticDrawings(torch.utils.data.Dataset):
+    """Seeded synthetic samples with the reference dataloader's tensor layout (the real
+    PlankAssembly dataset needs network access)."""
+
+    def __init__(self, n, spec: SynthSpec, seed=2022):
+        self.n, self.spec, self.seed = n, spec, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        rng = np.random.default_rng(self.seed + i)
+        s = synth_sample(rng, self.spec)
+        out = {"name": f"synth_{self.seed}_{i:06d}"}
+        out.update({k: torch.from_numpy(np.asarray(v)) for k, v in s.items()})
+        return out
+
+
+def parse_splits_list(path):
+    """reference dataset/data_utils.py:28-46: a split file lists one info json per line."""
+    with open(path) as f:
+        return [ln.strip() for ln in f if ln.strip()]
+
+
+class _Logger:
+    def __init__(self, root="lightning_logs"):
+        v = 0
+        while os.path.exists(os.path.join(root, f"version_{v}")):
+            v += 1
+        self.log_dir = os.path.join(root, f"version_{v}")
+        self.history = []
+
+    def log(self, name, value, step):
+        self.history.append((step, name, float(value)))
+
+
+class Trainer(torch.nn.Module):
+    """reference trainer_complete.py:19-129."""
+
+    with_type = True
+    default_lines = (8, 299)
+
+    def __init__(self, hparams):
+        super().__init__()
+        self.hparams_dict = dict(hparams)
+        cfg = CfgNode(hparams)
+        self.cfg = cfg
+        self.model = build_model(cfg)
+        self.matcher = build_matcher(cfg.THRESHOLD)
+        self.criterion = build_criterion()
+        self.logger = None
+        self.global_step = 0
+        self._logged = {}
+
+    # ------------------------------------------------------------------ logging (self.log of Lightning)
+    def log(self, name, value, **kw):
+        v = float(value)
+        self._logged[name] = v
+        if self.logger is not None:
+            self.logger.log(name, v, self.global_step)
+
+    # ------------------------------------------------------------------ data
+    def _spec(self):
+        d = self.cfg.DATA
+        hi = min(self.default_lines[1], (d.MAX_INPUT_LENGTH - 2) // d.NUM_INPUT_DOF)
+        return SynthSpec(d.MAX_INPUT_LENGTH, d.MAX_OUTPUT_LENGTH, (min(self.default_lines[0], hi), hi),
+                         (2, (d.MAX_OUTPUT_LENGTH - 1) // d.NUM_OUTPUT_DOF), self.with_type)
+
+    def _loader(self, split_key, n_default, shuffle, drop_last, seed):
+        split = self.cfg.get(split_key)
+        if split and os.path.exists(split) and os.path.isdir(str(self.cfg.get("ROOT", ""))):
+            raise NotImplementedError(
+                "reading the real infos/*.json (reference line_data.py) is the next scope row (SURVEY 8f rank 2); "
+                "this round trains on the seeded synthetic generator")
+        ds = SyntheticDrawings(int(self.cfg.get("SYNTHETIC_SAMPLES", n_default)), self._spec(), seed)
+        sampler = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=shuffle, drop_last=drop_last)
+            shuffle = False
+        return torch.utils.data.DataLoader(ds, batch_size=self.cfg.BATCH_SIZE, shuffle=shuffle, drop_last=drop_last,
+                                           num_workers=0, sampler=sampler)
+
+    def train_dataloader(self):
+        return self._loader("DATASETS_TRAIN", 256, True, True, 2022)
+
+    def val_dataloader(self):
+        return self._loader("DATASETS_VALID", 64, False, False, 9_000_000)
+
+    def test_dataloader(self):
+        return self._loader("DATASETS_TEST", 64, False, False, 9_500_000)
+
+    # ------------------------------------------------------------------ steps
+    def training_step(self, batch, batch_idx):
+        outputs = self.model(batch)
+        loss = torch.mean(outputs["loss"])
+        self._train_stats = (loss.detach(), torch.mean(outputs["accuracy"]).detach())
+        return loss
+
+    def _valid_pred(self, pred):
+        """reference trainer_complete.py:78-79 / 100-101: drop boxes with a zero extent (row 0 = bbox kept)."""
+        if len(pred) <= 1:
+            return pred
+        ok = torch.all(torch.abs(pred[1:, 3:] - pred[1:, :3]) != 0, dim=1)
+        return torch.concat((pred[:1], pred[1:][ok]))
+
+    def validation_step(self, batch, batch_idx):
+        outputs = self.model(batch)
+        for pred, gt in zip(outputs["predicts"], outputs["groundtruths"]):
+            vp = self._valid_pred(pred)
+            prec, rec, f1 = self.matcher(vp[1:], gt[1:])
+            self.criterion.update(prec, rec, f1)
+
+    def validation_epoch_end(self, outputs=None):
+        prec, rec, f1 = self.criterion.compute()
+        self.criterion.reset()
+        self.log("val/precision", prec); self.log("val/recall", rec); self.log("val/fmeasure", f1)
+
+    def test_step(self, batch, batch_idx):
+        outputs = self.model(batch)
+        out_dir = os.path.join(self.logger.log_dir, "pred_jsons")
+        os.makedirs(out_dir, exist_ok=True)
+        for name, pred, gt, atta in zip(batch["name"], outputs["predicts"], outputs["groundtruths"], outputs["attach"]):
+            vp = self._valid_pred(pred)
+            prec, rec, f1 = self.matcher(vp[1:], gt[1:])
+            self.criterion.update(prec, rec, f1)
+            atta = atta[: vp.numel()].cpu().numpy()
+            atta = atta[: len(atta) // 6 * 6].reshape(-1, 6).tolist()
+            with open(os.path.join(out_dir, f"{name}.json"), "w") as f:
+                json.dump({"prediction": vp.cpu().numpy().reshape(-1, 6).tolist(), "attach": atta,
+                           "groundtruth": gt.cpu().numpy().reshape(-1, 6).tolist(), "precision": prec.item(),
+                           "recall": rec.item(), "fmeasure": f1.item()}, f, indent=4, separators=(", ", ": "))
+
+    def test_epoch_end(self, outputs=None):
+        prec, rec, f1 = self.criterion.compute()
+        self.criterion.reset()
+        self.log("test/precision", prec); self.log("test/recall", rec); self.log("test/fmeasure", f1)
+
+    def configure_optimizers(self):
+        from .optim import FusedAdam
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        return {"optimizer": FusedAdam(self.model, lr=self.cfg.LR, grad_scale=1.0 / world)}
+
+    # ------------------------------------------------------------------ checkpoints (Lightning-shaped)
+    def checkpoint(self, epoch, optimizer=None):
+        return {"epoch": epoch, "global_step": self.global_step,
+                "state_dict": {"model." + k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                "hyper_parameters": {"hparams": self.hparams_dict}}
+
+    def load_checkpoint(self, path):
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        sd = ck.get("state_dict", ck)
+        sd = {(k[6:] if k.startswith("model.") else k): v for k, v in sd.items()}
+        self.model.load_state_dict(sd)
+        return ck
+
+
+class VisibleTrainer(Trainer):
+    """reference trainer_visible.py: no augmentation in the train loader (a no-op for synthetic data)."""
+    default_lines = (8, 249)
+
+
+class SidefaceTrainer(Trainer):
+    """reference trainer_sideface.py: side-face tokens, no ``input_type``; a sample with no detected
+    side faces (input = [END, PAD...]) scores 0 and writes an empty prediction (:46-52)."""
+    with_type = False
+    default_lines = (0, 74)
+
+    def test_step(self, batch, batch_idx):
+        outputs = self.model(batch)
+        out_dir = os.path.join(self.logger.log_dir, "pred_jsons")
+        os.makedirs(out_dir, exist_ok=True)
+        for name, mask, pred, gt in zip(batch["name"], batch["input_mask"], outputs["predicts"], outputs["groundtruths"]):
+            gtl = gt.cpu().numpy().reshape(-1, 6).tolist()
+            if bool(torch.all(mask[1:])):
+                predl, (prec, rec, f1) = [], (torch.tensor(0.0),) * 3
+            else:
+                vp = self._valid_pred(pred)
+                prec, rec, f1 = self.matcher(vp[1:], gt[1:])
+                self.criterion.update(prec, rec, f1)
+                predl = vp.cpu().numpy().reshape(-1, 6).tolist()
+            with open(os.path.join(out_dir, f"{name}.json"), "w") as f:
+                json.dump({"prediction": predl, "groundtruth": gtl, "precision": prec.item(), "recall": rec.item(),
+                           "fmeasure": f1.item()}, f, indent=4, separators=(", ", ": "))
+
+
+# ====================================================================================== loop + CLI
+def _to_device(batch, dev):
+    return {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
+    """The part of ``pl.Trainer.fit/test`` the reference relies on."""
+    seed, tkw, hparams = load_cli_config(config)
+    for k, v in (overrides or {}).items():
+        tkw[k] = v
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if seed is not None:
+        torch.manual_seed(int(seed)); np.random.seed(int(seed))
+    module = trainer_cls(hparams)
+    module.logger = _Logger()
+    if ckpt_path:
+        module.load_checkpoint(ckpt_path)
+    dev = torch.device("cuda", local)
+    module.model.to(dev)
+    if subcommand == "test":
+        module.model.eval()
+        with torch.no_grad():
+            for i, batch in enumerate(module.test_dataloader()):
+                module.test_step(_to_device(batch, dev), i)
+        module.test_epoch_end()
+        if rank == 0:
+            print({k: round(v, 4) for k, v in module._logged.items()})
+        return module
+    opt = module.configure_optimizers()["optimizer"]
+    sync = None
+    if world > 1:
+        from .distributed import GradSync
+        sync = GradSync(module.model)
+        sync.broadcast_parameters(0)
+    max_epochs = int(tkw.get("max_epochs", 1))
+    every = int(tkw.get("check_val_every_n_epoch", 1))
+    max_steps = int(tkw.get("max_steps", -1))
+    best = -1.0
+    loader = module.train_dataloader()
+    for epoch in range(max_epochs):
+        module.model.train()
+        if hasattr(loader.sampler, "set_epoch"):
+            loader.sampler.set_epoch(epoch)
+        t0, n = time.perf_counter(), 0
+        for i, batch in enumerate(loader):
+            opt.zero_grad()
+            loss = module.training_step(_to_device(batch, dev), i)
+            loss.backward()
+            opt.step()
+            module.global_step += 1
+            n += batch["input_value"].shape[0]
+            if 0 < max_steps <= module.global_step:
+                break
+        l, a = module._train_stats
+        module.log("train/loss", l); module.log("train/accuracy", a)
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"epoch {epoch}: train/loss {float(l):.4f} train/accuracy {float(a):.4f} "
+                  f"{n * world / (time.perf_counter() - t0):.1f} samples/s")
+        if (epoch + 1) % every == 0:
+            module.model.eval()
+            with torch.no_grad():
+                for i, batch in enumerate(module.val_dataloader()):
+                    module.validation_step(_to_device(batch, dev), i)
+            module.validation_epoch_end()
+            f1 = module._logged.get("val/fmeasure", 0.0)
+            if rank == 0:
+                os.makedirs(os.path.join(module.logger.log_dir, "checkpoints"), exist_ok=True)
+                ck = module.checkpoint(epoch, opt)
+                torch.save(ck, os.path.join(module.logger.log_dir, "checkpoints", "last.ckpt"))
+                if f1 > best:                                      # ModelCheckpoint(monitor=val/fmeasure, mode=max)
+                    best = f1
+                    name = (f"checkpoint_{epoch:03d}-precision={module._logged['val/precision']:.3f}-"
+                            f"recall={module._logged['val/recall']:.3f}-f1={f1:.3f}.ckpt")
+                    torch.save(ck, os.path.join(module.logger.log_dir, "checkpoints", name))
+                print({k: round(v, 4) for k, v in module._logged.items() if k.startswith("val/")})
+        if 0 < max_steps <= module.global_step:
+            break
+    if sync is not None:
+        dist.barrier()
+    return module
+
+
+def cli(trainer_cls, argv=None):
+    """``python trainer_complete.py fit --config configs/train_complete.yaml [--ckpt_path x] [--trainer.devices 1]``"""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] not in ("fit", "test", "validate"):
+        raise SystemExit("usage: <trainer>.py {fit,test} --config CONFIG [--ckpt_path CKPT] [--trainer.KEY VALUE ...]")
+    sub, config, ckpt, over = argv[0], None, None, {}
+    i = 1
+    while i < len(argv):
+        key, val = argv[i], argv[i + 1] if i + 1 < len(argv) else None
+        if "=" in key:
+            key, val = key.split("=", 1)
+            i += 1
+        else:
+            i += 2
+        if key == "--config":
+            config = val
+        elif key == "--ckpt_path":
+            ckpt = val
+        elif key.startswith("--trainer."):
+            try:
+                val = json.loads(val)
+            except (ValueError, TypeError):
+                pass
+            over[key[len("--trainer."):]] = val
+        else:
+            raise SystemExit(f"unknown argument {key}")
+    if config is None:
+        raise SystemExit("--config is required")
+    return run(trainer_cls, "test" if sub != "fit" else "fit", config, ckpt, over)
