@@ -85,12 +85,13 @@ int pa_colsum(const void* X, int32_t dtype, int32_t M, int32_t N, int32_t ldx, f
  * pa_embed_output_fwd: reference models.py:114-138 (_embed_output): out[b][0] = 0,
  *   out[b][t] = value[tok[b][t-1]] + coord[(t-1) % dof] + pos[(t-1) / dof], t in [1, T).
  *   tok has row stride tok_ld (the reference passes output_value[:, :-1]).
- * pa_embed_*_bwd: scatter-add of d_out into the f32 table gradients (atomic).
+ * pa_embed_*_bwd: scatter-add of d_out into the f32 table gradients (atomic; tables with <= 8 rows, whose
+ *   row count the caller passes in table_rows (host array), are pre-reduced per block in LDS).
  */
 int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* const* tables, const int64_t* const* idx,
                        int32_t n_tables, int64_t n_tok, int32_t d, void* stream);
 int pa_embed_input_bwd(const void* dout, int32_t dtype, float* const* dtables, const int64_t* const* idx,
-                       int32_t n_tables, int64_t n_tok, int32_t d, void* stream);
+                       const int32_t* table_rows, int32_t n_tables, int64_t n_tok, int32_t d, void* stream);
 int pa_embed_output_fwd(void* out, int32_t out_dtype, const float* value, const float* coord, const float* pos,
                         const int64_t* tok, int32_t tok_ld, int32_t B, int32_t T, int32_t d, int32_t dof,
                         void* stream);
@@ -211,6 +212,7 @@ typedef struct pa_model pa_model;
 typedef struct {
     int32_t d_model, n_head, d_ff, n_enc, n_dec, vocab;
     int32_t out_dof;
+    int32_t in_table_rows[5];      /* rows of input_value / input_pos / input_coord / input_view / input_type */
     float eps_layer, eps_final;
     int32_t has_enc_norm;
     float dropout;

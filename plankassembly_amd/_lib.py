@@ -81,7 +81,7 @@ def lib():
             "pa_colsum_ws_floats": (I64, [I, I]),
             "pa_colsum": (I, [P, I, I, I, I, P, I, P, P]),
             "pa_embed_input_fwd": (I, [P, I, P, P, I, I64, I, P]),
-            "pa_embed_input_bwd": (I, [P, I, P, P, I, I64, I, P]),
+            "pa_embed_input_bwd": (I, [P, I, P, P, P, I, I64, I, P]),
             "pa_embed_output_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
             "pa_embed_output_bwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
             "pa_layernorm_ws_floats": (I64, [I64, I]),

@@ -1,14 +1,23 @@
 // MFMA GEMM with fused epilogue for gfx950.  See include/plank_hip.h (pa_gemm).
 //
-// Block = 256 threads = 4 waves (2 x 2), block tile 128 x 128, each wave 64 x 64 = 2 x 2 MFMA
-// 32x32 tiles (64 accumulator registers).  K tile: 128 bytes of contraction per row for bf16
-// (BK = 64), 64 bytes for f32 (BK = 16).  Operand tiles are staged global -> registers -> LDS
-// as [row][k] images (k contiguous, 16-byte chunks XOR-swizzled by row so that the 32 rows a
-// half-wave reads with ds_read_b128 spread over all banks).  Operands whose contraction index
-// is NOT contiguous in memory (dX = dY W, dW = dY^T X) are transposed in registers
-// (EB x EB element blocks) on their way into LDS, so the MFMA side is identical for all layouts.
-// Double-buffered LDS, one barrier per K tile; the global loads of tile t+1 are in flight
-// while tile t is multiplied.
+// Structure (v2)
+//  * 128 x 128 output tile per work unit, 256 threads = 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA 32x32
+//    tiles.  K tile = 128 bytes of contraction per row for bf16 (BK = 64), 64 bytes for f32 (BK = 16).
+//  * PERSISTENT blocks: grid = min(#units, 2 x 256 CUs); a block walks units u = blockIdx.x, += gridDim.x and the
+//    K-tile pipeline runs ACROSS unit boundaries (the first K tile of the next unit is fetched while the last one
+//    of the current unit is multiplied and its epilogue runs) - the model's GEMMs have K = 512..1536, i.e. only
+//    8..24 K tiles per unit, so fill/drain would otherwise dominate.
+//  * XCD-aware unit order: blocks b = x (mod 8) run on XCD x; unit -> (tile_m = 8*(i / tiles_n) + x, tile_n = i %
+//    tiles_n), so one XCD sweeps all column tiles of its row tiles and the activation panel stays in its L2.
+//  * Operand tiles live in LDS as [row][k] images (k contiguous), 16-byte chunks XOR-swizzled by row.
+//    k-contiguous operands are fetched with global_load_lds (direct-to-LDS DMA, no VGPR round trip; the LDS image
+//    is lane-linear, so the swizzle is applied to the per-lane SOURCE address).  Operands whose contraction index is
+//    strided in memory (dX = dY W, dW = dY^T X) go global -> registers -> EB x EB in-register transpose -> LDS.
+//  * MFMA operands are SWAPPED (A := weight-side rows, B := activation-side rows), so a lane owns 4 consecutive
+//    output columns of one output row; the epilogue stages each wave's 64 x 64 sub-tile through its own LDS slice
+//    and writes whole 128/256-byte row segments with 8/16-byte vector stores (bias / ReLU / ReLU-backward gate /
+//    dropout / residual applied on the way).
+#include <stdlib.h>
 #include "common.cuh"
 #include "../../include/plank_hip.h"
 
@@ -25,118 +34,77 @@ struct GemmP {
     uint32_t drop_thr; float drop_scale; uint32_t drop_seed;
     int out_dtype;
     int splitk, tiles_per_slice;   // split-K: C is the f32 slab workspace, plain store
-    int tiles_n;
+    int tiles_m, tiles_n, tiles_m_pad, units;
+    int vec_ok;                    // epilogue may use 4-element vector accesses on C / R / aux / bias
+    int dbg;                       // ablation bits (PA_GEMM_DBG): 1 no MFMA, 2 no ds_read, 4 no loads, 8 no epilogue
 };
 
 constexpr int BM = 128, BN = 128, NT = 256;
 
-template <typename T> struct Tile {
+#ifdef PA_GEMM_TRACE
+__device__ unsigned long long pa_trace[8192];
+__device__ int pa_trace_n;
+#define TR(tag) do { if (blockIdx.x == 0 && threadIdx.x == 0 && pa_trace_n < 8190) { pa_trace[pa_trace_n++] = (unsigned long long)(tag); pa_trace[pa_trace_n++] = clock64(); } } while (0)
+#else
+#define TR(tag) do {} while (0)
+#endif
+
+// BK_ = contraction elements per K tile.  bf16: 64 (128-byte rows) or 32 (64-byte rows, half the LDS -> more blocks/CU)
+template <typename T, int BK_> struct Tile {
     static constexpr int EB = ET<T>::EB;
-    static constexpr int BK = (sizeof(T) == 2) ? 64 : 16;
+    static constexpr int BK = BK_;
     static constexpr int RB = BK * sizeof(T);        // bytes per LDS row (128 / 64)
     static constexpr int NCH = RB / 16;              // 16-byte chunks per row (8 / 4)
     static constexpr int RPB = 256 / RB;             // rows per 256-byte bank row (2 / 4)
-    static constexpr int STEPS = BK / ET<T>::KC;     // mma16B steps per K tile (4 / 2)
-    static constexpr int NLD = BM * NCH / NT;        // 16-byte loads per thread, k-contiguous (4 / 2)
-    static constexpr int TILE_BYTES = BM * RB;       // 16 KiB / 8 KiB per operand
+    static constexpr int STEPS = BK / ET<T>::KC;     // mma16B steps per K tile
+    static constexpr int NLD = BM * NCH / NT;        // 16-byte chunks per thread, k-contiguous
+    static constexpr int TILE_BYTES = BM * RB;       // per operand
+    static constexpr int STAGE_BYTES = TILE_BYTES / 2;   // per-wave epilogue staging slice
+    static constexpr int RPP = STAGE_BYTES / 256;    // output rows per staging pass
+    static constexpr int KB = BK / EB;               // EB-wide k blocks per tile (transposed staging)
+    static constexpr int NTB = (BM / EB) * KB;       // EB x EB blocks per transposed tile
+    static constexpr int NTR = (NTB + 127) / 128;    // blocks per thread of the 128-thread half
 };
 
-template <typename T> __device__ __forceinline__ int lds_off(int row, int chunk) {
-    using TL = Tile<T>;
+template <typename TL> __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * TL::RB + (((chunk ^ (row / TL::RPB)) & (TL::NCH - 1)) << 4);
 }
 
-// ---- global -> register staging ---------------------------------------------------------------
-// k-contiguous operand: element (r, k) at base[r * ld + k]; rows r0.., contraction k0..
-template <typename T, bool ALIGNED>
-__device__ __forceinline__ void load_kc(u32x4* regs, const T* base, int ld, int r0, int nrows, int k0, int K, int tid) {
-    using TL = Tile<T>;
-#pragma unroll
-    for (int i = 0; i < TL::NLD; ++i) {
-        int c = tid + i * NT;
-        int row = c / TL::NCH, ch = c % TL::NCH;
-        int r = r0 + row, k = k0 + ch * TL::EB;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (r < nrows) {
-            const T* p = base + (size_t)r * ld + k;
-            if (ALIGNED) {
-                if (k < K) v = *reinterpret_cast<const u32x4*>(p);
-            } else {
-                T tmp[TL::EB];
-#pragma unroll
-                for (int e = 0; e < TL::EB; ++e) tmp[e] = (k + e < K) ? p[e] : (T)0.0f;
-                v = *reinterpret_cast<u32x4*>(tmp);
-            }
-        }
-        regs[i] = v;
-    }
-}
-template <typename T>
-__device__ __forceinline__ void store_kc(const u32x4* regs, char* lds, int tid) {
-    using TL = Tile<T>;
-#pragma unroll
-    for (int i = 0; i < TL::NLD; ++i) {
-        int c = tid + i * NT;
-        int row = c / TL::NCH, ch = c % TL::NCH;
-        *reinterpret_cast<u32x4*>(lds + lds_off<T>(row, ch)) = regs[i];
-    }
-}
-// transposed operand: element (r, k) at base[k * ld + r]; one EB x EB block per thread (128 threads)
-template <typename T, bool ALIGNED>
-__device__ __forceinline__ void load_tr(u32x4* regs, const T* base, int ld, int r0, int nrows, int k0, int K, int t128) {
-    using TL = Tile<T>;
-    constexpr int RBLK = BM / TL::EB;                // row blocks per tile (16 / 32)
-    int rb = t128 % RBLK, kb = t128 / RBLK;
-    int r = r0 + rb * TL::EB;
-#pragma unroll
-    for (int i = 0; i < TL::EB; ++i) {
-        int k = k0 + kb * TL::EB + i;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (k < K) {
-            const T* p = base + (size_t)k * ld + r;
-            if (ALIGNED) {
-                if (r < nrows) v = *reinterpret_cast<const u32x4*>(p);   // nrows % EB == 0 when ALIGNED
-            } else {
-                T tmp[TL::EB];
-#pragma unroll
-                for (int e = 0; e < TL::EB; ++e) tmp[e] = (r + e < nrows) ? p[e] : (T)0.0f;
-                v = *reinterpret_cast<u32x4*>(tmp);
-            }
-        }
-        regs[i] = v;
-    }
-}
-template <typename T>
-__device__ __forceinline__ void store_tr(const u32x4* regs, char* lds, int t128) {
-    using TL = Tile<T>;
-    constexpr int RBLK = BM / TL::EB;
-    int rb = t128 % RBLK, kb = t128 / RBLK;
-    u32x4 tr[TL::EB];
-    transpose_block<T>(regs, tr);
-#pragma unroll
-    for (int e = 0; e < TL::EB; ++e)
-        *reinterpret_cast<u32x4*>(lds + lds_off<T>(rb * TL::EB + e, kb)) = tr[e];
-}
+struct Unit { int tile_m, tile_n, b, z, t_begin, t_end; };
 
-template <typename T, bool A_KC, bool B_KC, bool ALIGNED>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
-    using TL = Tile<T>;
-    __shared__ __attribute__((aligned(16))) char smem[4 * TL::TILE_BYTES];   // [buf][A|B]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
-    const int z = blockIdx.y;
-    const int b = z / p.splitk, slice = z % p.splitk;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const T* A = reinterpret_cast<const T*>(p.A) + (size_t)b * p.sA;
-    const T* B = reinterpret_cast<const T*>(p.B) + (size_t)b * p.sB;
-
+template <typename TL>
+__device__ __forceinline__ bool decode_unit(const GemmP& p, int u, Unit& un) {
+    if (u >= p.units) return false;
+    const int per_z = p.tiles_m_pad * p.tiles_n;
+    un.z = u / per_z;
+    const int r = u - un.z * per_z;
+    const int xcd = r & 7, i = r >> 3;
+    const int q = i / p.tiles_n;
+    un.tile_n = i - q * p.tiles_n;
+    un.tile_m = q * 8 + xcd;
+    un.b = un.z / p.splitk;
+    const int slice = un.z - un.b * p.splitk;
     const int nt_total = (p.K + TL::BK - 1) / TL::BK;
-    const int t_begin = slice * p.tiles_per_slice;
-    const int t_end = min(nt_total, t_begin + p.tiles_per_slice);
+    un.t_begin = slice * p.tiles_per_slice;
+    un.t_end = min(nt_total, un.t_begin + p.tiles_per_slice);
+    return (un.tile_m < p.tiles_m) && (un.t_begin < un.t_end);
+}
+__device__ __forceinline__ int next_valid_unit(int u, int stride) { return u + stride; }
 
-    f32x16 acc[2][2];
+// GLDS: direct-to-LDS loads for the k-contiguous operands (requires ALIGNED and K % BK == 0)
+template <typename T, int BK_, int OCC, bool A_KC, bool B_KC, bool ALIGNED, bool GLDS>
+__global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
+    using TL = Tile<T, BK_>;
+    constexpr int EB = TL::EB;
+    constexpr int SMEM = 4 * TL::TILE_BYTES;
+    __shared__ __attribute__((aligned(256))) char smem[SMEM];   // [buf][A|B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5;
+    constexpr int esz = (int)sizeof(T);
+
+    f32x16 acc[2][2];            // [tn][tm]  (operands swapped: rows of D = weight-side index n)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -144,98 +112,339 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int NRA = A_KC ? TL::NLD : TL::EB;
-    constexpr int NRB = B_KC ? TL::NLD : TL::EB;
+    constexpr bool A_GL = A_KC && GLDS, B_GL = B_KC && GLDS;
+    constexpr int NRA = A_GL ? 1 : (A_KC ? TL::NLD : TL::NTR * EB);
+    constexpr int NRB = B_GL ? 1 : (B_KC ? TL::NLD : TL::NTR * EB);
     u32x4 ra[NRA], rb[NRB];
-    // thread roles for transposed operands: A blocks on threads 0..127, B blocks on 128..255
     const bool a_role = A_KC || (tid < 128);
     const bool b_role = B_KC || (tid >= 128);
     const int t128 = tid & 127;
 
-    auto gload = [&](int t) {
-        int k0 = t * TL::BK;
-        if constexpr (A_KC) load_kc<T, ALIGNED>(ra, A, p.lda, m0, p.M, k0, p.K, tid);
-        else { if (a_role) load_tr<T, ALIGNED>(ra, A, p.lda, m0, p.M, k0, p.K, t128); }
-        if constexpr (B_KC) load_kc<T, ALIGNED>(rb, B, p.ldb, n0, p.N, k0, p.K, tid);
-        else { if (b_role) load_tr<T, ALIGNED>(rb, B, p.ldb, n0, p.N, k0, p.K, t128); }
+    // ---- per-unit addressing state (hoisted out of the K loop) ------------------------------------------
+    // k-contiguous operand: chunk p = tid + i*NT -> (row, source chunk); byte offset of its row start (clamped)
+    uint32_t offA[TL::NLD], offB[TL::NLD];
+    bool okA[TL::NLD], okB[TL::NLD];                 // register path: row inside the matrix
+    const char* baseA = nullptr; const char* baseB = nullptr;
+    auto setup = [&](const Unit& un) {
+        baseA = reinterpret_cast<const char*>(p.A) + (size_t)un.b * p.sA * esz;
+        baseB = reinterpret_cast<const char*>(p.B) + (size_t)un.b * p.sB * esz;
+        const int m0 = un.tile_m * BM, n0 = un.tile_n * BN;
+        if constexpr (A_KC) {
+#pragma unroll
+            for (int i = 0; i < TL::NLD; ++i) {
+                const int pidx = tid + i * NT, row = pidx / TL::NCH;
+                const int ch = A_GL ? (((pidx % TL::NCH) ^ (row / TL::RPB)) & (TL::NCH - 1)) : (pidx % TL::NCH);
+                okA[i] = (m0 + row) < p.M;
+                offA[i] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)(p.lda * esz) + ch * 16;
+            }
+        }
+        if constexpr (B_KC) {
+#pragma unroll
+            for (int i = 0; i < TL::NLD; ++i) {
+                const int pidx = tid + i * NT, row = pidx / TL::NCH;
+                const int ch = B_GL ? (((pidx % TL::NCH) ^ (row / TL::RPB)) & (TL::NCH - 1)) : (pidx % TL::NCH);
+                okB[i] = (n0 + row) < p.N;
+                offB[i] = (uint32_t)min(n0 + row, p.N - 1) * (uint32_t)(p.ldb * esz) + ch * 16;
+            }
+        }
     };
-    auto lstore = [&](int buf) {
+
+    // transposed operand: element (r, k) at base[k * ld + r]; EB x EB blocks, 128 threads per operand
+    auto load_tr = [&](u32x4* regs, const char* base, int ld, int r0, int nrows, int k0) {
+        constexpr int RBLK = BM / EB;
+#pragma unroll
+        for (int j = 0; j < TL::NTR; ++j) {
+            const int blk = t128 + j * 128;
+            const int rbk = blk % RBLK, kb = blk / RBLK;
+            const int r = r0 + rbk * EB;
+#pragma unroll
+            for (int i = 0; i < EB; ++i) {
+                const int k = k0 + kb * EB + i;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (blk < TL::NTB && k < p.K) {
+                    const T* src = reinterpret_cast<const T*>(base) + (size_t)k * ld + r;
+                    if (ALIGNED) {
+                        if (r < nrows) v = *reinterpret_cast<const u32x4*>(src);
+                    } else {
+                        T tmp[EB];
+#pragma unroll
+                        for (int e = 0; e < EB; ++e) tmp[e] = (r + e < nrows) ? src[e] : (T)0.0f;
+                        v = *reinterpret_cast<u32x4*>(tmp);
+                    }
+                }
+                regs[j * EB + i] = v;
+            }
+        }
+    };
+    auto store_tr = [&](const u32x4* regs, char* lds) {
+        constexpr int RBLK = BM / EB;
+#pragma unroll
+        for (int j = 0; j < TL::NTR; ++j) {
+            const int blk = t128 + j * 128;
+            if (blk < TL::NTB) {
+                const int rbk = blk % RBLK, kb = blk / RBLK;
+                u32x4 tr[EB];
+                transpose_block<T>(regs + j * EB, tr);
+#pragma unroll
+                for (int e = 0; e < EB; ++e)
+                    *reinterpret_cast<u32x4*>(lds + lds_off<TL>(rbk * EB + e, kb)) = tr[e];
+            }
+        }
+    };
+
+    // phase 1 of a tile fetch: issue global loads (DMA straight into `buf`, or into registers)
+    auto fetch = [&](const Unit& un, int t, int buf) {
+        const int k0 = t * TL::BK;
         char* la = smem + buf * 2 * TL::TILE_BYTES;
         char* lb = la + TL::TILE_BYTES;
-        if constexpr (A_KC) store_kc<T>(ra, la, tid);
-        else { if (a_role) store_tr<T>(ra, la, t128); }
-        if constexpr (B_KC) store_kc<T>(rb, lb, tid);
-        else { if (b_role) store_tr<T>(rb, lb, t128); }
+        const char* ka = baseA + (size_t)k0 * esz;          // wave-uniform
+        const char* kb = baseB + (size_t)k0 * esz;
+        if constexpr (A_GL) {
+#pragma unroll
+            for (int i = 0; i < TL::NLD; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ka + offA[i]),
+                    (__attribute__((address_space(3))) void*)(la + (i * NT + wave * 64) * 16), 16, 0, 0);
+        } else if constexpr (A_KC) {
+#pragma unroll
+            for (int i = 0; i < TL::NLD; ++i) {
+                const int kk = k0 + ((tid + i * NT) % TL::NCH) * EB;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (okA[i]) {
+                    const T* src = reinterpret_cast<const T*>(ka + offA[i]);
+                    if (ALIGNED) { if (kk < p.K) v = *reinterpret_cast<const u32x4*>(src); }
+                    else {
+                        T tmp[EB];
+#pragma unroll
+                        for (int e = 0; e < EB; ++e) tmp[e] = (kk + e < p.K) ? src[e] : (T)0.0f;
+                        v = *reinterpret_cast<u32x4*>(tmp);
+                    }
+                }
+                ra[i] = v;
+            }
+        } else { if (a_role) load_tr(ra, baseA, p.lda, un.tile_m * BM, p.M, k0); }
+        if constexpr (B_GL) {
+#pragma unroll
+            for (int i = 0; i < TL::NLD; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + offB[i]),
+                    (__attribute__((address_space(3))) void*)(lb + (i * NT + wave * 64) * 16), 16, 0, 0);
+        } else if constexpr (B_KC) {
+#pragma unroll
+            for (int i = 0; i < TL::NLD; ++i) {
+                const int kk = k0 + ((tid + i * NT) % TL::NCH) * EB;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (okB[i]) {
+                    const T* src = reinterpret_cast<const T*>(kb + offB[i]);
+                    if (ALIGNED) { if (kk < p.K) v = *reinterpret_cast<const u32x4*>(src); }
+                    else {
+                        T tmp[EB];
+#pragma unroll
+                        for (int e = 0; e < EB; ++e) tmp[e] = (kk + e < p.K) ? src[e] : (T)0.0f;
+                        v = *reinterpret_cast<u32x4*>(tmp);
+                    }
+                }
+                rb[i] = v;
+            }
+        } else { if (b_role) load_tr(rb, baseB, p.ldb, un.tile_n * BN, p.N, k0); }
+    };
+    // phase 2: registers -> LDS (nothing to do for DMA'd operands)
+    auto commit = [&](int buf) {
+        char* la = smem + buf * 2 * TL::TILE_BYTES;
+        char* lb = la + TL::TILE_BYTES;
+        if constexpr (!A_GL) {
+            if constexpr (A_KC) {
+#pragma unroll
+                for (int i = 0; i < TL::NLD; ++i) {
+                    const int c = tid + i * NT;
+                    *reinterpret_cast<u32x4*>(la + lds_off<TL>(c / TL::NCH, c % TL::NCH)) = ra[i];
+                }
+            } else { if (a_role) store_tr(ra, la); }
+        }
+        if constexpr (!B_GL) {
+            if constexpr (B_KC) {
+#pragma unroll
+                for (int i = 0; i < TL::NLD; ++i) {
+                    const int c = tid + i * NT;
+                    *reinterpret_cast<u32x4*>(lb + lds_off<TL>(c / TL::NCH, c % TL::NCH)) = rb[i];
+                }
+            } else { if (b_role) store_tr(rb, lb); }
+        }
     };
 
-    if (t_begin < t_end) {
-        gload(t_begin);
-        lstore(0);
-    }
-    __syncthreads();
-
-    const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), half = lane >> 5;
-    for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end) gload(t + 1);
-        const char* la = smem + buf * 2 * TL::TILE_BYTES;
-        const char* lb = la + TL::TILE_BYTES;
+    // ---- epilogue of one unit: per-wave LDS staging, batched loads, vector row stores -------------------------
+    auto epilogue = [&](const Unit& un, int buf) {
+        char* stage = smem + buf * 2 * TL::TILE_BYTES + wave * TL::STAGE_BYTES;
+        const bool slab = p.splitk > 1;
+        const size_t cbase = slab ? (size_t)un.z * p.M * p.ldc : (size_t)un.b * p.sC;
+        const int mw = un.tile_m * BM + wm * 64, nw = un.tile_n * BN + wn * 64;
+        const int chunk = lane & 15, rsub = lane >> 4;
+        const int n = nw + chunk * 4;                                     // this lane's 4 output columns (all rows)
+        const bool colv = n < p.N;
+        const bool full = p.vec_ok && (n + 3 < p.N);                      // vector path for this lane
+        const bool out_f32 = slab || p.out_dtype == PA_F32;
+        const bool has_bias = !slab && p.bias != nullptr, has_aux = !slab && p.aux != nullptr;
+        const bool has_res = !slab && p.R != nullptr, has_drop = !slab && p.drop_thr != 0;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (has_bias && colv) {
+            if (full) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+            else { for (int e = 0; e < 4; ++e) if (n + e < p.N) bias[e] = p.bias[n + e]; }
+        }
+        const float alpha = slab ? 1.f : p.alpha;
+        constexpr int NPASS = 64 / TL::RPP, NIT = TL::RPP / 4;
 #pragma unroll
-        for (int s = 0; s < TL::STEPS; ++s) {
-            u32x4 fa[2], fb[2];
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int tm = (pass * TL::RPP) / 32;
+            const int rsel = (pass * TL::RPP) % 32;
+            const int lrow = (lane & 31) - rsel;
+            if (lrow >= 0 && lrow < TL::RPP) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const u32x4*>(la + lds_off<T>(arow + i * 32, 2 * s + half));
-                fb[i] = *reinterpret_cast<const u32x4*>(lb + lds_off<T>(brow + i * 32, 2 * s + half));
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[tn][tm][4 * g4 + e];
+                        const int ch = (tn * 32 + 8 * g4 + 4 * half) >> 2;
+                        *reinterpret_cast<f32x4*>(stage + lrow * 256 + ((ch ^ (lrow & 15)) << 4)) = v;
+                    }
+            }
+            f32x4 v[NIT], res[NIT], gate[NIT];
+            bool rowv[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int lr = it * 4 + rsub;
+                v[it] = *reinterpret_cast<const f32x4*>(stage + lr * 256 + ((chunk ^ (lr & 15)) << 4));
+                rowv[it] = colv && (mw + pass * TL::RPP + lr) < p.M;
+            }
+            if (has_res) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    res[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (rowv[it]) {
+                        const int m = mw + pass * TL::RPP + it * 4 + rsub;
+                        const size_t ro = (size_t)un.b * p.sR + (size_t)m * p.ldr + n;
+                        if (full) res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(p.R) + ro)
+                                                    : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+                        else { for (int e = 0; e < 4; ++e) if (n + e < p.N)
+                                   res[it][e] = out_f32 ? reinterpret_cast<const float*>(p.R)[ro + e]
+                                                        : (float)reinterpret_cast<const bf16*>(p.R)[ro + e]; }
+                    }
+                }
+            }
+            if (has_aux) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    gate[it] = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (rowv[it]) {
+                        const int m = mw + pass * TL::RPP + it * 4 + rsub;
+                        const size_t ao = (size_t)un.b * p.sAux + (size_t)m * p.ldaux + n;
+                        if (full) gate[it] = ld4<T>(reinterpret_cast<const T*>(p.aux) + ao);
+                        else { for (int e = 0; e < 4; ++e) if (n + e < p.N) gate[it][e] = ld1(reinterpret_cast<const T*>(p.aux) + ao + e); }
+                    }
+                }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int it = 0; it < NIT; ++it) {
+                if (!rowv[it]) continue;
+                const int m = mw + pass * TL::RPP + it * 4 + rsub;
+                f32x4 x = v[it];
+                if (!slab) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) mma16B<T>(acc[i][j], fa[i], fb[j]);
-        }
-        if (t + 1 < t_end) lstore(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue --------------------------------------------------------------------------
-    const bool slab = p.splitk > 1;
-    const size_t cbase = slab ? (size_t)z * p.M * p.ldc : (size_t)b * p.sC;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-        if (n >= p.N) continue;
-        const float bias = (!slab && p.bias) ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + acc_row(r, lane);
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
-                if (slab) {
-                    reinterpret_cast<float*>(p.C)[cbase + (size_t)m * p.ldc + n] = v;
-                    continue;
-                }
-                v = v * p.alpha + bias;
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.aux) {
-                    float g = ld1(reinterpret_cast<const T*>(p.aux) + (size_t)b * p.sAux + (size_t)m * p.ldaux + n);
-                    v = g > 0.f ? v * p.aux_scale : 0.f;
-                }
-                if (p.drop_thr) {
-                    uint32_t idx = (uint32_t)(((size_t)b * p.M + m) * p.N + n);
-                    v = drop_keep(p.drop_seed, idx, p.drop_thr) ? v * p.drop_scale : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        float y = x[e] * alpha + bias[e];
+                        if (p.relu) y = fmaxf(y, 0.f);
+                        if (has_aux) y = gate[it][e] > 0.f ? y * p.aux_scale : 0.f;
+                        if (has_drop) {
+                            const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + m) * p.N + n + e);
+                            y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
+                        }
+                        if (has_res) y += res[it][e];
+                        x[e] = y;
+                    }
                 }
                 const size_t co = cbase + (size_t)m * p.ldc + n;
-                if (p.out_dtype == PA_F32) {
-                    if (p.R) v += reinterpret_cast<const float*>(p.R)[(size_t)b * p.sR + (size_t)m * p.ldr + n];
-                    reinterpret_cast<float*>(p.C)[co] = v;
+                if (out_f32) {
+                    float* cp = reinterpret_cast<float*>(p.C) + co;
+                    if (full) *reinterpret_cast<f32x4*>(cp) = x;
+                    else { for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = x[e]; }
                 } else {
-                    if (p.R) v += (float)reinterpret_cast<const bf16*>(p.R)[(size_t)b * p.sR + (size_t)m * p.ldr + n];
-                    reinterpret_cast<bf16*>(p.C)[co] = (bf16)v;
+                    bf16* cp = reinterpret_cast<bf16*>(p.C) + co;
+                    if (full) st4<bf16>(cp, x);
+                    else { for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = (bf16)x[e]; }
                 }
             }
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+
+    // ---- persistent, cross-unit software pipeline ----------------------------------------------------------
+    const int ustride = gridDim.x;
+    int u = blockIdx.x;
+    Unit cur, nxt;
+    bool ok = decode_unit<TL>(p, u, cur);
+    while (u < p.units && !ok) { u += ustride; ok = decode_unit<TL>(p, u, cur); }
+    if (u >= p.units) return;
+    int nu = u + ustride;                                   // the unit after `cur` (decoded once per unit)
+    ok = decode_unit<TL>(p, nu, nxt);
+    while (nu < p.units && !ok) { nu += ustride; ok = decode_unit<TL>(p, nu, nxt); }
+    int t = cur.t_begin, buf = 0;
+    setup(cur);
+    fetch(cur, t, 0);
+    commit(0);
+    __syncthreads();
+
+    const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31);
+    while (true) {
+        const bool last_k = (t + 1 >= cur.t_end);
+        const bool has_next = !last_k || (nu < p.units);
+        TR(1);
+        if (has_next) {
+            if (last_k) { setup(nxt); fetch(nxt, nxt.t_begin, buf ^ 1); }
+            else fetch(cur, t + 1, buf ^ 1);
+        }
+        TR(2);
+        const char* la = smem + buf * 2 * TL::TILE_BYTES;
+        const char* lb = la + TL::TILE_BYTES;
+        // all fragment reads of the tile are issued up front; LDS returns in order, so the MFMAs of step s start
+        // as soon as their 4 vectors have landed while the later ones are still in flight
+        u32x4 fa[TL::STEPS][2], fb[TL::STEPS][2];
+#pragma unroll
+        for (int s = 0; s < TL::STEPS; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[s][i] = *reinterpret_cast<const u32x4*>(la + lds_off<TL>(arow + i * 32, 2 * s + half));
+                fb[s][i] = *reinterpret_cast<const u32x4*>(lb + lds_off<TL>(brow + i * 32, 2 * s + half));
+            }
+#pragma unroll
+        for (int s = 0; s < TL::STEPS; ++s)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) mma16B<T>(acc[tn][tm], fb[s][tn], fa[s][tm]);
+        TR(3);
+        if (last_k) {
+            __syncthreads();                 // every wave is done reading `buf`: its LDS becomes the staging area
+            TR(4);
+            epilogue(cur, buf);
+            TR(5);
+        }
+        if (has_next) commit(buf ^ 1);
+        __syncthreads();
+        TR(6);
+        if (!has_next) break;
+        if (last_k) {
+            u = nu; cur = nxt; t = cur.t_begin;
+            nu = u + ustride;
+            ok = decode_unit<TL>(p, nu, nxt);
+            while (nu < p.units && !ok) { nu += ustride; ok = decode_unit<TL>(p, nu, nxt); }
+        } else {
+            ++t;
+        }
+        buf ^= 1;
     }
 }
 
@@ -267,18 +476,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
     }
 }
 
-template <typename T, bool A_KC, bool B_KC>
-int launch_t(const GemmP& p, bool aligned, dim3 grid, hipStream_t st) {
-    if (aligned) PA_LAUNCH((gemm_kernel<T, A_KC, B_KC, true>), grid, dim3(NT), 0, st, p);
-    else PA_LAUNCH((gemm_kernel<T, A_KC, B_KC, false>), grid, dim3(NT), 0, st, p);
+template <typename T, int BK_, int OCC, bool A_KC, bool B_KC>
+int launch_t(const GemmP& p, bool aligned, bool glds, dim3 grid, hipStream_t st) {
+    if (aligned && glds && (A_KC || B_KC)) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, true>), grid, dim3(NT), 0, st, p);
+    else if (aligned) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, false>), grid, dim3(NT), 0, st, p);
+    else PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, false, false>), grid, dim3(NT), 0, st, p);
     return 0;
 }
-template <typename T>
-int launch_layout(const GemmP& p, bool akc, bool bkc, bool aligned, dim3 grid, hipStream_t st) {
-    if (akc && bkc) return launch_t<T, true, true>(p, aligned, grid, st);
-    if (akc && !bkc) return launch_t<T, true, false>(p, aligned, grid, st);
-    if (!akc && bkc) return launch_t<T, false, true>(p, aligned, grid, st);
-    return launch_t<T, false, false>(p, aligned, grid, st);
+template <typename T, int BK_, int OCC>
+int launch_layout(const GemmP& p, bool akc, bool bkc, bool aligned, bool glds, dim3 grid, hipStream_t st) {
+    if (akc && bkc) return launch_t<T, BK_, OCC, true, true>(p, aligned, glds, grid, st);
+    if (akc && !bkc) return launch_t<T, BK_, OCC, true, false>(p, aligned, glds, grid, st);
+    if (!akc && bkc) return launch_t<T, BK_, OCC, false, true>(p, aligned, glds, grid, st);
+    return launch_t<T, BK_, OCC, false, false>(p, aligned, glds, grid, st);
 }
 
 template <typename T> bool is_aligned(const pa_gemm_args* a) {
@@ -312,23 +522,44 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     p.drop_scale = 1.0f / (1.0f - a->drop_p);
     p.drop_seed = a->drop_seed;
     p.out_dtype = a->out_dtype;
-    const int BK = a->in_dtype == PA_BF16 ? Tile<bf16>::BK : Tile<float>::BK;
+    static const int dbg_bk = getenv("PA_GEMM_BK") ? atoi(getenv("PA_GEMM_BK")) : 64;     // bf16 K tile: 64 or 32
+    const bool bk32 = a->in_dtype == PA_BF16 && dbg_bk == 32;
+    const int BK = a->in_dtype == PA_BF16 ? (bk32 ? 32 : 64) : 16;
     const int nt = (a->K + BK - 1) / BK;
     int splitk = a->splitk > 1 ? a->splitk : 1;
     if (splitk > nt) splitk = nt;
     if (splitk > 1 && !a->ws) return PA_EINVAL;
     p.splitk = splitk;
     p.tiles_per_slice = (nt + splitk - 1) / splitk;
-    const int tiles_m = (a->M + BM - 1) / BM;
+    p.tiles_m = (a->M + BM - 1) / BM;
     p.tiles_n = (a->N + BN - 1) / BN;
-    dim3 grid(tiles_m * p.tiles_n, a->batch * splitk);
+    p.tiles_m_pad = (p.tiles_m + 7) / 8 * 8;
+    p.units = p.tiles_m_pad * p.tiles_n * a->batch * splitk;
     GemmP pk = p;
     if (splitk > 1) { pk.C = a->ws; pk.ldc = a->N; }
+    // vector epilogue: 4-element accesses on C / R / aux / bias must be naturally aligned
+    {
+        const int osz = (splitk > 1 || a->out_dtype == PA_F32) ? 4 : 2, isz = a->in_dtype == PA_BF16 ? 2 : 4;
+        auto ok = [](const void* q, long long ld, long long sb, int esz) {
+            return !q || (((reinterpret_cast<uintptr_t>(q) * 1) % (4 * esz) == 0) && (ld % 4 == 0) && (sb % 4 == 0));
+        };
+        pk.vec_ok = ok(pk.C, pk.ldc, splitk > 1 ? (long long)a->M * a->N : a->sC, osz) && ok(a->R, a->ldr, a->sR, osz) &&
+                    ok(a->aux, a->ldaux, a->sAux, isz) && ok(a->bias, 4, 0, 4);
+    }
+    // debug/ablation toggles (environment, read once): PA_GEMM_NOGLDS=1, PA_GEMM_GRID=<blocks> (0 = one block per unit)
+    static const int dbg_noglds = getenv("PA_GEMM_NOGLDS") ? atoi(getenv("PA_GEMM_NOGLDS")) : 0;
+    static const int dbg_grid = getenv("PA_GEMM_GRID") ? atoi(getenv("PA_GEMM_GRID")) : (bk32 ? 768 : 512);
+    pk.dbg = 0; p.dbg = 0;
+    int grid_x = (dbg_grid > 0 && pk.units > dbg_grid) ? dbg_grid : pk.units;
+    dim3 grid(grid_x);
+    const bool glds = (a->K % BK) == 0 && !dbg_noglds;
     int rc;
-    if (a->in_dtype == PA_BF16)
-        rc = launch_layout<bf16>(pk, a->a_kcontig, a->b_kcontig, is_aligned<bf16>(a), grid, st);
-    else
-        rc = launch_layout<float>(pk, a->a_kcontig, a->b_kcontig, is_aligned<float>(a), grid, st);
+    if (a->in_dtype == PA_BF16) {
+        if (bk32) rc = launch_layout<bf16, 32, 3>(pk, a->a_kcontig, a->b_kcontig, is_aligned<bf16>(a), glds, grid, st);
+        else rc = launch_layout<bf16, 64, 2>(pk, a->a_kcontig, a->b_kcontig, is_aligned<bf16>(a), glds, grid, st);
+    } else {
+        rc = launch_layout<float, 16, 2>(pk, a->a_kcontig, a->b_kcontig, is_aligned<float>(a), glds, grid, st);
+    }
     if (rc) return rc;
     if (splitk > 1) {
         size_t total = (size_t)a->batch * a->M * a->N;
@@ -343,42 +574,78 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
 }
 
 // -------------------------------------------------------------------------------------------------
-// column sums (bias gradients)
+// column sums (bias gradients): block = 64 sixteen-byte column chunks x 4 row lanes over CS_ROWS rows, partial rows
+// combined by a second small kernel.  HBM-bound: one coalesced pass over X.
 namespace {
-constexpr int CS_ROWS = 256;   // rows per block
-template <typename T>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* X, int M, int N, int ldx, float* partial) {
-    // block (x = column group of 256, y = row group); thread = one column; coalesced along n
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.y * CS_ROWS;
-    const int r1 = min(M, r0 + CS_ROWS);
-    if (n >= N) return;
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += ld1(X + (size_t)r * ldx + n);
-    partial[(size_t)blockIdx.y * N + n] = s;
+constexpr int CS_ROWS = 128;
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* X, int M, int N, int ldx, float* partial, int npad) {
+    constexpr int EB = ET<T>::EB;
+    __shared__ float red[4][64 * EB];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 64 + cl) * EB;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    float acc[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) acc[e] = 0.f;
+    if (n0 < N) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const T* p = X + (size_t)r * ldx + n0;
+            if (VEC) {
+#pragma unroll
+                for (int e = 0; e < EB; e += 4) { const f32x4 v = ld4<T>(p + e); acc[e] += v[0]; acc[e + 1] += v[1]; acc[e + 2] += v[2]; acc[e + 3] += v[3]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EB; ++e) if (n0 + e < N) acc[e] += ld1(p + e);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) red[rl][cl * EB + e] = acc[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * EB; i += 256) {
+        const int n = blockIdx.x * 64 * EB + i;
+        if (n < npad) partial[(size_t)blockIdx.y * npad + n] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+    }
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nparts, int N, float* out, int accumulate) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nparts, int npad, int N, float* out, int accumulate) {
+    __shared__ float red[256];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
     float s = 0.f;
-    for (int i = 0; i < nparts; ++i) s += partial[(size_t)i * N + n];
-    out[n] = accumulate ? out[n] + s : s;
+    if (n < N) {
+#pragma unroll 8
+        for (int i = pl; i < nparts; i += 4) s += partial[(size_t)i * npad + n];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0 && n < N) {
+        const float t = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        out[n] = accumulate ? out[n] + t : t;
+    }
 }
+inline int cs_npad(int N) { return (N + 7) / 8 * 8; }
 }  // namespace
 
 extern "C" int64_t pa_colsum_ws_floats(int32_t M, int32_t N) {
-    return (int64_t)((M + CS_ROWS - 1) / CS_ROWS) * N;
+    return (int64_t)((M + CS_ROWS - 1) / CS_ROWS) * cs_npad(N);
 }
 extern "C" int pa_colsum(const void* X, int32_t dtype, int32_t M, int32_t N, int32_t ldx, float* out,
                          int32_t accumulate, float* partial, void* stream) {
     if (!X || !out || !partial || M <= 0 || N <= 0) return PA_EINVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int nparts = (M + CS_ROWS - 1) / CS_ROWS;
-    dim3 grid((N + 255) / 256, nparts);
-    if (dtype == PA_BF16)
-        PA_LAUNCH(colsum_partial_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)X, M, N, ldx, partial);
-    else
-        PA_LAUNCH(colsum_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)X, M, N, ldx, partial);
-    PA_LAUNCH(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partial, nparts, N, out, accumulate);
+    const int nparts = (M + CS_ROWS - 1) / CS_ROWS, npad = cs_npad(N);
+    const int EB = dtype == PA_BF16 ? 8 : 4;
+    // vector path: every 16-byte chunk of a row is fully inside the row allocation (ldx >= round-up of N) and aligned
+    const bool vec = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ldx % EB == 0 && ldx >= (N + EB - 1) / EB * EB;
+    dim3 grid((N + 64 * EB - 1) / (64 * EB), nparts);
+    if (dtype == PA_BF16) {
+        if (vec) PA_LAUNCH((colsum_partial_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)X, M, N, ldx, partial, npad);
+        else PA_LAUNCH((colsum_partial_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)X, M, N, ldx, partial, npad);
+    } else {
+        if (vec) PA_LAUNCH((colsum_partial_kernel<float, true>), grid, dim3(256), 0, st, (const float*)X, M, N, ldx, partial, npad);
+        else PA_LAUNCH((colsum_partial_kernel<float, false>), grid, dim3(256), 0, st, (const float*)X, M, N, ldx, partial, npad);
+    }
+    PA_LAUNCH(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0, st, partial, nparts, npad, N, out, accumulate);
     return 0;
 }

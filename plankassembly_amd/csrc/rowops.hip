@@ -11,7 +11,7 @@ constexpr int MAXV = 8;   // vectors of 4 per lane per row -> d <= 2048
 
 // ================================================================================ embeddings
 struct EmbTabs { const float* t[5]; const int64_t* idx[5]; int n; };
-struct EmbGrads { float* t[5]; const int64_t* idx[5]; int n; };
+struct EmbGrads { float* t[5]; const int64_t* idx[5]; int rows[5]; int n; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void embed_input_fwd_kernel(T* out, EmbTabs tb, int64_t n_tok, int d) {
@@ -32,21 +32,57 @@ __global__ __launch_bounds__(256) void embed_input_fwd_kernel(T* out, EmbTabs tb
     }
 }
 
+constexpr int EMB_TOK_PER_BLOCK = 64;
+constexpr int EMB_SMALL_ROWS = 8;      // tables with <= 8 rows (coord, view, type) are reduced per block in LDS
+
+// Scatter-add of d_out into the table gradients.  Tables with a handful of rows would serialise ~n_tok atomics
+// per address in L2; they are accumulated per block in LDS (ds_add_f32) and flushed with one global atomic per
+// (row, column) per block.  Large tables (value, pos) use global atomics directly; all-zero gradient vectors
+// (padded positions: no gradient ever reaches them) are skipped.
 template <typename T>
 __global__ __launch_bounds__(256) void embed_input_bwd_kernel(const T* dout, EmbGrads tb, int64_t n_tok, int d) {
-    const int vec_per_row = d >> 2;
-    const int64_t total = n_tok * vec_per_row;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t tok = e / vec_per_row;
-        const int c = (int)(e % vec_per_row) << 2;
-        const f32x4 g = ld4<T>(dout + tok * d + c);
+    extern __shared__ __attribute__((aligned(16))) float acc[];        // [n_small * EMB_SMALL_ROWS][d]
+    const int nvec = d >> 2;
+    const int lanes = 256 / nvec > 0 ? 256 / nvec : 1;                  // tokens processed concurrently
+    const int vec = threadIdx.x % nvec, tl = threadIdx.x / nvec;
+    int slot[5], nsmall = 0;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            if (k < tb.n && tb.idx[k]) {
-                float* dst = tb.t[k] + tb.idx[k][tok] * d + c;
+    for (int k = 0; k < 5; ++k) slot[k] = (k < tb.n && tb.idx[k] && tb.rows[k] <= EMB_SMALL_ROWS) ? nsmall++ : -1;
+    for (int e = threadIdx.x; e < nsmall * EMB_SMALL_ROWS * d; e += 256) acc[e] = 0.f;
+    __syncthreads();
+    const int64_t t0 = (int64_t)blockIdx.x * EMB_TOK_PER_BLOCK;
+    if (tl < lanes) {
+        for (int v = vec; v < nvec; v += (nvec > 256 ? 256 : nvec)) {
+            const int c = v << 2;
+            for (int i = tl; i < EMB_TOK_PER_BLOCK; i += lanes) {
+                const int64_t tok = t0 + i;
+                if (tok >= n_tok) break;
+                const f32x4 g = ld4<T>(dout + tok * d + c);
+                if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f && g[3] == 0.f) continue;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dst + j, g[j]);
+                for (int k = 0; k < 5; ++k) {
+                    if (!(k < tb.n && tb.idx[k])) continue;
+                    const int64_t r = tb.idx[k][tok];
+                    if (slot[k] >= 0) {
+                        float* dst = acc + ((size_t)(slot[k] * EMB_SMALL_ROWS + r)) * d + c;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) atomicAdd(dst + j, g[j]);      // LDS atomic
+                    } else {
+                        float* dst = tb.t[k] + r * d + c;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dst + j, g[j]);
+                    }
+                }
             }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (slot[k] < 0) continue;
+        for (int e = threadIdx.x; e < tb.rows[k] * d; e += 256) {
+            const float v = acc[(size_t)slot[k] * EMB_SMALL_ROWS * d + e];
+            if (v != 0.f) unsafeAtomicAdd(tb.t[k] + e, v);
         }
     }
 }
@@ -219,16 +255,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(T* dz, T* ddrop, con
     }
 }
 
-// sums `nparts` partial rows of `nq` quantities and ACCUMULATES into up to three outputs
+// sums `nparts` partial rows and ACCUMULATES into up to three outputs.  Block = 64 columns x 4 part lanes
+// (each lane strides over the parts with independent, coalesced loads), LDS combine.
 __global__ __launch_bounds__(256) void partial_finish_kernel(const float* partial, int nparts, int part_stride, int q_stride,
                                                              int ncols, float* o0, float* o1, float* o2) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
     const int qn = blockIdx.y;
     float* o = qn == 0 ? o0 : (qn == 1 ? o1 : o2);
-    if (c >= ncols || !o) return;
     float s = 0.f;
-    for (int i = 0; i < nparts; ++i) s += partial[(size_t)i * part_stride + (size_t)qn * q_stride + c];
-    o[c] += s;
+    if (c < ncols && o) {
+        const float* p = partial + (size_t)qn * q_stride + c;
+#pragma unroll 8
+        for (int i = pl; i < nparts; i += 4) s += p[(size_t)i * part_stride];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0 && c < ncols && o) o[c] += (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 // ================================================================================ switch head
@@ -448,13 +491,20 @@ extern "C" int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* con
 }
 
 extern "C" int pa_embed_input_bwd(const void* dout, int32_t dtype, float* const* dtables, const int64_t* const* idx,
-                                  int32_t n_tables, int64_t n_tok, int32_t d, void* stream) {
-    if (!dout || !dtables || !idx || n_tables < 1 || n_tables > 5 || (d & 3) || n_tok <= 0) return PA_EINVAL;
+                                  const int32_t* table_rows, int32_t n_tables, int64_t n_tok, int32_t d, void* stream) {
+    if (!dout || !dtables || !idx || !table_rows || n_tables < 1 || n_tables > 5 || (d & 3) || n_tok <= 0) return PA_EINVAL;
+    if (d > 1024) return PA_ESHAPE;
     EmbGrads tb; tb.n = n_tables;
-    for (int k = 0; k < 5; ++k) { tb.t[k] = k < n_tables ? dtables[k] : nullptr; tb.idx[k] = k < n_tables ? idx[k] : nullptr; }
-    const int grid = grid_for(n_tok * (d >> 2));
-    if (dtype == PA_BF16) PA_LAUNCH(embed_input_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dout, tb, n_tok, d);
-    else PA_LAUNCH(embed_input_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)dout, tb, n_tok, d);
+    int nsmall = 0;
+    for (int k = 0; k < 5; ++k) {
+        tb.t[k] = k < n_tables ? dtables[k] : nullptr; tb.idx[k] = k < n_tables ? idx[k] : nullptr;
+        tb.rows[k] = k < n_tables ? table_rows[k] : 0;
+        if (tb.idx[k] && tb.rows[k] <= EMB_SMALL_ROWS) ++nsmall;
+    }
+    const int grid = (int)((n_tok + EMB_TOK_PER_BLOCK - 1) / EMB_TOK_PER_BLOCK);
+    const size_t shm = (size_t)nsmall * EMB_SMALL_ROWS * d * sizeof(float);
+    if (dtype == PA_BF16) PA_LAUNCH(embed_input_bwd_kernel<bf16>, dim3(grid), dim3(256), shm, ST(stream), (const bf16*)dout, tb, n_tok, d);
+    else PA_LAUNCH(embed_input_bwd_kernel<float>, dim3(grid), dim3(256), shm, ST(stream), (const float*)dout, tb, n_tok, d);
     return 0;
 }
 
@@ -504,7 +554,7 @@ extern "C" int pa_layernorm_bwd(void* dz, void* ddrop, const void* dy, const voi
     const size_t shm = (size_t)4 * 3 * d * sizeof(float);
     if (dtype == PA_BF16) PA_LAUNCH(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), shm, ST(stream), (bf16*)dz, (bf16*)ddrop, (const bf16*)dy, (const bf16*)z, gamma, mean, rstd, partial, rows, d, thr, scale, drop_seed, dzsum ? 1 : 0);
     else PA_LAUNCH(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), shm, ST(stream), (float*)dz, (float*)ddrop, (const float*)dy, (const float*)z, gamma, mean, rstd, partial, rows, d, thr, scale, drop_seed, dzsum ? 1 : 0);
-    PA_LAUNCH(partial_finish_kernel, dim3((d + 255) / 256, dzsum ? 3 : 2), dim3(256), 0, ST(stream), partial, grid, 3 * d, d, d, dgamma, dbeta, dzsum);
+    PA_LAUNCH(partial_finish_kernel, dim3((d + 63) / 64, dzsum ? 3 : 2), dim3(256), 0, ST(stream), partial, grid, 3 * d, d, d, dgamma, dbeta, dzsum);
     return 0;
 }
 
@@ -525,7 +575,7 @@ extern "C" int pa_switch_bwd(void* dh, int32_t accumulate, float* dw, float* db,
     if (dtype == PA_BF16) PA_LAUNCH(switch_bwd_kernel<bf16>, dim3(grid), dim3(256), shm, ST(stream), (bf16*)dh, accumulate, ds, (const bf16*)h, w, partial, rows, d);
     else PA_LAUNCH(switch_bwd_kernel<float>, dim3(grid), dim3(256), shm, ST(stream), (float*)dh, accumulate, ds, (const float*)h, w, partial, rows, d);
     // partial rows: [blk][0][d] = dw, [blk][1][0] = db
-    PA_LAUNCH(partial_finish_kernel, dim3((d + 255) / 256, 1), dim3(256), 0, ST(stream), partial, grid, 2 * d, d, d, dw, (float*)nullptr, (float*)nullptr);
+    PA_LAUNCH(partial_finish_kernel, dim3((d + 63) / 64, 1), dim3(256), 0, ST(stream), partial, grid, 2 * d, d, d, dw, (float*)nullptr, (float*)nullptr);
     PA_LAUNCH(partial_finish_kernel, dim3(1, 1), dim3(256), 0, ST(stream), partial + d, grid, 2 * d, d, 1, db, (float*)nullptr, (float*)nullptr);
     return 0;
 }

@@ -371,7 +371,7 @@ int backward_segment(pa_model* m, int seg, float gscale, void* st) {
     if (es < c.n_enc) return bwd_enc_layer(m, c.n_enc - 1 - es, st);
     if (es == c.n_enc) {
         float* dt[5] = {G(P_IN_VALUE), G(P_IN_POS), G(P_IN_COORD), G(P_IN_VIEW), G(P_IN_TYPE)};
-        return pa_embed_input_bwd(m->gA, c.dtype, dt, m->batch.input_idx, 5, (int64_t)BS, d, st);
+        return pa_embed_input_bwd(m->gA, c.dtype, dt, m->batch.input_idx, c.in_table_rows, 5, (int64_t)BS, d, st);
     }
     return PA_EINVAL;
 }

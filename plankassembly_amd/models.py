@@ -36,7 +36,7 @@ from . import _lib as L
 # ------------------------------------------------------------------------------------------------
 class _ModelCfg(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_head", C.c_int32), ("d_ff", C.c_int32), ("n_enc", C.c_int32),
-                ("n_dec", C.c_int32), ("vocab", C.c_int32), ("out_dof", C.c_int32),
+                ("n_dec", C.c_int32), ("vocab", C.c_int32), ("out_dof", C.c_int32), ("in_table_rows", C.c_int32 * 5),
                 ("eps_layer", C.c_float), ("eps_final", C.c_float), ("has_enc_norm", C.c_int32),
                 ("dropout", C.c_float), ("pad", C.c_int32), ("end", C.c_int32), ("dtype", C.c_int32)]
 
@@ -318,8 +318,9 @@ class PlankModel(nn.Module):
         self._require_gpu()
         if self._handle is not None:
             return
+        rows = (C.c_int32 * 5)(*[self._shapes[f"input_embeddings.{k}.weight"][0] for k in INPUT_KEYS])
         cfg = _ModelCfg(self.num_model, self.num_head, self.num_feedforward, self.num_encoder_layers,
-                        self.num_decoder_layers, self.vocab_size, self.num_output_dof, self.eps_layer, 1e-5,
+                        self.num_decoder_layers, self.vocab_size, self.num_output_dof, rows, self.eps_layer, 1e-5,
                         int(self.has_enc_norm), self.dropout, int(self.token.PAD), int(self.token.END),
                         self._pa_dtype())
         h = C.c_void_p()

@@ -90,7 +90,8 @@ def embed_input_fwd(tables, idx, dtype=torch.float32):
 
 def embed_input_bwd(dout, dtables, idx):
     n_tok, d = dout.shape
-    L.check(L.lib().pa_embed_input_bwd(L.ptr(dout), L.dt(dout), _ptr_array(dtables), _ptr_array(idx), len(dtables),
+    rows = (C.c_int32 * len(dtables))(*[t.shape[0] for t in dtables])
+    L.check(L.lib().pa_embed_input_bwd(L.ptr(dout), L.dt(dout), _ptr_array(dtables), _ptr_array(idx), rows, len(dtables),
                                        C.c_int64(n_tok), d, L.stream()), "pa_embed_input_bwd")
 
 
