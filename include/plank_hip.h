@@ -71,6 +71,16 @@ typedef struct {
 } pa_gemm_args;
 int pa_gemm(const pa_gemm_args* a, void* stream);
 
+/* Batched 2-D transposes dst[c][r] = src[r][c] (one launch for a table of matrices; descriptors live in device
+ * memory, tile_begin = prefix sum of ceil(rows/64)*ceil(cols/64)).  Keeps the transposed shadow of the Linear
+ * weights current so the backward GEMM dX = dY W runs with both operands k-contiguous. */
+typedef struct {
+    const void* src; void* dst;
+    int32_t rows, cols, ld_src, ld_dst;
+    int32_t tile_begin, pad_;
+} pa_tr_desc;
+int pa_transpose_many(const pa_tr_desc* descs_dev, int32_t n_desc, int32_t total_tiles, int32_t dtype, void* stream);
+
 /* column sums: out[n] (+)= sum_m X[m][n]  (bias gradients).  f32 out. `partial` is scratch of
  * pa_colsum_ws_floats(M,N) floats. */
 int64_t pa_colsum_ws_floats(int32_t M, int32_t N);
@@ -202,6 +212,10 @@ int pa_cast(void* dst, int32_t dst_dtype, const void* src, int32_t src_dtype, in
  * state_dict (plankassembly_amd/models.py PARAM_ORDER):
  *   params_f32 : f32 master parameters (embedding tables, biases, LayerNorm affine are read here)
  *   params_lp  : the same tensors in the compute dtype (GEMM B operands); = params_f32 for PA_F32
+ *   params_lpT : (pa_model_bind_transposed, optional) transposed copies W^T [in][out] of the 2-D Linear weights
+ *                at the same table positions (NULL entries = not available): dX = dY W then runs as a
+ *                k-contiguous GEMM against W^T.  The caller refreshes them after each optimizer step
+ *                (pa_transpose_many).
  *   grads      : f32 gradients (may be NULL for inference).  Gradients that are produced by
  *                accumulation (embedding tables, LayerNorm affine, out_proj/linear2 biases, switch
  *                head) are ADDED to: the caller zeroes the gradient buffer before backward.
@@ -237,6 +251,7 @@ int pa_model_create(const pa_model_cfg* cfg, pa_model** out);
 void pa_model_destroy(pa_model* m);
 int pa_model_num_params(const pa_model* m);
 int pa_model_bind(pa_model* m, void* const* params_f32, void* const* params_lp, void* const* grads);
+int pa_model_bind_transposed(pa_model* m, void* const* params_lpT);
 int64_t pa_model_train_ws_bytes(pa_model* m, int32_t B, int32_t S, int32_t T);
 /* stats (device, f32[4]): [0] sum of -log p(label) over non-PAD labels, [1] #non-PAD, [2] #correct.
  * loss = stats[0]/stats[1] (reference models.py:221), accuracy = stats[2]/(stats[1]+1e-10) (:227);

@@ -409,22 +409,39 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
         TR(2);
         const char* la = smem + buf * 2 * TL::TILE_BYTES;
         const char* lb = la + TL::TILE_BYTES;
-        // all fragment reads of the tile are issued up front; LDS returns in order, so the MFMAs of step s start
-        // as soon as their 4 vectors have landed while the later ones are still in flight
-        u32x4 fa[TL::STEPS][2], fb[TL::STEPS][2];
+        if constexpr (A_GL && B_GL) {
+            // all fragment reads of the tile are issued up front; LDS returns in order, so the MFMAs of step s start
+            // as soon as their 4 vectors have landed while the later ones are still in flight
+            u32x4 fa[TL::STEPS][2], fb[TL::STEPS][2];
 #pragma unroll
-        for (int s = 0; s < TL::STEPS; ++s)
+            for (int s = 0; s < TL::STEPS; ++s)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[s][i] = *reinterpret_cast<const u32x4*>(la + lds_off<TL>(arow + i * 32, 2 * s + half));
-                fb[s][i] = *reinterpret_cast<const u32x4*>(lb + lds_off<TL>(brow + i * 32, 2 * s + half));
+                for (int i = 0; i < 2; ++i) {
+                    fa[s][i] = *reinterpret_cast<const u32x4*>(la + lds_off<TL>(arow + i * 32, 2 * s + half));
+                    fb[s][i] = *reinterpret_cast<const u32x4*>(lb + lds_off<TL>(brow + i * 32, 2 * s + half));
+                }
+#pragma unroll
+            for (int s = 0; s < TL::STEPS; ++s)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) mma16B<T>(acc[tn][tm], fb[s][tn], fa[s][tm]);
+        } else {
+            // staging registers are live in these variants: keep the fragment footprint to two steps
+#pragma unroll
+            for (int s = 0; s < TL::STEPS; ++s) {
+                u32x4 fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[i] = *reinterpret_cast<const u32x4*>(la + lds_off<TL>(arow + i * 32, 2 * s + half));
+                    fb[i] = *reinterpret_cast<const u32x4*>(lb + lds_off<TL>(brow + i * 32, 2 * s + half));
+                }
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) mma16B<T>(acc[tn][tm], fb[tn], fa[tm]);
             }
-#pragma unroll
-        for (int s = 0; s < TL::STEPS; ++s)
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm) mma16B<T>(acc[tn][tm], fb[s][tn], fa[s][tm]);
+        }
         TR(3);
         if (last_k) {
             __syncthreads();                 // every wave is done reading `buf`: its LDS becomes the staging area
@@ -626,6 +643,39 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial,
 }
 inline int cs_npad(int N) { return (N + 7) / 8 * 8; }
 }  // namespace
+
+// -------------------------------------------------------------------------------------------------
+// batched 2-D transposes (bf16/f32): dst[c][r] = src[r][c] for a table of matrices, one launch.  Used to keep a
+// transposed shadow of the Linear weights so that dX = dY W runs on the k-contiguous fast path.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_many_kernel(const pa_tr_desc* descs, int n_desc) {
+    __shared__ T tile[64][65];
+    int t = blockIdx.x, di = 0;
+    while (di + 1 < n_desc && t >= descs[di + 1].tile_begin) ++di;     // few dozen descriptors: linear scan
+    const pa_tr_desc d = descs[di];
+    t -= d.tile_begin;
+    const int tiles_c = (d.cols + 63) / 64;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const T* src = reinterpret_cast<const T*>(d.src);
+    T* dst = reinterpret_cast<T*>(d.dst);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4)
+        if (r0 + i < d.rows && c0 + tx < d.cols) tile[i][tx] = src[(size_t)(r0 + i) * d.ld_src + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4)
+        if (c0 + i < d.cols && r0 + tx < d.rows) dst[(size_t)(c0 + i) * d.ld_dst + r0 + tx] = tile[tx][i];
+}
+}  // namespace
+
+extern "C" int pa_transpose_many(const pa_tr_desc* descs_dev, int32_t n_desc, int32_t total_tiles, int32_t dtype, void* stream) {
+    if (!descs_dev || n_desc <= 0 || total_tiles <= 0) return PA_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == PA_BF16) PA_LAUNCH(transpose_many_kernel<bf16>, dim3(total_tiles), dim3(256), 0, st, descs_dev, n_desc);
+    else if (dtype == PA_F32) PA_LAUNCH(transpose_many_kernel<float>, dim3(total_tiles), dim3(256), 0, st, descs_dev, n_desc);
+    else return PA_EINVAL;
+    return 0;
+}
 
 extern "C" int64_t pa_colsum_ws_floats(int32_t M, int32_t N) {
     return (int64_t)((M + CS_ROWS - 1) / CS_ROWS) * cs_npad(N);

@@ -40,6 +40,7 @@ struct pa_model {
     pa_model_cfg cfg;
     int n_params;
     std::vector<void*> pf, pl, gr;     // f32 params, low-precision (GEMM operand) params, f32 grads
+    std::vector<void*> plT;            // optional transposed low-precision weights (NULL = absent)
     bool bound = false;
     // ---- per-step state (valid between train_fwd and train_bwd) ----
     bool have_fwd = false;

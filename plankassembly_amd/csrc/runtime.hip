@@ -32,14 +32,15 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
         g.alpha = 1.f; g.relu = relu; g.aux_scale = 1.f; g.drop_p = drop_p; g.drop_seed = seed; g.splitk = 1;
         return pa_gemm(&g, st);
     }
-    // dX[M,K] = dY[M,N] x W[N][K]  (+ R)   (optionally relu-backward gated by aux)
+    // dX[M,K] = dY[M,N] x W[N][K]  (+ R)   (optionally relu-backward gated by aux).
+    // WT (optional): transposed weight, element (k, n) at WT[k * ldwt + n]  -> both operands k-contiguous.
     int linear_dx(const void* dY, int lddy, const void* W, int ldw, void* dX, int lddx, int M, int N, int K,
                   const void* R = nullptr, int ldr = 0, const void* aux = nullptr, int ldaux = 0,
-                  float aux_scale = 1.f) const {
+                  float aux_scale = 1.f, const void* WT = nullptr, int ldwt = 0) const {
         pa_gemm_args g; memset(&g, 0, sizeof(g));
-        g.A = dY; g.B = W; g.C = dX; g.R = R; g.aux = aux;
-        g.M = M; g.N = K; g.K = N; g.lda = lddy; g.ldb = ldw; g.ldc = lddx; g.ldr = ldr; g.ldaux = ldaux;
-        g.batch = 1; g.a_kcontig = 1; g.b_kcontig = 0;
+        g.A = dY; g.B = WT ? WT : W; g.C = dX; g.R = R; g.aux = aux;
+        g.M = M; g.N = K; g.K = N; g.lda = lddy; g.ldb = WT ? ldwt : ldw; g.ldc = lddx; g.ldr = ldr; g.ldaux = ldaux;
+        g.batch = 1; g.a_kcontig = 1; g.b_kcontig = WT ? 1 : 0;
         g.in_dtype = dt(); g.out_dtype = dt();
         g.alpha = 1.f; g.aux_scale = aux_scale; g.splitk = 1;
         return pa_gemm(&g, st);
@@ -251,7 +252,7 @@ int bwd_heads(pa_model* m, float gscale, void* st) {
         g.a_kcontig = 0; g.ldr = d; g.sR = (int64_t)T * d;
         RC(pa_gemm(&g, st));
     }
-    RC(k.linear_dx(m->gB, d, m->pl[tl + T_PTR_W], d, m->gA, d, BT, d, d, m->gA, d));
+    RC(k.linear_dx(m->gB, d, m->pl[tl + T_PTR_W], d, m->gA, d, BT, d, d, m->gA, d, nullptr, 0, 1.f, m->plT[tl + T_PTR_W], d));
     RC(k.linear_dw(m->gB, d, m->hid, d, G(tl + T_PTR_W), G(tl + T_PTR_B), BT, d, d));
     RC(pa_switch_bwd(m->gA, 1, G(tl + T_SW_W), G(tl + T_SW_B), m->dsw, m->hid, c.dtype, (const float*)m->pf[tl + T_SW_W],
                      m->partial, (int64_t)BT, d, st));
@@ -274,9 +275,9 @@ int bwd_ffn(pa_model* m, Ctx& k, int rows, const void* z, const float* mean, con
     RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, z, (const float*)m->pf[nw], mean, rstd, G(nw), G(nw + 1),
                 G(w2 + 1), rows, p, seed_out));
     RC(k.linear_dw(ddrop, d, hff, ff, G(w2), nullptr, rows, d, ff));
-    RC(k.linear_dx(ddrop, d, m->pl[w2], ff, m->gF, ff, rows, d, ff, nullptr, 0, hff, ff, 1.0f / (1.0f - p)));
+    RC(k.linear_dx(ddrop, d, m->pl[w2], ff, m->gF, ff, rows, d, ff, nullptr, 0, hff, ff, 1.0f / (1.0f - p), m->plT[w2], d));
     RC(k.linear_dw(m->gF, ff, yin, d, G(w1), G(w1 + 1), rows, ff, d));
-    RC(k.linear_dx(m->gF, ff, m->pl[w1], d, m->gA, d, rows, ff, d, m->gB, d));
+    RC(k.linear_dx(m->gF, ff, m->pl[w1], d, m->gA, d, rows, ff, d, m->gB, d, nullptr, 0, 1.f, m->plT[w1], ff));
     return 0;
 }
 
@@ -298,26 +299,29 @@ int bwd_dec_layer(pa_model* m, int i, void* st) {
     RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, t.z2, (const float*)m->pf[pb + D_N2_W], t.m2, t.r2, G(pb + D_N2_W),
                 G(pb + D_N2_B), G(pb + D_CA_OUT_B), BT, p, site_seed(m->seed, sb + 3)));
     RC(k.linear_dw(ddrop, d, t.o_ca, d, G(pb + D_CA_OUT_W), nullptr, BT, d, d));
-    RC(k.linear_dx(ddrop, d, m->pl[pb + D_CA_OUT_W], d, m->gD, d, BT, d, d));
+    RC(k.linear_dx(ddrop, d, m->pl[pb + D_CA_OUT_W], d, m->gD, d, BT, d, d, nullptr, 0, nullptr, 0, 1.f, m->plT[pb + D_CA_OUT_W], d));
     RC(k.attn(true, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, 2 * d, t.o_ca, t.lse_ca, m->batch.input_mask, T, S, 0, p,
               site_seed(m->seed, sb + 2), m->gD, m->gE, d, m->gKV, (char*)m->gKV + d * e, 2 * d));
     float* dWin = G(pb + D_CA_IN_W); float* dbin = G(pb + D_CA_IN_B);
     RC(k.linear_dw(m->gE, d, t.y1, d, dWin, dbin, BT, d, d));
     RC(k.linear_dw(m->gKV, 2 * d, memory, d, dWin + (size_t)d * d, dbin + d, BS, 2 * d, d));
-    RC(k.linear_dx(m->gKV, 2 * d, (const char*)m->pl[pb + D_CA_IN_W] + (size_t)d * d * e, d, m->dmem, d, BS, 2 * d, d,
-                   m->dmem_written ? m->dmem : nullptr, d));
+    {
+        const void* wt = m->plT[pb + D_CA_IN_W];                       // W_in^T is [d][3d]; K/V rows of W_in = its columns d..3d
+        RC(k.linear_dx(m->gKV, 2 * d, (const char*)m->pl[pb + D_CA_IN_W] + (size_t)d * d * e, d, m->dmem, d, BS, 2 * d, d,
+                       m->dmem_written ? m->dmem : nullptr, d, nullptr, 0, 1.f, wt ? (const char*)wt + (size_t)d * e : nullptr, 3 * d));
+    }
     m->dmem_written = true;
-    RC(k.linear_dx(m->gE, d, m->pl[pb + D_CA_IN_W], d, m->gA, d, BT, d, d, m->gB, d));
+    RC(k.linear_dx(m->gE, d, m->pl[pb + D_CA_IN_W], d, m->gA, d, BT, d, d, m->gB, d, nullptr, 0, 1.f, m->plT[pb + D_CA_IN_W], 3 * d));
     // self attention block: z1 = Y[i] + drop(out_proj(attn(qkv(Y[i]))))
     RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, t.z1, (const float*)m->pf[pb + D_N1_W], t.m1, t.r1, G(pb + D_N1_W),
                 G(pb + D_N1_B), G(pb + D_SA_OUT_B), BT, p, site_seed(m->seed, sb + 1)));
     RC(k.linear_dw(ddrop, d, t.o_sa, d, G(pb + D_SA_OUT_W), nullptr, BT, d, d));
-    RC(k.linear_dx(ddrop, d, m->pl[pb + D_SA_OUT_W], d, m->gD, d, BT, d, d));
+    RC(k.linear_dx(ddrop, d, m->pl[pb + D_SA_OUT_W], d, m->gD, d, BT, d, d, nullptr, 0, nullptr, 0, 1.f, m->plT[pb + D_SA_OUT_W], d));
     RC(k.attn(true, t.qkv, 3 * d, (char*)t.qkv + d * e, (char*)t.qkv + 2 * d * e, 3 * d, t.o_sa, t.lse_sa,
               m->batch.output_mask, T, T, 1, p, site_seed(m->seed, sb + 0), m->gD, m->gQ3, 3 * d,
               (char*)m->gQ3 + d * e, (char*)m->gQ3 + 2 * d * e, 3 * d));
     RC(k.linear_dw(m->gQ3, 3 * d, m->Y[i], d, G(pb + D_SA_IN_W), G(pb + D_SA_IN_B), BT, 3 * d, d));
-    RC(k.linear_dx(m->gQ3, 3 * d, m->pl[pb + D_SA_IN_W], d, m->gA, d, BT, 3 * d, d, m->gB, d));
+    RC(k.linear_dx(m->gQ3, 3 * d, m->pl[pb + D_SA_IN_W], d, m->gA, d, BT, 3 * d, d, m->gB, d, nullptr, 0, 1.f, m->plT[pb + D_SA_IN_W], 3 * d));
     return 0;
 }
 
@@ -336,11 +340,11 @@ int bwd_enc_layer(pa_model* m, int i, void* st) {
     RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, t.z1, (const float*)m->pf[pb + E_N1_W], t.m1, t.r1, G(pb + E_N1_W),
                 G(pb + E_N1_B), G(pb + E_OUT_B), BS, p, site_seed(m->seed, 8 * i + 1)));
     RC(k.linear_dw(ddrop, d, t.o, d, G(pb + E_OUT_W), nullptr, BS, d, d));
-    RC(k.linear_dx(ddrop, d, m->pl[pb + E_OUT_W], d, m->gD, d, BS, d, d));
+    RC(k.linear_dx(ddrop, d, m->pl[pb + E_OUT_W], d, m->gD, d, BS, d, d, nullptr, 0, nullptr, 0, 1.f, m->plT[pb + E_OUT_W], d));
     RC(k.attn(true, t.qkv, 3 * d, (char*)t.qkv + d * e, (char*)t.qkv + 2 * d * e, 3 * d, t.o, t.lse, m->batch.input_mask, S, S, 0,
               p, site_seed(m->seed, 8 * i + 0), m->gD, m->gQ3, 3 * d, (char*)m->gQ3 + d * e, (char*)m->gQ3 + 2 * d * e, 3 * d));
     RC(k.linear_dw(m->gQ3, 3 * d, m->X[i], d, G(pb + E_IN_W), G(pb + E_IN_B), BS, 3 * d, d));
-    RC(k.linear_dx(m->gQ3, 3 * d, m->pl[pb + E_IN_W], d, m->gA, d, BS, 3 * d, d, m->gB, d));
+    RC(k.linear_dx(m->gQ3, 3 * d, m->pl[pb + E_IN_W], d, m->gA, d, BS, 3 * d, d, m->gB, d, nullptr, 0, 1.f, m->plT[pb + E_IN_W], 3 * d));
     return 0;
 }
 
@@ -391,6 +395,7 @@ extern "C" int pa_model_create(const pa_model_cfg* cfg, pa_model** out) {
     m->cfg = *cfg;
     m->n_params = P_FIXED_HEAD + cfg->n_enc * E_COUNT + 2 + cfg->n_dec * D_COUNT + 2 + T_COUNT;
     m->pf.assign(m->n_params, nullptr); m->pl.assign(m->n_params, nullptr); m->gr.assign(m->n_params, nullptr);
+    m->plT.assign(m->n_params, nullptr);
     *out = m;
     return 0;
 }
@@ -406,6 +411,12 @@ extern "C" int pa_model_bind(pa_model* m, void* const* params_f32, void* const* 
         m->pf[i] = params_f32[i]; m->pl[i] = params_lp[i]; m->gr[i] = grads ? grads[i] : nullptr;
     }
     m->bound = true;
+    return 0;
+}
+
+extern "C" int pa_model_bind_transposed(pa_model* m, void* const* params_lpT) {
+    if (!m) return PA_EINVAL;
+    for (int i = 0; i < m->n_params; ++i) m->plT[i] = params_lpT ? params_lpT[i] : nullptr;
     return 0;
 }
 

@@ -41,6 +41,11 @@ class _ModelCfg(C.Structure):
                 ("dropout", C.c_float), ("pad", C.c_int32), ("end", C.c_int32), ("dtype", C.c_int32)]
 
 
+class _TrDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("ld_src", C.c_int32), ("ld_dst", C.c_int32), ("tile_begin", C.c_int32), ("pad_", C.c_int32)]
+
+
 class _Batch(C.Structure):
     _fields_ = [("input_idx", C.c_void_p * 5), ("input_mask", C.c_void_p), ("output_value", C.c_void_p),
                 ("output_label", C.c_void_p), ("output_mask", C.c_void_p),
@@ -197,6 +202,8 @@ class PlankModel(nn.Module):
         self._gflat = None
         self._gtmp = None
         self._shadow = None
+        self._shadowT = None
+        self._tr_descs = None
         self._shadow_version = -1
         self._handle = None
         self._ws = None
@@ -246,7 +253,8 @@ class PlankModel(nn.Module):
                 p.data = view
                 p.grad = None
         self._flat = flat
-        self._gflat = self._gtmp = self._shadow = None
+        self._gflat = self._gtmp = self._shadow = self._shadowT = None
+        self._tr_descs = None
         self._shadow_version = -1
         self._drop_handle()
 
@@ -349,6 +357,41 @@ class PlankModel(nn.Module):
         gr = self._ptr_table(g, 4) if g is not None else None
         L.check(L.lib().pa_model_bind(self._handle, pf, pl, gr), "pa_model_bind")
         self._bound_grads = g
+        if self.compute_dtype == "bf16":
+            self._setup_transposed_shadow()
+
+    def _setup_transposed_shadow(self):
+        """bf16 shadow of W^T for every 2-D Linear weight whose transpose stays 16-byte aligned (all but
+        vocab_head): the backward dX = dY W then runs as a k-contiguous GEMM (csrc/runtime.hip linear_dx)."""
+        if self._shadowT is not None:
+            return
+        dev = self._flat.device
+        self._shadowT = torch.zeros(self._numel, dtype=torch.bfloat16, device=dev)
+        n = len(self._order)
+        tab = (C.c_void_p * n)()
+        descs, tiles = [], 0
+        for i, k in enumerate(self._order):
+            s = self._shapes[k]
+            is_linear_w = len(s) == 2 and ("proj" in k or "linear" in k or k == "pointer_head.weight")
+            if not is_linear_w or s[0] % 8 or s[1] % 8:
+                tab[i] = None
+                continue
+            off = self._offsets[k] * 2
+            tab[i] = self._shadowT.data_ptr() + off
+            d = _TrDesc(self._shadow.data_ptr() + off, self._shadowT.data_ptr() + off, s[0], s[1], s[1], s[0], tiles, 0)
+            tiles += ((s[0] + 63) // 64) * ((s[1] + 63) // 64)
+            descs.append(d)
+        arr = (_TrDesc * len(descs))(*descs)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self._tr_descs = (host.to(dev), len(descs), tiles)
+        L.check(L.lib().pa_model_bind_transposed(self._handle, tab), "pa_model_bind_transposed")
+
+    def refresh_transposed(self):
+        """Re-derive the W^T shadow from the bf16 shadow (one batched transpose launch)."""
+        if self._tr_descs is None:
+            return
+        d, n, tiles = self._tr_descs
+        L.check(L.lib().pa_transpose_many(L.ptr(d), n, tiles, L.PA_BF16, L.stream()), "pa_transpose_many")
 
     def _ensure_grads(self):
         if self._gflat is None:
@@ -362,10 +405,12 @@ class PlankModel(nn.Module):
             L.check(L.lib().pa_cast(L.ptr(self._shadow), L.PA_BF16, L.ptr(self._flat), L.PA_F32,
                                     C.c_int64(self._numel), L.stream()), "pa_cast")
             self._shadow_version = v
+            self.refresh_transposed()
 
     def mark_shadow_fresh(self):
         """Called by the fused optimizer, which refreshes the bf16 shadow inside its own kernel."""
         self._shadow_version = self._flat._version
+        self.refresh_transposed()
 
     # ---------------------------------------------------------------------------------- batches
     def _make_batch(self, batch, with_output=True):
