@@ -40,6 +40,8 @@ struct GemmP {
 };
 
 constexpr int BM = 128, BN = 128, NT = 256;
+__device__ __attribute__((aligned(16))) const uint32_t pa_zero16[4] = {0u, 0u, 0u, 0u};   // source of out-of-range DMA lanes
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #ifdef PA_GEMM_TRACE
 __device__ unsigned long long pa_trace[8192];
@@ -91,8 +93,12 @@ __device__ __forceinline__ bool decode_unit(const GemmP& p, int u, Unit& un) {
 }
 __device__ __forceinline__ int next_valid_unit(int u, int stride) { return u + stride; }
 
-// GLDS: direct-to-LDS loads for the k-contiguous operands (requires ALIGNED and K % BK == 0)
-template <typename T, int BK_, int OCC, bool A_KC, bool B_KC, bool ALIGNED, bool GLDS>
+// GLDS: direct-to-LDS loads for the k-contiguous operands (requires ALIGNED and K % BK == 0).
+// TRG (bf16): operands whose contraction index is strided in memory are DMA'd into LDS in their NATURAL layout
+//   ([k][row], 256-byte rows, 64-byte units XOR-swizzled by k&3) and the MFMA fragments are formed by
+//   ds_read_b64_tr_b16 (in each 16-lane group lane L supplies row L>>2 / column 4*(L&3) of a 4 x 16 patch and
+//   lane i receives column i) - no register transposes, no staging VGPRs.  Lanes whose k is past K read zeros.
+template <typename T, int BK_, int OCC, bool A_KC, bool B_KC, bool ALIGNED, bool GLDS, bool TRG>
 __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
     using TL = Tile<T, BK_>;
     constexpr int EB = TL::EB;
@@ -113,8 +119,10 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     constexpr bool A_GL = A_KC && GLDS, B_GL = B_KC && GLDS;
-    constexpr int NRA = A_GL ? 1 : (A_KC ? TL::NLD : TL::NTR * EB);
-    constexpr int NRB = B_GL ? 1 : (B_KC ? TL::NLD : TL::NTR * EB);
+    constexpr bool A_TG = !A_KC && TRG, B_TG = !B_KC && TRG;
+    static_assert(!TRG || (sizeof(T) == 2 && BK_ == 64), "transposing LDS reads: bf16, 64-deep K tile");
+    constexpr int NRA = (A_GL || A_TG) ? 1 : (A_KC ? TL::NLD : TL::NTR * EB);
+    constexpr int NRB = (B_GL || B_TG) ? 1 : (B_KC ? TL::NLD : TL::NTR * EB);
     u32x4 ra[NRA], rb[NRB];
     const bool a_role = A_KC || (tid < 128);
     const bool b_role = B_KC || (tid >= 128);
@@ -145,6 +153,25 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                 const int ch = B_GL ? (((pidx % TL::NCH) ^ (row / TL::RPB)) & (TL::NCH - 1)) : (pidx % TL::NCH);
                 okB[i] = (n0 + row) < p.N;
                 offB[i] = (uint32_t)min(n0 + row, p.N - 1) * (uint32_t)(p.ldb * esz) + ch * 16;
+            }
+        }
+        // natural image: LDS chunk pidx = (k row = pidx >> 4, position = pidx & 15) holds source chunk pos ^ ((row & 3) << 2)
+        if constexpr (A_TG) {
+#pragma unroll
+            for (int i = 0; i < TL::NLD; ++i) {
+                const int pidx = tid + i * NT, row = pidx >> 4;
+                const int col = m0 + (((pidx & 15) ^ ((row & 3) << 2)) << 3);
+                okA[i] = col < p.M;
+                offA[i] = (uint32_t)row * (uint32_t)(p.lda * esz) + (uint32_t)col * esz;
+            }
+        }
+        if constexpr (B_TG) {
+#pragma unroll
+            for (int i = 0; i < TL::NLD; ++i) {
+                const int pidx = tid + i * NT, row = pidx >> 4;
+                const int col = n0 + (((pidx & 15) ^ ((row & 3) << 2)) << 3);
+                okB[i] = col < p.N;
+                offB[i] = (uint32_t)row * (uint32_t)(p.ldb * esz) + (uint32_t)col * esz;
             }
         }
     };
@@ -221,6 +248,15 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                 }
                 ra[i] = v;
             }
+        } else if constexpr (A_TG) {
+            const char* kra = baseA + (size_t)k0 * p.lda * esz;            // wave-uniform: first k row of the tile
+#pragma unroll
+            for (int i = 0; i < TL::NLD; ++i) {
+                const bool in = okA[i] && (k0 + ((tid + i * NT) >> 4)) < p.K;
+                const char* src = in ? kra + offA[i] : reinterpret_cast<const char*>(pa_zero16);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                    (__attribute__((address_space(3))) void*)(la + (i * NT + wave * 64) * 16), 16, 0, 0);
+            }
         } else { if (a_role) load_tr(ra, baseA, p.lda, un.tile_m * BM, p.M, k0); }
         if constexpr (B_GL) {
 #pragma unroll
@@ -244,13 +280,22 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                 }
                 rb[i] = v;
             }
+        } else if constexpr (B_TG) {
+            const char* krb = baseB + (size_t)k0 * p.ldb * esz;
+#pragma unroll
+            for (int i = 0; i < TL::NLD; ++i) {
+                const bool in = okB[i] && (k0 + ((tid + i * NT) >> 4)) < p.K;
+                const char* src = in ? krb + offB[i] : reinterpret_cast<const char*>(pa_zero16);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                    (__attribute__((address_space(3))) void*)(lb + (i * NT + wave * 64) * 16), 16, 0, 0);
+            }
         } else { if (b_role) load_tr(rb, baseB, p.ldb, un.tile_n * BN, p.N, k0); }
     };
     // phase 2: registers -> LDS (nothing to do for DMA'd operands)
     auto commit = [&](int buf) {
         char* la = smem + buf * 2 * TL::TILE_BYTES;
         char* lb = la + TL::TILE_BYTES;
-        if constexpr (!A_GL) {
+        if constexpr (!A_GL && !A_TG) {
             if constexpr (A_KC) {
 #pragma unroll
                 for (int i = 0; i < TL::NLD; ++i) {
@@ -259,7 +304,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                 }
             } else { if (a_role) store_tr(ra, la); }
         }
-        if constexpr (!B_GL) {
+        if constexpr (!B_GL && !B_TG) {
             if constexpr (B_KC) {
 #pragma unroll
                 for (int i = 0; i < TL::NLD; ++i) {
@@ -398,6 +443,18 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
     __syncthreads();
 
     const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31);
+    // transposing reads: lane-constant byte offset of fragment group i inside the natural image (k row 8*half + (L>>2),
+    // column window + 16*(G&1) + 4*(L&3); 64-byte units XOR-swizzled by the k row & 3 = (L>>2)&3)
+    int trA[2] = {0, 0}, trB[2] = {0, 0};
+    {
+        const int L = lane & 15, G = lane >> 4, kr = 8 * half + (L >> 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ca = (wm * 64 + i * 32 + 16 * (G & 1) + 4 * (L & 3)) * 2, cb = (wn * 64 + i * 32 + 16 * (G & 1) + 4 * (L & 3)) * 2;
+            trA[i] = kr * 256 + ((((ca >> 6) ^ ((L >> 2) & 3)) << 6) | (ca & 63));
+            trB[i] = kr * 256 + ((((cb >> 6) ^ ((L >> 2) & 3)) << 6) | (cb & 63));
+        }
+    }
     while (true) {
         const bool last_k = (t + 1 >= cur.t_end);
         const bool has_next = !last_k || (nu < p.units);
@@ -409,17 +466,37 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
         TR(2);
         const char* la = smem + buf * 2 * TL::TILE_BYTES;
         const char* lb = la + TL::TILE_BYTES;
-        if constexpr (A_GL && B_GL) {
+        // fragment (step s, 32-row group i) of the A-role / B-role tile
+        auto ldA = [&](int s, int i) -> u32x4 {
+            if constexpr (A_TG) {
+                const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(la + trA[i] + s * 4096));
+                const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(la + trA[i] + s * 4096 + 1024));
+                u32x4 f; const u32x2 a0 = *reinterpret_cast<const u32x2*>(&x0), a1 = *reinterpret_cast<const u32x2*>(&x1);
+                f[0] = a0[0]; f[1] = a0[1]; f[2] = a1[0]; f[3] = a1[1];
+                return f;
+            } else {
+                return *reinterpret_cast<const u32x4*>(la + lds_off<TL>(arow + i * 32, 2 * s + half));
+            }
+        };
+        auto ldB = [&](int s, int i) -> u32x4 {
+            if constexpr (B_TG) {
+                const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lb + trB[i] + s * 4096));
+                const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lb + trB[i] + s * 4096 + 1024));
+                u32x4 f; const u32x2 b0 = *reinterpret_cast<const u32x2*>(&x0), b1 = *reinterpret_cast<const u32x2*>(&x1);
+                f[0] = b0[0]; f[1] = b0[1]; f[2] = b1[0]; f[3] = b1[1];
+                return f;
+            } else {
+                return *reinterpret_cast<const u32x4*>(lb + lds_off<TL>(brow + i * 32, 2 * s + half));
+            }
+        };
+        if constexpr ((A_GL || A_TG) && (B_GL || B_TG)) {
             // all fragment reads of the tile are issued up front; LDS returns in order, so the MFMAs of step s start
-            // as soon as their 4 vectors have landed while the later ones are still in flight
+            // as soon as their vectors have landed while the later ones are still in flight
             u32x4 fa[TL::STEPS][2], fb[TL::STEPS][2];
 #pragma unroll
             for (int s = 0; s < TL::STEPS; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    fa[s][i] = *reinterpret_cast<const u32x4*>(la + lds_off<TL>(arow + i * 32, 2 * s + half));
-                    fb[s][i] = *reinterpret_cast<const u32x4*>(lb + lds_off<TL>(brow + i * 32, 2 * s + half));
-                }
+                for (int i = 0; i < 2; ++i) { fa[s][i] = ldA(s, i); fb[s][i] = ldB(s, i); }
 #pragma unroll
             for (int s = 0; s < TL::STEPS; ++s)
 #pragma unroll
@@ -427,15 +504,12 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
 #pragma unroll
                     for (int tm = 0; tm < 2; ++tm) mma16B<T>(acc[tn][tm], fb[s][tn], fa[s][tm]);
         } else {
-            // staging registers are live in these variants: keep the fragment footprint to two steps
+            // staging registers are live in these variants: keep the fragment footprint to one step
 #pragma unroll
             for (int s = 0; s < TL::STEPS; ++s) {
                 u32x4 fa[2], fb[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    fa[i] = *reinterpret_cast<const u32x4*>(la + lds_off<TL>(arow + i * 32, 2 * s + half));
-                    fb[i] = *reinterpret_cast<const u32x4*>(lb + lds_off<TL>(brow + i * 32, 2 * s + half));
-                }
+                for (int i = 0; i < 2; ++i) { fa[i] = ldA(s, i); fb[i] = ldB(s, i); }
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -495,9 +569,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
 
 template <typename T, int BK_, int OCC, bool A_KC, bool B_KC>
 int launch_t(const GemmP& p, bool aligned, bool glds, dim3 grid, hipStream_t st) {
-    if (aligned && glds && (A_KC || B_KC)) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, true>), grid, dim3(NT), 0, st, p);
-    else if (aligned) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, false>), grid, dim3(NT), 0, st, p);
-    else PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, false, false>), grid, dim3(NT), 0, st, p);
+    constexpr bool CAN_TR = sizeof(T) == 2 && BK_ == 64 && !(A_KC && B_KC);
+    if (aligned && glds) {
+        if constexpr (CAN_TR) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, true, true>), grid, dim3(NT), 0, st, p);
+        else if constexpr (A_KC || B_KC) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, true, false>), grid, dim3(NT), 0, st, p);
+        else PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, false, false>), grid, dim3(NT), 0, st, p);
+    }
+    else if (aligned) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, false, false>), grid, dim3(NT), 0, st, p);
+    else PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, false, false, false>), grid, dim3(NT), 0, st, p);
     return 0;
 }
 template <typename T, int BK_, int OCC>
@@ -569,7 +648,7 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     pk.dbg = 0; p.dbg = 0;
     int grid_x = (dbg_grid > 0 && pk.units > dbg_grid) ? dbg_grid : pk.units;
     dim3 grid(grid_x);
-    const bool glds = (a->K % BK) == 0 && !dbg_noglds;
+    const bool glds = ((a->K % BK) == 0 || (!a->a_kcontig && !a->b_kcontig && a->in_dtype == PA_BF16 && !bk32)) && !dbg_noglds;
     int rc;
     if (a->in_dtype == PA_BF16) {
         if (bk32) rc = launch_layout<bf16, 32, 3>(pk, a->a_kcontig, a->b_kcontig, is_aligned<bf16>(a), glds, grid, st);
