@@ -615,6 +615,363 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP p) {
 }
 
 // =====================================================================================================
+// bf16 kernels, v2: K / V (resp. Q / dO) tiles are DMA'd (global_load_lds) into LDS in their NATURAL [row][dh]
+// layout only; the transposed MFMA operands (V^T for O^T += V^T P^T, K^T for dQ^T, Q^T / dO^T for dK^T / dV^T) are
+// formed by ds_read_b64_tr_b16 from that same image (in each 16-lane group lane L supplies row L>>2, column
+// 4*(L&3) of a 4 x 16 patch; lane i receives column i).  No staging registers, no in-register transposes, half
+// the LDS of v1 for the backward kernels.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int DH> struct BT {
+    static constexpr int RBN = DH * 2;                 // natural row bytes
+    static constexpr int NCHR = RBN / 16;              // 16-byte chunks per row
+    static constexpr int NAT = BSTR * RBN;             // bytes of a 64-row natural tile
+    static constexpr int NCHUNK = BSTR * NCHR;         // chunks per tile
+    static constexpr int NLD = (NCHUNK + NTH - 1) / NTH;
+    static constexpr int NS = DH / 16;
+    static constexpr int NDT = (DH + 31) / 32;
+};
+
+// DMA one 64-row natural tile (rows row0.. of a [nrows][ld] bf16 matrix, DH columns at column offset 0 of `base`)
+template <int DH>
+__device__ __forceinline__ void glds_nat(char* lds, const bf16* base, int ld, int row0, int nrows, int tid, int wave) {
+    using B = BT<DH>;
+    constexpr int RPB = (B::RBN >= 256) ? 1 : 256 / B::RBN;
+#pragma unroll
+    for (int i = 0; i < B::NLD; ++i) {
+        const int p = tid + i * NTH;
+        if (B::NCHUNK % NTH == 0 || p < B::NCHUNK) {
+            const int row = p / B::NCHR;
+            const int ch = ((p % B::NCHR) ^ (row / RPB)) & (B::NCHR - 1);       // source chunk that belongs at position p
+            const int r = min(row0 + row, nrows - 1);                            // clamp: masked rows still read finite data
+            const bf16* src = base + (size_t)r * ld + ch * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                (__attribute__((address_space(3))) void*)(lds + (i * NTH + wave * 64) * 16), 16, 0, 0);
+        }
+    }
+}
+
+// acc[dt] (32 d x 32) += NAT^T[d][rows] (A operand via transposing reads) x P (B operand = this lane's 16 accumulator
+// values of a 32-row sub-tile starting at row0; value r <-> row 8*(r>>2) + 4*half + (r&3))
+template <int DH>
+__device__ __forceinline__ void mma_tr_nat(f32x16* acc, const char* nat, int row0, const f32x16& pv, int lane) {
+    using B = BT<DH>;
+    const int half = lane >> 5, L = lane & 15, G = lane >> 4;
+    u32x4 pb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) pb[u][w] = pack_bf16(pv[8 * u + 2 * w], pv[8 * u + 2 * w + 1]);
+#pragma unroll
+    for (int dt = 0; dt < B::NDT; ++dt) {
+        const int col = dt * 32 + 16 * (G & 1) + 4 * (L & 3);            // dh column this lane fetches for the patch
+        const bool ok = col < DH;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 a = {0u, 0u, 0u, 0u};
+            if (ok) {
+                const int r0 = row0 + 16 * u + 4 * half + (L >> 2), r1 = r0 + 8;
+                const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(nat + swz_off<B::RBN>(r0, col >> 3) + (col & 7) * 2));
+                const s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(nat + swz_off<B::RBN>(r1, col >> 3) + (col & 7) * 2));
+                const u32x2 a0 = *reinterpret_cast<const u32x2*>(&x0), a1 = *reinterpret_cast<const u32x2*>(&x1);
+                a[0] = a0[0]; a[1] = a0[1]; a[2] = a1[0]; a[3] = a1[1];
+            }
+            mma16B<bf16>(acc[dt], a, pb[u]);
+        }
+    }
+}
+
+template <int DH>
+__global__ __launch_bounds__(NTH, 2) void attn_fwd_bf16_kernel(AttnP p) {
+    using A = AT<bf16, DH>;
+    using B = BT<DH>;
+    constexpr int BUF = 2 * B::NAT + 64;
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
+    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
+    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
+    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * p.Lk : nullptr;
+    const int qrow = q0 + wave * 32 + (lane & 31);
+
+    u32x4 qreg[A::NS];
+    load_row_regs<bf16, DH>(qreg, Qp, p.ldq, qrow, p.Lq, lane);
+    int nsteps = (p.Lk + BSTR - 1) / BSTR;
+    if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+
+    f32x16 oacc[A::NDT];
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl = p.scale * LOG2E;
+    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.nk4);
+
+    auto issue = [&](int step, int buf) {
+        char* base = smem + buf * BUF;
+        const int k0 = step * BSTR;
+        glds_nat<DH>(base, Kp, p.ldk, k0, p.Lk, tid, wave);
+        glds_nat<DH>(base + B::NAT, Vp, p.ldv, k0, p.Lk, tid, wave);
+        if (tid < BSTR) {
+            const int key = k0 + tid;
+            reinterpret_cast<uint8_t*>(base + 2 * B::NAT)[tid] = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+        }
+    };
+    if (nsteps > 0) issue(0, 0);
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        const char* knat = smem + buf * BUF;
+        const char* vnat = knat + B::NAT;
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(knat + 2 * B::NAT);
+        const int k0 = step * BSTR;
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+            mma_nat<bf16, DH>(sacc[kt], knat, kt * 32, qreg, lane);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int koff = kt * 32 + 8 * g + 4 * half;
+                const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + koff + e;
+                    float x = sacc[kt][4 * g + e] * sl;
+                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
+                    x = masked ? -INFINITY : x;
+                    sacc[kt][4 * g + e] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (__any(mx > m_run + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float ms = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2(m_run - ms);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            m_run = m_new;
+        }
+        const float m_safe = (m_run == -INFINITY) ? 0.f : m_run;
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint32_t hsh = 0;
+                if (p.drop_thr) hsh = drop_hash4(p.drop_seed, drow + ((k0 + kt * 32 + 8 * g + 4 * half) >> 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pe = fast_exp2(sacc[kt][4 * g + e] - m_safe);
+                    lsum += pe;
+                    if (p.drop_thr) pe = drop_keep4(hsh, e, p.drop_thr) ? pe * p.drop_scale : 0.f;
+                    sacc[kt][4 * g + e] = pe;
+                }
+            }
+        l_run += lsum;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) mma_tr_nat<DH>(oacc, vnat, kt * 32, sacc[kt], lane);
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    bf16* Op = reinterpret_cast<bf16*>(p.o) + (size_t)b * p.Lq * p.ldo + h * DH;
+    store_rows<bf16, DH>(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);
+    if (half == 0 && qrow < p.Lq && p.lse)
+        p.lse[((size_t)b * p.H + h) * p.Lq + qrow] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : 0.f;
+}
+
+template <int DH>
+__global__ __launch_bounds__(NTH, 2) void attn_bwd_dq_bf16_kernel(AttnP p) {
+    using A = AT<bf16, DH>;
+    using B = BT<DH>;
+    constexpr int BUF = 2 * B::NAT + 64;
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
+    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
+    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
+    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
+    const bf16* dOp = reinterpret_cast<const bf16*>(p.dout) + (size_t)b * p.Lq * p.lddo + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * p.Lk : nullptr;
+    const int qrow = q0 + wave * 32 + (lane & 31);
+
+    u32x4 qreg[A::NS], doreg[A::NS];
+    load_row_regs<bf16, DH>(qreg, Qp, p.ldq, qrow, p.Lq, lane);
+    load_row_regs<bf16, DH>(doreg, dOp, p.lddo, qrow, p.Lq, lane);
+    const size_t srow = ((size_t)b * p.H + h) * p.Lq + qrow;
+    const float lse2 = (qrow < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
+    const float dlt = (qrow < p.Lq) ? p.delta[srow] : 0.f;
+    int nsteps = (p.Lk + BSTR - 1) / BSTR;
+    if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+
+    f32x16 dqacc[A::NDT];
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
+    const float sl = p.scale * LOG2E;
+    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.nk4);
+
+    auto issue = [&](int step, int buf) {
+        char* base = smem + buf * BUF;
+        const int k0 = step * BSTR;
+        glds_nat<DH>(base, Kp, p.ldk, k0, p.Lk, tid, wave);
+        glds_nat<DH>(base + B::NAT, Vp, p.ldv, k0, p.Lk, tid, wave);
+        if (tid < BSTR) {
+            const int key = k0 + tid;
+            reinterpret_cast<uint8_t*>(base + 2 * B::NAT)[tid] = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+        }
+    };
+    if (nsteps > 0) issue(0, 0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        const char* knat = smem + buf * BUF;
+        const char* vnat = knat + B::NAT;
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(knat + 2 * B::NAT);
+        const int k0 = step * BSTR;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+            mma_nat<bf16, DH>(sacc, knat, kt * 32, qreg, lane);
+            mma_nat<bf16, DH>(dpacc, vnat, kt * 32, doreg, lane);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int koff = kt * 32 + 8 * g + 4 * half;
+                const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
+                uint32_t hsh = 0;
+                if (p.drop_thr) hsh = drop_hash4(p.drop_seed, drow + ((k0 + koff) >> 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + koff + e;
+                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
+                    const float pe = masked ? 0.f : fast_exp2(sacc[4 * g + e] * sl - lse2);
+                    float dp = dpacc[4 * g + e];
+                    if (p.drop_thr) dp = drop_keep4(hsh, e, p.drop_thr) ? dp * p.drop_scale : 0.f;
+                    sacc[4 * g + e] = pe * (dp - dlt) * p.scale;          // dS^T
+                }
+            }
+            mma_tr_nat<DH>(dqacc, knat, kt * 32, sacc, lane);            // dQ^T += K^T dS^T
+        }
+        __syncthreads();
+    }
+    bf16* dQp = reinterpret_cast<bf16*>(p.dq) + (size_t)b * p.Lq * p.lddq + h * DH;
+    store_rows<bf16, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, 1.0f, lane);
+}
+
+template <int DH>
+__global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP p) {
+    using A = AT<bf16, DH>;
+    using B = BT<DH>;
+    constexpr int BUF = 2 * B::NAT + 2 * 64 * 4;
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * BOWN;
+    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
+    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
+    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
+    const bf16* dOp = reinterpret_cast<const bf16*>(p.dout) + (size_t)b * p.Lq * p.lddo + h * DH;
+    const int krow = key0 + wave * 32 + (lane & 31);
+    const bool kmasked = (krow >= p.Lk) || (p.kpm && p.kpm[(size_t)b * p.Lk + krow]);
+
+    u32x4 kreg[A::NS], vreg[A::NS];
+    load_row_regs<bf16, DH>(kreg, Kp, p.ldk, krow, p.Lk, lane);
+    load_row_regs<bf16, DH>(vreg, Vp, p.ldv, krow, p.Lk, lane);
+    const int nsteps = (p.Lq + BSTR - 1) / BSTR;
+    const int step0 = p.causal ? (key0 / BSTR) : 0;
+
+    f32x16 dkacc[A::NDT], dvacc[A::NDT];
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkacc[dt][r] = 0.f; dvacc[dt][r] = 0.f; }
+    const float sl = p.scale * LOG2E;
+
+    auto issue = [&](int step, int buf) {
+        char* base = smem + buf * BUF;
+        const int r0 = step * BSTR;
+        glds_nat<DH>(base, Qp, p.ldq, r0, p.Lq, tid, wave);
+        glds_nat<DH>(base + B::NAT, dOp, p.lddo, r0, p.Lq, tid, wave);
+        if (tid < BSTR) {
+            const int qr = r0 + tid;
+            const size_t srow = ((size_t)b * p.H + h) * p.Lq + qr;
+            float* aux = reinterpret_cast<float*>(base + 2 * B::NAT);
+            aux[tid] = (qr < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;      // +inf -> p = 0 for rows past Lq
+            aux[64 + tid] = (qr < p.Lq) ? p.delta[srow] : 0.f;
+        }
+    };
+    if (step0 < nsteps) issue(step0, 0);
+    __syncthreads();
+    for (int step = step0; step < nsteps; ++step) {
+        const int buf = (step - step0) & 1;
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        const char* qnat = smem + buf * BUF;
+        const char* donat = qnat + B::NAT;
+        const float* aux = reinterpret_cast<const float*>(qnat + 2 * B::NAT);
+        const int r0 = step * BSTR;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+            mma_nat<bf16, DH>(sacc, qnat, qt * 32, kreg, lane);        // S[q][key]
+            mma_nat<bf16, DH>(dpacc, donat, qt * 32, vreg, lane);      // dP[q][key]
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qoff = qt * 32 + 8 * g + 4 * half;
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(aux + qoff);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(aux + 64 + qoff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qr = r0 + qoff + e;
+                    const bool masked = kmasked || (p.causal && krow > qr);
+                    float pe = masked ? 0.f : fast_exp2(sacc[4 * g + e] * sl - l4[e]);
+                    float dp = dpacc[4 * g + e];
+                    float pd = pe;
+                    if (p.drop_thr) {
+                        const uint32_t idx4 = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qr) * p.nk4 + (krow >> 2));
+                        const bool keep = drop_keep4(drop_hash4(p.drop_seed, idx4), krow & 3, p.drop_thr);
+                        dp = keep ? dp * p.drop_scale : 0.f;
+                        pd = keep ? pe * p.drop_scale : 0.f;
+                    }
+                    sacc[4 * g + e] = pd;
+                    dpacc[4 * g + e] = pe * (dp - d4[e]) * p.scale;
+                }
+            }
+            mma_tr_nat<DH>(dvacc, donat, qt * 32, sacc, lane);         // dV^T += dO^T P
+            mma_tr_nat<DH>(dkacc, qnat, qt * 32, dpacc, lane);         // dK^T += Q^T dS
+        }
+        __syncthreads();
+    }
+    bf16* dKp = reinterpret_cast<bf16*>(p.dk) + (size_t)b * p.Lk * p.lddk + h * DH;
+    bf16* dVp = reinterpret_cast<bf16*>(p.dv) + (size_t)b * p.Lk * p.lddv + h * DH;
+    store_rows<bf16, DH>(dKp, p.lddk, krow, p.Lk, dkacc, 1.0f, lane);
+    store_rows<bf16, DH>(dVp, p.lddv, krow, p.Lk, dvacc, 1.0f, lane);
+}
+
+// =====================================================================================================
 AttnP make_params(const pa_attn_args* a) {
     AttnP p;
     p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o; p.lse = a->lse; p.kpm = a->kpm;
@@ -638,7 +995,24 @@ template <typename K> int set_lds(K kern, int bytes) {
     return 0;
 }
 
+template <int DH> int run_fwd_bf16(const AttnP& p, hipStream_t st) {
+    const int shm = 2 * (2 * BT<DH>::NAT + 64);
+    dim3 grid((p.Lq + BOWN - 1) / BOWN, p.H, p.B);
+    PA_LAUNCH((attn_fwd_bf16_kernel<DH>), grid, dim3(NTH), shm, st, p);
+    return 0;
+}
+template <int DH> int run_bwd_bf16(const AttnP& p, hipStream_t st) {
+    const int64_t total = (int64_t)p.B * p.H * p.Lq;
+    PA_LAUNCH((attn_delta_kernel<bf16, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    int shm = 2 * (2 * BT<DH>::NAT + 2 * 64 * 4);
+    PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH>), dim3((p.Lk + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
+    shm = 2 * (2 * BT<DH>::NAT + 64);
+    PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH>), dim3((p.Lq + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
+    return 0;
+}
+
 template <typename T, int DH> int run_fwd(const AttnP& p, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) return run_fwd_bf16<DH>(p, st);
     const int shm = 2 * Smem<T, DH>::BUF_FWD;
     int rc = set_lds(attn_fwd_kernel<T, DH>, shm);
     if (rc) return rc;
@@ -647,6 +1021,7 @@ template <typename T, int DH> int run_fwd(const AttnP& p, hipStream_t st) {
     return 0;
 }
 template <typename T, int DH> int run_bwd(const AttnP& p, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) return run_bwd_bf16<DH>(p, st);
     const int64_t total = (int64_t)p.B * p.H * p.Lq;
     PA_LAUNCH((attn_delta_kernel<T, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
     int shm = 2 * Smem<T, DH>::BUF_DKV;
