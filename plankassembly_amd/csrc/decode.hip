@@ -17,7 +17,8 @@
 
 struct DecodeLayout {
     int B = 0, S = 0, Tmax = 0;
-    std::vector<void*> cross_kv, self_kv;      // per decoder layer: [B*S][2d], [B][Tmax][2d]
+    std::vector<void*> cross_k, cross_v, self_k, self_v;   // per decoder layer, per-head contiguous: [B][H][S|Tmax][dh]
+    void* kv_tmp;                              // [B*S][2d] projection output before the per-head re-layout
     void *hid_cache, *x, *qkv, *ao, *z, *y, *q, *ff, *pfeat, *h;
     float *vlog, *mean, *rstd;
     int64_t *tokens, *attach; int32_t *first_end, *t_dev;
@@ -48,20 +49,39 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(T* x, const float* value
     }
 }
 
+// K/V caches are kept per head ([B][H][L][dh], each (b, h) a contiguous stream): reading 128-byte head slices out of
+// [B*L][2d] rows is a 2 KiB-strided access that camps on two L2 channels per XCD.
 template <typename T>
-__global__ __launch_bounds__(256) void dec_append_kv_kernel(T* cache, const T* qkv, const int32_t* t_dev, int B, int Tmax, int d) {
-    const int t = *t_dev;
-    const int vec = (2 * d) >> 2;
+__global__ __launch_bounds__(256) void dec_append_kv_kernel(T* kc, T* vc, const T* qkv, const int32_t* t_dev, int B, int Tmax, int d, int H) {
+    const int t = *t_dev, dh = d / H;
+    const int vec = d >> 2;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < B * vec; e += gridDim.x * 256) {
         const int b = e / vec, c = (e % vec) << 2;
-        st4<T>(cache + ((int64_t)b * Tmax + t) * 2 * d + c, ld4<T>(qkv + (int64_t)b * 3 * d + d + c));
+        const int h = c / dh, cc = c % dh;
+        const int64_t dst = (((int64_t)b * H + h) * Tmax + t) * dh + cc;
+        st4<T>(kc + dst, ld4<T>(qkv + (int64_t)b * 3 * d + d + c));
+        st4<T>(vc + dst, ld4<T>(qkv + (int64_t)b * 3 * d + 2 * d + c));
+    }
+}
+// [B*S][2d] (k | v) -> K [B][H][S][dh], V [B][H][S][dh]
+template <typename T>
+__global__ __launch_bounds__(256) void dec_split_heads_kernel(T* kc, T* vc, const T* kv, int B, int S, int d, int H) {
+    const int dh = d / H, vec = d >> 2;
+    const int64_t total = (int64_t)B * S * vec;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / vec;
+        const int c = (int)(e % vec) << 2;
+        const int b = (int)(row / S), s = (int)(row % S), h = c / dh, cc = c % dh;
+        const int64_t dst = (((int64_t)b * H + h) * S + s) * dh + cc;
+        st4<T>(kc + dst, ld4<T>(kv + row * 2 * d + c));
+        st4<T>(vc + dst, ld4<T>(kv + row * 2 * d + d + c));
     }
 }
 
 // single-query attention; grid (H, B), 4 waves.  Lk = fixed_lk or *t_dev + 1.
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int ldq, const T* kv, int64_t kv_bstride, int ldkv,
-                                                       int voff, const uint8_t* kpm, int fixed_lk, const int32_t* t_dev,
+__global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int ldq, const T* kc, const T* vc, int Lmax,
+                                                       const uint8_t* kpm, int fixed_lk, const int32_t* t_dev,
                                                        int d, float scale) {
     constexpr int EB = ET<T>::EB;
     constexpr int LPR = DH / EB;             // lanes per key row
@@ -72,8 +92,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int l
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane % LPR, slot = lane / LPR;
     const int Lk = fixed_lk > 0 ? fixed_lk : (*t_dev + 1);
-    const T* kb = kv + (int64_t)b * kv_bstride + h * DH + c * EB;
-    const T* vb = kb + voff;
+    constexpr int ldkv = DH;                                     // per-head contiguous cache
+    const int64_t bh = ((int64_t)b * gridDim.x + h) * Lmax * DH + c * EB;
+    const T* kb = kc + bh;
+    const T* vb = vc + bh;
     const uint8_t* mk = kpm ? kpm + (int64_t)b * Lk : nullptr;
     float qv[EB];
     {
@@ -85,30 +107,46 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int l
     float m = -INFINITY, l = 0.f, acc[EB];
 #pragma unroll
     for (int e = 0; e < EB; ++e) acc[e] = 0.f;
-    for (int base = wave * KPW; base < Lk; base += 4 * KPW) {
-        const int key = base + slot;
-        const bool in = key < Lk;
-        float kx[EB], vx[EB];
+    constexpr int UN = 4;                                // key groups per iteration: 2*UN 16-byte loads in flight per lane
+    for (int base0 = wave * KPW; base0 < Lk; base0 += 4 * KPW * UN) {
+        f32x4 kq[UN][EB / 4], vq[UN][EB / 4];
+        bool okk[UN];
 #pragma unroll
-        for (int e = 0; e < EB; e += 4) {
-            f32x4 k4 = {0.f, 0.f, 0.f, 0.f}, v4 = k4;
-            if (in) { k4 = ld4<T>(kb + (int64_t)key * ldkv + e); v4 = ld4<T>(vb + (int64_t)key * ldkv + e); }
-            kx[e] = k4[0]; kx[e + 1] = k4[1]; kx[e + 2] = k4[2]; kx[e + 3] = k4[3];
-            vx[e] = v4[0]; vx[e + 1] = v4[1]; vx[e + 2] = v4[2]; vx[e + 3] = v4[3];
+        for (int j = 0; j < UN; ++j) {
+            const int key = base0 + j * 4 * KPW + slot;
+            const bool in = key < Lk;
+            okk[j] = in && !(mk && mk[in ? key : 0]);
+#pragma unroll
+            for (int e = 0; e < EB / 4; ++e) {
+                kq[j][e] = f32x4{0.f, 0.f, 0.f, 0.f}; vq[j][e] = kq[j][e];
+                if (in) { kq[j][e] = ld4<T>(kb + (int64_t)key * ldkv + 4 * e); vq[j][e] = ld4<T>(vb + (int64_t)key * ldkv + 4 * e); }
+            }
         }
-        float s = 0.f;
+        float s[UN];
 #pragma unroll
-        for (int e = 0; e < EB; ++e) s += qv[e] * kx[e];
+        for (int j = 0; j < UN; ++j) {
+            float a = 0.f;
 #pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
-        const bool ok = in && !(mk && mk[key]);
-        if (ok) {
-            s *= sl;
-            const float mn = fmaxf(m, s);
-            const float alpha = exp2f(m - mn), p = exp2f(s - mn);
-            l = l * alpha + p;
+            for (int e = 0; e < EB; ++e) a += qv[e] * kq[j][e >> 2][e & 3];
 #pragma unroll
-            for (int e = 0; e < EB; ++e) acc[e] = acc[e] * alpha + p * vx[e];
+            for (int o = 1; o < LPR; o <<= 1) a += __shfl_xor(a, o);
+            s[j] = okk[j] ? a * sl : -INFINITY;
+        }
+        float mn = m;
+#pragma unroll
+        for (int j = 0; j < UN; ++j) mn = fmaxf(mn, s[j]);
+        if (mn > -INFINITY) {
+            const float alpha = exp2f(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int e = 0; e < EB; ++e) acc[e] *= alpha;
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                const float pj = exp2f(s[j] - mn);           // exp2(-inf) = 0 for masked / out-of-range keys
+                l += pj;
+#pragma unroll
+                for (int e = 0; e < EB; ++e) acc[e] += pj * vq[j][e >> 2][e & 3];
+            }
             m = mn;
         }
     }
@@ -259,11 +297,12 @@ size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tm
     const size_t e = c.dtype == PA_BF16 ? 2 : 4, d = c.d_model, ff = c.d_ff;
     Arena a{base, 0};
     L->B = B; L->S = S; L->Tmax = Tmax;
-    L->cross_kv.resize(c.n_dec); L->self_kv.resize(c.n_dec);
+    L->cross_k.resize(c.n_dec); L->cross_v.resize(c.n_dec); L->self_k.resize(c.n_dec); L->self_v.resize(c.n_dec);
     for (int i = 0; i < c.n_dec; ++i) {
-        L->cross_kv[i] = a.take((size_t)B * S * 2 * d * e);
-        L->self_kv[i] = a.take((size_t)B * Tmax * 2 * d * e);
+        L->cross_k[i] = a.take((size_t)B * S * d * e); L->cross_v[i] = a.take((size_t)B * S * d * e);
+        L->self_k[i] = a.take((size_t)B * Tmax * d * e); L->self_v[i] = a.take((size_t)B * Tmax * d * e);
     }
+    L->kv_tmp = a.take((size_t)B * S * 2 * d * e);
     L->hid_cache = a.take((size_t)B * Tmax * d * e);
     L->x = a.take(B * d * e); L->qkv = a.take(B * 3 * d * e); L->ao = a.take(B * d * e); L->z = a.take(B * d * e);
     L->y = a.take(B * d * e); L->q = a.take(B * d * e); L->ff = a.take(B * ff * e); L->pfeat = a.take(B * d * e);
@@ -277,16 +316,16 @@ size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tm
 }
 
 template <typename T>
-int launch_attn(pa_model* m, T* out, const T* q, int ldq, const T* kv, int64_t bstride, int ldkv, int voff, const uint8_t* kpm,
+int launch_attn(pa_model* m, T* out, const T* q, int ldq, const T* kc, const T* vc, int Lmax, const uint8_t* kpm,
                 int fixed_lk, const int32_t* t_dev, int B, void* st) {
     const int d = m->cfg.d_model, H = m->cfg.n_head, dh = d / H;
     const float scale = 1.0f / sqrtf((float)dh);
     dim3 grid(H, B);
     hipStream_t s = (hipStream_t)st;
     switch (dh) {
-        case 16: PA_LAUNCH((dec_attn_kernel<T, 16>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
-        case 32: PA_LAUNCH((dec_attn_kernel<T, 32>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
-        case 64: PA_LAUNCH((dec_attn_kernel<T, 64>), grid, dim3(256), 0, s, out, q, ldq, kv, bstride, ldkv, voff, kpm, fixed_lk, t_dev, d, scale); break;
+        case 16: PA_LAUNCH((dec_attn_kernel<T, 16>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale); break;
+        case 32: PA_LAUNCH((dec_attn_kernel<T, 32>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale); break;
+        case 64: PA_LAUNCH((dec_attn_kernel<T, 64>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale); break;
         default: return PA_ESHAPE;
     }
     return 0;
@@ -308,14 +347,14 @@ int step_impl(pa_model* m, void* st) {
     for (int i = 0; i < c.n_dec; ++i) {
         const int pb = m->dec_base(i);
         RC(linear(m, x, PL(pb + D_SA_IN_W), PF(pb + D_SA_IN_B), L->qkv, 3 * d, B, 3 * d, d, 0, nullptr, -1, st));
-        PA_LAUNCH(dec_append_kv_kernel<T>, dim3((B * (2 * d / 4) + 255) / 256), dim3(256), 0, s, (T*)L->self_kv[i],
-                           (const T*)L->qkv, L->t_dev, B, Tmax, d);
-        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->qkv, 3 * d, (const T*)L->self_kv[i], (int64_t)Tmax * 2 * d, 2 * d, d, nullptr, 0,
+        PA_LAUNCH(dec_append_kv_kernel<T>, dim3((B * (d / 4) + 255) / 256), dim3(256), 0, s, (T*)L->self_k[i], (T*)L->self_v[i],
+                           (const T*)L->qkv, L->t_dev, B, Tmax, d, c.n_head);
+        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->qkv, 3 * d, (const T*)L->self_k[i], (const T*)L->self_v[i], Tmax, nullptr, 0,
                           L->t_dev, B, st));
         RC(linear(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), L->z, d, B, d, d, 0, x, -1, st));
         RC(pa_layernorm_fwd(L->y, L->z, PF(pb + D_N1_W), PF(pb + D_N1_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
         RC(linear(m, L->y, PL(pb + D_CA_IN_W), PF(pb + D_CA_IN_B), L->q, d, B, d, d, 0, nullptr, -1, st));
-        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->q, d, (const T*)L->cross_kv[i], (int64_t)S * 2 * d, 2 * d, d, L->kpm, S,
+        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->q, d, (const T*)L->cross_k[i], (const T*)L->cross_v[i], S, L->kpm, S,
                           L->t_dev, B, st));
         RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z, d, B, d, d, 0, L->y, -1, st));
         RC(pa_layernorm_fwd(L->x, L->z, PF(pb + D_N2_W), PF(pb + D_N2_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
@@ -365,7 +404,13 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
     for (int i = 0; i < c.n_dec; ++i) {       // cross-attention K/V of the memory: once per sequence, not per step
         const int pb = m->dec_base(i);
         RC(linear(m, memory, (const char*)m->pl[pb + D_CA_IN_W] + (size_t)d * d * e, (const float*)m->pf[pb + D_CA_IN_B] + d,
-                  L->cross_kv[i], 2 * d, B * S, 2 * d, d, 0, nullptr, -1, stream));
+                  L->kv_tmp, 2 * d, B * S, 2 * d, d, 0, nullptr, -1, stream));
+        if (c.dtype == PA_BF16)
+            PA_LAUNCH(dec_split_heads_kernel<bf16>, dim3(2048), dim3(256), 0, s, (bf16*)L->cross_k[i], (bf16*)L->cross_v[i],
+                      (const bf16*)L->kv_tmp, B, S, d, c.n_head);
+        else
+            PA_LAUNCH(dec_split_heads_kernel<float>, dim3(2048), dim3(256), 0, s, (float*)L->cross_k[i], (float*)L->cross_v[i],
+                      (const float*)L->kv_tmp, B, S, d, c.n_head);
     }
     hipError_t he = hipMemcpyAsync(L->kpm, m->batch.input_mask, (size_t)B * S, hipMemcpyDeviceToDevice, s);
     if (he != hipSuccess) return (int)he;

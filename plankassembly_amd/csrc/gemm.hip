@@ -98,11 +98,15 @@ __device__ __forceinline__ int next_valid_unit(int u, int stride) { return u + s
 //   ([k][row], 256-byte rows, 64-byte units XOR-swizzled by k&3) and the MFMA fragments are formed by
 //   ds_read_b64_tr_b16 (in each 16-lane group lane L supplies row L>>2 / column 4*(L&3) of a 4 x 16 patch and
 //   lane i receives column i) - no register transposes, no staging VGPRs.  Lanes whose k is past K read zeros.
-template <typename T, int BK_, int OCC, bool A_KC, bool B_KC, bool ALIGNED, bool GLDS, bool TRG>
+// NST: LDS pipeline stages.  3 is only available when both operands are DMA'd: tile i+2 is in flight while tile i
+//   is multiplied, synchronised with counted s_waitcnt vmcnt + raw s_barrier (a __syncthreads() would drain the DMA
+//   queue).  Used for small problems (one block per CU anyway), where every K tile would otherwise pay a full
+//   memory round trip.
+template <typename T, int BK_, int OCC, bool A_KC, bool B_KC, bool ALIGNED, bool GLDS, bool TRG, int NST>
 __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
     using TL = Tile<T, BK_>;
     constexpr int EB = TL::EB;
-    constexpr int SMEM = 4 * TL::TILE_BYTES;
+    constexpr int SMEM = NST * 2 * TL::TILE_BYTES;      // NST == 1: 32 KiB -> four blocks per CU hide each other's latencies
     __shared__ __attribute__((aligned(256))) char smem[SMEM];   // [buf][A|B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,6 +124,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
 
     constexpr bool A_GL = A_KC && GLDS, B_GL = B_KC && GLDS;
     constexpr bool A_TG = !A_KC && TRG, B_TG = !B_KC && TRG;
+    constexpr bool ALL_DMA = (A_GL || A_TG) && (B_GL || B_TG);
+    static_assert(NST == 2 || ((NST == 3 || NST == 1) && ALL_DMA), "1- and 3-stage variants need both operands DMA'd");
     static_assert(!TRG || (sizeof(T) == 2 && BK_ == 64), "transposing LDS reads: bf16, 64-deep K tile");
     constexpr int NRA = (A_GL || A_TG) ? 1 : (A_KC ? TL::NLD : TL::NTR * EB);
     constexpr int NRB = (B_GL || B_TG) ? 1 : (B_KC ? TL::NLD : TL::NTR * EB);
@@ -315,6 +321,17 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
         }
     };
 
+    // bias of this lane's 4 output columns, fetched at unit start so the epilogue does not open with a dependent load
+    f32x4 ubias = {0.f, 0.f, 0.f, 0.f};
+    auto load_bias = [&](const Unit& un) {
+        ubias = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias && p.splitk == 1) {
+            const int n = un.tile_n * BN + wn * 64 + (lane & 15) * 4;
+            if (p.vec_ok && n + 3 < p.N) ubias = *reinterpret_cast<const f32x4*>(p.bias + n);
+            else { for (int e = 0; e < 4; ++e) if (n + e < p.N) ubias[e] = p.bias[n + e]; }
+        }
+    };
+
     // ---- epilogue of one unit: per-wave LDS staging, batched loads, vector row stores -------------------------
     auto epilogue = [&](const Unit& un, int buf) {
         char* stage = smem + buf * 2 * TL::TILE_BYTES + wave * TL::STAGE_BYTES;
@@ -328,11 +345,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
         const bool out_f32 = slab || p.out_dtype == PA_F32;
         const bool has_bias = !slab && p.bias != nullptr, has_aux = !slab && p.aux != nullptr;
         const bool has_res = !slab && p.R != nullptr, has_drop = !slab && p.drop_thr != 0;
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (has_bias && colv) {
-            if (full) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
-            else { for (int e = 0; e < 4; ++e) if (n + e < p.N) bias[e] = p.bias[n + e]; }
-        }
+        const f32x4 bias = has_bias ? ubias : f32x4{0.f, 0.f, 0.f, 0.f};   // fetched when the unit started (load_bias)
         const float alpha = slab ? 1.f : p.alpha;
         constexpr int NPASS = 64 / TL::RPP, NIT = TL::RPP / 4;
 #pragma unroll
@@ -428,20 +441,6 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
 
     // ---- persistent, cross-unit software pipeline ----------------------------------------------------------
     const int ustride = gridDim.x;
-    int u = blockIdx.x;
-    Unit cur, nxt;
-    bool ok = decode_unit<TL>(p, u, cur);
-    while (u < p.units && !ok) { u += ustride; ok = decode_unit<TL>(p, u, cur); }
-    if (u >= p.units) return;
-    int nu = u + ustride;                                   // the unit after `cur` (decoded once per unit)
-    ok = decode_unit<TL>(p, nu, nxt);
-    while (nu < p.units && !ok) { nu += ustride; ok = decode_unit<TL>(p, nu, nxt); }
-    int t = cur.t_begin, buf = 0;
-    setup(cur);
-    fetch(cur, t, 0);
-    commit(0);
-    __syncthreads();
-
     const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31);
     // transposing reads: lane-constant byte offset of fragment group i inside the natural image (k row 8*half + (L>>2),
     // column window + 16*(G&1) + 4*(L&3); 64-byte units XOR-swizzled by the k row & 3 = (L>>2)&3)
@@ -455,18 +454,10 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
             trB[i] = kr * 256 + ((((cb >> 6) ^ ((L >> 2) & 3)) << 6) | (cb & 63));
         }
     }
-    while (true) {
-        const bool last_k = (t + 1 >= cur.t_end);
-        const bool has_next = !last_k || (nu < p.units);
-        TR(1);
-        if (has_next) {
-            if (last_k) { setup(nxt); fetch(nxt, nxt.t_begin, buf ^ 1); }
-            else fetch(cur, t + 1, buf ^ 1);
-        }
-        TR(2);
+    // multiply the K tile held in LDS stage `buf` into the accumulators
+    auto compute = [&](int buf) {
         const char* la = smem + buf * 2 * TL::TILE_BYTES;
         const char* lb = la + TL::TILE_BYTES;
-        // fragment (step s, 32-row group i) of the A-role / B-role tile
         auto ldA = [&](int s, int i) -> u32x4 {
             if constexpr (A_TG) {
                 const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(la + trA[i] + s * 4096));
@@ -489,7 +480,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                 return *reinterpret_cast<const u32x4*>(lb + lds_off<TL>(brow + i * 32, 2 * s + half));
             }
         };
-        if constexpr ((A_GL || A_TG) && (B_GL || B_TG)) {
+        if constexpr (ALL_DMA && NST != 1) {
             // all fragment reads of the tile are issued up front; LDS returns in order, so the MFMAs of step s start
             // as soon as their vectors have landed while the later ones are still in flight
             u32x4 fa[TL::STEPS][2], fb[TL::STEPS][2];
@@ -516,26 +507,113 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                     for (int tm = 0; tm < 2; ++tm) mma16B<T>(acc[tn][tm], fb[tn], fa[tm]);
             }
         }
-        TR(3);
-        if (last_k) {
-            __syncthreads();                 // every wave is done reading `buf`: its LDS becomes the staging area
-            TR(4);
-            epilogue(cur, buf);
-            TR(5);
-        }
-        if (has_next) commit(buf ^ 1);
+    };
+    // first valid unit at or after u
+    auto seek = [&](int u, Unit& un) -> int {
+        bool ok = decode_unit<TL>(p, u, un);
+        while (u < p.units && !ok) { u += ustride; ok = decode_unit<TL>(p, u, un); }
+        return u;
+    };
+
+    if constexpr (NST == 2) {
+        Unit cur, nxt;
+        int u = seek(blockIdx.x, cur);
+        if (u >= p.units) return;
+        int nu = seek(u + ustride, nxt);                    // the unit after `cur` (decoded once per unit)
+        int t = cur.t_begin, buf = 0;
+        setup(cur);
+        load_bias(cur);
+        fetch(cur, t, 0);
+        commit(0);
         __syncthreads();
-        TR(6);
-        if (!has_next) break;
-        if (last_k) {
-            u = nu; cur = nxt; t = cur.t_begin;
-            nu = u + ustride;
-            ok = decode_unit<TL>(p, nu, nxt);
-            while (nu < p.units && !ok) { nu += ustride; ok = decode_unit<TL>(p, nu, nxt); }
-        } else {
-            ++t;
+        while (true) {
+            const bool last_k = (t + 1 >= cur.t_end);
+            const bool has_next = !last_k || (nu < p.units);
+            TR(1);
+            if (has_next) {
+                if (last_k) { setup(nxt); fetch(nxt, nxt.t_begin, buf ^ 1); }
+                else fetch(cur, t + 1, buf ^ 1);
+            }
+            TR(2);
+            compute(buf);
+            TR(3);
+            if (last_k) {
+                __syncthreads();                 // every wave is done reading `buf`: its LDS becomes the staging area
+                TR(4);
+                epilogue(cur, buf);
+                TR(5);
+            }
+            if (has_next) commit(buf ^ 1);
+            __syncthreads();
+            TR(6);
+            if (!has_next) break;
+            if (last_k) { u = nu; cur = nxt; t = cur.t_begin; load_bias(cur); nu = seek(u + ustride, nxt); }
+            else ++t;
+            buf ^= 1;
         }
-        buf ^= 1;
+    } else if constexpr (NST == 1) {
+        // ---- single LDS stage, no intra-block overlap: 4 blocks per CU overlap each other instead ----------------
+        Unit cur;
+        int u = seek(blockIdx.x, cur);
+        while (u < p.units) {
+            setup(cur);
+            load_bias(cur);
+            for (int t = cur.t_begin; t < cur.t_end; ++t) {
+                fetch(cur, t, 0);
+                __syncthreads();                 // (drains the DMA queue) tile landed
+                compute(0);
+                __syncthreads();                 // everyone is done reading the stage
+            }
+            epilogue(cur, 0);
+            __syncthreads();                     // staging slices free before the next unit's DMA overwrites them
+            u = seek(u + ustride, cur);
+        }
+    } else {
+        // ---- 3-stage DMA ring: item i is multiplied while items i+1 and i+2 are in flight ------------------------
+        constexpr int LPT = 2 * TL::NLD;                   // DMA instructions per thread per item
+        struct Cur { int u, t; Unit un; };
+        auto advance = [&](Cur& c) {                      // c := item after c  (c.u >= p.units: none)
+            if (c.t + 1 < c.un.t_end) { ++c.t; return; }
+            c.u = seek(c.u + ustride, c.un);
+            c.t = c.un.t_begin;
+        };
+        Cur c0;
+        c0.u = seek(blockIdx.x, c0.un);
+        if (c0.u >= p.units) return;
+        c0.t = c0.un.t_begin;
+        Cur c1 = c0; advance(c1);
+        Cur c2 = c1; if (c1.u < p.units) advance(c2);
+        int fetched_u = c0.u;
+        setup(c0.un);
+        load_bias(c0.un);
+        fetch(c0.un, c0.t, 0);
+        if (c1.u < p.units) {
+            if (c1.u != fetched_u) { setup(c1.un); fetched_u = c1.u; }
+            fetch(c1.un, c1.t, 1);
+        }
+        int st = 0;
+        while (true) {
+            const bool has1 = c1.u < p.units, has2 = has1 && (c2.u < p.units);
+            // item c0 has landed when at most the DMAs of the one younger item are still outstanding
+            if (has1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // ... for every wave; and stage (st+2)%3 is free again
+            if (has2) {
+                if (c2.u != fetched_u) { setup(c2.un); fetched_u = c2.u; }
+                fetch(c2.un, c2.t, (st + 2) % 3);
+            }
+            compute(st);
+            if (c0.t + 1 >= c0.un.t_end) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();              // all waves done reading stage st: it becomes the staging area
+                epilogue(c0.un, st);
+            }
+            if (!has1) break;
+            if (c1.u != c0.u) load_bias(c1.un);
+            c0 = c1; c1 = c2;
+            if (has2) advance(c2);
+            st = (st + 1) % 3;
+        }
     }
 }
 
@@ -570,13 +648,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
 template <typename T, int BK_, int OCC, bool A_KC, bool B_KC>
 int launch_t(const GemmP& p, bool aligned, bool glds, dim3 grid, hipStream_t st) {
     constexpr bool CAN_TR = sizeof(T) == 2 && BK_ == 64 && !(A_KC && B_KC);
+    constexpr bool ALLD = (A_KC && B_KC) || CAN_TR;        // both operands DMA'd when glds is usable
+    static const int dbg_nst = getenv("PA_GEMM_NST") ? atoi(getenv("PA_GEMM_NST")) : 0;   // 0 auto, 2 / 3 forced
+    const bool deep = ALLD && sizeof(T) == 2 && BK_ == 64 && dbg_nst == 3;
+    const bool flat = ALLD && sizeof(T) == 2 && BK_ == 64 && dbg_nst == 1;
     if (aligned && glds) {
-        if constexpr (CAN_TR) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, true, true>), grid, dim3(NT), 0, st, p);
-        else if constexpr (A_KC || B_KC) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, true, false>), grid, dim3(NT), 0, st, p);
-        else PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, false, false>), grid, dim3(NT), 0, st, p);
+        if constexpr (ALLD && sizeof(T) == 2 && BK_ == 64) {
+            if (deep) {
+                PA_LAUNCH((gemm_kernel<T, BK_, 1, A_KC, B_KC, true, true, CAN_TR, 3>), grid, dim3(NT), 0, st, p);
+                return 0;
+            }
+            if (flat) {
+                PA_LAUNCH((gemm_kernel<T, BK_, 4, A_KC, B_KC, true, true, CAN_TR, 1>), grid, dim3(NT), 0, st, p);
+                return 0;
+            }
+        }
+        if constexpr (CAN_TR) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, true, true, 2>), grid, dim3(NT), 0, st, p);
+        else if constexpr (A_KC || B_KC) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, true, false, 2>), grid, dim3(NT), 0, st, p);
+        else PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, false, false, 2>), grid, dim3(NT), 0, st, p);
     }
-    else if (aligned) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, false, false>), grid, dim3(NT), 0, st, p);
-    else PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, false, false, false>), grid, dim3(NT), 0, st, p);
+    else if (aligned) PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, false, false, 2>), grid, dim3(NT), 0, st, p);
+    else PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, false, false, false, 2>), grid, dim3(NT), 0, st, p);
     return 0;
 }
 template <typename T, int BK_, int OCC>
@@ -644,7 +736,8 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     }
     // debug/ablation toggles (environment, read once): PA_GEMM_NOGLDS=1, PA_GEMM_GRID=<blocks> (0 = one block per unit)
     static const int dbg_noglds = getenv("PA_GEMM_NOGLDS") ? atoi(getenv("PA_GEMM_NOGLDS")) : 0;
-    static const int dbg_grid = getenv("PA_GEMM_GRID") ? atoi(getenv("PA_GEMM_GRID")) : (bk32 ? 768 : 512);
+    static const int dbg_grid = getenv("PA_GEMM_GRID") ? atoi(getenv("PA_GEMM_GRID")) :
+                                (getenv("PA_GEMM_NST") && atoi(getenv("PA_GEMM_NST")) == 1 ? 1024 : (bk32 ? 768 : 512));
     pk.dbg = 0; p.dbg = 0;
     int grid_x = (dbg_grid > 0 && pk.units > dbg_grid) ? dbg_grid : pk.units;
     dim3 grid(grid_x);
