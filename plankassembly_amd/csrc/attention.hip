@@ -622,6 +622,24 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP p) {
 // the LDS of v1 for the backward kernels.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// Blocks are launched as a 1-D grid and decoded XCD-aware: the hardware places block L on XCD L % 8, and the blocks
+// that stream the same (batch, head) K/V (or Q/dO) panel should share one XCD's L2.  XCD x therefore owns the pairs
+// p = x (mod 8) and walks all their tiles; falls back to the plain order when #pairs is not a multiple of 8.
+__device__ __forceinline__ void decode_block(int ntiles, int H, int Bn, int& tile, int& h, int& b) {
+    const int L = blockIdx.x, npairs = H * Bn;
+    int pair;
+    if ((npairs & 7) == 0) {
+        const int x = L & 7, j = L >> 3;
+        tile = j % ntiles;
+        pair = (j / ntiles) * 8 + x;
+    } else {
+        tile = L % ntiles;
+        pair = L / ntiles;
+    }
+    h = pair % H;
+    b = pair / H;
+}
+
 template <int DH> struct BT {
     static constexpr int RBN = DH * 2;                 // natural row bytes
     static constexpr int NCHR = RBN / 16;              // 16-byte chunks per row
@@ -684,14 +702,16 @@ __device__ __forceinline__ void mma_tr_nat(f32x16* acc, const char* nat, int row
 }
 
 template <int DH>
-__global__ __launch_bounds__(NTH, 2) void attn_fwd_bf16_kernel(AttnP p) {
+__global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP p) {
     using A = AT<bf16, DH>;
     using B = BT<DH>;
     constexpr int BUF = 2 * B::NAT + 64;
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
+    int tile_, h, b;
+    decode_block((p.Lq + BOWN - 1) / BOWN, p.H, p.B, tile_, h, b);
+    const int q0 = tile_ * BOWN;
     const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
     const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
     const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
@@ -798,14 +818,16 @@ __global__ __launch_bounds__(NTH, 2) void attn_fwd_bf16_kernel(AttnP p) {
 }
 
 template <int DH>
-__global__ __launch_bounds__(NTH, 2) void attn_bwd_dq_bf16_kernel(AttnP p) {
+__global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP p) {
     using A = AT<bf16, DH>;
     using B = BT<DH>;
     constexpr int BUF = 2 * B::NAT + 64;
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
+    int tile_, h, b;
+    decode_block((p.Lq + BOWN - 1) / BOWN, p.H, p.B, tile_, h, b);
+    const int q0 = tile_ * BOWN;
     const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
     const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
     const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
@@ -888,7 +910,9 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * BOWN;
+    int tile_, h, b;
+    decode_block((p.Lk + BOWN - 1) / BOWN, p.H, p.B, tile_, h, b);
+    const int key0 = tile_ * BOWN;
     const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
     const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
     const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
@@ -997,7 +1021,7 @@ template <typename K> int set_lds(K kern, int bytes) {
 
 template <int DH> int run_fwd_bf16(const AttnP& p, hipStream_t st) {
     const int shm = 2 * (2 * BT<DH>::NAT + 64);
-    dim3 grid((p.Lq + BOWN - 1) / BOWN, p.H, p.B);
+    dim3 grid(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B);
     PA_LAUNCH((attn_fwd_bf16_kernel<DH>), grid, dim3(NTH), shm, st, p);
     return 0;
 }
@@ -1005,9 +1029,9 @@ template <int DH> int run_bwd_bf16(const AttnP& p, hipStream_t st) {
     const int64_t total = (int64_t)p.B * p.H * p.Lq;
     PA_LAUNCH((attn_delta_kernel<bf16, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
     int shm = 2 * (2 * BT<DH>::NAT + 2 * 64 * 4);
-    PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH>), dim3((p.Lk + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
+    PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH>), dim3(((p.Lk + BOWN - 1) / BOWN) * p.H * p.B), dim3(NTH), shm, st, p);
     shm = 2 * (2 * BT<DH>::NAT + 64);
-    PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH>), dim3((p.Lq + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
+    PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH>), dim3(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B), dim3(NTH), shm, st, p);
     return 0;
 }
 
