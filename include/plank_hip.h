@@ -99,9 +99,15 @@ int pa_colsum(const void* X, int32_t dtype, int32_t M, int32_t N, int32_t ldx, f
  *   row count the caller passes in table_rows (host array), are pre-reduced per block in LDS).
  */
 int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* const* tables, const int64_t* const* idx,
-                       int32_t n_tables, int64_t n_tok, int32_t d, void* stream);
+                       const int32_t* rowmap, int32_t n_tables, int64_t n_tok, int32_t d, void* stream);
 int pa_embed_input_bwd(const void* dout, int32_t dtype, float* const* dtables, const int64_t* const* idx,
-                       const int32_t* table_rows, int32_t n_tables, int64_t n_tok, int32_t d, void* stream);
+                       const int32_t* rowmap, const int32_t* table_rows, int32_t n_tables, int64_t n_tok, int32_t d,
+                       void* stream);
+/* Row packing ("unpadding"): mask uint8 [B][S] (1 = PAD) -> cu int32 [2B+1] (cu[b] = #valid rows before batch element
+ * b, cu[B] = total; entries B+1..2B are scratch) and rowmap int32 [B*S] (rowmap[packed row] = b*S + s).  Padded
+ * encoder positions never reach the loss (they are masked as keys everywhere), so the encoder stack can run on the
+ * packed rows only; rowmap (optional, NULL = identity) lets the embedding kernels gather / scatter packed rows. */
+int pa_pack_rows(const uint8_t* mask, int32_t B, int32_t S, int32_t* cu, int32_t* rowmap, void* stream);
 int pa_embed_output_fwd(void* out, int32_t out_dtype, const float* value, const float* coord, const float* pos,
                         const int64_t* tok, int32_t tok_ld, int32_t B, int32_t T, int32_t d, int32_t dof,
                         void* stream);
@@ -159,6 +165,10 @@ typedef struct {
     /* backward only */
     const void* dout; void* dq; void* dk; void* dv; float* delta;
     int32_t lddo, lddq, lddk, lddv;
+    /* variable-length ("unpadded") batches: int32 [B+1] row offsets of the packed Q resp. K/V rows of each batch
+     * element, or NULL for the dense [B][L] layout.  With offsets, Lq/Lk are the per-batch maxima (grid size and
+     * layout of lse/delta [B][H][Lq]); no padding mask is needed because padded tokens are simply not there. */
+    const int32_t* cu_q; const int32_t* cu_k;
 } pa_attn_args;
 int pa_attn_fwd(const pa_attn_args* a, void* stream);
 int pa_attn_bwd(const pa_attn_args* a, void* stream);
@@ -240,6 +250,9 @@ typedef struct {
     const int64_t* output_label;   /* [B][T] */
     const uint8_t* output_mask;    /* [B][T] */
     int32_t B, S, T;
+    /* optional packed-encoder mode (pa_pack_rows): all three set, or cu_in == NULL for the dense path.  n_valid is the
+     * host copy of cu_in[B] (the one device->host read of a training step). */
+    const int32_t* cu_in; const int32_t* rowmap; int32_t n_valid;
 } pa_batch;
 
 #define PA_T_MEMORY 0

@@ -44,7 +44,8 @@ class AttnArgs(C.Structure):
                 ("dtype", C.c_int32),
                 ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
                 ("delta", C.c_void_p),
-                ("lddo", C.c_int32), ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32)]
+                ("lddo", C.c_int32), ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32),
+                ("cu_q", C.c_void_p), ("cu_k", C.c_void_p)]
 
 
 _lib = None
@@ -80,8 +81,9 @@ def lib():
             "pa_gemm": (I, [P, P]),
             "pa_colsum_ws_floats": (I64, [I, I]),
             "pa_colsum": (I, [P, I, I, I, I, P, I, P, P]),
-            "pa_embed_input_fwd": (I, [P, I, P, P, I, I64, I, P]),
-            "pa_embed_input_bwd": (I, [P, I, P, P, P, I, I64, I, P]),
+            "pa_embed_input_fwd": (I, [P, I, P, P, P, I, I64, I, P]),
+            "pa_embed_input_bwd": (I, [P, I, P, P, P, P, I, I64, I, P]),
+            "pa_pack_rows": (I, [P, I, I, P, P, P]),
             "pa_embed_output_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
             "pa_embed_output_bwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
             "pa_layernorm_ws_floats": (I64, [I64, I]),

@@ -29,6 +29,7 @@ constexpr float RESCALE_THR = 8.0f;   // log2 units: running max is only raised 
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+struct AttnP;
 struct AttnP {
     const void* q; const void* k; const void* v; void* o; float* lse; const uint8_t* kpm;
     int B, H, Lq, Lk;
@@ -37,7 +38,19 @@ struct AttnP {
     uint32_t drop_thr; float drop_scale; uint32_t drop_seed; int nk4;
     const void* dout; void* dq; void* dk; void* dv; float* delta;
     int lddo, lddq, lddk, lddv;
+    const int32_t* cu_q; const int32_t* cu_k;     // packed (variable-length) row offsets per batch element, or NULL
 };
+
+// Variable-length ("unpadded") batches: with cu_q / cu_k given, batch element b owns rows [cu[b], cu[b+1]) of the
+// packed Q resp. K/V matrices; Lq / Lk in the launch parameters are then only the maxima (grid size, layout of the
+// per-row statistics lse/delta [B][H][Lq_max] and of the dropout counter).  Returns the per-batch view.
+__device__ __forceinline__ AttnP batch_view(const AttnP& pin, int b, int& qoff, int& koff) {
+    AttnP p = pin;
+    qoff = b * pin.Lq; koff = b * pin.Lk;
+    if (pin.cu_q) { qoff = pin.cu_q[b]; p.Lq = pin.cu_q[b + 1] - qoff; }
+    if (pin.cu_k) { koff = pin.cu_k[b]; p.Lk = pin.cu_k[b + 1] - koff; }
+    return p;
+}
 
 template <typename T, int DH> struct AT {
     static constexpr int EB = ET<T>::EB, KC = ET<T>::KC;
@@ -219,15 +232,18 @@ template <typename T, int DH> struct Smem {
 // =====================================================================================================
 // forward
 template <typename T, int DH>
-__global__ __launch_bounds__(NTH) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(NTH) void attn_fwd_kernel(AttnP pin) {
     using A = AT<T, DH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
-    const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
-    const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
-    const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
-    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * p.Lk : nullptr;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (q0 >= p.Lq) return;
+    const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
     const int qrow = q0 + wave * 32 + (lane & 31);
 
     u32x4 qreg[A::NS];
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(NTH) void attn_fwd_kernel(AttnP p) {
         }
         const float m_safe = (m_run == -INFINITY) ? 0.f : m_run;
         float lsum = 0.f;
-        const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.nk4);
+        const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qrow) * p.nk4);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -355,24 +371,27 @@ __global__ __launch_bounds__(NTH) void attn_fwd_kernel(AttnP p) {
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    T* Op = reinterpret_cast<T*>(p.o) + (size_t)b * p.Lq * p.ldo + h * DH;
+    T* Op = reinterpret_cast<T*>(p.o) + (size_t)qoff * p.ldo + h * DH;
     store_rows<T, DH>(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);
     if (half == 0 && qrow < p.Lq && p.lse)
-        p.lse[((size_t)b * p.H + h) * p.Lq + qrow] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : 0.f;
+        p.lse[((size_t)b * p.H + h) * pin.Lq + qrow] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : 0.f;
 }
 
 // =====================================================================================================
 // delta[b][h][q] = sum_d dO[q][d] * O[q][d]
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
-    const int64_t total = (int64_t)p.B * p.H * p.Lq;
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnP pin) {
+    const int64_t total = (int64_t)pin.B * pin.H * pin.Lq;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    const int q = (int)(i % p.Lq);
-    const int h = (int)((i / p.Lq) % p.H);
-    const int b = (int)(i / ((int64_t)p.Lq * p.H));
-    const T* o = reinterpret_cast<const T*>(p.o) + ((size_t)b * p.Lq + q) * p.ldo + h * DH;
-    const T* g = reinterpret_cast<const T*>(p.dout) + ((size_t)b * p.Lq + q) * p.lddo + h * DH;
+    const int q = (int)(i % pin.Lq);
+    const int h = (int)((i / pin.Lq) % pin.H);
+    const int b = (int)(i / ((int64_t)pin.Lq * pin.H));
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (q >= p.Lq) { p.delta[i] = 0.f; return; }
+    const T* o = reinterpret_cast<const T*>(p.o) + ((size_t)qoff + q) * p.ldo + h * DH;
+    const T* g = reinterpret_cast<const T*>(p.dout) + ((size_t)qoff + q) * p.lddo + h * DH;
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < DH; c += 4) {
@@ -385,22 +404,25 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP p) {
 // =====================================================================================================
 // backward, dQ: block owns 128 queries, streams keys
 template <typename T, int DH>
-__global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP p) {
+__global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP pin) {
     using A = AT<T, DH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
-    const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
-    const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
-    const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
-    const T* dOp = reinterpret_cast<const T*>(p.dout) + (size_t)b * p.Lq * p.lddo + h * DH;
-    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * p.Lk : nullptr;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (q0 >= p.Lq) return;
+    const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const T* dOp = reinterpret_cast<const T*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
     const int qrow = q0 + wave * 32 + (lane & 31);
 
     u32x4 qreg[A::NS], doreg[A::NS];
     load_row_regs<T, DH>(qreg, Qp, p.ldq, qrow, p.Lq, lane);
     load_row_regs<T, DH>(doreg, dOp, p.lddo, qrow, p.Lq, lane);
-    const size_t srow = ((size_t)b * p.H + h) * p.Lq + qrow;
+    const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qrow;
     const float lse2 = (qrow < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
     const float dlt = (qrow < p.Lq) ? p.delta[srow] : 0.f;
 
@@ -413,7 +435,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
     const float sl = p.scale * LOG2E;
-    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.nk4);
+    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qrow) * p.nk4);
 
     u32x4 st[A::NITEM][4];
     uint8_t mreg = 0;
@@ -490,24 +512,27 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP p) {
         if (step + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
-    T* dQp = reinterpret_cast<T*>(p.dq) + (size_t)b * p.Lq * p.lddq + h * DH;
+    T* dQp = reinterpret_cast<T*>(p.dq) + (size_t)qoff * p.lddq + h * DH;
     store_rows<T, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, 1.0f, lane);
 }
 
 // =====================================================================================================
 // backward, dK/dV: block owns 128 keys, streams queries
 template <typename T, int DH>
-__global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP p) {
+__global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP pin) {
     using A = AT<T, DH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * BOWN;
-    const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
-    const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
-    const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
-    const T* dOp = reinterpret_cast<const T*>(p.dout) + (size_t)b * p.Lq * p.lddo + h * DH;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (key0 >= p.Lk) return;
+    const T* Qp = reinterpret_cast<const T*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const T* Kp = reinterpret_cast<const T*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const T* Vp = reinterpret_cast<const T*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const T* dOp = reinterpret_cast<const T*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
     const int krow = key0 + wave * 32 + (lane & 31);
-    const bool kmasked = (krow >= p.Lk) || (p.kpm && p.kpm[(size_t)b * p.Lk + krow]);
+    const bool kmasked = (krow >= p.Lk) || (p.kpm && p.kpm[(size_t)b * pin.Lk + krow]);
 
     u32x4 kreg[A::NS], vreg[A::NS];
     load_row_regs<T, DH>(kreg, Kp, p.ldk, krow, p.Lk, lane);
@@ -538,7 +563,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP p) {
         }
         if (tid < BSTR) {
             const int qr = r0 + tid;
-            const size_t srow = ((size_t)b * p.H + h) * p.Lq + qr;
+            const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qr;
             lreg = (qr < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
             dreg = (qr < p.Lq) ? p.delta[srow] : 0.f;
         }
@@ -593,7 +618,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP p) {
                     float dp = dpacc[4 * g + e];
                     float pd = pe;
                     if (p.drop_thr) {
-                        const uint32_t idx4 = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qr) * p.nk4 + (krow >> 2));
+                        const uint32_t idx4 = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qr) * p.nk4 + (krow >> 2));
                         const bool keep = drop_keep4(drop_hash4(p.drop_seed, idx4), krow & 3, p.drop_thr);
                         dp = keep ? dp * p.drop_scale : 0.f;
                         pd = keep ? pe * p.drop_scale : 0.f;
@@ -608,8 +633,8 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP p) {
         if (step + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
-    T* dKp = reinterpret_cast<T*>(p.dk) + (size_t)b * p.Lk * p.lddk + h * DH;
-    T* dVp = reinterpret_cast<T*>(p.dv) + (size_t)b * p.Lk * p.lddv + h * DH;
+    T* dKp = reinterpret_cast<T*>(p.dk) + (size_t)koff * p.lddk + h * DH;
+    T* dVp = reinterpret_cast<T*>(p.dv) + (size_t)koff * p.lddv + h * DH;
     store_rows<T, DH>(dKp, p.lddk, krow, p.Lk, dkacc, 1.0f, lane);
     store_rows<T, DH>(dVp, p.lddv, krow, p.Lk, dvacc, 1.0f, lane);
 }
@@ -702,7 +727,7 @@ __device__ __forceinline__ void mma_tr_nat(f32x16* acc, const char* nat, int row
 }
 
 template <int DH>
-__global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP p) {
+__global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP pin) {
     using A = AT<bf16, DH>;
     using B = BT<DH>;
     constexpr int BUF = 2 * B::NAT + 64;
@@ -710,12 +735,15 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP p) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b;
-    decode_block((p.Lq + BOWN - 1) / BOWN, p.H, p.B, tile_, h, b);
+    decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b);
     const int q0 = tile_ * BOWN;
-    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
-    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
-    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
-    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * p.Lk : nullptr;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (q0 >= p.Lq) return;
+    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
     const int qrow = q0 + wave * 32 + (lane & 31);
 
     u32x4 qreg[A::NS];
@@ -730,7 +758,7 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP p) {
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float sl = p.scale * LOG2E;
-    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.nk4);
+    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qrow) * p.nk4);
 
     auto issue = [&](int step, int buf) {
         char* base = smem + buf * BUF;
@@ -811,14 +839,14 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP p) {
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    bf16* Op = reinterpret_cast<bf16*>(p.o) + (size_t)b * p.Lq * p.ldo + h * DH;
+    bf16* Op = reinterpret_cast<bf16*>(p.o) + (size_t)qoff * p.ldo + h * DH;
     store_rows<bf16, DH>(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);
     if (half == 0 && qrow < p.Lq && p.lse)
-        p.lse[((size_t)b * p.H + h) * p.Lq + qrow] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : 0.f;
+        p.lse[((size_t)b * p.H + h) * pin.Lq + qrow] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : 0.f;
 }
 
 template <int DH>
-__global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP p) {
+__global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP pin) {
     using A = AT<bf16, DH>;
     using B = BT<DH>;
     constexpr int BUF = 2 * B::NAT + 64;
@@ -826,19 +854,22 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP p) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b;
-    decode_block((p.Lq + BOWN - 1) / BOWN, p.H, p.B, tile_, h, b);
+    decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b);
     const int q0 = tile_ * BOWN;
-    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
-    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
-    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
-    const bf16* dOp = reinterpret_cast<const bf16*>(p.dout) + (size_t)b * p.Lq * p.lddo + h * DH;
-    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * p.Lk : nullptr;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (q0 >= p.Lq) return;
+    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const bf16* dOp = reinterpret_cast<const bf16*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
     const int qrow = q0 + wave * 32 + (lane & 31);
 
     u32x4 qreg[A::NS], doreg[A::NS];
     load_row_regs<bf16, DH>(qreg, Qp, p.ldq, qrow, p.Lq, lane);
     load_row_regs<bf16, DH>(doreg, dOp, p.lddo, qrow, p.Lq, lane);
-    const size_t srow = ((size_t)b * p.H + h) * p.Lq + qrow;
+    const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qrow;
     const float lse2 = (qrow < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
     const float dlt = (qrow < p.Lq) ? p.delta[srow] : 0.f;
     int nsteps = (p.Lk + BSTR - 1) / BSTR;
@@ -850,7 +881,7 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
     const float sl = p.scale * LOG2E;
-    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qrow) * p.nk4);
+    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qrow) * p.nk4);
 
     auto issue = [&](int step, int buf) {
         char* base = smem + buf * BUF;
@@ -898,12 +929,12 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP p) {
         }
         __syncthreads();
     }
-    bf16* dQp = reinterpret_cast<bf16*>(p.dq) + (size_t)b * p.Lq * p.lddq + h * DH;
+    bf16* dQp = reinterpret_cast<bf16*>(p.dq) + (size_t)qoff * p.lddq + h * DH;
     store_rows<bf16, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, 1.0f, lane);
 }
 
 template <int DH>
-__global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP p) {
+__global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
     using A = AT<bf16, DH>;
     using B = BT<DH>;
     constexpr int BUF = 2 * B::NAT + 2 * 64 * 4;
@@ -911,14 +942,17 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP p) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b;
-    decode_block((p.Lk + BOWN - 1) / BOWN, p.H, p.B, tile_, h, b);
+    decode_block((pin.Lk + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b);
     const int key0 = tile_ * BOWN;
-    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)b * p.Lq * p.ldq + h * DH;
-    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)b * p.Lk * p.ldk + h * DH;
-    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)b * p.Lk * p.ldv + h * DH;
-    const bf16* dOp = reinterpret_cast<const bf16*>(p.dout) + (size_t)b * p.Lq * p.lddo + h * DH;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (key0 >= p.Lk) return;
+    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const bf16* dOp = reinterpret_cast<const bf16*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
     const int krow = key0 + wave * 32 + (lane & 31);
-    const bool kmasked = (krow >= p.Lk) || (p.kpm && p.kpm[(size_t)b * p.Lk + krow]);
+    const bool kmasked = (krow >= p.Lk) || (p.kpm && p.kpm[(size_t)b * pin.Lk + krow]);
 
     u32x4 kreg[A::NS], vreg[A::NS];
     load_row_regs<bf16, DH>(kreg, Kp, p.ldk, krow, p.Lk, lane);
@@ -940,7 +974,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP p) {
         glds_nat<DH>(base + B::NAT, dOp, p.lddo, r0, p.Lq, tid, wave);
         if (tid < BSTR) {
             const int qr = r0 + tid;
-            const size_t srow = ((size_t)b * p.H + h) * p.Lq + qr;
+            const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qr;
             float* aux = reinterpret_cast<float*>(base + 2 * B::NAT);
             aux[tid] = (qr < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;      // +inf -> p = 0 for rows past Lq
             aux[64 + tid] = (qr < p.Lq) ? p.delta[srow] : 0.f;
@@ -975,7 +1009,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP p) {
                     float dp = dpacc[4 * g + e];
                     float pd = pe;
                     if (p.drop_thr) {
-                        const uint32_t idx4 = (uint32_t)((((size_t)b * p.H + h) * p.Lq + qr) * p.nk4 + (krow >> 2));
+                        const uint32_t idx4 = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qr) * p.nk4 + (krow >> 2));
                         const bool keep = drop_keep4(drop_hash4(p.drop_seed, idx4), krow & 3, p.drop_thr);
                         dp = keep ? dp * p.drop_scale : 0.f;
                         pd = keep ? pe * p.drop_scale : 0.f;
@@ -989,8 +1023,8 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP p) {
         }
         __syncthreads();
     }
-    bf16* dKp = reinterpret_cast<bf16*>(p.dk) + (size_t)b * p.Lk * p.lddk + h * DH;
-    bf16* dVp = reinterpret_cast<bf16*>(p.dv) + (size_t)b * p.Lk * p.lddv + h * DH;
+    bf16* dKp = reinterpret_cast<bf16*>(p.dk) + (size_t)koff * p.lddk + h * DH;
+    bf16* dVp = reinterpret_cast<bf16*>(p.dv) + (size_t)koff * p.lddv + h * DH;
     store_rows<bf16, DH>(dKp, p.lddk, krow, p.Lk, dkacc, 1.0f, lane);
     store_rows<bf16, DH>(dVp, p.lddv, krow, p.Lk, dvacc, 1.0f, lane);
 }
@@ -1008,6 +1042,7 @@ AttnP make_params(const pa_attn_args* a) {
     p.drop_seed = a->drop_seed;
     p.dout = a->dout; p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.delta = a->delta;
     p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
+    p.cu_q = a->cu_q; p.cu_k = a->cu_k;
     return p;
 }
 

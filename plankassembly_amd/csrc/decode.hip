@@ -23,6 +23,8 @@ struct DecodeLayout {
     float *vlog, *mean, *rstd;
     int64_t *tokens, *attach; int32_t *first_end, *t_dev;
     uint8_t* kpm;                              // copy of input_mask: the captured step must not depend on batch tensors
+    int32_t* cu;                               // copy of the packed-row offsets (NULL: dense memory + kpm)
+    int32_t* cu_store;
 };
 
 namespace {
@@ -65,13 +67,16 @@ __global__ __launch_bounds__(256) void dec_append_kv_kernel(T* kc, T* vc, const 
 }
 // [B*S][2d] (k | v) -> K [B][H][S][dh], V [B][H][S][dh]
 template <typename T>
-__global__ __launch_bounds__(256) void dec_split_heads_kernel(T* kc, T* vc, const T* kv, int B, int S, int d, int H) {
+__global__ __launch_bounds__(256) void dec_split_heads_kernel(T* kc, T* vc, const T* kv, int64_t rows, int S, int d, int H,
+                                                              const int32_t* cu, const int32_t* rowmap) {
     const int dh = d / H, vec = d >> 2;
-    const int64_t total = (int64_t)B * S * vec;
+    const int64_t total = rows * vec;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t row = e / vec;
         const int c = (int)(e % vec) << 2;
-        const int b = (int)(row / S), s = (int)(row % S), h = c / dh, cc = c % dh;
+        int b = (int)(row / S), s = (int)(row % S);
+        if (cu) { b = rowmap[row] / S; s = (int)row - cu[b]; }          // packed memory: s-th valid position of element b
+        const int h = c / dh, cc = c % dh;
         const int64_t dst = (((int64_t)b * H + h) * S + s) * dh + cc;
         st4<T>(kc + dst, ld4<T>(kv + row * 2 * d + c));
         st4<T>(vc + dst, ld4<T>(kv + row * 2 * d + d + c));
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256) void dec_split_heads_kernel(T* kc, T* vc, cons
 template <typename T, int DH>
 __global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int ldq, const T* kc, const T* vc, int Lmax,
                                                        const uint8_t* kpm, int fixed_lk, const int32_t* t_dev,
-                                                       int d, float scale) {
+                                                       int d, float scale, const int32_t* cu) {
     constexpr int EB = ET<T>::EB;
     constexpr int LPR = DH / EB;             // lanes per key row
     constexpr int KPW = 64 / LPR;            // keys per wave step
@@ -91,12 +96,12 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int l
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane % LPR, slot = lane / LPR;
-    const int Lk = fixed_lk > 0 ? fixed_lk : (*t_dev + 1);
+    const int Lk = cu ? (cu[b + 1] - cu[b]) : (fixed_lk > 0 ? fixed_lk : (*t_dev + 1));
     constexpr int ldkv = DH;                                     // per-head contiguous cache
     const int64_t bh = ((int64_t)b * gridDim.x + h) * Lmax * DH + c * EB;
     const T* kb = kc + bh;
     const T* vb = vc + bh;
-    const uint8_t* mk = kpm ? kpm + (int64_t)b * Lk : nullptr;
+    const uint8_t* mk = kpm ? kpm + (int64_t)b * Lmax : nullptr;
     float qv[EB];
     {
         const T* qp = q + (int64_t)b * ldq + h * DH + c * EB;
@@ -312,20 +317,21 @@ size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tm
     L->tokens = (int64_t*)a.take((size_t)B * Tmax * 8); L->attach = (int64_t*)a.take((size_t)B * Tmax * 8);
     L->first_end = (int32_t*)a.take(B * 4); L->t_dev = (int32_t*)a.take(256);
     L->kpm = (uint8_t*)a.take((size_t)B * S);
+    L->cu_store = (int32_t*)a.take((size_t)(B + 1) * 4);
     return a.off;
 }
 
 template <typename T>
 int launch_attn(pa_model* m, T* out, const T* q, int ldq, const T* kc, const T* vc, int Lmax, const uint8_t* kpm,
-                int fixed_lk, const int32_t* t_dev, int B, void* st) {
+                int fixed_lk, const int32_t* t_dev, int B, void* st, const int32_t* cu = nullptr) {
     const int d = m->cfg.d_model, H = m->cfg.n_head, dh = d / H;
     const float scale = 1.0f / sqrtf((float)dh);
     dim3 grid(H, B);
     hipStream_t s = (hipStream_t)st;
     switch (dh) {
-        case 16: PA_LAUNCH((dec_attn_kernel<T, 16>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale); break;
-        case 32: PA_LAUNCH((dec_attn_kernel<T, 32>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale); break;
-        case 64: PA_LAUNCH((dec_attn_kernel<T, 64>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale); break;
+        case 16: PA_LAUNCH((dec_attn_kernel<T, 16>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale, cu); break;
+        case 32: PA_LAUNCH((dec_attn_kernel<T, 32>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale, cu); break;
+        case 64: PA_LAUNCH((dec_attn_kernel<T, 64>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale, cu); break;
         default: return PA_ESHAPE;
     }
     return 0;
@@ -354,8 +360,8 @@ int step_impl(pa_model* m, void* st) {
         RC(linear(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), L->z, d, B, d, d, 0, x, -1, st));
         RC(pa_layernorm_fwd(L->y, L->z, PF(pb + D_N1_W), PF(pb + D_N1_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
         RC(linear(m, L->y, PL(pb + D_CA_IN_W), PF(pb + D_CA_IN_B), L->q, d, B, d, d, 0, nullptr, -1, st));
-        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->q, d, (const T*)L->cross_k[i], (const T*)L->cross_v[i], S, L->kpm, S,
-                          L->t_dev, B, st));
+        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->q, d, (const T*)L->cross_k[i], (const T*)L->cross_v[i], S, L->cu ? nullptr : L->kpm, S,
+                          L->t_dev, B, st, L->cu));
         RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z, d, B, d, d, 0, L->y, -1, st));
         RC(pa_layernorm_fwd(L->x, L->z, PF(pb + D_N2_W), PF(pb + D_N2_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
         RC(linear(m, L->x, PL(pb + D_L1_W), PF(pb + D_L1_B), L->ff, ff, B, ff, d, 1, nullptr, -1, st));
@@ -404,13 +410,19 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
     for (int i = 0; i < c.n_dec; ++i) {       // cross-attention K/V of the memory: once per sequence, not per step
         const int pb = m->dec_base(i);
         RC(linear(m, memory, (const char*)m->pl[pb + D_CA_IN_W] + (size_t)d * d * e, (const float*)m->pf[pb + D_CA_IN_B] + d,
-                  L->kv_tmp, 2 * d, B * S, 2 * d, d, 0, nullptr, -1, stream));
+                  L->kv_tmp, 2 * d, m->NE, 2 * d, d, 0, nullptr, -1, stream));
         if (c.dtype == PA_BF16)
             PA_LAUNCH(dec_split_heads_kernel<bf16>, dim3(2048), dim3(256), 0, s, (bf16*)L->cross_k[i], (bf16*)L->cross_v[i],
-                      (const bf16*)L->kv_tmp, B, S, d, c.n_head);
+                      (const bf16*)L->kv_tmp, (int64_t)m->NE, S, d, c.n_head, m->batch.cu_in, m->batch.rowmap);
         else
             PA_LAUNCH(dec_split_heads_kernel<float>, dim3(2048), dim3(256), 0, s, (float*)L->cross_k[i], (float*)L->cross_v[i],
-                      (const float*)L->kv_tmp, B, S, d, c.n_head);
+                      (const float*)L->kv_tmp, (int64_t)m->NE, S, d, c.n_head, m->batch.cu_in, m->batch.rowmap);
+    }
+    L->cu = nullptr;
+    if (m->batch.cu_in) {
+        hipError_t hc = hipMemcpyAsync(L->cu_store, m->batch.cu_in, (size_t)(B + 1) * 4, hipMemcpyDeviceToDevice, s);
+        if (hc != hipSuccess) return (int)hc;
+        L->cu = L->cu_store;
     }
     hipError_t he = hipMemcpyAsync(L->kpm, m->batch.input_mask, (size_t)B * S, hipMemcpyDeviceToDevice, s);
     if (he != hipSuccess) return (int)he;

@@ -46,6 +46,7 @@ struct pa_model {
     bool have_fwd = false;
     pa_batch batch;
     int B = 0, S = 0, T = 0;
+    int NE = 0;                        // encoder rows actually processed: B*S, or the number of valid rows when packed
     uint32_t seed = 0; float p_drop = 0.f;
     size_t esz = 4;
     std::vector<void*> X, Y;           // layer inputs/outputs chain (X[0..n_enc], Y[0..n_dec])

@@ -10,8 +10,8 @@ namespace {
 constexpr int MAXV = 8;   // vectors of 4 per lane per row -> d <= 2048
 
 // ================================================================================ embeddings
-struct EmbTabs { const float* t[5]; const int64_t* idx[5]; int n; };
-struct EmbGrads { float* t[5]; const int64_t* idx[5]; int rows[5]; int n; };
+struct EmbTabs { const float* t[5]; const int64_t* idx[5]; int n; const int32_t* rowmap; };
+struct EmbGrads { float* t[5]; const int64_t* idx[5]; int rows[5]; int n; const int32_t* rowmap; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void embed_input_fwd_kernel(T* out, EmbTabs tb, int64_t n_tok, int d) {
@@ -20,11 +20,12 @@ __global__ __launch_bounds__(256) void embed_input_fwd_kernel(T* out, EmbTabs tb
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t tok = e / vec_per_row;
         const int c = (int)(e % vec_per_row) << 2;
+        const int64_t st = tb.rowmap ? (int64_t)tb.rowmap[tok] : tok;     // packed row -> position in the [B*S] id tensors
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             if (k < tb.n && tb.idx[k]) {
-                const int64_t r = tb.idx[k][tok];
+                const int64_t r = tb.idx[k][st];
                 acc += *reinterpret_cast<const f32x4*>(tb.t[k] + r * d + c);
             }
         }
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void embed_input_bwd_kernel(const T* dout, Emb
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
                     if (!(k < tb.n && tb.idx[k])) continue;
-                    const int64_t r = tb.idx[k][tok];
+                    const int64_t r = tb.idx[k][tb.rowmap ? (int64_t)tb.rowmap[tok] : tok];
                     if (slot[k] >= 0) {
                         float* dst = acc + ((size_t)(slot[k] * EMB_SMALL_ROWS + r)) * d + c;
 #pragma unroll
@@ -125,6 +126,44 @@ __global__ __launch_bounds__(256) void embed_output_bwd_kernel(const T* dout, fl
         float* p2 = dpos + (int64_t)((t - 1) / dof) * d + c;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { unsafeAtomicAdd(p0 + j, g[j]); unsafeAtomicAdd(p1 + j, g[j]); unsafeAtomicAdd(p2 + j, g[j]); }
+    }
+}
+
+// ================================================================================ row packing
+// "Unpadding": padded encoder positions never influence the loss, so the encoder runs on the valid rows only.
+// cu[b] = number of valid positions before batch element b (cu[B] = total), rowmap[packed row] = b*S + s.
+__global__ __launch_bounds__(256) void pack_count_kernel(const uint8_t* mask, int S, int32_t* cnt) {
+    __shared__ int red[4];
+    const int b = blockIdx.x;
+    int c = 0;
+    for (int s = threadIdx.x; s < S; s += 256) c += mask[(size_t)b * S + s] ? 0 : 1;
+    c = (int)wave_sum((float)c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[b] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void pack_scan_kernel(const int32_t* cnt, int B, int32_t* cu) {
+    if (threadIdx.x == 0) { int a = 0; for (int b = 0; b < B; ++b) { cu[b] = a; a += cnt[b]; } cu[B] = a; }
+}
+__global__ __launch_bounds__(256) void pack_fill_kernel(const uint8_t* mask, int S, const int32_t* cu, int32_t* rowmap) {
+    __shared__ int wsum[4];
+    __shared__ int base;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = cu[b];
+    __syncthreads();
+    for (int s0 = 0; s0 < S; s0 += 256) {
+        const int s = s0 + threadIdx.x;
+        const bool v = s < S && !mask[(size_t)b * S + s];
+        const unsigned long long bal = __ballot(v);
+        const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (v) rowmap[off + rank] = b * S + s;
+        __syncthreads();
+        if (threadIdx.x == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
     }
 }
 
@@ -480,9 +519,9 @@ inline int grid_for(int64_t work_items, int per_block = 256, int cap = 4096) {
 extern "C" int pa_version(void) { return 1; }
 
 extern "C" int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* const* tables, const int64_t* const* idx,
-                                  int32_t n_tables, int64_t n_tok, int32_t d, void* stream) {
+                                  const int32_t* rowmap, int32_t n_tables, int64_t n_tok, int32_t d, void* stream) {
     if (!out || !tables || !idx || n_tables < 1 || n_tables > 5 || (d & 3) || n_tok <= 0) return PA_EINVAL;
-    EmbTabs tb; tb.n = n_tables;
+    EmbTabs tb; tb.n = n_tables; tb.rowmap = rowmap;
     for (int k = 0; k < 5; ++k) { tb.t[k] = k < n_tables ? tables[k] : nullptr; tb.idx[k] = k < n_tables ? idx[k] : nullptr; }
     const int grid = grid_for(n_tok * (d >> 2));
     if (out_dtype == PA_BF16) PA_LAUNCH(embed_input_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)out, tb, n_tok, d);
@@ -491,10 +530,11 @@ extern "C" int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* con
 }
 
 extern "C" int pa_embed_input_bwd(const void* dout, int32_t dtype, float* const* dtables, const int64_t* const* idx,
-                                  const int32_t* table_rows, int32_t n_tables, int64_t n_tok, int32_t d, void* stream) {
+                                  const int32_t* rowmap, const int32_t* table_rows, int32_t n_tables, int64_t n_tok, int32_t d,
+                                  void* stream) {
     if (!dout || !dtables || !idx || !table_rows || n_tables < 1 || n_tables > 5 || (d & 3) || n_tok <= 0) return PA_EINVAL;
     if (d > 1024) return PA_ESHAPE;
-    EmbGrads tb; tb.n = n_tables;
+    EmbGrads tb; tb.n = n_tables; tb.rowmap = rowmap;
     int nsmall = 0;
     for (int k = 0; k < 5; ++k) {
         tb.t[k] = k < n_tables ? dtables[k] : nullptr; tb.idx[k] = k < n_tables ? idx[k] : nullptr;
@@ -525,6 +565,15 @@ extern "C" int pa_embed_output_bwd(const void* dout, int32_t dtype, float* dvalu
     const int grid = grid_for((int64_t)B * T * (d >> 2));
     if (dtype == PA_BF16) PA_LAUNCH(embed_output_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (const bf16*)dout, dvalue, dcoord, dpos, tok, tok_ld, B, T, d, dof);
     else PA_LAUNCH(embed_output_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)dout, dvalue, dcoord, dpos, tok, tok_ld, B, T, d, dof);
+    return 0;
+}
+
+extern "C" int pa_pack_rows(const uint8_t* mask, int32_t B, int32_t S, int32_t* cu, int32_t* rowmap, void* stream) {
+    if (!mask || !cu || !rowmap || B <= 0 || S <= 0) return PA_EINVAL;
+    // cu[B+1 .. 2B] doubles as scratch for the per-row counts (caller allocates 2B+1 ints)
+    PA_LAUNCH(pack_count_kernel, dim3(B), dim3(256), 0, ST(stream), mask, S, cu + B + 1);
+    PA_LAUNCH(pack_scan_kernel, dim3(1), dim3(64), 0, ST(stream), cu + B + 1, B, cu);
+    PA_LAUNCH(pack_fill_kernel, dim3(B), dim3(256), 0, ST(stream), mask, S, cu, rowmap);
     return 0;
 }
 

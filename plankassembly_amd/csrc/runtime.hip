@@ -79,8 +79,9 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
     int attn(bool bwd, const void* q, int ldq, const void* k, const void* v, int ldkv, void* o, float* lse,
              const uint8_t* kpm, int Lq, int Lk, int causal, float drop_p, uint32_t seed,
              const void* dout = nullptr, void* dq = nullptr, int lddq = 0, void* dk = nullptr, void* dv = nullptr,
-             int lddkv = 0) const {
+             int lddkv = 0, const int32_t* cu_q = nullptr, const int32_t* cu_k = nullptr) const {
         pa_attn_args a; memset(&a, 0, sizeof(a));
+        a.cu_q = cu_q; a.cu_k = cu_k;
         const int d = m->cfg.d_model, H = m->cfg.n_head;
         a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.kpm = kpm;
         a.B = m->B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = d / H;
@@ -150,14 +151,16 @@ int pa_train_forward_impl(pa_model* m, void* st) {
     const pa_model_cfg& c = m->cfg;
     Ctx k{m, st};
     const int d = c.d_model, ff = c.d_ff, B = m->B, S = m->S, T = m->T;
-    const int BS = B * S, BT = B * T;
+    const int BS = m->NE, BT = B * T;          // BS: encoder rows (packed when the batch carries cu_in)
+    const int32_t* cu = m->batch.cu_in;
+    const uint8_t* in_mask = cu ? nullptr : m->batch.input_mask;   // packed rows need no padding mask
     const float p = m->p_drop;
     auto PF = [&](int i) { return (const float*)m->pf[i]; };
     auto PL = [&](int i) { return (const void*)m->pl[i]; };
     // ---- encoder (reference models.py:103-112, 206) ----
     {
         const float* tabs[5] = {PF(P_IN_VALUE), PF(P_IN_POS), PF(P_IN_COORD), PF(P_IN_VIEW), PF(P_IN_TYPE)};
-        RC(pa_embed_input_fwd(m->X[0], c.dtype, tabs, m->batch.input_idx, 5, (int64_t)BS, d, st));
+        RC(pa_embed_input_fwd(m->X[0], c.dtype, tabs, m->batch.input_idx, m->batch.rowmap, 5, (int64_t)BS, d, st));
     }
     for (int i = 0; i < c.n_enc; ++i) {
         const int pb = m->enc_base(i);
@@ -165,7 +168,7 @@ int pa_train_forward_impl(pa_model* m, void* st) {
         const size_t e = m->esz;
         RC(k.linear(m->X[i], d, PL(pb + E_IN_W), PF(pb + E_IN_B), t.qkv, 3 * d, BS, 3 * d, d));
         RC(k.attn(false, t.qkv, 3 * d, (char*)t.qkv + d * e, (char*)t.qkv + 2 * d * e, 3 * d, t.o, t.lse,
-                  m->batch.input_mask, S, S, 0, p, site_seed(m->seed, 8 * i + 0)));
+                  in_mask, S, S, 0, p, site_seed(m->seed, 8 * i + 0), nullptr, nullptr, 0, nullptr, nullptr, 0, cu, cu));
         RC(k.linear(t.o, d, PL(pb + E_OUT_W), PF(pb + E_OUT_B), t.z1, d, BS, d, d, 0, p, site_seed(m->seed, 8 * i + 1), m->X[i], d));
         RC(k.ln_fwd(t.y1, t.z1, PF(pb + E_N1_W), PF(pb + E_N1_B), t.m1, t.r1, BS, c.eps_layer));
         RC(k.linear(t.y1, d, PL(pb + E_L1_W), PF(pb + E_L1_B), t.hff, ff, BS, ff, d, 1, p, site_seed(m->seed, 8 * i + 2)));
@@ -194,8 +197,8 @@ int pa_train_forward_impl(pa_model* m, void* st) {
         // cross attention: q from y1 (rows 0..d of in_proj), k/v from memory (rows d..3d)
         RC(k.linear(t.y1, d, PL(pb + D_CA_IN_W), PF(pb + D_CA_IN_B), t.q_ca, d, BT, d, d));
         RC(k.linear(memory, d, (const char*)PL(pb + D_CA_IN_W) + (size_t)d * d * e, PF(pb + D_CA_IN_B) + d, t.kv_ca, 2 * d, BS, 2 * d, d));
-        RC(k.attn(false, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, 2 * d, t.o_ca, t.lse_ca, m->batch.input_mask, T, S, 0, p,
-                  site_seed(m->seed, sb + 2)));
+        RC(k.attn(false, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, 2 * d, t.o_ca, t.lse_ca, in_mask, T, S, 0, p,
+                  site_seed(m->seed, sb + 2), nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, cu));
         RC(k.linear(t.o_ca, d, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), t.z2, d, BT, d, d, 0, p, site_seed(m->seed, sb + 3), t.y1, d));
         RC(k.ln_fwd(t.y2, t.z2, PF(pb + D_N2_W), PF(pb + D_N2_B), t.m2, t.r2, BT, c.eps_layer));
         RC(k.linear(t.y2, d, PL(pb + D_L1_W), PF(pb + D_L1_B), t.hff, ff, BT, ff, d, 1, p, site_seed(m->seed, sb + 4)));
@@ -284,7 +287,9 @@ int bwd_ffn(pa_model* m, Ctx& k, int rows, const void* z, const float* mean, con
 int bwd_dec_layer(pa_model* m, int i, void* st) {
     const pa_model_cfg& c = m->cfg;
     Ctx k{m, st};
-    const int d = c.d_model, B = m->B, S = m->S, T = m->T, BS = B * S, BT = B * T;
+    const int d = c.d_model, B = m->B, S = m->S, T = m->T, BS = m->NE, BT = B * T;
+    const int32_t* cu = m->batch.cu_in;
+    const uint8_t* in_mask = cu ? nullptr : m->batch.input_mask;
     const float p = m->p_drop;
     const size_t e = m->esz;
     const int pb = m->dec_base(i);
@@ -300,8 +305,8 @@ int bwd_dec_layer(pa_model* m, int i, void* st) {
                 G(pb + D_N2_B), G(pb + D_CA_OUT_B), BT, p, site_seed(m->seed, sb + 3)));
     RC(k.linear_dw(ddrop, d, t.o_ca, d, G(pb + D_CA_OUT_W), nullptr, BT, d, d));
     RC(k.linear_dx(ddrop, d, m->pl[pb + D_CA_OUT_W], d, m->gD, d, BT, d, d, nullptr, 0, nullptr, 0, 1.f, m->plT[pb + D_CA_OUT_W], d));
-    RC(k.attn(true, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, 2 * d, t.o_ca, t.lse_ca, m->batch.input_mask, T, S, 0, p,
-              site_seed(m->seed, sb + 2), m->gD, m->gE, d, m->gKV, (char*)m->gKV + d * e, 2 * d));
+    RC(k.attn(true, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, 2 * d, t.o_ca, t.lse_ca, in_mask, T, S, 0, p,
+              site_seed(m->seed, sb + 2), m->gD, m->gE, d, m->gKV, (char*)m->gKV + d * e, 2 * d, nullptr, cu));
     float* dWin = G(pb + D_CA_IN_W); float* dbin = G(pb + D_CA_IN_B);
     RC(k.linear_dw(m->gE, d, t.y1, d, dWin, dbin, BT, d, d));
     RC(k.linear_dw(m->gKV, 2 * d, memory, d, dWin + (size_t)d * d, dbin + d, BS, 2 * d, d));
@@ -328,7 +333,9 @@ int bwd_dec_layer(pa_model* m, int i, void* st) {
 int bwd_enc_layer(pa_model* m, int i, void* st) {
     const pa_model_cfg& c = m->cfg;
     Ctx k{m, st};
-    const int d = c.d_model, B = m->B, S = m->S, BS = B * S;
+    const int d = c.d_model, S = m->S, BS = m->NE;
+    const int32_t* cu = m->batch.cu_in;
+    const uint8_t* in_mask = cu ? nullptr : m->batch.input_mask;
     const float p = m->p_drop;
     const size_t e = m->esz;
     const int pb = m->enc_base(i);
@@ -341,8 +348,8 @@ int bwd_enc_layer(pa_model* m, int i, void* st) {
                 G(pb + E_N1_B), G(pb + E_OUT_B), BS, p, site_seed(m->seed, 8 * i + 1)));
     RC(k.linear_dw(ddrop, d, t.o, d, G(pb + E_OUT_W), nullptr, BS, d, d));
     RC(k.linear_dx(ddrop, d, m->pl[pb + E_OUT_W], d, m->gD, d, BS, d, d, nullptr, 0, nullptr, 0, 1.f, m->plT[pb + E_OUT_W], d));
-    RC(k.attn(true, t.qkv, 3 * d, (char*)t.qkv + d * e, (char*)t.qkv + 2 * d * e, 3 * d, t.o, t.lse, m->batch.input_mask, S, S, 0,
-              p, site_seed(m->seed, 8 * i + 0), m->gD, m->gQ3, 3 * d, (char*)m->gQ3 + d * e, (char*)m->gQ3 + 2 * d * e, 3 * d));
+    RC(k.attn(true, t.qkv, 3 * d, (char*)t.qkv + d * e, (char*)t.qkv + 2 * d * e, 3 * d, t.o, t.lse, in_mask, S, S, 0,
+              p, site_seed(m->seed, 8 * i + 0), m->gD, m->gQ3, 3 * d, (char*)m->gQ3 + d * e, (char*)m->gQ3 + 2 * d * e, 3 * d, cu, cu));
     RC(k.linear_dw(m->gQ3, 3 * d, m->X[i], d, G(pb + E_IN_W), G(pb + E_IN_B), BS, 3 * d, d));
     RC(k.linear_dx(m->gQ3, 3 * d, m->pl[pb + E_IN_W], d, m->gA, d, BS, 3 * d, d, m->gB, d, nullptr, 0, 1.f, m->plT[pb + E_IN_W], 3 * d));
     return 0;
@@ -351,7 +358,7 @@ int bwd_enc_layer(pa_model* m, int i, void* st) {
 int backward_segment(pa_model* m, int seg, float gscale, void* st) {
     const pa_model_cfg& c = m->cfg;
     Ctx k{m, st};
-    const int d = c.d_model, B = m->B, S = m->S, T = m->T, BS = B * S;
+    const int d = c.d_model, B = m->B, T = m->T, BS = m->NE;
     auto G = [&](int j) { return (float*)m->gr[j]; };
     if (seg == 0) { m->dmem_written = false; return bwd_heads(m, gscale, st); }
     if (seg <= c.n_dec) return bwd_dec_layer(m, c.n_dec - seg, st);
@@ -375,7 +382,7 @@ int backward_segment(pa_model* m, int seg, float gscale, void* st) {
     if (es < c.n_enc) return bwd_enc_layer(m, c.n_enc - 1 - es, st);
     if (es == c.n_enc) {
         float* dt[5] = {G(P_IN_VALUE), G(P_IN_POS), G(P_IN_COORD), G(P_IN_VIEW), G(P_IN_TYPE)};
-        return pa_embed_input_bwd(m->gA, c.dtype, dt, m->batch.input_idx, c.in_table_rows, 5, (int64_t)BS, d, st);
+        return pa_embed_input_bwd(m->gA, c.dtype, dt, m->batch.input_idx, m->batch.rowmap, c.in_table_rows, 5, (int64_t)BS, d, st);
     }
     return PA_EINVAL;
 }
@@ -434,6 +441,12 @@ extern "C" int pa_model_train_fwd(pa_model* m, const pa_batch* batch, void* ws, 
     const size_t need = pa_train_layout(m, (char*)ws, batch->B, batch->S, batch->T);
     if ((int64_t)need > ws_bytes) return PA_EINVAL;
     m->batch = *batch; m->B = batch->B; m->S = batch->S; m->T = batch->T;
+    if (batch->cu_in) {
+        if (!batch->rowmap || batch->n_valid <= 0 || batch->n_valid > batch->B * batch->S) return PA_EINVAL;
+        m->NE = batch->n_valid;
+    } else {
+        m->NE = batch->B * batch->S;
+    }
     m->seed = seed; m->p_drop = training ? m->cfg.dropout : 0.f;
     m->stats = stats;
     m->have_fwd = false;
@@ -459,7 +472,7 @@ extern "C" int pa_model_tensor(pa_model* m, int32_t which, void** ptr, int64_t* 
     if (!m || !ptr || !numel || m->B == 0) return PA_EINVAL;
     const int64_t d = m->cfg.d_model;
     switch (which) {
-        case PA_T_MEMORY: *ptr = m->cfg.has_enc_norm ? m->memory : m->X[m->cfg.n_enc]; *numel = (int64_t)m->B * m->S * d; return 0;
+        case PA_T_MEMORY: *ptr = m->cfg.has_enc_norm ? m->memory : m->X[m->cfg.n_enc]; *numel = (int64_t)m->NE * d; return 0;
         case PA_T_HIDDENS: *ptr = m->hid; *numel = (int64_t)m->B * m->T * d; return 0;
         case PA_T_VOCAB_LOGITS: *ptr = m->vlog; *numel = (int64_t)m->B * m->T * m->ldv; return 0;
         case PA_T_PTR_LOGITS: *ptr = m->plog; *numel = (int64_t)m->B * m->T * m->T; return 0;

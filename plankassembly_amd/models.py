@@ -49,7 +49,8 @@ class _TrDesc(C.Structure):
 class _Batch(C.Structure):
     _fields_ = [("input_idx", C.c_void_p * 5), ("input_mask", C.c_void_p), ("output_value", C.c_void_p),
                 ("output_label", C.c_void_p), ("output_mask", C.c_void_p),
-                ("B", C.c_int32), ("S", C.c_int32), ("T", C.c_int32)]
+                ("B", C.c_int32), ("S", C.c_int32), ("T", C.c_int32),
+                ("cu_in", C.c_void_p), ("rowmap", C.c_void_p), ("n_valid", C.c_int32)]
 
 
 INPUT_KEYS = ("input_value", "input_pos", "input_coord", "input_view", "input_type")
@@ -119,6 +120,8 @@ class PlankModel(nn.Module):
             raise ValueError("only ACTIVATION: relu is implemented (all reference configs use it)")
         if num_input_dof != 4 or num_view < 1:
             pass
+        # run the encoder on the valid (non-PAD) rows only; PLANK_UNPAD=0 keeps the dense layout
+        self.unpad = os.environ.get("PLANK_UNPAD", "1") != "0"
         compute_dtype = compute_dtype or os.environ.get("PLANK_COMPUTE_DTYPE", "f32")
         if compute_dtype not in ("f32", "bf16"):
             raise ValueError("compute_dtype must be 'f32' or 'bf16'")
@@ -430,6 +433,19 @@ class PlankModel(nn.Module):
         m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
         keep.append(m)
         b.input_mask = m.data_ptr()
+        if self.unpad:
+            # pack the encoder to its valid rows (padded positions never reach the loss).  A batch that went through
+            # prepare_batch() carries the packing already; otherwise it is computed here, which costs the one
+            # device->host read (n_valid) of the step.
+            pack = batch.get("_pack")
+            if pack is None or pack[0].device != m.device:
+                pack = self._pack(m)
+            cu, rowmap, n_valid = pack
+            keep += [cu, rowmap]
+            b.cu_in, b.rowmap, b.n_valid = cu.data_ptr(), rowmap.data_ptr(), n_valid
+            self._last_pack = (cu, rowmap, n_valid, B, S)
+        else:
+            self._last_pack = None
         T = self.max_output_length
         if with_output:
             ov = batch["output_value"].to(device=self._flat.device, dtype=torch.int64).contiguous()
@@ -441,6 +457,27 @@ class PlankModel(nn.Module):
             b.output_value, b.output_label, b.output_mask = ov.data_ptr(), ol.data_ptr(), om.data_ptr()
         b.B, b.S, b.T = B, S, T
         return b, keep
+
+    def _pack(self, mask_u8):
+        B, S = mask_u8.shape
+        cu = torch.empty(2 * B + 1, dtype=torch.int32, device=mask_u8.device)
+        rowmap = torch.empty(B * S, dtype=torch.int32, device=mask_u8.device)
+        L.check(L.lib().pa_pack_rows(L.ptr(mask_u8), B, S, L.ptr(cu), L.ptr(rowmap), L.stream()), "pa_pack_rows")
+        return cu, rowmap, int(cu[B])
+
+    def prepare_batch(self, batch):
+        """Move a collated batch to the model's device and attach the encoder row packing (``_pack``: valid-row
+        offsets per sample, packed-row -> position map, number of valid rows).  Doing this when the batch is built
+        (dataloader / before the timed region) keeps the training loop free of device->host reads; forward() accepts
+        unprepared batches too."""
+        self._require_gpu()
+        dev = self._flat.device
+        out = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        if self.unpad:
+            msk = out["input_mask"].contiguous()
+            msk = msk.view(torch.uint8) if msk.dtype == torch.bool else msk.to(torch.uint8)
+            out["_pack"] = self._pack(msk)
+        return out
 
     def _workspace(self, B, S, T):
         need = int(L.lib().pa_model_train_ws_bytes(self._handle, B, S, T))
@@ -539,7 +576,13 @@ class PlankModel(nn.Module):
         dt = torch.float32 if (which in ("vocab_logits", "ptr_logits") or self.compute_dtype == "f32") else torch.bfloat16
         esz = 4 if dt == torch.float32 else 2
         off = p.value - self._ws.data_ptr()
-        return self._ws[off: off + n.value * esz].view(dt).clone()
+        t = self._ws[off: off + n.value * esz].view(dt).clone()
+        if which == "memory" and getattr(self, "_last_pack", None) is not None:
+            cu, rowmap, nv, B, S = self._last_pack                    # scatter the packed rows back to [B*S, d] (zeros at PAD)
+            full = torch.zeros(B * S, self.num_model, dtype=dt, device=t.device)
+            full[rowmap[:nv].long()] = t.view(nv, self.num_model)
+            return full.view(-1)
+        return t
 
 
 def build_model(cfg):

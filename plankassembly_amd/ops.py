@@ -79,20 +79,31 @@ def _ptr_array(tensors):
     return arr
 
 
-def embed_input_fwd(tables, idx, dtype=torch.float32):
-    n_tok = next(i for i in idx if i is not None).numel()
+def embed_input_fwd(tables, idx, dtype=torch.float32, rowmap=None, n_rows=None):
+    n_tok = n_rows if n_rows is not None else next(i for i in idx if i is not None).numel()
     d = tables[0].shape[1]
     out = torch.empty(n_tok, d, dtype=dtype, device=tables[0].device)
-    L.check(L.lib().pa_embed_input_fwd(L.ptr(out), L.dt(out), _ptr_array(tables), _ptr_array(idx), len(tables),
+    L.check(L.lib().pa_embed_input_fwd(L.ptr(out), L.dt(out), _ptr_array(tables), _ptr_array(idx), L.ptr(rowmap), len(tables),
                                        C.c_int64(n_tok), d, L.stream()), "pa_embed_input_fwd")
     return out
 
 
-def embed_input_bwd(dout, dtables, idx):
+def pack_rows(mask):
+    """mask: bool/uint8 [B, S] (True = PAD).  Returns (cu int32 [B+1], rowmap int32 [n_valid], n_valid)."""
+    B, S = mask.shape
+    m8 = mask.to(torch.uint8).contiguous()
+    cu = torch.empty(2 * B + 1, dtype=torch.int32, device=mask.device)
+    rowmap = torch.empty(B * S, dtype=torch.int32, device=mask.device)
+    L.check(L.lib().pa_pack_rows(L.ptr(m8), B, S, L.ptr(cu), L.ptr(rowmap), L.stream()), "pa_pack_rows")
+    n = int(cu[B])
+    return cu[: B + 1], rowmap[:n], n
+
+
+def embed_input_bwd(dout, dtables, idx, rowmap=None):
     n_tok, d = dout.shape
     rows = (C.c_int32 * len(dtables))(*[t.shape[0] for t in dtables])
-    L.check(L.lib().pa_embed_input_bwd(L.ptr(dout), L.dt(dout), _ptr_array(dtables), _ptr_array(idx), rows, len(dtables),
-                                       C.c_int64(n_tok), d, L.stream()), "pa_embed_input_bwd")
+    L.check(L.lib().pa_embed_input_bwd(L.ptr(dout), L.dt(dout), _ptr_array(dtables), _ptr_array(idx), L.ptr(rowmap), rows,
+                                       len(dtables), C.c_int64(n_tok), d, L.stream()), "pa_embed_input_bwd")
 
 
 def embed_output_fwd(value, coord, pos, tok, T, dof=6, dtype=torch.float32):
@@ -131,15 +142,18 @@ def layernorm_bwd(dy, z, gamma, mean, rstd, dgamma, dbeta, dzsum=None, drop_p=0.
     return dz, ddrop
 
 
-def _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H):
-    B, Lq = q.shape[0], q.shape[1]
-    Lk = k.shape[1]
-    dh = q.shape[2] // H
+def _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H, cu_q=None, cu_k=None, B=None, Lq=None, Lk=None):
+    if B is None:
+        B, Lq = q.shape[0], q.shape[1]
+        Lk = k.shape[1]
+    dh = q.shape[-1] // H
     a = L.AttnArgs()
     a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
     a.kpm = kpm.data_ptr() if kpm is not None else None
     a.B, a.H, a.Lq, a.Lk, a.dh = B, H, Lq, Lk, dh
-    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1), k.stride(1), v.stride(1), o.stride(1)
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(-2), k.stride(-2), v.stride(-2), o.stride(-2)
+    a.cu_q = cu_q.data_ptr() if cu_q is not None else None
+    a.cu_k = cu_k.data_ptr() if cu_k is not None else None
     a.causal = int(causal)
     a.scale = scale if scale is not None else 1.0 / math.sqrt(dh)
     a.drop_p, a.drop_seed = drop_p, drop_seed
@@ -226,3 +240,25 @@ def cast(src, dtype):
     L.check(L.lib().pa_cast(L.ptr(dst), L.dt(dst), L.ptr(src), L.dt(src), C.c_int64(src.numel()), L.stream()),
             "pa_cast")
     return dst
+
+
+def attn_varlen_fwd(q, k, v, H, cu_q, cu_k, B, Lq_max, Lk_max, causal=False, scale=None, drop_p=0.0, drop_seed=0):
+    """Packed ("unpadded") attention: q [Nq, H*dh], k/v [Nk, H*dh] with int32 row offsets cu_q / cu_k [B+1]
+    (either may be None = dense [B*L] rows).  Returns (o [Nq, H*dh], lse [B, H, Lq_max])."""
+    o = torch.empty(q.shape[0], q.shape[1], dtype=q.dtype, device=q.device)
+    lse = _f32(B, H, Lq_max, device=q.device)
+    a = _attn_args(q, k, v, o, lse, None, causal, scale, drop_p, drop_seed, H, cu_q, cu_k, B, Lq_max, Lk_max)
+    L.check(L.lib().pa_attn_fwd(C.byref(a), L.stream()), "pa_attn_fwd")
+    return o, lse
+
+
+def attn_varlen_bwd(dout, q, k, v, o, lse, H, cu_q, cu_k, B, Lq_max, Lk_max, causal=False, scale=None, drop_p=0.0, drop_seed=0):
+    a = _attn_args(q, k, v, o, lse, None, causal, scale, drop_p, drop_seed, H, cu_q, cu_k, B, Lq_max, Lk_max)
+    dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
+    dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+    delta = _f32(lse.shape, device=q.device)
+    a.dout, a.dq, a.dk, a.dv, a.delta = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
+    a.lddo, a.lddq, a.lddk, a.lddv = dout.stride(-2), dq.stride(-2), dk.stride(-2), dv.stride(-2)
+    L.check(L.lib().pa_attn_bwd(C.byref(a), L.stream()), "pa_attn_bwd")
+    return dq, dk, dv

@@ -215,7 +215,9 @@ class SidefaceTrainer(Trainer):
 
 
 # ====================================================================================== loop + CLI
-def _to_device(batch, dev):
+def _to_device(batch, dev, model=None):
+    if model is not None and hasattr(model, "prepare_batch"):
+        return model.prepare_batch(batch)
     return {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
@@ -243,7 +245,7 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
         module.model.eval()
         with torch.no_grad():
             for i, batch in enumerate(module.test_dataloader()):
-                module.test_step(_to_device(batch, dev), i)
+                module.test_step(_to_device(batch, dev, module.model), i)
         module.test_epoch_end()
         if rank == 0:
             print({k: round(v, 4) for k, v in module._logged.items()})
@@ -266,7 +268,7 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
         t0, n = time.perf_counter(), 0
         for i, batch in enumerate(loader):
             opt.zero_grad()
-            loss = module.training_step(_to_device(batch, dev), i)
+            loss = module.training_step(_to_device(batch, dev, module.model), i)
             loss.backward()
             opt.step()
             module.global_step += 1
@@ -283,7 +285,7 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
             module.model.eval()
             with torch.no_grad():
                 for i, batch in enumerate(module.val_dataloader()):
-                    module.validation_step(_to_device(batch, dev), i)
+                    module.validation_step(_to_device(batch, dev, module.model), i)
             module.validation_epoch_end()
             f1 = module._logged.get("val/fmeasure", 0.0)
             if rank == 0:

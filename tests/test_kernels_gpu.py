@@ -349,3 +349,51 @@ def test_adam_vs_oracle():
     assert float((pd.cpu() - params["x"]).abs().max()) < 2e-7
     assert rel_err(md, m["x"]) < 1e-5 and rel_err(vd, v["x"]) < 1e-4   # (1-b2) is rounded to f32 on the device
     assert torch.equal(pb.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------ packed (unpadded) batches
+def test_pack_rows_matches_nonzero():
+    g = torch.Generator().manual_seed(90)
+    mask = torch.rand(5, 77, generator=g) < 0.4
+    mask[2] = True; mask[2, 0] = False                    # an "empty" row: only END is valid
+    cu, rowmap, n = ops.pack_rows(mask.to(DEV))
+    valid = (~mask).flatten().nonzero().flatten()
+    assert n == valid.numel()
+    assert torch.equal(rowmap.cpu().long(), valid)
+    cnt = (~mask).sum(1)
+    assert torch.equal(cu.cpu().long(), torch.cat((torch.zeros(1, dtype=torch.long), cnt.cumsum(0))))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,dh,Lq,Lk,self_attn", [(3, 4, 16, 70, 70, True), (4, 8, 64, 128, 300, False), (2, 8, 64, 260, 260, True)])
+def test_attention_varlen_matches_masked_dense(dtype, B, H, dh, Lq, Lk, self_attn):
+    """Packed K/V (and Q for self-attention) without any mask == dense attention with a key-padding mask."""
+    dm = H * dh
+    g = torch.Generator().manual_seed(91)
+    lens = torch.randint(1, Lk + 1, (B,), generator=g)
+    lens[0] = Lk
+    kpm = torch.arange(Lk)[None, :] >= lens[:, None]
+    x = rnd(B, Lk, 3 * dm, dtype=dtype, seed=92)
+    qd = x[..., :dm] if self_attn else rnd(B, Lq, dm, dtype=dtype, seed=93)
+    kd, vd = x[..., dm:2 * dm], x[..., 2 * dm:]
+    dout = rnd(B, Lq, dm, dtype=dtype, seed=94)
+    qr, kr, vr = (t.float().contiguous().requires_grad_(True) for t in (qd, kd, vd))
+    ref, _ = attn_ref(qr, kr, vr, H, kpm, False)
+    qvalid = ~kpm if self_attn else torch.ones(B, Lq, dtype=torch.bool)
+    ref.backward(dout.float() * qvalid[..., None])       # padded query rows carry no gradient
+    sel_k = (~kpm).flatten().nonzero().flatten()
+    cu_k = torch.cat((torch.zeros(1, dtype=torch.long), lens.cumsum(0))).to(torch.int32).to(DEV)
+    xp = x.reshape(B * Lk, 3 * dm)[sel_k].to(DEV)         # packed rows keep the in_proj layout [N, 3*dm]
+    kp, vp = xp[:, dm:2 * dm], xp[:, 2 * dm:]
+    if self_attn:
+        qp, cu_q, sel_q = xp[:, :dm], cu_k, sel_k
+    else:
+        qp, cu_q, sel_q = qd.reshape(B * Lq, dm).to(DEV), None, torch.arange(B * Lq)
+    dop = dout.reshape(B * Lq, dm)[sel_q].to(DEV)
+    o, lse = ops.attn_varlen_fwd(qp, kp, vp, H, cu_q, cu_k, B, Lq, Lk)
+    t = tol(dtype)
+    assert rel_err(o, ref.reshape(B * Lq, dm)[sel_q]) < t
+    dq, dk, dv = ops.attn_varlen_bwd(dop, qp, kp, vp, o, lse, H, cu_q, cu_k, B, Lq, Lk)
+    assert rel_err(dq, qr.grad.reshape(B * Lq, dm)[sel_q]) < t
+    assert rel_err(dk, kr.grad.reshape(B * Lk, dm)[sel_k]) < t
+    assert rel_err(dv, vr.grad.reshape(B * Lk, dm)[sel_k]) < t
