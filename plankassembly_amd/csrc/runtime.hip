@@ -65,7 +65,7 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
         }
         g.splitk = sk; g.ws = m->splitws;
         RC(pa_gemm(&g, st));
-        if (db) RC(pa_colsum(dY, dt(), M, N, lddy, db, 0, m->partial, st));
+        if (db) RC(pa_colsum(dY, dt(), M, N, lddy, db, 1, m->partial, st));   // gradients are zero-initialised by the caller
         return 0;
     }
     int ln_fwd(void* y, const void* z, const float* g, const float* b, float* mean, float* rstd, int64_t rows, float eps) const {
