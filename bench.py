@@ -102,6 +102,54 @@ def kernel_rooflines(B):
     return out
 
 
+def gemm_census(model, batch, train_step):
+    """Per-launch census of the GEMM kernel over ONE training step: the library records every pa_gemm() argument
+    block of the step (pa_gemm_record), then each recorded launch is replayed on the same buffers under HIP
+    events.  Returns {family: {launches, flops, seconds}} with family = operand layout (which selects the kernel
+    instantiation): 'tt' both operands k-contiguous (forward and dX Linears), 'nn' neither (dW, split-K), else 'mixed'."""
+    import ctypes as C
+    from plankassembly_amd import _lib as L
+    lib = L.lib()
+    torch.cuda.synchronize()
+    lib.pa_gemm_record(1)
+    train_step(0)
+    torch.cuda.synchronize()
+    n = lib.pa_gemm_record(0)
+    rec = (L.GemmArgs * n)()
+    n = lib.pa_gemm_recorded(C.cast(rec, C.c_void_p), n)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fam = {}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    reps = 5
+    for i in range(n):
+        a = rec[i]
+        ref = C.cast(C.byref(a), C.c_void_p)
+        lib.pa_gemm(ref, st)
+        ev[0].record()
+        for _ in range(reps):
+            lib.pa_gemm(ref, st)
+        ev[1].record()
+        ev[1].synchronize()
+        t = ev[0].elapsed_time(ev[1]) * 1e-3 / reps
+        key = "tt" if (a.a_kcontig and a.b_kcontig) else ("nn" if not (a.a_kcontig or a.b_kcontig) else "mixed")
+        f = fam.setdefault(key, dict(launches=0, flops=0.0, seconds=0.0))
+        f["launches"] += 1
+        f["flops"] += 2.0 * a.M * a.N * a.K * a.batch
+        f["seconds"] += t
+    return fam
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of one kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json,
+    made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask, clipped by the cgroup CPU quota, capped at 64
     (torch's CPU kernels stop scaling - and oversubscription is catastrophic - well before that)."""
@@ -225,6 +273,11 @@ def main():
     dt = float(tt.item())
     loss = float(out["loss"].detach())
     assert math.isfinite(loss), "training diverged"
+    census = None
+    if rank == 0 and not args.no_kernels:
+        census = gemm_census(model, batches[0], train_step)
+        log("gemm census: " + ", ".join(f"{k}: {v['launches']} launches, {v['seconds'] / v['launches'] * 1e6:.1f} us avg, "
+                                         f"{v['flops'] / v['seconds'] / 1e12:.0f} TF" for k, v in census.items()))
     samples_s = args.steps * B * world / dt
     log(f"train: {samples_s:.1f} samples/s, {dt / args.steps * 1e3:.2f} ms/step, loss {loss:.4f}")
     train_flops = 3.0 * fwd_flops_per_sample(S_IN, T_OUT) * B      # per GPU step
@@ -293,13 +346,20 @@ def main():
             "train_tflops_per_gpu": step_tflops, "train_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
             "decode": decode,
         }
+        if census and "tt" in census:
+            # dominant kernel of the step by time: gemm_kernel<bf16, BK=64, A/B k-contiguous> = every forward and dX Linear
+            c = census["tt"]
+            ach = c["flops"] / c["seconds"] / 1e12
+            line["roofline"] = {"kernel": "gemm_kernel<bf16,BK=64,2 waves/SIMD,A_KC,B_KC,aligned,direct-to-LDS,NST=2> - all "
+                                          "forward + dX Linear launches of one train step (replayed per launch)",
+                                "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_tt"),
+                                "launches_per_step": c["launches"],
+                                "algorithmic_flops_per_launch": c["flops"] / c["launches"],
+                                "avg_launch_us": c["seconds"] / c["launches"] * 1e6}
+            line["gemm_census"] = {k: {"launches": v["launches"], "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
+                                       "tflops": round(v["flops"] / v["seconds"] / 1e12, 1)} for k, v in census.items()}
         if kern:
-            a = kern["attn_fwd_enc_self"]
-            line["roofline"] = {"kernel": "attn_fwd_kernel<bf16,64> (encoder self-attention, B=%d H=8 S=1024 dh=64, "
-                                          "key-padding mask, dropout 0.2)" % B,
-                                "bound": "mfma", "achieved": a["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                "frac": a["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
-                                "algorithmic_flops_per_launch": a["flops"], "avg_launch_ms": a["ms"]}
             line["kernels"] = {k: {"ms": round(v["ms"], 4), "tflops": round(v["tflops"], 1),
                                    "mfma_frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4)} for k, v in kern.items()}
         if cpu:

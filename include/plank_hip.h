@@ -70,6 +70,11 @@ typedef struct {
     int32_t splitk;
 } pa_gemm_args;
 int pa_gemm(const pa_gemm_args* a, void* stream);
+/* Measurement hook (bench.py's roofline census; no reference counterpart): pa_gemm_record(1) starts appending every
+ * pa_gemm() argument block to a host-side list; pa_gemm_record(0) returns the count so far; pa_gemm_recorded() copies
+ * up to `cap` recorded blocks out and stops recording.  Replaying the blocks re-launches the same GEMMs. */
+int pa_gemm_record(int32_t enable);
+int pa_gemm_recorded(pa_gemm_args* out, int32_t cap);
 
 /* Batched 2-D transposes dst[c][r] = src[r][c] (one launch for a table of matrices; descriptors live in device
  * memory, tile_begin = prefix sum of ceil(rows/64)*ceil(cols/64)).  Keeps the transposed shadow of the Linear

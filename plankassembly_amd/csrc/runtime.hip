@@ -3,6 +3,7 @@
 // plankassembly/models.py:190-233, train_step) and a hand-derived backward, over one caller-owned
 // workspace ("arena").  Host-only logic: no device allocation, no synchronisation, enqueue-only
 // (hipGraph capturable).  See include/plank_hip.h (pa_model_*).
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <new>
@@ -58,7 +59,8 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
         const int nkt = (M + ktile - 1) / ktile;
         int sk = 1;
         if (tiles < 256) {
-            sk = (512 + tiles - 1) / tiles;
+            static const int target = getenv("PA_DW_UNITS") ? atoi(getenv("PA_DW_UNITS")) : 256;   // one round of the one-block-per-CU kernel
+            sk = target / tiles > 0 ? target / tiles : 1;
             if (sk > 16) sk = 16;
             if (sk > nkt / 4) sk = nkt / 4 > 0 ? nkt / 4 : 1;
             while (sk > 1 && (size_t)sk * N * K > m->splitws_floats) --sk;

@@ -25,6 +25,6 @@ int main(int argc, char** argv) {
     std::vector<unsigned long long> tr(n);
     hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(pa_trace), n * 8);
     unsigned long long prev = n ? tr[1] : 0, t0 = prev;
-    for (int i = 0; i + 1 < n && i < 140; i += 2) { printf("tag %llu  +%6llu  (t=%llu)\n", tr[i], tr[i + 1] - prev, tr[i + 1] - t0); prev = tr[i + 1]; }
+    for (int i = 0; i + 1 < n && i < 900; i += 2) { printf("tag %llu  +%6llu  (t=%llu)\n", tr[i], tr[i + 1] - prev, tr[i + 1] - t0); prev = tr[i + 1]; }
     return 0;
 }
