@@ -778,32 +778,37 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
     const char* kA = nullptr; const char* kB = nullptr; int k_dma = 0;
     const size_t stepA = A_KC ? (size_t)TL::BK * esz : (size_t)TL::BK * p.lda * esz;
     const size_t stepB = B_KC ? (size_t)TL::BK * esz : (size_t)TL::BK * p.ldb * esz;
+    // one quarter of an item's DMA: Q = 0, 1 -> A chunks {0,1}, {2,3}; Q = 2, 3 -> B chunks {0,1}, {2,3}
+    auto fetch_q = [&](int stage, auto Q_) {
+        constexpr int Q = decltype(Q_)::value;
+        char* lx = smem + stage * STAGE + (Q >= 2 ? TL::TILE_BYTES : 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = (Q & 1) * 2 + j;
+            const char* src;
+            if constexpr (Q < 2) {
+                if constexpr (A_KC) src = kA + offA[i];
+                else {
+                    const bool in = okA[i] && (k_dma + ((tid + i * NT) >> 4)) < p.K;
+                    src = in ? kA + offA[i] : reinterpret_cast<const char*>(pa_zero16);
+                }
+            } else {
+                if constexpr (B_KC) src = kB + offB[i];
+                else {
+                    const bool in = okB[i] && (k_dma + ((tid + i * NT) >> 4)) < p.K;
+                    src = in ? kB + offB[i] : reinterpret_cast<const char*>(pa_zero16);
+                }
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                (__attribute__((address_space(3))) void*)(lx + (i * NT + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    auto fetch_done = [&]() { kA += stepA; kB += stepB; k_dma += TL::BK; };
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
     auto fetch = [&](int stage) {
-        char* la = smem + stage * STAGE;
-        char* lb = la + TL::TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < TL::NLD; ++i) {
-            const char* src;
-            if constexpr (A_KC) src = kA + offA[i];
-            else {
-                const bool in = okA[i] && (k_dma + ((tid + i * NT) >> 4)) < p.K;
-                src = in ? kA + offA[i] : reinterpret_cast<const char*>(pa_zero16);
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                (__attribute__((address_space(3))) void*)(la + (i * NT + wave * 64) * 16), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < TL::NLD; ++i) {
-            const char* src;
-            if constexpr (B_KC) src = kB + offB[i];
-            else {
-                const bool in = okB[i] && (k_dma + ((tid + i * NT) >> 4)) < p.K;
-                src = in ? kB + offB[i] : reinterpret_cast<const char*>(pa_zero16);
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                (__attribute__((address_space(3))) void*)(lb + (i * NT + wave * 64) * 16), 16, 0, 0);
-        }
-        kA += stepA; kB += stepB; k_dma += TL::BK;
+        fetch_q(stage, Q0{}); fetch_q(stage, Q1{}); fetch_q(stage, Q2{}); fetch_q(stage, Q3{});
+        fetch_done();
     };
 
     // ---- fragment reads (lane-constant offsets inside a stage) ------------------------------------------------
@@ -833,47 +838,64 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
     }
 #define PA_RD128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
 #define PA_RDTR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
-    // f[0..1] = A fragments (row groups 0, 1), f[2..3] = B fragments of k-step S of the tile at LDS address `st`
-    auto frag = [&](u32x4 (&f)[4], uint32_t st, auto S_) {
-        constexpr int S = decltype(S_)::value;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
+    // f[0..1] = A fragments (row groups 0, 1), f[2..3] = B fragments of k-step S of the tile at LDS address `st`;
+    // rd1 issues the read(s) of ONE fragment W (0, 1: A; 2, 3: B)
+    auto rd1 = [&](u32x4 (&f)[4], uint32_t st, auto S_, auto W_) {
+        constexpr int S = decltype(S_)::value, W = decltype(W_)::value, i = W & 1;
+        if constexpr (W < 2) {
             if constexpr (A_TG) {
                 u32x2 lo, hi; const uint32_t ad = st + fa_off[i];
                 PA_RDTR(lo, ad, S * 4096); PA_RDTR(hi, ad, S * 4096 + 1024);
-                f[i][0] = lo[0]; f[i][1] = lo[1]; f[i][2] = hi[0]; f[i][3] = hi[1];
-            } else {
-                const uint32_t ad = st + fa_off[i] + xs[S];
-                PA_RD128(f[i], ad, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
+                f[W][0] = lo[0]; f[W][1] = lo[1]; f[W][2] = hi[0]; f[W][3] = hi[1];
+            } else { const uint32_t ad = st + fa_off[i] + xs[S]; PA_RD128(f[W], ad, 0); }
+        } else {
             if constexpr (B_TG) {
                 u32x2 lo, hi; const uint32_t ad = st + fb_off[i];
                 PA_RDTR(lo, ad, TL::TILE_BYTES + S * 4096); PA_RDTR(hi, ad, TL::TILE_BYTES + S * 4096 + 1024);
-                f[2 + i][0] = lo[0]; f[2 + i][1] = lo[1]; f[2 + i][2] = hi[0]; f[2 + i][3] = hi[1];
-            } else {
-                const uint32_t ad = st + fb_off[i] + xs[S];
-                PA_RD128(f[2 + i], ad, TL::TILE_BYTES);
-            }
+                f[W][0] = lo[0]; f[W][1] = lo[1]; f[W][2] = hi[0]; f[W][3] = hi[1];
+            } else { const uint32_t ad = st + fb_off[i] + xs[S]; PA_RD128(f[W], ad, TL::TILE_BYTES); }
         }
     };
-    // all but the newest NRD LDS reads have returned -> `f` (issued one k-step earlier) is complete
-    auto wait_frag = [&](u32x4 (&f)[4], bool newer_in_flight) {
-        if (newer_in_flight) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(NRD));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+    using W0 = std::integral_constant<int, 0>; using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>; using W3 = std::integral_constant<int, 3>;
+    auto frag = [&](u32x4 (&f)[4], uint32_t st, auto S_) { rd1(f, st, S_, W0{}); rd1(f, st, S_, W1{}); rd1(f, st, S_, W2{}); rd1(f, st, S_, W3{}); };
+    // every LDS read issued so far has returned (and `f` is complete)
+    auto wait_frag = [&](u32x4 (&f)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
     };
-    auto mma = [&](const u32x4 (&f)[4]) {
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) mma16B<T>(acc[tn][tm], f[2 + tn], f[tm]);
-    };
-    const bool dbg_nomma = p.dbg & 1, dbg_nord = p.dbg & 2, dbg_nobar = p.dbg & 8;
-#define MMA(F) do { if (!dbg_nomma) mma(F); } while (0)
+    // The MFMAs stay compiler builtins (an asm MFMA is opaque to the hazard recogniser: accumulator copies at control-
+    // flow joins would read stale registers); the scheduler keeps them interleaved with the asm-volatile reads:
+    // "MFMA, LDS read, MFMA, LDS read, ..." - each read is issued while the previous MFMA executes.
+#define PA_MFMA(ACC, X, Y) mma16B<T>(ACC, X, Y)
+
+#ifdef PA_GEMM_ABLATE      // timing ablations (wrong results): PA_GEMM_DBG bits 1 no MFMA, 2 no LDS reads, 4 no DMA, 8 no barriers
+    const bool dbg_nomma = p.dbg & 1, dbg_nord = p.dbg & 2, dbg_nodma = p.dbg & 4, dbg_nobar = p.dbg & 8;
+#define MMA1(ACC, X, Y) do { if (!dbg_nomma) PA_MFMA(ACC, X, Y); } while (0)
+#define RD1(F, st, S, W) do { if (!dbg_nord) rd1(F, st, S, W); } while (0)
 #define FRAG(F, st, S) do { if (!dbg_nord) frag(F, st, S); } while (0)
 #define BAR() do { if (!dbg_nobar) __builtin_amdgcn_s_barrier(); } while (0)
+#define DMA(x) do { if (!dbg_nodma) { x; } } while (0)
+#else
+#define MMA1(ACC, X, Y) PA_MFMA(ACC, X, Y)
+#define RD1(F, st, S, W) rd1(F, st, S, W)
+#define FRAG(F, st, S) frag(F, st, S)
+#define BAR() __builtin_amdgcn_s_barrier()
+#define DMA(x) do { x; } while (0)
+#endif
+    int sd = 0;                                 // LDS stage the next DMA item goes to
+    // one k-step: the four MFMAs on `fc`, interleaved with the reads of the next k-step's fragments into `fn`
+    // (RD = false: no next k-step) and, in the hot loop, with one quarter of the DMA three items ahead
+    auto step = [&](u32x4 (&fc)[4], u32x4 (&fn)[4], uint32_t stn, auto SN_, auto RD_, auto DQ_) {
+        constexpr bool RD = decltype(RD_)::value;
+        constexpr int DQ = decltype(DQ_)::value;       // -1: no DMA in this step
+        wait_frag(fc);
+        MMA1(acc[0][0], fc[2], fc[0]); if constexpr (RD) RD1(fn, stn, SN_, W0{});
+        MMA1(acc[0][1], fc[2], fc[1]); if constexpr (RD) RD1(fn, stn, SN_, W1{});
+        if constexpr (DQ >= 0) DMA(fetch_q(sd, std::integral_constant<int, (DQ >= 0 ? DQ : 0)>{}));
+        MMA1(acc[1][0], fc[3], fc[0]); if constexpr (RD) RD1(fn, stn, SN_, W2{});
+        MMA1(acc[1][1], fc[3], fc[1]); if constexpr (RD) RD1(fn, stn, SN_, W3{});
+    };
+    using NoQ = std::integral_constant<int, -1>;
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
     auto epilogue = [&](const Unit& un) {
@@ -1028,10 +1050,9 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
     cmp_enter(blockIdx.x);
     if (cc_u >= p.units) return;
     dma_enter(blockIdx.x);
-    const int dbg = p.dbg;
-    int sd = 0, pending = 0;                    // pending: items issued and not yet finished by the MFMAs
+    int pending = 0;                            // items issued and not yet finished by the MFMAs
     auto issue = [&]() {
-        if (!(dbg & 4)) fetch(sd);
+        DMA(fetch(sd));
         sd = (sd + 1) & (NSTG - 1);
         ++pending;
         if (++cd_t >= cd_end) dma_enter(cd_u + ustride);
@@ -1055,31 +1076,26 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
     // in flight and a next item exists, so the body is branch-free; the general body handles the ends of the stream.
     auto item = [&](auto HOT_) -> bool {
         constexpr bool HOT = decltype(HOT_)::value;
+        using QA = std::integral_constant<int, HOT ? 0 : -1>; using QB = std::integral_constant<int, HOT ? 1 : -1>;
+        using QC = std::integral_constant<int, HOT ? 2 : -1>; using QD = std::integral_constant<int, HOT ? 3 : -1>;
         const uint32_t st = lds0 + sc * STAGE;
-        // k-step 0; barrier A: every wave has finished the previous item, so its stage may be refilled
-        FRAG(F1, st, S1{});
+        // barrier A: every wave has finished the previous item, so its stage may be refilled (HOT: the DMA of the item
+        // three ahead is spread over the four k-steps; otherwise it is issued here in one go)
         BAR();
-        if constexpr (HOT) { if (!(dbg & 4)) fetch(sd); sd = (sd + 1) & (NSTG - 1); ++cd_t; }
-        else { if (cd_u < p.units) issue(); }
-        wait_frag(F0, true);
-        MMA(F0);
-        FRAG(F0, st, S2{});
-        wait_frag(F1, true);
-        MMA(F1);
-        FRAG(F1, st, S3{});
-        wait_frag(F0, true);
-        MMA(F0);
-        // k-step 3; barrier B: the next item has landed for every wave -> its first fragments can be read
+        if constexpr (!HOT) { if (cd_u < p.units) issue(); }
+        step(F0, F1, st, S1{}, std::true_type{}, QA{});
+        step(F1, F0, st, S2{}, std::true_type{}, QB{});
+        step(F0, F1, st, S3{}, std::true_type{}, QC{});
+        // last k-step; barrier B: the next item has landed for every wave -> its first fragments are read meanwhile
         const bool has_next = HOT || pending >= 2;
         if (has_next) {
-            if constexpr (HOT) wait_items(2); else wait_items(pending - 2);
+            if constexpr (HOT) { DMA(fetch_q(sd, Q3{}); fetch_done()); sd = (sd + 1) & (NSTG - 1); ++cd_t; wait_items(2); }
+            else wait_items(pending - 2);
             BAR();
-            FRAG(F0, lds0 + ((sc + 1) & (NSTG - 1)) * STAGE, S0{});
-            wait_frag(F1, true);
+            step(F1, F0, lds0 + ((sc + 1) & (NSTG - 1)) * STAGE, S0{}, std::true_type{}, NoQ{});
         } else {
-            wait_frag(F1, false);
+            step(F1, F0, st, S0{}, std::false_type{}, NoQ{});
         }
-        MMA(F1);
         sc = (sc + 1) & (NSTG - 1);
         if constexpr (HOT) { ++cc_t; return true; }
         else {
@@ -1102,9 +1118,12 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
     }
 #undef PA_RD128
 #undef PA_RDTR
-#undef MMA
+#undef MMA1
+#undef RD1
 #undef FRAG
 #undef BAR
+#undef DMA
+#undef PA_MFMA
 }
 
 // split-K second pass: sum the slabs and apply the epilogue

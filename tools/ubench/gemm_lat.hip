@@ -4,6 +4,8 @@
 #include "../../plankassembly_amd/csrc/gemm.hip"
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
+#include <vector>
 int main(int argc, char** argv) {
     int M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]);
     int akc = argc > 4 ? atoi(argv[4]) : 1, bkc = argc > 5 ? atoi(argv[5]) : 1, sk = argc > 6 ? atoi(argv[6]) : 1;
@@ -15,6 +17,24 @@ int main(int argc, char** argv) {
     g.A = A; g.B = B; g.C = C; g.bias = sk > 1 ? nullptr : bias; g.ws = ws; g.M = M; g.N = N; g.K = K;
     g.lda = akc ? K : M; g.ldb = bkc ? K : N; g.ldc = N; g.batch = 1;
     g.a_kcontig = akc; g.b_kcontig = bkc; g.in_dtype = PA_BF16; g.out_dtype = sk > 1 ? PA_F32 : PA_BF16; g.alpha = 1.f; g.aux_scale = 1.f; g.splitk = sk;
+    // correctness spot check on small problems (random data, CPU reference)
+    if ((long long)M * N * K <= (1LL << 28) && akc && bkc && sk == 1) {
+        std::vector<uint16_t> ha((size_t)M * K), hb((size_t)N * K), hc((size_t)M * N);
+        uint32_t r = 12345u;
+        auto rnd = [&]() { r = r * 1664525u + 1013904223u; float f = ((r >> 9) & 0xffff) / 65536.0f - 0.5f; uint32_t u; memcpy(&u, &f, 4); return (uint16_t)(u >> 16); };
+        for (auto& x : ha) x = rnd();
+        for (auto& x : hb) x = rnd();
+        (void)hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice); (void)hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
+        int rc = pa_gemm(&g, 0); (void)hipDeviceSynchronize();
+        (void)hipMemcpy(hc.data(), C, hc.size() * 2, hipMemcpyDeviceToHost);
+        auto f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float x; memcpy(&x, &u, 4); return x; };
+        double maxerr = 0; int bad = 0;
+        for (int m = 0; m < M; m += (M > 256 ? 37 : 1)) for (int n = 0; n < N; n += (N > 256 ? 11 : 1)) {
+            double acc = 0; for (int k = 0; k < K; ++k) acc += (double)f(ha[(size_t)m * K + k]) * f(hb[(size_t)n * K + k]);
+            double e = fabs(acc - f(hc[(size_t)m * N + n])); if (e > maxerr) maxerr = e; if (e > 0.05 + 0.02 * fabs(acc)) ++bad;
+        }
+        printf("check rc %d max abs err %.4f bad %d\n", rc, maxerr, bad);
+    }
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0);
