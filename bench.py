@@ -103,10 +103,11 @@ def kernel_rooflines(B):
 
 
 def gemm_census(model, batch, train_step):
-    """Per-launch census of the GEMM kernel over ONE training step: the library records every pa_gemm() argument
-    block of the step (pa_gemm_record), then each recorded launch is replayed on the same buffers under HIP
-    events.  Returns {family: {launches, flops, seconds}} with family = operand layout (which selects the kernel
-    instantiation): 'tt' both operands k-contiguous (forward and dX Linears), 'nn' neither (dW, split-K), else 'mixed'."""
+    """Per-launch census of the GEMM kernels over ONE training step: the library records every pa_gemm() argument
+    block of the step and the kernel it dispatched to (pa_gemm_record), then each recorded launch is replayed on the
+    same buffers under HIP events.  Returns {family: {launches, flops, seconds}}; family = kernel + operand layout:
+    'ring' = gemm3_kernel (one block per CU, 4-stage LDS ring), 'pair' = gemm_kernel (two blocks per CU);
+    'tt' both operands k-contiguous (forward and dX Linears), 'nn' neither (dW, split-K, incl. its reduce pass)."""
     import ctypes as C
     from plankassembly_amd import _lib as L
     lib = L.lib()
@@ -116,7 +117,9 @@ def gemm_census(model, batch, train_step):
     torch.cuda.synchronize()
     n = lib.pa_gemm_record(0)
     rec = (L.GemmArgs * n)()
+    kinds = (C.c_int32 * n)()
     n = lib.pa_gemm_recorded(C.cast(rec, C.c_void_p), n)
+    nk = lib.pa_gemm_recorded_kinds(C.cast(kinds, C.c_void_p), n)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fam = {}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -131,7 +134,8 @@ def gemm_census(model, batch, train_step):
         ev[1].record()
         ev[1].synchronize()
         t = ev[0].elapsed_time(ev[1]) * 1e-3 / reps
-        key = "tt" if (a.a_kcontig and a.b_kcontig) else ("nn" if not (a.a_kcontig or a.b_kcontig) else "mixed")
+        lay = "tt" if (a.a_kcontig and a.b_kcontig) else ("nn" if not (a.a_kcontig or a.b_kcontig) else "mixed")
+        key = ("ring" if (i < nk and kinds[i] == 1) else "pair") + "_" + lay
         f = fam.setdefault(key, dict(launches=0, flops=0.0, seconds=0.0))
         f["launches"] += 1
         f["flops"] += 2.0 * a.M * a.N * a.K * a.batch
@@ -346,14 +350,18 @@ def main():
             "train_tflops_per_gpu": step_tflops, "train_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
             "decode": decode,
         }
-        if census and "tt" in census:
-            # dominant kernel of the step by time: gemm_kernel<bf16, BK=64, A/B k-contiguous> = every forward and dX Linear
-            c = census["tt"]
+        if census:
+            # dominant kernel of the step by time: gemm3_kernel<A_KC, B_KC> (k-contiguous operands) = the forward and dX
+            # Linears whose tile count fits one round of the 256 CUs
+            key = max(census, key=lambda k: census[k]["seconds"])
+            c = census[key]
+            names = {"ring_tt": "gemm3_kernel<true,true> (bf16, 128x128x64 tiles, one block per CU, 4-stage LDS ring)",
+                     "ring_nn": "gemm3_kernel<false,false> (bf16 dW, split-K, incl. splitk_reduce_kernel)",
+                     "pair_tt": "gemm_kernel<bf16,64,2,true,true,...> (two blocks per CU)"}
             ach = c["flops"] / c["seconds"] / 1e12
-            line["roofline"] = {"kernel": "gemm_kernel<bf16,BK=64,2 waves/SIMD,A_KC,B_KC,aligned,direct-to-LDS,NST=2> - all "
-                                          "forward + dX Linear launches of one train step (replayed per launch)",
+            line["roofline"] = {"kernel": names.get(key, key) + " - every launch of it in one train step, replayed under HIP events",
                                 "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_tt"),
+                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_" + key),
                                 "launches_per_step": c["launches"],
                                 "algorithmic_flops_per_launch": c["flops"] / c["launches"],
                                 "avg_launch_us": c["seconds"] / c["launches"] * 1e6}

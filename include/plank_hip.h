@@ -75,6 +75,12 @@ int pa_gemm(const pa_gemm_args* a, void* stream);
  * up to `cap` recorded blocks out and stops recording.  Replaying the blocks re-launches the same GEMMs. */
 int pa_gemm_record(int32_t enable);
 int pa_gemm_recorded(pa_gemm_args* out, int32_t cap);
+/* Kernel each recorded launch was dispatched to (valid until the next pa_gemm_record(1)):
+ * PA_GEMM_KIND_RING = gemm3_kernel (one block per CU, 4-stage LDS ring; single-round bf16 launches),
+ * PA_GEMM_KIND_PAIR = gemm_kernel (two blocks per CU; everything else). */
+#define PA_GEMM_KIND_PAIR 0
+#define PA_GEMM_KIND_RING 1
+int pa_gemm_recorded_kinds(int32_t* out, int32_t cap);
 
 /* Batched 2-D transposes dst[c][r] = src[r][c] (one launch for a table of matrices; descriptors live in device
  * memory, tile_begin = prefix sum of ceil(rows/64)*ceil(cols/64)).  Keeps the transposed shadow of the Linear

@@ -1193,9 +1193,11 @@ template <typename T> bool is_aligned(const pa_gemm_args* a) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     bool ok = al16(a->A) && al16(a->B) && (a->lda % EB == 0) && (a->ldb % EB == 0) &&
               (a->sA % EB == 0) && (a->sB % EB == 0);
-    // vectors run along K for k-contiguous operands, along the row index for transposed ones
-    ok = ok && (a->a_kcontig ? (a->K % EB == 0) : (a->M % EB == 0));
-    ok = ok && (a->b_kcontig ? (a->K % EB == 0) : (a->N % EB == 0));
+    // vectors run along K for k-contiguous operands, along the row index for transposed ones; a transposed operand
+    // whose last vector straddles M (N) is fine when the row stride covers it: the extra elements only feed output
+    // rows (columns) that are never stored
+    ok = ok && (a->a_kcontig ? (a->K % EB == 0) : (a->lda >= (a->M + EB - 1) / EB * EB));
+    ok = ok && (a->b_kcontig ? (a->K % EB == 0) : (a->ldb >= (a->N + EB - 1) / EB * EB));
     return ok;
 }
 
@@ -1205,11 +1207,16 @@ template <typename T> bool is_aligned(const pa_gemm_args* a) {
 // bench.py can replay exactly the launches of one training step under HIP events (per-launch roofline census).
 namespace {
 std::vector<pa_gemm_args>* g_rec = nullptr;
+std::vector<int32_t>* g_rec_kind = nullptr;      // kernel each recorded launch was dispatched to (PA_GEMM_KIND_*)
 std::mutex g_rec_mu;
 }
 extern "C" int pa_gemm_record(int32_t enable) {
     std::lock_guard<std::mutex> lk(g_rec_mu);
-    if (enable) { delete g_rec; g_rec = new std::vector<pa_gemm_args>(); return 0; }
+    if (enable) {
+        delete g_rec; g_rec = new std::vector<pa_gemm_args>();
+        delete g_rec_kind; g_rec_kind = new std::vector<int32_t>();
+        return 0;
+    }
     return g_rec ? (int)g_rec->size() : 0;
 }
 extern "C" int pa_gemm_recorded(pa_gemm_args* out, int32_t cap) {
@@ -1218,6 +1225,13 @@ extern "C" int pa_gemm_recorded(pa_gemm_args* out, int32_t cap) {
     const int n = (int)g_rec->size() < cap ? (int)g_rec->size() : cap;
     for (int i = 0; i < n; ++i) out[i] = (*g_rec)[i];
     delete g_rec; g_rec = nullptr;
+    return n;
+}
+extern "C" int pa_gemm_recorded_kinds(int32_t* out, int32_t cap) {
+    std::lock_guard<std::mutex> lk(g_rec_mu);
+    if (!g_rec_kind) return 0;
+    const int n = (int)g_rec_kind->size() < cap ? (int)g_rec_kind->size() : cap;
+    for (int i = 0; i < n; ++i) out[i] = (*g_rec_kind)[i];
     return n;
 }
 
@@ -1279,7 +1293,9 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     // v3 (one block per CU, 4-stage ring) wins while the launch is a single round of units (latency-bound shapes);
     // with more rounds the two-blocks-per-CU kernel overlaps better.  PA_GEMM_V3=2 forces v3 for every eligible launch.
     const int valid_units = p.tiles_m * p.tiles_n * a->batch * splitk;
-    if (use_v3 && (valid_units <= 256 || use_v3 == 2) && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds && is_aligned<bf16>(a) && v3_layout_ok) {
+    const bool go_v3 = use_v3 && (valid_units <= 256 || use_v3 == 2) && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds && is_aligned<bf16>(a) && v3_layout_ok;
+    if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR); }
+    if (go_v3) {
         const int g3 = pk.units < 256 ? pk.units : 256;
         if (a->a_kcontig && a->b_kcontig) PA_LAUNCH((gemm3_kernel<true, true>), dim3(g3), dim3(NT), 0, st, pk);
         else if (a->a_kcontig) PA_LAUNCH((gemm3_kernel<true, false>), dim3(g3), dim3(NT), 0, st, pk);

@@ -44,6 +44,38 @@ def test_gemm_layouts(dtype, akc, bkc, M, N, K):
     assert rel_err(out, ref) < tol(dtype), (rel_err(out, ref))
 
 
+# Long-K / multi-unit bf16 shapes: these exercise the ring kernel's steady-state ("hot") items, its stream across unit
+# boundaries (persistent blocks: 1000 x 2100 -> 8 x 17 tiles <= 256 blocks; 4100 x 4100 -> 33 x 33 tiles, several units per
+# block when forced) and the two-blocks-per-CU kernel on the multi-round shapes.
+@pytest.mark.parametrize("akc,bkc", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("M,N,K,sk", [(1000, 2100, 1024, 1), (520, 512, 2048, 4), (256, 384, 4096, 8), (4100, 1030, 640, 1)])
+def test_gemm_long_k_bf16(akc, bkc, M, N, K, sk):
+    a = rnd(M, K, dtype=torch.bfloat16, seed=11, scale=0.5)
+    b = rnd(N, K, dtype=torch.bfloat16, seed=12, scale=0.5)
+    ref = a.float() @ b.float().t()
+    ad = (a if akc else a.t().contiguous()).to(DEV)
+    bd = (b if bkc else b.t().contiguous()).to(DEV)
+    out = ops.gemm(ad, bd, a_kcontig=akc, b_kcontig=bkc, out_dtype=torch.float32, splitk=sk)
+    assert rel_err(out, ref) < 1e-2, rel_err(out, ref)
+
+
+def test_gemm_ring_epilogue_bf16():
+    """bias + dropout + residual / relu + gate on a one-round launch with a ragged last row tile (M = 7940 as in the packed encoder)."""
+    M, N, K = 7940, 512, 512
+    a, b = rnd(M, K, dtype=torch.bfloat16, seed=13, scale=0.3), rnd(N, K, dtype=torch.bfloat16, seed=14, scale=0.3)
+    bias, res = rnd(N, seed=15), rnd(M, N, dtype=torch.bfloat16, seed=16)
+    acc = a.float() @ b.float().t()
+    out = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=res.to(DEV))
+    assert rel_err(out, acc + bias + res.float()) < 2.5e-2
+    out = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), relu=True)
+    assert rel_err(out, torch.relu(acc + bias)) < 2.5e-2
+    # dropout is the same counter-based mask whichever kernel runs: compare with the 2-blocks-per-CU result on a sub-problem
+    o1 = ops.gemm(a[:200].to(DEV), b.to(DEV), bias=bias.to(DEV), drop_p=0.25, drop_seed=99, out_dtype=torch.float32)
+    keep = (o1 != 0).float().cpu()
+    assert abs(float(keep.mean()) - 0.75) < 0.01
+    assert rel_err(o1.cpu(), keep * (acc[:200] + bias) / 0.75) < 2.5e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(dtype):
     M, N, K = 300, 200, 128

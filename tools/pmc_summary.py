@@ -17,8 +17,10 @@ import re
 import sys
 
 KEYS = [  # json key -> regex on the demangled kernel name
-    ("gemm_tt", r"gemm_kernel<__bf16, 64, 2, true, true, true, true, false, 2>"),
-    ("gemm_nn_dw", r"gemm_kernel<__bf16, 64, 2, false, false, true, true, true, 2>"),
+    ("gemm_ring_tt", r"gemm3_kernel<true, true>"),
+    ("gemm_ring_nn", r"gemm3_kernel<false, false>"),
+    ("gemm_pair_tt", r"gemm_kernel<__bf16, 64, 2, true, true, true, true, false, 2>"),
+    ("gemm_pair_nn", r"gemm_kernel<__bf16, 64, 2, false, false, true, true, true, 2>"),
     ("attn_fwd", r"attn_fwd_bf16_kernel<64>"),
     ("attn_bwd_dq", r"attn_bwd_dq_bf16_kernel<64>"),
     ("attn_bwd_dkv", r"attn_bwd_dkv_bf16_kernel<64>"),
