@@ -284,8 +284,32 @@ def main():
                                          f"{v['flops'] / v['seconds'] / 1e12:.0f} TF" for k, v in census.items()))
     samples_s = args.steps * B * world / dt
     log(f"train: {samples_s:.1f} samples/s, {dt / args.steps * 1e3:.2f} ms/step, loss {loss:.4f}")
-    train_flops = 3.0 * fwd_flops_per_sample(S_IN, T_OUT) * B      # per GPU step
+    train_flops = 3.0 * fwd_flops_per_sample(S_IN, T_OUT) * B      # per GPU step, counted at the padded length (dense-equivalent)
     step_tflops = train_flops * args.steps / dt / 1e12
+    valid_rows = sum(bt["_pack"][2] for bt in batches) / len(batches) if model.unpad else B * S_IN
+
+    # secondary: the same step with the encoder left padded (what the reference computes row for row), rank 0, N=1 only
+    dense = None
+    if rank == 0 and world == 1 and not args.no_kernels and model.unpad:
+        model.unpad = False
+        dbatches = [{k: v for k, v in bt.items() if k != "_pack"} for bt in batches]
+        def dense_step(i):
+            opt.zero_grad()
+            o = model(dbatches[i % len(dbatches)])
+            o["loss"].backward()
+            opt.step()
+        for i in range(3):
+            dense_step(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(10):
+            dense_step(i)
+        torch.cuda.synchronize()
+        ddt = (time.perf_counter() - t1) / 10
+        dense = dict(value=B / ddt, unit="samples/s", ms_per_step=ddt * 1e3,
+                     note="encoder not packed: all B*S rows computed under the key-padding mask")
+        model.unpad = True
+        log(f"dense (padded encoder): {dense['value']:.1f} samples/s, {dense['ms_per_step']:.2f} ms/step")
 
     # ------------------------------------------------------------------ greedy decode
     decode = None
@@ -347,7 +371,11 @@ def main():
                                    f"S={S_IN} (MAX_INPUT_LENGTH {S_IN + 1}), T={T_OUT}, batch {B}/GPU",
                        "global_batch": B * world, "seq_len": S_IN, "parallelism": f"dp{world}"},
             "final_loss": loss,
-            "train_tflops_per_gpu": step_tflops, "train_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
+            "encoder_rows": {"padded": B * S_IN, "valid_avg": valid_rows,
+                             "note": "padded encoder rows are packed away before the first layer (results identical: "
+                                     "they never reach the loss); `dense_padded` is the same step without packing"},
+            "dense_padded": dense,
+            "train_dense_equiv_tflops_per_gpu": step_tflops, "train_dense_equiv_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
             "decode": decode,
         }
         if census:
