@@ -203,7 +203,7 @@ __device__ __forceinline__ void load_row_regs(u32x4* regs, const T* base, int ld
 
 // store a transposed-product accumulator (lane = row, registers = d) as rows of [row][d]
 template <typename T, int DH>
-__device__ __forceinline__ void store_rows(T* base, int ld, int row, int nrows, const f32x16* acc, float mul, int lane) {
+__device__ __forceinline__ void store_rows(T* base, int ld, int row, int nrows, const f32x16* acc, float mul, int lane, bool zero = false) {
     using A = AT<T, DH>;
     if (row >= nrows) return;
 #pragma unroll
@@ -214,7 +214,7 @@ __device__ __forceinline__ void store_rows(T* base, int ld, int row, int nrows, 
             if (d < DH) {
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = acc[dt][4 * g + e] * mul;
+                for (int e = 0; e < 4; ++e) o[e] = zero ? 0.f : acc[dt][4 * g + e] * mul;
                 st4<T>(base + (size_t)row * ld + d, o);
             }
         }
@@ -787,24 +787,34 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP pin) {
             for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
             mma_nat<bf16, DH>(sacc[kt], knat, kt * 32, qreg, lane);
         }
+        // Softmax arithmetic in the log2 domain on the RAW scores (the scale is folded into one FMA per element):
+        // m_run = running max of s * sl.  Masks are only evaluated on tiles that can contain a masked key (key-padding
+        // mask present, tail of the sequence, or the causal diagonal) - wave-uniform test.
+        const bool need_mask = (mp != nullptr) || (k0 + BSTR > p.Lk) || (p.causal && (k0 + BSTR - 1 > q0 + wave * 32));
         float mx = -INFINITY;
+        if (need_mask) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int koff = kt * 32 + 8 * g + 4 * half;
-                const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
+                for (int g = 0; g < 4; ++g) {
+                    const int koff = kt * 32 + 8 * g + 4 * half;
+                    const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = k0 + koff + e;
-                    float x = sacc[kt][4 * g + e] * sl;
-                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
-                    x = masked ? -INFINITY : x;
-                    sacc[kt][4 * g + e] = x;
-                    mx = fmaxf(mx, x);
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = k0 + koff + e;
+                        const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
+                        const float x = masked ? -INFINITY : sacc[kt][4 * g + e];
+                        sacc[kt][4 * g + e] = x;
+                        mx = fmaxf(mx, x);
+                    }
                 }
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(sacc[kt][r], sacc[kt][r + 1]));     // v_max3_f32
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl;
         if (__any(mx > m_run + RESCALE_THR)) {
             const float m_new = fmaxf(m_run, mx);
             const float ms = (m_new == -INFINITY) ? 0.f : m_new;
@@ -816,8 +826,9 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP pin) {
                 for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
             m_run = m_new;
         }
-        const float m_safe = (m_run == -INFINITY) ? 0.f : m_run;
+        const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
         float lsum = 0.f;
+        // dropout: survivors are NOT rescaled here - 1/(1-p) is folded into the final normalisation
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -826,9 +837,9 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP pin) {
                 if (p.drop_thr) hsh = drop_hash4(p.drop_seed, drow + ((k0 + kt * 32 + 8 * g + 4 * half) >> 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float pe = fast_exp2(sacc[kt][4 * g + e] - m_safe);
+                    float pe = fast_exp2(__builtin_fmaf(sacc[kt][4 * g + e], sl, nm));
                     lsum += pe;
-                    if (p.drop_thr) pe = drop_keep4(hsh, e, p.drop_thr) ? pe * p.drop_scale : 0.f;
+                    if (p.drop_thr) pe = drop_keep4(hsh, e, p.drop_thr) ? pe : 0.f;
                     sacc[kt][4 * g + e] = pe;
                 }
             }
@@ -838,7 +849,7 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP pin) {
         __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const float inv = l_tot > 0.f ? (p.drop_thr ? p.drop_scale : 1.0f) / l_tot : 0.f;
     bf16* Op = reinterpret_cast<bf16*>(p.o) + (size_t)qoff * p.ldo + h * DH;
     store_rows<bf16, DH>(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);
     if (half == 0 && qrow < p.Lq && p.lse)
@@ -871,7 +882,10 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP pin) {
     load_row_regs<bf16, DH>(doreg, dOp, p.lddo, qrow, p.Lq, lane);
     const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qrow;
     const float lse2 = (qrow < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
-    const float dlt = (qrow < p.Lq) ? p.delta[srow] : 0.f;
+    // dS = P o (drop(dP) - delta) * scale with drop(x) = keep ? x / (1-p) : 0  ==  P o (keep ? dP : 0 - delta * (1-p)) * scale / (1-p):
+    // the two constant factors move to the final store, delta is pre-multiplied once
+    const float keep_p = p.drop_thr ? 1.0f / p.drop_scale : 1.0f;
+    const float dlt = (qrow < p.Lq) ? p.delta[srow] * keep_p : 0.f;
     int nsteps = (p.Lk + BSTR - 1) / BSTR;
     if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
 
@@ -909,20 +923,26 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP pin) {
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
             mma_nat<bf16, DH>(sacc, knat, kt * 32, qreg, lane);
             mma_nat<bf16, DH>(dpacc, vnat, kt * 32, doreg, lane);
+            const bool need_mask = (mp != nullptr) || (k0 + BSTR > p.Lk) || (p.causal && (k0 + BSTR - 1 > q0 + wave * 32));
+            const float nl = -lse2;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int koff = kt * 32 + 8 * g + 4 * half;
-                const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
+                uint32_t m4 = 0;
+                if (need_mask) m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
                 uint32_t hsh = 0;
                 if (p.drop_thr) hsh = drop_hash4(p.drop_seed, drow + ((k0 + koff) >> 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int key = k0 + koff + e;
-                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
-                    const float pe = masked ? 0.f : fast_exp2(sacc[4 * g + e] * sl - lse2);
+                    float pe = fast_exp2(__builtin_fmaf(sacc[4 * g + e], sl, nl));
+                    if (need_mask) {
+                        const int key = k0 + koff + e;
+                        const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
+                        pe = masked ? 0.f : pe;
+                    }
                     float dp = dpacc[4 * g + e];
-                    if (p.drop_thr) dp = drop_keep4(hsh, e, p.drop_thr) ? dp * p.drop_scale : 0.f;
-                    sacc[4 * g + e] = pe * (dp - dlt) * p.scale;          // dS^T
+                    if (p.drop_thr) dp = drop_keep4(hsh, e, p.drop_thr) ? dp : 0.f;
+                    sacc[4 * g + e] = pe * (dp - dlt);                      // dS^T / (scale / (1-p))
                 }
             }
             mma_tr_nat<DH>(dqacc, knat, kt * 32, sacc, lane);            // dQ^T += K^T dS^T
@@ -930,7 +950,7 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP pin) {
         __syncthreads();
     }
     bf16* dQp = reinterpret_cast<bf16*>(p.dq) + (size_t)qoff * p.lddq + h * DH;
-    store_rows<bf16, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, 1.0f, lane);
+    store_rows<bf16, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, p.scale * (p.drop_thr ? p.drop_scale : 1.0f), lane);
 }
 
 template <int DH>
@@ -966,6 +986,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkacc[dt][r] = 0.f; dvacc[dt][r] = 0.f; }
     const float sl = p.scale * LOG2E;
+    const float keep_p = p.drop_thr ? 1.0f / p.drop_scale : 1.0f;
 
     auto issue = [&](int step, int buf) {
         char* base = smem + buf * BUF;
@@ -977,7 +998,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
             const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qr;
             float* aux = reinterpret_cast<float*>(base + 2 * B::NAT);
             aux[tid] = (qr < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;      // +inf -> p = 0 for rows past Lq
-            aux[64 + tid] = (qr < p.Lq) ? p.delta[srow] : 0.f;
+            aux[64 + tid] = (qr < p.Lq) ? p.delta[srow] * keep_p : 0.f;     // delta * (1-p), see the dQ kernel
         }
     };
     if (step0 < nsteps) issue(step0, 0);
@@ -996,6 +1017,9 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
             mma_nat<bf16, DH>(sacc, qnat, qt * 32, kreg, lane);        // S[q][key]
             mma_nat<bf16, DH>(dpacc, donat, qt * 32, vreg, lane);      // dP[q][key]
+            // A masked KEY (this lane's row) gets its accumulators zeroed at the end instead of per element; the causal
+            // test only runs on the q tiles that straddle the diagonal (wave-uniform).
+            const bool need_causal = p.causal && (key0 + wave * 32 + 31 > r0 + qt * 32);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int qoff = qt * 32 + 8 * g + 4 * half;
@@ -1004,18 +1028,18 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int qr = r0 + qoff + e;
-                    const bool masked = kmasked || (p.causal && krow > qr);
-                    float pe = masked ? 0.f : fast_exp2(sacc[4 * g + e] * sl - l4[e]);
+                    float pe = fast_exp2(__builtin_fmaf(sacc[4 * g + e], sl, -l4[e]));
+                    if (need_causal) pe = (krow > qr) ? 0.f : pe;
                     float dp = dpacc[4 * g + e];
                     float pd = pe;
                     if (p.drop_thr) {
                         const uint32_t idx4 = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qr) * p.nk4 + (krow >> 2));
                         const bool keep = drop_keep4(drop_hash4(p.drop_seed, idx4), krow & 3, p.drop_thr);
-                        dp = keep ? dp * p.drop_scale : 0.f;
-                        pd = keep ? pe * p.drop_scale : 0.f;
+                        dp = keep ? dp : 0.f;
+                        pd = keep ? pe : 0.f;
                     }
-                    sacc[4 * g + e] = pd;
-                    dpacc[4 * g + e] = pe * (dp - d4[e]) * p.scale;
+                    sacc[4 * g + e] = pd;                                  // P_drop * (1-p)
+                    dpacc[4 * g + e] = pe * (dp - d4[e]);                  // dS * (1-p) / scale
                 }
             }
             mma_tr_nat<DH>(dvacc, donat, qt * 32, sacc, lane);         // dV^T += dO^T P
@@ -1025,8 +1049,10 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
     }
     bf16* dKp = reinterpret_cast<bf16*>(p.dk) + (size_t)koff * p.lddk + h * DH;
     bf16* dVp = reinterpret_cast<bf16*>(p.dv) + (size_t)koff * p.lddv + h * DH;
-    store_rows<bf16, DH>(dKp, p.lddk, krow, p.Lk, dkacc, 1.0f, lane);
-    store_rows<bf16, DH>(dVp, p.lddv, krow, p.Lk, dvacc, 1.0f, lane);
+    const float ds = p.drop_thr ? p.drop_scale : 1.0f;
+    // masked key: select (not multiply) - its accumulators may hold inf/NaN from exponentials the softmax never saw
+    store_rows<bf16, DH>(dKp, p.lddk, krow, p.Lk, dkacc, kmasked ? 0.f : p.scale * ds, lane, kmasked);
+    store_rows<bf16, DH>(dVp, p.lddv, krow, p.Lk, dvacc, kmasked ? 0.f : ds, lane, kmasked);
 }
 
 // =====================================================================================================
