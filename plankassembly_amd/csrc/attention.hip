@@ -885,7 +885,22 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP pin) {
     // dS = P o (drop(dP) - delta) * scale with drop(x) = keep ? x / (1-p) : 0  ==  P o (keep ? dP : 0 - delta * (1-p)) * scale / (1-p):
     // the two constant factors move to the final store, delta is pre-multiplied once
     const float keep_p = p.drop_thr ? 1.0f / p.drop_scale : 1.0f;
-    const float dlt = (qrow < p.Lq) ? p.delta[srow] * keep_p : 0.f;
+    // delta[q] = sum_d dO[q][d] * O[q][d] is computed here (each half-wave lane holds half of the row) and published
+    // for the dK/dV kernel, which is launched after this one - no separate delta pass
+    float dsum = 0.f;
+    {
+        const bf16* Op = reinterpret_cast<const bf16*>(p.o) + (size_t)qoff * p.ldo + h * DH;
+        u32x4 oreg[A::NS];
+        load_row_regs<bf16, DH>(oreg, Op, p.ldo, qrow, p.Lq, lane);
+#pragma unroll
+        for (int s_ = 0; s_ < A::NS; ++s_)
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                dsum += bf16_lo(oreg[s_][w]) * bf16_lo(doreg[s_][w]) + bf16_hi(oreg[s_][w]) * bf16_hi(doreg[s_][w]);
+        dsum += __shfl_xor(dsum, 32);
+        if (half == 0 && qrow < p.Lq) p.delta[srow] = dsum;
+    }
+    const float dlt = (qrow < p.Lq) ? dsum * keep_p : 0.f;
     int nsteps = (p.Lk + BSTR - 1) / BSTR;
     if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
 
@@ -1087,12 +1102,10 @@ template <int DH> int run_fwd_bf16(const AttnP& p, hipStream_t st) {
     return 0;
 }
 template <int DH> int run_bwd_bf16(const AttnP& p, hipStream_t st) {
-    const int64_t total = (int64_t)p.B * p.H * p.Lq;
-    PA_LAUNCH((attn_delta_kernel<bf16, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
-    int shm = 2 * (2 * BT<DH>::NAT + 2 * 64 * 4);
+    int shm = 2 * (2 * BT<DH>::NAT + 64);
+    PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH>), dim3(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B), dim3(NTH), shm, st, p);   // also writes delta
+    shm = 2 * (2 * BT<DH>::NAT + 2 * 64 * 4);
     PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH>), dim3(((p.Lk + BOWN - 1) / BOWN) * p.H * p.B), dim3(NTH), shm, st, p);
-    shm = 2 * (2 * BT<DH>::NAT + 64);
-    PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH>), dim3(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B), dim3(NTH), shm, st, p);
     return 0;
 }
 
