@@ -68,8 +68,11 @@ typedef struct {
     float aux_scale;
     float drop_p; uint32_t drop_seed;
     int32_t splitk;
+    int32_t splitk_defer;   /* 1: only write the f32 slabs to `ws`; the caller reduces them later (pa_splitk_reduce_many) */
 } pa_gemm_args;
 int pa_gemm(const pa_gemm_args* a, void* stream);
+/* Slices pa_gemm really uses for a requested `splitk` (= number of slabs it writes; <= splitk). */
+int pa_gemm_effective_splitk(int32_t K, int32_t in_dtype, int32_t splitk);
 /* Measurement hook (bench.py's roofline census; no reference counterpart): pa_gemm_record(1) starts appending every
  * pa_gemm() argument block to a host-side list; pa_gemm_record(0) returns the count so far; pa_gemm_recorded() copies
  * up to `cap` recorded blocks out and stops recording.  Replaying the blocks re-launches the same GEMMs. */
@@ -81,6 +84,17 @@ int pa_gemm_recorded(pa_gemm_args* out, int32_t cap);
 #define PA_GEMM_KIND_PAIR 0
 #define PA_GEMM_KIND_RING 1
 int pa_gemm_recorded_kinds(int32_t* out, int32_t cap);
+
+/* Deferred split-K reduction for plain f32 outputs (weight gradients): out[m][n] = sum_s ws[s][m][n], one launch for
+ * up to PA_MAX_REDUCE launches of pa_gemm(splitk_defer = 1).  The backward pass queues every dW of a segment and
+ * reduces them together (13 launches per step instead of 69).  No reference counterpart (torch accumulates dW
+ * inside its GEMM). */
+#define PA_MAX_REDUCE 16
+typedef struct {
+    const float* ws; float* out;
+    int32_t rows, cols, ld_out, splitk;
+} pa_reduce_desc;
+int pa_splitk_reduce_many(const pa_reduce_desc* descs, int32_t n_desc, void* stream);
 
 /* Batched 2-D transposes dst[c][r] = src[r][c] (one launch for a table of matrices; descriptors live in device
  * memory, tile_begin = prefix sum of ceil(rows/64)*ceil(cols/64)).  Keeps the transposed shadow of the Linear

@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
                 ("batch", C.c_int32), ("a_kcontig", C.c_int32), ("b_kcontig", C.c_int32),
                 ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("alpha", C.c_float), ("relu", C.c_int32),
                 ("aux_scale", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
-                ("splitk", C.c_int32)]
+                ("splitk", C.c_int32), ("splitk_defer", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -79,9 +79,11 @@ def lib():
         sig = {
             "pa_version": (I, []),
             "pa_gemm": (I, [P, P]),
+            "pa_gemm_effective_splitk": (I, [I, I, I]),
             "pa_gemm_record": (I, [I]),
             "pa_gemm_recorded": (I, [P, I]),
             "pa_gemm_recorded_kinds": (I, [P, I]),
+            "pa_splitk_reduce_many": (I, [P, I, P]),
             "pa_colsum_ws_floats": (I64, [I, I]),
             "pa_colsum": (I, [P, I, I, I, I, P, I, P, P]),
             "pa_embed_input_fwd": (I, [P, I, P, P, P, I, I64, I, P]),

@@ -1235,6 +1235,18 @@ extern "C" int pa_gemm_recorded_kinds(int32_t* out, int32_t cap) {
     return n;
 }
 
+// number of NON-EMPTY contraction slices pa_gemm uses for a requested split (slices are whole K tiles of 64 bf16 / 16 f32
+// elements; rounding the slice length up can leave trailing slices empty - those must not exist, their slabs would
+// never be written)
+extern "C" int pa_gemm_effective_splitk(int32_t K, int32_t in_dtype, int32_t splitk) {
+    const int BK = in_dtype == PA_BF16 ? 64 : 16;
+    const int nt = (K + BK - 1) / BK;
+    int sk = splitk > 1 ? splitk : 1;
+    if (sk > nt) sk = nt;
+    const int per = (nt + sk - 1) / sk;
+    return (nt + per - 1) / per;
+}
+
 extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return PA_EINVAL;
     if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec) g_rec->push_back(*a); }
@@ -1260,6 +1272,7 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     const int nt = (a->K + BK - 1) / BK;
     int splitk = a->splitk > 1 ? a->splitk : 1;
     if (splitk > nt) splitk = nt;
+    splitk = (nt + (nt + splitk - 1) / splitk - 1) / ((nt + splitk - 1) / splitk);   // drop slices that would be empty (pa_gemm_effective_splitk)
     if (splitk > 1 && !a->ws) return PA_EINVAL;
     p.splitk = splitk;
     p.tiles_per_slice = (nt + splitk - 1) / splitk;
@@ -1310,6 +1323,11 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         rc = launch_layout<float, 16, 2>(pk, a->a_kcontig, a->b_kcontig, is_aligned<float>(a), glds, grid, st);
     }
     if (rc) return rc;
+    if (splitk > 1 && a->splitk_defer) {
+        // the caller reduces the slabs later: only plain f32 outputs qualify (no epilogue would be applied)
+        if (a->out_dtype != PA_F32 || a->bias || a->R || a->aux || a->relu || a->drop_p > 0.f || a->alpha != 1.f || a->batch != 1) return PA_EINVAL;
+        return 0;
+    }
     if (splitk > 1) {
         size_t total = (size_t)a->batch * a->M * a->N;
         int blocks = (int)((total + 255) / 256);
@@ -1319,6 +1337,48 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         else
             PA_LAUNCH(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, p, (const float*)a->ws);
     }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// deferred split-K reduction of several plain f32 outputs in one launch (include/plank_hip.h)
+namespace {
+struct ReduceTab { pa_reduce_desc d[PA_MAX_REDUCE]; int begin[PA_MAX_REDUCE + 1]; int n; };
+__global__ __launch_bounds__(256) void splitk_reduce_many_kernel(ReduceTab t) {
+    // block -> descriptor (few entries: linear scan), then 1024 consecutive floats of its output
+    int di = 0;
+    while (di + 1 < t.n && (int)blockIdx.x >= t.begin[di + 1]) ++di;
+    const pa_reduce_desc d = t.d[di];
+    const size_t total = (size_t)d.rows * d.cols;
+    const size_t e0 = ((size_t)(blockIdx.x - t.begin[di]) * 256 + threadIdx.x) * 4;
+    if (e0 >= total) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if ((d.cols & 3) == 0) {
+#pragma unroll 4
+        for (int s = 0; s < d.splitk; ++s) acc += *reinterpret_cast<const f32x4*>(d.ws + (size_t)s * total + e0);
+        const size_t m = e0 / d.cols, n = e0 - m * d.cols;
+        *reinterpret_cast<f32x4*>(d.out + m * d.ld_out + n) = acc;
+    } else {
+        for (int j = 0; j < 4 && e0 + j < total; ++j) {
+            float v = 0.f;
+            for (int s = 0; s < d.splitk; ++s) v += d.ws[(size_t)s * total + e0 + j];
+            const size_t m = (e0 + j) / d.cols, n = (e0 + j) - m * d.cols;
+            d.out[m * d.ld_out + n] = v;
+        }
+    }
+}
+}  // namespace
+extern "C" int pa_splitk_reduce_many(const pa_reduce_desc* descs, int32_t n_desc, void* stream) {
+    if (!descs || n_desc <= 0 || n_desc > PA_MAX_REDUCE) return PA_EINVAL;
+    ReduceTab t; t.n = n_desc; t.begin[0] = 0;
+    for (int i = 0; i < n_desc; ++i) {
+        const pa_reduce_desc& d = descs[i];
+        if (!d.ws || !d.out || d.rows <= 0 || d.cols <= 0 || d.splitk < 1 || d.ld_out < d.cols) return PA_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(d.ws) & 15) || (reinterpret_cast<uintptr_t>(d.out) & 15) || ((d.cols & 3) == 0 && (d.ld_out & 3))) return PA_EALIGN;
+        t.d[i] = d;
+        t.begin[i + 1] = t.begin[i] + (int)(((size_t)d.rows * d.cols + 1023) / 1024);
+    }
+    PA_LAUNCH(splitk_reduce_many_kernel, dim3(t.begin[n_desc]), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), t);
     return 0;
 }
 

@@ -65,7 +65,17 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
             if (sk > nkt / 4) sk = nkt / 4 > 0 ? nkt / 4 : 1;
             while (sk > 1 && (size_t)sk * N * K > m->splitws_floats) --sk;
         }
+        sk = pa_gemm_effective_splitk(M, dt(), sk);             // slabs actually written
         g.splitk = sk; g.ws = m->splitws;
+        // queue the reduction: all weight gradients of a segment are reduced by one launch at its end (flush_reduce)
+        const size_t need = (size_t)sk * N * K;
+        if (sk > 1 && m->ndefer < PA_MAX_REDUCE && m->slab_used + need <= m->splitws_floats && (K & 3) == 0) {
+            g.ws = m->splitws + m->slab_used;
+            g.splitk_defer = 1;
+            pa_reduce_desc& rd = m->defer[m->ndefer++];
+            rd.ws = m->splitws + m->slab_used; rd.out = dW; rd.rows = N; rd.cols = K; rd.ld_out = K; rd.splitk = sk;
+            m->slab_used += (need + 3) / 4 * 4;
+        }
         RC(pa_gemm(&g, st));
         if (db) RC(pa_colsum(dY, dt(), M, N, lddy, db, 1, m->partial, st));   // gradients are zero-initialised by the caller
         return 0;
@@ -140,8 +150,11 @@ size_t pa_train_layout(pa_model* m, char* base, int B, int S, int T) {
     const size_t cs = (size_t)pa_colsum_ws_floats((int)R, (int)(wide > (size_t)m->ldv ? wide : m->ldv));
     if (cs > part) part = cs;
     m->partial = (float*)a.take(part * 4);
+    // split-K slabs of every weight gradient of one backward segment (they are reduced together at its end):
+    // a decoder layer is the largest segment (self in/out, cross in/out, two FFN weights), <= 16 slices each
     const size_t wmax = (3 * d * d > d * ff ? 3 * d * d : d * ff);
-    m->splitws_floats = 16 * wmax;
+    const size_t wlayer = 8 * d * d + 2 * d * ff + (size_t)m->ldv * d;
+    m->splitws_floats = 16 * (wlayer > wmax ? wlayer : wmax);
     m->splitws = (float*)a.take(m->splitws_floats * 4);
     return a.off;
 }
@@ -357,7 +370,17 @@ int bwd_enc_layer(pa_model* m, int i, void* st) {
     return 0;
 }
 
+int backward_segment_body(pa_model* m, int seg, float gscale, void* st);
 int backward_segment(pa_model* m, int seg, float gscale, void* st) {
+    m->ndefer = 0; m->slab_used = 0;
+    RC(backward_segment_body(m, seg, gscale, st));
+    if (m->ndefer > 0) {                                   // one reduction launch for the segment's weight gradients
+        RC(pa_splitk_reduce_many(m->defer, m->ndefer, st));
+        m->ndefer = 0; m->slab_used = 0;
+    }
+    return 0;
+}
+int backward_segment_body(pa_model* m, int seg, float gscale, void* st) {
     const pa_model_cfg& c = m->cfg;
     Ctx k{m, st};
     const int d = c.d_model, B = m->B, T = m->T, BS = m->NE;

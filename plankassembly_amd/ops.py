@@ -19,7 +19,7 @@ def _f32(*shape, device):
 
 
 def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, residual=None, aux=None, aux_scale=1.0,
-         relu=False, alpha=1.0, drop_p=0.0, drop_seed=0, out_dtype=None, splitk=1, out=None):
+         relu=False, alpha=1.0, drop_p=0.0, drop_seed=0, out_dtype=None, splitk=1, out=None, defer=False):
     """C[b] = epi(alpha * A[b] @ B[b]).  a: [batch?, M, K] (or [K, M] if not a_kcontig);
     b: [batch?, N, K] if b_kcontig (Linear weight layout) else [K, N]."""
     batched = a.dim() == 3
@@ -53,13 +53,32 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, residual=None, aux=
     g.in_dtype, g.out_dtype = L.dt(a), L.dt(out)
     g.alpha, g.relu, g.aux_scale = alpha, int(relu), aux_scale
     g.drop_p, g.drop_seed = drop_p, drop_seed
+    splitk = int(L.lib().pa_gemm_effective_splitk(K, L.dt(a), splitk))       # slabs actually written
     g.splitk = splitk
     ws = None
     if splitk > 1:
         ws = _f32(splitk * batch * M * N, device=a.device)
         g.ws = ws.data_ptr()
+        g.splitk_defer = int(defer)
     L.check(L.lib().pa_gemm(C.byref(g), L.stream()), "pa_gemm")
+    if defer and splitk > 1:
+        return out, ws, splitk  # slabs only: reduce with splitk_reduce_many([(ws, out, splitk), ...])
     return out
+
+
+class ReduceDesc(C.Structure):          # mirrors pa_reduce_desc
+    _fields_ = [("ws", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("ld_out", C.c_int32), ("splitk", C.c_int32)]
+
+
+def splitk_reduce_many(items):
+    """items: [(ws, out[rows, cols] f32, splitk)]: out = sum of the splitk slabs in ws, one launch for all items."""
+    n = len(items)
+    descs = (ReduceDesc * n)()
+    for i, (ws, out, sk) in enumerate(items):
+        descs[i].ws, descs[i].out = ws.data_ptr(), out.data_ptr()
+        descs[i].rows, descs[i].cols, descs[i].ld_out, descs[i].splitk = out.shape[0], out.shape[1], out.stride(0), sk
+    L.check(L.lib().pa_splitk_reduce_many(C.cast(descs, C.c_void_p), n, L.stream()), "pa_splitk_reduce_many")
 
 
 def colsum(x, out=None, accumulate=False):

@@ -59,6 +59,22 @@ def test_gemm_long_k_bf16(akc, bkc, M, N, K, sk):
     assert rel_err(out, ref) < 1e-2, rel_err(out, ref)
 
 
+def test_gemm_deferred_splitk_reduce():
+    """Weight-gradient path: several split-K GEMMs write only their f32 slabs, one launch reduces all of them.
+    (K = 1000 with 5 requested slices is the case where rounding leaves the last slice empty: 16 K tiles -> 4 slices.)"""
+    items, refs = [], []
+    for i, (M, N, K, sk) in enumerate([(512, 512, 2048, 8), (1536, 512, 1000, 5), (514, 512, 2048, 8), (64, 36, 300, 3)]):
+        a = rnd(K, M, dtype=torch.bfloat16, seed=20 + i, scale=0.5)          # dY [rows, M] (contraction strided)
+        b = rnd(K, N, dtype=torch.bfloat16, seed=30 + i, scale=0.5)          # X  [rows, N]
+        out, ws, sk = ops.gemm(a.to(DEV), b.to(DEV), a_kcontig=False, b_kcontig=False, out_dtype=torch.float32, splitk=sk, defer=True)
+        out.fill_(float("nan"))                                               # the GEMM itself must not have produced the output
+        items.append((ws, out, sk))
+        refs.append(a.float().t() @ b.float())
+    ops.splitk_reduce_many(items)
+    for (ws, out, sk), ref in zip(items, refs):
+        assert rel_err(out, ref) < 1e-2
+
+
 def test_gemm_ring_epilogue_bf16():
     """bias + dropout + residual / relu + gate on a one-round launch with a ragged last row tile (M = 7940 as in the packed encoder)."""
     M, N, K = 7940, 512, 512
