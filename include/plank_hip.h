@@ -85,6 +85,16 @@ int pa_gemm_recorded(pa_gemm_args* out, int32_t cap);
 #define PA_GEMM_KIND_RING 1
 int pa_gemm_recorded_kinds(int32_t* out, int32_t cap);
 
+/* Column sums of several matrices in one launch: out[n] += sum_m X[m][n] (f32 atomics; outputs are accumulated
+ * into).  The backward pass queues the bias gradients of a segment (dY buffers stay live until its end) and sums
+ * them together.  Rows must be 16-byte aligned vectors (PA_EALIGN otherwise - use pa_colsum). */
+#define PA_MAX_COLSUM 8
+typedef struct {
+    const void* X; float* out;
+    int32_t M, N, ldx, pad_;
+} pa_colsum_desc;
+int pa_colsum_many(const pa_colsum_desc* descs, int32_t n_desc, int32_t dtype, void* stream);
+
 /* Deferred split-K reduction for plain f32 outputs (weight gradients): out[m][n] = sum_s ws[s][m][n], one launch for
  * up to PA_MAX_REDUCE launches of pa_gemm(splitk_defer = 1).  The backward pass queues every dW of a segment and
  * reduces them together (13 launches per step instead of 69).  No reference counterpart (torch accumulates dW

@@ -84,6 +84,7 @@ def lib():
             "pa_gemm_recorded": (I, [P, I]),
             "pa_gemm_recorded_kinds": (I, [P, I]),
             "pa_splitk_reduce_many": (I, [P, I, P]),
+            "pa_colsum_many": (I, [P, I, I, P]),
             "pa_colsum_ws_floats": (I64, [I, I]),
             "pa_colsum": (I, [P, I, I, I, I, P, I, P, P]),
             "pa_embed_input_fwd": (I, [P, I, P, P, P, I, I64, I, P]),

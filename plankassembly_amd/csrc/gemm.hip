@@ -1389,12 +1389,12 @@ namespace {
 constexpr int CS_ROWS = 128;
 // out[n] += sum over this block's rows (f32 atomics: one per column per 128-row block)
 template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, int ldx, float* out) {
+__device__ __forceinline__ void colsum_block(const T* X, int M, int N, int ldx, float* out, int bx, int by) {
     constexpr int EB = ET<T>::EB;
     __shared__ float red[4][64 * EB];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int n0 = (blockIdx.x * 64 + cl) * EB;
-    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    const int n0 = (bx * 64 + cl) * EB;
+    const int r0 = by * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
     float acc[EB];
 #pragma unroll
     for (int e = 0; e < EB; ++e) acc[e] = 0.f;
@@ -1415,11 +1415,45 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, i
     for (int e = 0; e < EB; ++e) red[rl][cl * EB + e] = acc[e];
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * EB; i += 256) {
-        const int n = blockIdx.x * 64 * EB + i;
+        const int n = bx * 64 * EB + i;
         if (n < N) unsafeAtomicAdd(out + n, (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]));
     }
 }
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, int ldx, float* out) {
+    colsum_block<T, VEC>(X, M, N, ldx, out, blockIdx.x, blockIdx.y);
+}
+// several matrices in one launch: block -> (descriptor, column block, row block)
+struct ColsumTab { pa_colsum_desc d[PA_MAX_COLSUM]; int begin[PA_MAX_COLSUM + 1]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_many_kernel(ColsumTab t) {
+    constexpr int EB = ET<T>::EB;
+    int di = 0;
+    while (di + 1 < t.n && (int)blockIdx.x >= t.begin[di + 1]) ++di;
+    const pa_colsum_desc d = t.d[di];
+    const int nbx = (d.N + 64 * EB - 1) / (64 * EB);
+    const int rel = blockIdx.x - t.begin[di];
+    colsum_block<T, true>(reinterpret_cast<const T*>(d.X), d.M, d.N, d.ldx, d.out, rel % nbx, rel / nbx);
+}
 }  // namespace
+extern "C" int pa_colsum_many(const pa_colsum_desc* descs, int32_t n_desc, int32_t dtype, void* stream) {
+    if (!descs || n_desc <= 0 || n_desc > PA_MAX_COLSUM) return PA_EINVAL;
+    const int EB = dtype == PA_BF16 ? 8 : 4;
+    ColsumTab t; t.n = n_desc; t.begin[0] = 0;
+    for (int i = 0; i < n_desc; ++i) {
+        const pa_colsum_desc& d = descs[i];
+        if (!d.X || !d.out || d.M <= 0 || d.N <= 0) return PA_EINVAL;
+        // vector path only: 16-byte aligned rows whose allocation covers the last vector
+        if ((reinterpret_cast<uintptr_t>(d.X) & 15) || d.ldx % EB || d.ldx < (d.N + EB - 1) / EB * EB) return PA_EALIGN;
+        t.d[i] = d;
+        t.begin[i + 1] = t.begin[i] + ((d.N + 64 * EB - 1) / (64 * EB)) * ((d.M + CS_ROWS - 1) / CS_ROWS);
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == PA_BF16) PA_LAUNCH(colsum_many_kernel<bf16>, dim3(t.begin[n_desc]), dim3(256), 0, st, t);
+    else if (dtype == PA_F32) PA_LAUNCH(colsum_many_kernel<float>, dim3(t.begin[n_desc]), dim3(256), 0, st, t);
+    else return PA_EINVAL;
+    return 0;
+}
 
 // -------------------------------------------------------------------------------------------------
 // batched 2-D transposes (bf16/f32): dst[c][r] = src[r][c] for a table of matrices, one launch.  Used to keep a

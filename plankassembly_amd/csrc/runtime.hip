@@ -77,7 +77,17 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
             m->slab_used += (need + 3) / 4 * 4;
         }
         RC(pa_gemm(&g, st));
-        if (db) RC(pa_colsum(dY, dt(), M, N, lddy, db, 1, m->partial, st));   // gradients are zero-initialised by the caller
+        if (db) {   // gradients are zero-initialised by the caller: accumulate
+            const int EB = dt() == PA_BF16 ? 8 : 4;
+            const bool vec = (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && lddy % EB == 0 && lddy >= (N + EB - 1) / EB * EB;
+            if (m->defer_ok && vec && m->ncs < PA_MAX_COLSUM) {
+                // inside a layer segment every dY buffer is written once: sum all its bias gradients in one launch at the end
+                pa_colsum_desc& cd = m->cs[m->ncs++];
+                cd.X = dY; cd.out = db; cd.M = M; cd.N = N; cd.ldx = lddy; cd.pad_ = 0;
+            } else {
+                RC(pa_colsum(dY, dt(), M, N, lddy, db, 1, m->partial, st));
+            }
+        }
         return 0;
     }
     int ln_fwd(void* y, const void* z, const float* g, const float* b, float* mean, float* rstd, int64_t rows, float eps) const {
@@ -372,8 +382,11 @@ int bwd_enc_layer(pa_model* m, int i, void* st) {
 
 int backward_segment_body(pa_model* m, int seg, float gscale, void* st);
 int backward_segment(pa_model* m, int seg, float gscale, void* st) {
-    m->ndefer = 0; m->slab_used = 0;
+    m->ndefer = 0; m->slab_used = 0; m->ncs = 0;
+    m->defer_ok = seg >= 1 && seg != m->cfg.n_dec + 1 && seg != m->cfg.n_dec + 2;     // layer segments (not the heads: they reuse buffers)
     RC(backward_segment_body(m, seg, gscale, st));
+    m->defer_ok = false;
+    if (m->ncs > 0) { RC(pa_colsum_many(m->cs, m->ncs, m->cfg.dtype, st)); m->ncs = 0; }
     if (m->ndefer > 0) {                                   // one reduction launch for the segment's weight gradients
         RC(pa_splitk_reduce_many(m->defer, m->ndefer, st));
         m->ndefer = 0; m->slab_used = 0;

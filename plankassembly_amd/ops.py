@@ -66,6 +66,21 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, residual=None, aux=
     return out
 
 
+class ColsumDesc(C.Structure):          # mirrors pa_colsum_desc
+    _fields_ = [("X", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("ldx", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
+def colsum_many(items):
+    """items: [(x[M, N], out[N] f32)]: out += column sums of x, one launch for all items."""
+    n = len(items)
+    descs = (ColsumDesc * n)()
+    for i, (x, out) in enumerate(items):
+        descs[i].X, descs[i].out = x.data_ptr(), out.data_ptr()
+        descs[i].M, descs[i].N, descs[i].ldx = x.shape[0], x.shape[1], x.stride(0)
+    L.check(L.lib().pa_colsum_many(C.cast(descs, C.c_void_p), n, L.dt(items[0][0]), L.stream()), "pa_colsum_many")
+
+
 class ReduceDesc(C.Structure):          # mirrors pa_reduce_desc
     _fields_ = [("ws", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("ld_out", C.c_int32), ("splitk", C.c_int32)]

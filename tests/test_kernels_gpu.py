@@ -59,6 +59,17 @@ def test_gemm_long_k_bf16(akc, bkc, M, N, K, sk):
     assert rel_err(out, ref) < 1e-2, rel_err(out, ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_colsum_many(dtype):
+    shapes = [(7940, 1536), (2048, 512), (300, 1024), (129, 520)]
+    xs = [rnd(M, N, dtype=dtype, seed=40 + i) for i, (M, N) in enumerate(shapes)]
+    outs = [torch.full((N,), 1.5, device=DEV) for _, N in shapes]            # accumulated into
+    ops.colsum_many([(x.to(DEV), o) for x, o in zip(xs, outs)])
+    for x, o in zip(xs, outs):
+        ref = x.float().sum(0) + 1.5
+        assert float((o.cpu() - ref).abs().max()) < (1e-3 if dtype == torch.float32 else 1e-2) * (1 + float(ref.abs().max()))
+
+
 def test_gemm_deferred_splitk_reduce():
     """Weight-gradient path: several split-K GEMMs write only their f32 slabs, one launch reduces all of them.
     (K = 1000 with 5 requested slices is the case where rounding leaves the last slice empty: 16 K tiles -> 4 slices.)"""
