@@ -85,6 +85,12 @@ int pa_gemm_recorded(pa_gemm_args* out, int32_t cap);
 #define PA_GEMM_KIND_RING 1
 int pa_gemm_recorded_kinds(int32_t* out, int32_t cap);
 
+/* Several weight-gradient GEMMs (dW = dY^T X: bf16 operands, contraction index strided in both, f32 output, no
+ * epilogue, batch 1; splitk > 1 only with splitk_defer) in one launch of the ring kernel: its unit stream runs through
+ * all members.  PA_EINVAL when a member does not qualify - the caller then launches them one by one with pa_gemm. */
+#define PA_MAX_GROUP 8
+int pa_gemm_group(const pa_gemm_args* args, int32_t n, void* stream);
+
 /* Column sums of several matrices in one launch: out[n] += sum_m X[m][n] (f32 atomics; outputs are accumulated
  * into).  The backward pass queues the bias gradients of a segment (dY buffers stay live until its end) and sums
  * them together.  Rows must be 16-byte aligned vectors (PA_EALIGN otherwise - use pa_colsum). */

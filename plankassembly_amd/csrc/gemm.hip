@@ -41,6 +41,7 @@ struct GemmP {
     int splitk, tiles_per_slice;   // split-K: C is the f32 slab workspace, plain store
     int tiles_m, tiles_n, tiles_m_pad, units;   // tiles_m_pad == tiles_m: plain row-major unit order (no XCD interleave)
     int vec_ok;                    // epilogue may use 4-element vector accesses on C / R / aux / bias
+    int plain_order;               // units enumerate (tile_m, tile_n) row-major instead of the XCD interleave
     int dbg;                       // ablation bits (PA_GEMM_DBG): 1 no MFMA, 2 no ds_read, 4 no loads, 8 no epilogue
 };
 
@@ -90,7 +91,7 @@ __device__ __forceinline__ bool decode_unit(const GemmP& p, int u, Unit& un) {
     const int per_z = p.tiles_m_pad * p.tiles_n;
     un.z = u / per_z;
     const int r = u - un.z * per_z;
-    if (p.tiles_m_pad == p.tiles_m && (p.tiles_m & 7)) {          // small problem: plain order, every unit valid
+    if (p.plain_order) {                                           // small / grouped problem: plain order, every unit valid
         un.tile_m = r / p.tiles_n;
         un.tile_n = r - un.tile_m * p.tiles_n;
     } else {
@@ -710,6 +711,13 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
     }
 }
 
+constexpr int PA_MAX_GROUP_ = 8;
+struct GemmGroup { GemmP p[PA_MAX_GROUP_]; int begin[PA_MAX_GROUP_ + 1]; int n; };
+__device__ __forceinline__ const GemmP& first_problem(const GemmP& p) { return p; }
+__device__ __forceinline__ const GemmP& first_problem(const GemmGroup& g) { return g.p[0]; }
+__device__ __forceinline__ int total_units_of(const GemmP& p) { return p.units; }
+__device__ __forceinline__ int total_units_of(const GemmGroup& g) { return g.begin[g.n]; }
+
 // -------------------------------------------------------------------------------------------------
 // v3 (bf16, both operands DMA'd): ONE block per CU (4 waves, one per SIMD, up to 512 VGPRs each), a 4-stage LDS
 // ring of K tiles and a K loop that is software-pipelined at k-step granularity, so the three per-CU engines run
@@ -722,8 +730,14 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
 // Synchronisation per item: barrier A (stage of the previous item is free -> its DMA may be overwritten) and
 // barrier B (counted s_waitcnt vmcnt: the next item has landed for every wave).  The epilogue uses a per-wave
 // staging slice outside the ring (no block barrier) and straight-line code (no waits between stores).
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
+// PT = GemmP (one problem) or GemmGroup (several problems in one launch: the unit stream runs through all of them; used
+// for the weight gradients of a backward segment).  pd / pc = problem the DMA cursor / the compute cursor is in.
+template <bool A_KC, bool B_KC, typename PT>
+__global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
+    constexpr bool GROUP = std::is_same<PT, GemmGroup>::value;
+    GemmP pd = first_problem(prm), pc = first_problem(prm);
+    int pd_i = 0, pc_i = 0;                                   // GROUP: index of pd / pc in the table
+    const int total_units = total_units_of(prm);
     using T = bf16;
     using TL = Tile<bf16, 64>;
     constexpr int NSTG = 4, STAGE = 2 * TL::TILE_BYTES, EPI = 8192;   // EPI: 32 rows x 64 f32 per wave
@@ -748,8 +762,8 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
     bool okA[TL::NLD], okB[TL::NLD];
     const char* baseA = nullptr; const char* baseB = nullptr;
     auto setup = [&](const Unit& un) {
-        baseA = reinterpret_cast<const char*>(p.A) + (size_t)un.b * p.sA * esz;
-        baseB = reinterpret_cast<const char*>(p.B) + (size_t)un.b * p.sB * esz;
+        baseA = reinterpret_cast<const char*>(pd.A) + (size_t)un.b * pd.sA * esz;
+        baseB = reinterpret_cast<const char*>(pd.B) + (size_t)un.b * pd.sB * esz;
         const int m0 = un.tile_m * BM, n0 = un.tile_n * BN;
 #pragma unroll
         for (int i = 0; i < TL::NLD; ++i) {
@@ -757,27 +771,26 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
             if constexpr (A_KC) {
                 const int row = pidx / TL::NCH, ch = ((pidx % TL::NCH) ^ (row / TL::RPB)) & (TL::NCH - 1);
                 okA[i] = true;
-                offA[i] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)(p.lda * esz) + ch * 16;
+                offA[i] = (uint32_t)min(m0 + row, pd.M - 1) * (uint32_t)(pd.lda * esz) + ch * 16;
             } else {
                 const int row = pidx >> 4, col = m0 + (((pidx & 15) ^ ((row & 3) << 2)) << 3);
-                okA[i] = col < p.M;
-                offA[i] = (uint32_t)row * (uint32_t)(p.lda * esz) + (uint32_t)col * esz;
+                okA[i] = col < pd.M;
+                offA[i] = (uint32_t)row * (uint32_t)(pd.lda * esz) + (uint32_t)col * esz;
             }
             if constexpr (B_KC) {
                 const int row = pidx / TL::NCH, ch = ((pidx % TL::NCH) ^ (row / TL::RPB)) & (TL::NCH - 1);
                 okB[i] = true;
-                offB[i] = (uint32_t)min(n0 + row, p.N - 1) * (uint32_t)(p.ldb * esz) + ch * 16;
+                offB[i] = (uint32_t)min(n0 + row, pd.N - 1) * (uint32_t)(pd.ldb * esz) + ch * 16;
             } else {
                 const int row = pidx >> 4, col = n0 + (((pidx & 15) ^ ((row & 3) << 2)) << 3);
-                okB[i] = col < p.N;
-                offB[i] = (uint32_t)row * (uint32_t)(p.ldb * esz) + (uint32_t)col * esz;
+                okB[i] = col < pd.N;
+                offB[i] = (uint32_t)row * (uint32_t)(pd.ldb * esz) + (uint32_t)col * esz;
             }
         }
     };
     // kA / kB: wave-uniform start of the DMA cursor's current K tile (advanced by one tile per item); k_dma: its first k
     const char* kA = nullptr; const char* kB = nullptr; int k_dma = 0;
-    const size_t stepA = A_KC ? (size_t)TL::BK * esz : (size_t)TL::BK * p.lda * esz;
-    const size_t stepB = B_KC ? (size_t)TL::BK * esz : (size_t)TL::BK * p.ldb * esz;
+    size_t stepA = 0, stepB = 0;               // bytes per K tile along the DMA source (set per unit in dma_enter)
     // one quarter of an item's DMA: Q = 0, 1 -> A chunks {0,1}, {2,3}; Q = 2, 3 -> B chunks {0,1}, {2,3}
     auto fetch_q = [&](int stage, auto Q_) {
         constexpr int Q = decltype(Q_)::value;
@@ -789,13 +802,13 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
             if constexpr (Q < 2) {
                 if constexpr (A_KC) src = kA + offA[i];
                 else {
-                    const bool in = okA[i] && (k_dma + ((tid + i * NT) >> 4)) < p.K;
+                    const bool in = okA[i] && (k_dma + ((tid + i * NT) >> 4)) < pd.K;
                     src = in ? kA + offA[i] : reinterpret_cast<const char*>(pa_zero16);
                 }
             } else {
                 if constexpr (B_KC) src = kB + offB[i];
                 else {
-                    const bool in = okB[i] && (k_dma + ((tid + i * NT) >> 4)) < p.K;
+                    const bool in = okB[i] && (k_dma + ((tid + i * NT) >> 4)) < pd.K;
                     src = in ? kB + offB[i] : reinterpret_cast<const char*>(pa_zero16);
                 }
             }
@@ -869,7 +882,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
 #define PA_MFMA(ACC, X, Y) mma16B<T>(ACC, X, Y)
 
 #ifdef PA_GEMM_ABLATE      // timing ablations (wrong results): PA_GEMM_DBG bits 1 no MFMA, 2 no LDS reads, 4 no DMA, 8 no barriers
-    const bool dbg_nomma = p.dbg & 1, dbg_nord = p.dbg & 2, dbg_nodma = p.dbg & 4, dbg_nobar = p.dbg & 8;
+    const bool dbg_nomma = pc.dbg & 1, dbg_nord = pc.dbg & 2, dbg_nodma = pc.dbg & 4, dbg_nobar = pc.dbg & 8;
 #define MMA1(ACC, X, Y) do { if (!dbg_nomma) PA_MFMA(ACC, X, Y); } while (0)
 #define RD1(F, st, S, W) do { if (!dbg_nord) rd1(F, st, S, W); } while (0)
 #define FRAG(F, st, S) do { if (!dbg_nord) frag(F, st, S); } while (0)
@@ -900,21 +913,21 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
     // ---- epilogue ------------------------------------------------------------------------------------------------
     auto epilogue = [&](const Unit& un) {
         char* stage = smem + NSTG * STAGE + wave * EPI;
-        const bool slab = p.splitk > 1;
-        const size_t cbase = slab ? (size_t)un.z * p.M * p.ldc : (size_t)un.b * p.sC;
+        const bool slab = pc.splitk > 1;
+        const size_t cbase = slab ? (size_t)un.z * pc.M * pc.ldc : (size_t)un.b * pc.sC;
         const int mw = un.tile_m * BM + wm * 64, nw = un.tile_n * BN + wn * 64;
         const int chunk = lane & 15, rsub = lane >> 4;
         const int n = nw + chunk * 4;
-        const bool out_f32 = slab || p.out_dtype == PA_F32;
-        const bool has_bias = !slab && p.bias != nullptr, has_aux = !slab && p.aux != nullptr;
-        const bool has_res = !slab && p.R != nullptr, has_drop = !slab && p.drop_thr != 0;
-        const bool fast = p.vec_ok && (nw + 64 <= p.N);                   // wave-uniform
-        const float alpha = slab ? 1.f : p.alpha;
+        const bool out_f32 = slab || pc.out_dtype == PA_F32;
+        const bool has_bias = !slab && pc.bias != nullptr, has_aux = !slab && pc.aux != nullptr;
+        const bool has_res = !slab && pc.R != nullptr, has_drop = !slab && pc.drop_thr != 0;
+        const bool fast = pc.vec_ok && (nw + 64 <= pc.N);                   // wave-uniform
+        const float alpha = slab ? 1.f : pc.alpha;
         constexpr int NIT = 8;
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
         if (has_bias) {
-            if (fast) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
-            else { for (int e = 0; e < 4; ++e) if (n + e < p.N) bias[e] = p.bias[n + e]; }
+            if (fast) bias = *reinterpret_cast<const f32x4*>(pc.bias + n);
+            else { for (int e = 0; e < 4; ++e) if (n + e < pc.N) bias[e] = pc.bias[n + e]; }
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {          // pass = tm: output rows mw + 32*pass .. +31
@@ -941,16 +954,16 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
                 if (has_res) {
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
-                        const size_t ro = (size_t)un.b * p.sR + (size_t)min(mp + it * 4, p.M - 1) * p.ldr + n;
-                        res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(p.R) + ro)
-                                          : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+                        const size_t ro = (size_t)un.b * pc.sR + (size_t)min(mp + it * 4, pc.M - 1) * pc.ldr + n;
+                        res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(pc.R) + ro)
+                                          : ld4<bf16>(reinterpret_cast<const bf16*>(pc.R) + ro);
                     }
                 }
                 if (has_aux) {
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
-                        const size_t ao = (size_t)un.b * p.sAux + (size_t)min(mp + it * 4, p.M - 1) * p.ldaux + n;
-                        gate[it] = ld4<T>(reinterpret_cast<const T*>(p.aux) + ao);
+                        const size_t ao = (size_t)un.b * pc.sAux + (size_t)min(mp + it * 4, pc.M - 1) * pc.ldaux + n;
+                        gate[it] = ld4<T>(reinterpret_cast<const T*>(pc.aux) + ao);
                     }
                 }
                 if (!slab) {
@@ -959,11 +972,11 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float y = x[it][e] * alpha + bias[e];
-                            if (p.relu) y = fmaxf(y, 0.f);
-                            if (has_aux) y = gate[it][e] > 0.f ? y * p.aux_scale : 0.f;
+                            if (pc.relu) y = fmaxf(y, 0.f);
+                            if (has_aux) y = gate[it][e] > 0.f ? y * pc.aux_scale : 0.f;
                             if (has_drop) {
-                                const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + mp + it * 4) * p.N + n + e);
-                                y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
+                                const uint32_t idx = (uint32_t)(((size_t)un.b * pc.M + mp + it * 4) * pc.N + n + e);
+                                y = drop_keep(pc.drop_seed, idx, pc.drop_thr) ? y * pc.drop_scale : 0.f;
                             }
                             if (has_res) y += res[it][e];
                             x[it][e] = y;
@@ -973,10 +986,10 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int m = mp + it * 4;
-                    if (m < p.M) {
-                        const size_t co = cbase + (size_t)m * p.ldc + n;
-                        if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = x[it];
-                        else st4<bf16>(reinterpret_cast<bf16*>(p.C) + co, x[it]);
+                    if (m < pc.M) {
+                        const size_t co = cbase + (size_t)m * pc.ldc + n;
+                        if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(pc.C) + co) = x[it];
+                        else st4<bf16>(reinterpret_cast<bf16*>(pc.C) + co, x[it]);
                     }
                 }
             } else {
@@ -984,29 +997,29 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
 #pragma unroll 1
                 for (int it = 0; it < NIT; ++it) {
                     const int m = mp + it * 4;
-                    if (m >= p.M) continue;
+                    if (m >= pc.M) continue;
                     for (int e = 0; e < 4; ++e) {
-                        if (n + e >= p.N) continue;
+                        if (n + e >= pc.N) continue;
                         float y = x[it][e];
                         if (!slab) {
                             y = y * alpha + bias[e];
-                            if (p.relu) y = fmaxf(y, 0.f);
+                            if (pc.relu) y = fmaxf(y, 0.f);
                             if (has_aux) {
-                                const float g = ld1(reinterpret_cast<const T*>(p.aux) + (size_t)un.b * p.sAux + (size_t)m * p.ldaux + n + e);
-                                y = g > 0.f ? y * p.aux_scale : 0.f;
+                                const float g = ld1(reinterpret_cast<const T*>(pc.aux) + (size_t)un.b * pc.sAux + (size_t)m * pc.ldaux + n + e);
+                                y = g > 0.f ? y * pc.aux_scale : 0.f;
                             }
                             if (has_drop) {
-                                const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + m) * p.N + n + e);
-                                y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
+                                const uint32_t idx = (uint32_t)(((size_t)un.b * pc.M + m) * pc.N + n + e);
+                                y = drop_keep(pc.drop_seed, idx, pc.drop_thr) ? y * pc.drop_scale : 0.f;
                             }
                             if (has_res) {
-                                const size_t ro = (size_t)un.b * p.sR + (size_t)m * p.ldr + n + e;
-                                y += out_f32 ? reinterpret_cast<const float*>(p.R)[ro] : (float)reinterpret_cast<const bf16*>(p.R)[ro];
+                                const size_t ro = (size_t)un.b * pc.sR + (size_t)m * pc.ldr + n + e;
+                                y += out_f32 ? reinterpret_cast<const float*>(pc.R)[ro] : (float)reinterpret_cast<const bf16*>(pc.R)[ro];
                             }
                         }
-                        const size_t co = cbase + (size_t)m * p.ldc + n + e;
-                        if (out_f32) reinterpret_cast<float*>(p.C)[co] = y;
-                        else reinterpret_cast<bf16*>(p.C)[co] = (bf16)y;
+                        const size_t co = cbase + (size_t)m * pc.ldc + n + e;
+                        if (out_f32) reinterpret_cast<float*>(pc.C)[co] = y;
+                        else reinterpret_cast<bf16*>(pc.C)[co] = (bf16)y;
                     }
                 }
             }
@@ -1024,31 +1037,43 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
     // cursor.  Per item each only bumps a tile counter; units are decoded (integer divisions, address set-up) once
     // per unit and cursor, off the common path.
     const int ustride = gridDim.x;
-    auto seek = [&](int u, Unit& un) -> int {
-        bool ok = decode_unit<TL>(p, u, un);
-        while (u < p.units && !ok) { u += ustride; ok = decode_unit<TL>(p, u, un); }
+    // first valid unit >= u; GROUP: px / pi follow the unit into its problem (units only ever move forward)
+    auto seek = [&](int u, Unit& un, GemmP& px, int& pi) -> int {
+        while (u < total_units) {
+            int local = u;
+            if constexpr (GROUP) {
+                bool moved = false;
+                while (u >= prm.begin[pi + 1]) { ++pi; moved = true; }
+                if (moved) px = prm.p[pi];
+                local = u - prm.begin[pi];
+            }
+            if (decode_unit<TL>(px, local, un)) break;
+            u += ustride;
+        }
         return u;
     };
     int cd_u, cd_t = 0, cd_end = 0;             // DMA cursor: unit, next tile, end tile
     int cc_u, cc_t = 0, cc_end = 0;             // compute cursor
     auto dma_enter = [&](int u) {               // position the DMA cursor at the first valid unit >= u
         Unit un;
-        cd_u = seek(u, un);
-        if (cd_u < p.units) {
+        cd_u = seek(u, un, pd, pd_i);
+        if (cd_u < total_units) {
             setup(un);
             cd_t = un.t_begin; cd_end = un.t_end;
             k_dma = un.t_begin * TL::BK;
-            kA = baseA + (A_KC ? (size_t)k_dma * esz : (size_t)k_dma * p.lda * esz);
-            kB = baseB + (B_KC ? (size_t)k_dma * esz : (size_t)k_dma * p.ldb * esz);
+            stepA = A_KC ? (size_t)TL::BK * esz : (size_t)TL::BK * pd.lda * esz;
+            stepB = B_KC ? (size_t)TL::BK * esz : (size_t)TL::BK * pd.ldb * esz;
+            kA = baseA + (A_KC ? (size_t)k_dma * esz : (size_t)k_dma * pd.lda * esz);
+            kB = baseB + (B_KC ? (size_t)k_dma * esz : (size_t)k_dma * pd.ldb * esz);
         }
     };
     Unit cun;                                   // unit of the compute cursor (for its epilogue)
     auto cmp_enter = [&](int u) {
-        cc_u = seek(u, cun);
+        cc_u = seek(u, cun, pc, pc_i);
         cc_t = cun.t_begin; cc_end = cun.t_end;
     };
     cmp_enter(blockIdx.x);
-    if (cc_u >= p.units) return;
+    if (cc_u >= total_units) return;
     dma_enter(blockIdx.x);
     int pending = 0;                            // items issued and not yet finished by the MFMAs
     auto issue = [&]() {
@@ -1064,7 +1089,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 #pragma unroll 1
-    for (int k = 0; k < 3; ++k) if (cd_u < p.units) issue();
+    for (int k = 0; k < 3; ++k) if (cd_u < total_units) issue();
     wait_items(pending - 1);
     __builtin_amdgcn_s_barrier();
     int sc = 0;
@@ -1082,7 +1107,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(GemmP p) {
         // barrier A: every wave has finished the previous item, so its stage may be refilled (HOT: the DMA of the item
         // three ahead is spread over the four k-steps; otherwise it is issued here in one go)
         BAR();
-        if constexpr (!HOT) { if (cd_u < p.units) issue(); }
+        if constexpr (!HOT) { if (cd_u < total_units) issue(); }
         step(F0, F1, st, S1{}, std::true_type{}, QA{});
         step(F1, F0, st, S2{}, std::true_type{}, QB{});
         step(F0, F1, st, S3{}, std::true_type{}, QC{});
@@ -1278,7 +1303,8 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     p.tiles_per_slice = (nt + splitk - 1) / splitk;
     p.tiles_m = (a->M + BM - 1) / BM;
     p.tiles_n = (a->N + BN - 1) / BN;
-    p.tiles_m_pad = p.tiles_m < 8 ? p.tiles_m : (p.tiles_m + 7) / 8 * 8;   // < 8 row tiles: the XCD interleave would leave most units empty
+    p.plain_order = p.tiles_m < 8;                                        // < 8 row tiles: the XCD interleave would leave most units empty
+    p.tiles_m_pad = p.plain_order ? p.tiles_m : (p.tiles_m + 7) / 8 * 8;
     p.units = p.tiles_m_pad * p.tiles_n * a->batch * splitk;
     GemmP pk = p;
     if (splitk > 1) { pk.C = a->ws; pk.ldc = a->N; }
@@ -1310,10 +1336,10 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR); }
     if (go_v3) {
         const int g3 = pk.units < 256 ? pk.units : 256;
-        if (a->a_kcontig && a->b_kcontig) PA_LAUNCH((gemm3_kernel<true, true>), dim3(g3), dim3(NT), 0, st, pk);
-        else if (a->a_kcontig) PA_LAUNCH((gemm3_kernel<true, false>), dim3(g3), dim3(NT), 0, st, pk);
-        else if (a->b_kcontig) PA_LAUNCH((gemm3_kernel<false, true>), dim3(g3), dim3(NT), 0, st, pk);
-        else PA_LAUNCH((gemm3_kernel<false, false>), dim3(g3), dim3(NT), 0, st, pk);
+        if (a->a_kcontig && a->b_kcontig) PA_LAUNCH((gemm3_kernel<true, true, GemmP>), dim3(g3), dim3(NT), 0, st, pk);
+        else if (a->a_kcontig) PA_LAUNCH((gemm3_kernel<true, false, GemmP>), dim3(g3), dim3(NT), 0, st, pk);
+        else if (a->b_kcontig) PA_LAUNCH((gemm3_kernel<false, true, GemmP>), dim3(g3), dim3(NT), 0, st, pk);
+        else PA_LAUNCH((gemm3_kernel<false, false, GemmP>), dim3(g3), dim3(NT), 0, st, pk);
         rc = 0;
     } else
     if (a->in_dtype == PA_BF16) {
@@ -1337,6 +1363,48 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         else
             PA_LAUNCH(splitk_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, p, (const float*)a->ws);
     }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Several weight-gradient GEMMs in ONE launch of the ring kernel (include/plank_hip.h: pa_gemm_group).  Every member
+// must be: bf16 operands with the contraction index strided in both (dY^T X), f32 output, no epilogue beyond the
+// split-K slab store (splitk > 1 requires splitk_defer), batch 1, 16-byte aligned.  Anything else: PA_EINVAL and the
+// caller launches the members one by one.
+extern "C" int pa_gemm_group(const pa_gemm_args* args, int32_t n, void* stream) {
+    if (!args || n <= 0 || n > PA_MAX_GROUP) return PA_EINVAL;
+    static_assert(PA_MAX_GROUP == PA_MAX_GROUP_, "header / kernel table size");
+    GemmGroup g; g.n = n; g.begin[0] = 0;
+    int valid = 0;
+    for (int i = 0; i < n; ++i) {
+        const pa_gemm_args* a = &args[i];
+        if (!a->A || !a->B || !a->C || a->M <= 0 || a->N <= 0 || a->K <= 0) return PA_EINVAL;
+        if (a->in_dtype != PA_BF16 || a->out_dtype != PA_F32 || a->a_kcontig || a->b_kcontig || a->batch != 1) return PA_EINVAL;
+        if (a->bias || a->R || a->aux || a->relu || a->drop_p > 0.f || a->alpha != 1.f) return PA_EINVAL;
+        if (!is_aligned<bf16>(a)) return PA_EINVAL;
+        const int nt = (a->K + 63) / 64;
+        int splitk = a->splitk > 1 ? a->splitk : 1;
+        if (splitk > nt) splitk = nt;
+        splitk = (nt + (nt + splitk - 1) / splitk - 1) / ((nt + splitk - 1) / splitk);
+        if (splitk > 1 && (!a->ws || !a->splitk_defer)) return PA_EINVAL;
+        GemmP& p = g.p[i];
+        p = GemmP{};
+        p.A = a->A; p.B = a->B; p.M = a->M; p.N = a->N; p.K = a->K;
+        p.lda = a->lda; p.ldb = a->ldb; p.batch = 1;
+        p.alpha = 1.f; p.aux_scale = 1.f; p.drop_scale = 1.f; p.out_dtype = PA_F32;
+        p.splitk = splitk; p.tiles_per_slice = (nt + splitk - 1) / splitk;
+        p.tiles_m = (a->M + BM - 1) / BM; p.tiles_n = (a->N + BN - 1) / BN;
+        p.tiles_m_pad = p.tiles_m; p.plain_order = 1;                    // plain unit order: every unit valid
+        p.units = p.tiles_m * p.tiles_n * splitk;
+        if (splitk > 1) { p.C = a->ws; p.ldc = a->N; }
+        else { p.C = a->C; p.ldc = a->ldc; }
+        p.vec_ok = ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 3) == 0) ? 1 : 0;
+        g.begin[i + 1] = g.begin[i] + p.units;
+        valid += p.units;
+        if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec) { g_rec->push_back(*a); if (g_rec_kind) g_rec_kind->push_back(PA_GEMM_KIND_RING); } }
+    }
+    const int grid = valid < 256 ? valid : 256;
+    PA_LAUNCH((gemm3_kernel<false, false, GemmGroup>), dim3(grid), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), g);
     return 0;
 }
 

@@ -76,7 +76,11 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
             rd.ws = m->splitws + m->slab_used; rd.out = dW; rd.rows = N; rd.cols = K; rd.ld_out = K; rd.splitk = sk;
             m->slab_used += (need + 3) / 4 * 4;
         }
-        RC(pa_gemm(&g, st));
+        if (m->defer_ok && g.splitk_defer == (sk > 1 ? 1 : 0) && m->ndwq < PA_MAX_GROUP) {
+            m->dwq[m->ndwq++] = g;                               // launched with the segment's other weight gradients (flush)
+        } else {
+            RC(pa_gemm(&g, st));
+        }
         if (db) {   // gradients are zero-initialised by the caller: accumulate
             const int EB = dt() == PA_BF16 ? 8 : 4;
             const bool vec = (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && lddy % EB == 0 && lddy >= (N + EB - 1) / EB * EB;
@@ -151,6 +155,10 @@ size_t pa_train_layout(pa_model* m, char* base, int B, int S, int T) {
     m->plog = (float*)a.take(BT * T * 4); m->sw = (float*)a.take(BT * 4); m->row_lse = (float*)a.take(BT * 2 * 4);
     // backward temporaries
     m->gA = a.take(R * d * e); m->gB = a.take(R * d * e); m->gC = a.take(R * d * e); m->gD = a.take(R * d * e);
+    // per-site copies of the LayerNorm-backward outputs (dz, dropped dz): the weight-gradient GEMMs that read them are
+    // queued and run together at the end of the layer's backward segment, so a later site must not overwrite them
+    m->gBs[0] = m->gB; m->gCs[0] = m->gC;
+    for (int s_ = 1; s_ < 3; ++s_) { m->gBs[s_] = a.take(R * d * e); m->gCs[s_] = a.take(R * d * e); }
     m->gE = a.take(R * d * e); m->gF = a.take(R * ff * e); m->gQ3 = a.take(R * 3 * d * e);
     m->gKV = a.take(BS * 2 * d * e); m->dmem = a.take(BS * d * e);
     m->dvlog = a.take(BT * m->ldv * e); m->dplog = a.take(BT * T * e); m->dsw = (float*)a.take(BT * 4);
@@ -294,18 +302,19 @@ int bwd_heads(pa_model* m, float gscale, void* st) {
 // FFN block backward shared by encoder/decoder layers.  In: gA = d(layer output).  Out: gA = d(FFN input y).
 int bwd_ffn(pa_model* m, Ctx& k, int rows, const void* z, const float* mean, const float* rstd, const void* hff,
             const void* yin, int w1, int w2, int nw, uint32_t seed_inner, uint32_t seed_out) {
+    void* const gB = m->gBs[0]; void* const gC = m->gCs[0];
     const pa_model_cfg& c = m->cfg;
     const int d = c.d_model, ff = c.d_ff;
     const float p = m->p_drop;
     auto G = [&](int i) { return (float*)m->gr[i]; };
     (void)seed_inner;
-    void* ddrop = p > 0.f ? m->gC : m->gB;
-    RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, z, (const float*)m->pf[nw], mean, rstd, G(nw), G(nw + 1),
+    void* ddrop = p > 0.f ? gC : gB;
+    RC(k.ln_bwd(gB, p > 0.f ? gC : nullptr, m->gA, z, (const float*)m->pf[nw], mean, rstd, G(nw), G(nw + 1),
                 G(w2 + 1), rows, p, seed_out));
     RC(k.linear_dw(ddrop, d, hff, ff, G(w2), nullptr, rows, d, ff));
     RC(k.linear_dx(ddrop, d, m->pl[w2], ff, m->gF, ff, rows, d, ff, nullptr, 0, hff, ff, 1.0f / (1.0f - p), m->plT[w2], d));
     RC(k.linear_dw(m->gF, ff, yin, d, G(w1), G(w1 + 1), rows, ff, d));
-    RC(k.linear_dx(m->gF, ff, m->pl[w1], d, m->gA, d, rows, ff, d, m->gB, d, nullptr, 0, 1.f, m->plT[w1], ff));
+    RC(k.linear_dx(m->gF, ff, m->pl[w1], d, m->gA, d, rows, ff, d, gB, d, nullptr, 0, 1.f, m->plT[w1], ff));
     return 0;
 }
 
@@ -325,8 +334,9 @@ int bwd_dec_layer(pa_model* m, int i, void* st) {
     RC(bwd_ffn(m, k, BT, t.z3, t.m3, t.r3, t.hff, t.y2, pb + D_L1_W, pb + D_L2_W, pb + D_N3_W,
                site_seed(m->seed, sb + 4), site_seed(m->seed, sb + 5)));
     // cross attention block: z2 = y1 + drop(out_proj(attn(q(y1), kv(memory))))
-    void* ddrop = p > 0.f ? m->gC : m->gB;
-    RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, t.z2, (const float*)m->pf[pb + D_N2_W], t.m2, t.r2, G(pb + D_N2_W),
+    void* gB = m->gBs[1]; void* gC = m->gCs[1];
+    void* ddrop = p > 0.f ? gC : gB;
+    RC(k.ln_bwd(gB, p > 0.f ? gC : nullptr, m->gA, t.z2, (const float*)m->pf[pb + D_N2_W], t.m2, t.r2, G(pb + D_N2_W),
                 G(pb + D_N2_B), G(pb + D_CA_OUT_B), BT, p, site_seed(m->seed, sb + 3)));
     RC(k.linear_dw(ddrop, d, t.o_ca, d, G(pb + D_CA_OUT_W), nullptr, BT, d, d));
     RC(k.linear_dx(ddrop, d, m->pl[pb + D_CA_OUT_W], d, m->gD, d, BT, d, d, nullptr, 0, nullptr, 0, 1.f, m->plT[pb + D_CA_OUT_W], d));
@@ -341,9 +351,10 @@ int bwd_dec_layer(pa_model* m, int i, void* st) {
                        m->dmem_written ? m->dmem : nullptr, d, nullptr, 0, 1.f, wt ? (const char*)wt + (size_t)d * e : nullptr, 3 * d));
     }
     m->dmem_written = true;
-    RC(k.linear_dx(m->gE, d, m->pl[pb + D_CA_IN_W], d, m->gA, d, BT, d, d, m->gB, d, nullptr, 0, 1.f, m->plT[pb + D_CA_IN_W], 3 * d));
+    RC(k.linear_dx(m->gE, d, m->pl[pb + D_CA_IN_W], d, m->gA, d, BT, d, d, gB, d, nullptr, 0, 1.f, m->plT[pb + D_CA_IN_W], 3 * d));
     // self attention block: z1 = Y[i] + drop(out_proj(attn(qkv(Y[i]))))
-    RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, t.z1, (const float*)m->pf[pb + D_N1_W], t.m1, t.r1, G(pb + D_N1_W),
+    gB = m->gBs[2]; gC = m->gCs[2]; ddrop = p > 0.f ? gC : gB;
+    RC(k.ln_bwd(gB, p > 0.f ? gC : nullptr, m->gA, t.z1, (const float*)m->pf[pb + D_N1_W], t.m1, t.r1, G(pb + D_N1_W),
                 G(pb + D_N1_B), G(pb + D_SA_OUT_B), BT, p, site_seed(m->seed, sb + 1)));
     RC(k.linear_dw(ddrop, d, t.o_sa, d, G(pb + D_SA_OUT_W), nullptr, BT, d, d));
     RC(k.linear_dx(ddrop, d, m->pl[pb + D_SA_OUT_W], d, m->gD, d, BT, d, d, nullptr, 0, nullptr, 0, 1.f, m->plT[pb + D_SA_OUT_W], d));
@@ -351,7 +362,7 @@ int bwd_dec_layer(pa_model* m, int i, void* st) {
               m->batch.output_mask, T, T, 1, p, site_seed(m->seed, sb + 0), m->gD, m->gQ3, 3 * d,
               (char*)m->gQ3 + d * e, (char*)m->gQ3 + 2 * d * e, 3 * d));
     RC(k.linear_dw(m->gQ3, 3 * d, m->Y[i], d, G(pb + D_SA_IN_W), G(pb + D_SA_IN_B), BT, 3 * d, d));
-    RC(k.linear_dx(m->gQ3, 3 * d, m->pl[pb + D_SA_IN_W], d, m->gA, d, BT, 3 * d, d, m->gB, d, nullptr, 0, 1.f, m->plT[pb + D_SA_IN_W], 3 * d));
+    RC(k.linear_dx(m->gQ3, 3 * d, m->pl[pb + D_SA_IN_W], d, m->gA, d, BT, 3 * d, d, gB, d, nullptr, 0, 1.f, m->plT[pb + D_SA_IN_W], 3 * d));
     return 0;
 }
 
@@ -368,24 +379,31 @@ int bwd_enc_layer(pa_model* m, int i, void* st) {
     auto G = [&](int j) { return (float*)m->gr[j]; };
     RC(bwd_ffn(m, k, BS, t.z2, t.m2, t.r2, t.hff, t.y1, pb + E_L1_W, pb + E_L2_W, pb + E_N2_W,
                site_seed(m->seed, 8 * i + 2), site_seed(m->seed, 8 * i + 3)));
-    void* ddrop = p > 0.f ? m->gC : m->gB;
-    RC(k.ln_bwd(m->gB, p > 0.f ? m->gC : nullptr, m->gA, t.z1, (const float*)m->pf[pb + E_N1_W], t.m1, t.r1, G(pb + E_N1_W),
+    void* const gB = m->gBs[2]; void* const gC = m->gCs[2];
+    void* ddrop = p > 0.f ? gC : gB;
+    RC(k.ln_bwd(gB, p > 0.f ? gC : nullptr, m->gA, t.z1, (const float*)m->pf[pb + E_N1_W], t.m1, t.r1, G(pb + E_N1_W),
                 G(pb + E_N1_B), G(pb + E_OUT_B), BS, p, site_seed(m->seed, 8 * i + 1)));
     RC(k.linear_dw(ddrop, d, t.o, d, G(pb + E_OUT_W), nullptr, BS, d, d));
     RC(k.linear_dx(ddrop, d, m->pl[pb + E_OUT_W], d, m->gD, d, BS, d, d, nullptr, 0, nullptr, 0, 1.f, m->plT[pb + E_OUT_W], d));
     RC(k.attn(true, t.qkv, 3 * d, (char*)t.qkv + d * e, (char*)t.qkv + 2 * d * e, 3 * d, t.o, t.lse, in_mask, S, S, 0,
               p, site_seed(m->seed, 8 * i + 0), m->gD, m->gQ3, 3 * d, (char*)m->gQ3 + d * e, (char*)m->gQ3 + 2 * d * e, 3 * d, cu, cu));
     RC(k.linear_dw(m->gQ3, 3 * d, m->X[i], d, G(pb + E_IN_W), G(pb + E_IN_B), BS, 3 * d, d));
-    RC(k.linear_dx(m->gQ3, 3 * d, m->pl[pb + E_IN_W], d, m->gA, d, BS, 3 * d, d, m->gB, d, nullptr, 0, 1.f, m->plT[pb + E_IN_W], 3 * d));
+    RC(k.linear_dx(m->gQ3, 3 * d, m->pl[pb + E_IN_W], d, m->gA, d, BS, 3 * d, d, gB, d, nullptr, 0, 1.f, m->plT[pb + E_IN_W], 3 * d));
     return 0;
 }
 
 int backward_segment_body(pa_model* m, int seg, float gscale, void* st);
 int backward_segment(pa_model* m, int seg, float gscale, void* st) {
-    m->ndefer = 0; m->slab_used = 0; m->ncs = 0;
+    m->ndefer = 0; m->slab_used = 0; m->ncs = 0; m->ndwq = 0;
     m->defer_ok = seg >= 1 && seg != m->cfg.n_dec + 1 && seg != m->cfg.n_dec + 2;     // layer segments (not the heads: they reuse buffers)
     RC(backward_segment_body(m, seg, gscale, st));
     m->defer_ok = false;
+    if (m->ndwq > 0) {                                     // all weight-gradient GEMMs of the segment: one ring-kernel launch
+        int rc = m->ndwq > 1 ? pa_gemm_group(m->dwq, m->ndwq, st) : PA_EINVAL;
+        if (rc == PA_EINVAL) { rc = 0; for (int i = 0; i < m->ndwq && !rc; ++i) rc = pa_gemm(&m->dwq[i], st); }
+        m->ndwq = 0;
+        RC(rc);
+    }
     if (m->ncs > 0) { RC(pa_colsum_many(m->cs, m->ncs, m->cfg.dtype, st)); m->ncs = 0; }
     if (m->ndefer > 0) {                                   // one reduction launch for the segment's weight gradients
         RC(pa_splitk_reduce_many(m->defer, m->ndefer, st));

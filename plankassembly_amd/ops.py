@@ -66,6 +66,36 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, residual=None, aux=
     return out
 
 
+def dw_group(items):
+    """Weight gradients dW_i = dY_i^T @ X_i for [(dY[rows, M], X[rows, N], splitk)], bf16 in / f32 out: ONE ring-kernel
+    launch for all products (pa_gemm_group) plus one reduction launch for the split ones."""
+    n = len(items)
+    args = (L.GemmArgs * n)()
+    outs, keep, red = [], [], []
+    for i, (dy, x, sk) in enumerate(items):
+        rows, M = dy.shape
+        N = x.shape[1]
+        sk = int(L.lib().pa_gemm_effective_splitk(rows, L.dt(dy), sk))
+        out = torch.empty(M, N, dtype=torch.float32, device=dy.device)
+        g = args[i]
+        g.A, g.B, g.C = dy.data_ptr(), x.data_ptr(), out.data_ptr()
+        g.M, g.N, g.K = M, N, rows
+        g.lda, g.ldb, g.ldc = dy.stride(0), x.stride(0), out.stride(0)
+        g.batch, g.a_kcontig, g.b_kcontig = 1, 0, 0
+        g.in_dtype, g.out_dtype = L.dt(dy), L.dt(out)
+        g.alpha, g.aux_scale, g.splitk = 1.0, 1.0, sk
+        if sk > 1:
+            ws = _f32(sk * M * N, device=dy.device)
+            g.ws, g.splitk_defer = ws.data_ptr(), 1
+            keep.append(ws)
+            red.append((ws, out, sk))
+        outs.append(out)
+    L.check(L.lib().pa_gemm_group(C.cast(args, C.c_void_p), n, L.stream()), "pa_gemm_group")
+    if red:
+        splitk_reduce_many(red)
+    return outs
+
+
 class ColsumDesc(C.Structure):          # mirrors pa_colsum_desc
     _fields_ = [("X", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("ldx", C.c_int32),
                 ("pad_", C.c_int32)]

@@ -70,6 +70,21 @@ def test_colsum_many(dtype):
         assert float((o.cpu() - ref).abs().max()) < (1e-3 if dtype == torch.float32 else 1e-2) * (1 + float(ref.abs().max()))
 
 
+def test_gemm_group_weight_gradients():
+    """One launch for the dW GEMMs of a whole layer (different shapes, split and unsplit members, ragged row counts)."""
+    shapes = [(7940, 1536, 512, 5), (7940, 512, 512, 16), (7940, 1024, 512, 8), (7940, 512, 1024, 8),    # encoder layer
+              (2048, 512, 512, 8), (2048, 1024, 512, 1), (300, 136, 72, 2)]
+    items, refs = [], []
+    for i, (rows, M, N, sk) in enumerate(shapes):
+        dy = rnd(rows, M, dtype=torch.bfloat16, seed=50 + i, scale=0.3)
+        x = rnd(rows, N, dtype=torch.bfloat16, seed=60 + i, scale=0.3)
+        items.append((dy.to(DEV), x.to(DEV), sk))
+        refs.append(dy.float().t() @ x.float())
+    outs = ops.dw_group(items)
+    for out, ref in zip(outs, refs):
+        assert rel_err(out, ref) < 1e-2, rel_err(out, ref)
+
+
 def test_gemm_deferred_splitk_reduce():
     """Weight-gradient path: several split-K GEMMs write only their f32 slabs, one launch reduces all of them.
     (K = 1000 with 5 requested slices is the case where rounding leaves the last slice empty: 16 K tiles -> 4 slices.)"""
