@@ -176,6 +176,19 @@ int pa_layernorm_bwd(void* dz, void* ddrop, const void* dy, const void* z, const
                      const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dzsum,
                      float* partial, int64_t rows, int32_t d, int32_t dtype,
                      float drop_p, uint32_t drop_seed, void* stream);
+/* The same in two steps, so that several LayerNorm backward passes share ONE finishing launch: _partial writes only the
+ * per-block partial sums (pa_layernorm_bwd_nparts(rows) blocks x 3 x d floats, a distinct `partial` buffer per pass until
+ * finished); pa_layernorm_finish_many adds them to dgamma / dbeta / dzsum (dzsum may be NULL). */
+int pa_layernorm_bwd_partial(void* dz, void* ddrop, const void* dy, const void* z, const float* gamma,
+                             const float* mean, const float* rstd, int32_t want_dzsum, float* partial,
+                             int64_t rows, int32_t d, int32_t dtype, float drop_p, uint32_t drop_seed, void* stream);
+int32_t pa_layernorm_bwd_nparts(int64_t rows);
+#define PA_MAX_LN_FINISH 4
+typedef struct {
+    const float* partial; float* dgamma; float* dbeta; float* dzsum;
+    int32_t nparts, pad_;
+} pa_ln_finish_desc;
+int pa_layernorm_finish_many(const pa_ln_finish_desc* descs, int32_t n, int32_t d, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head attention core: softmax(Q K^T * scale + mask) V per (batch, head), flash-style

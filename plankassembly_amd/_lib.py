@@ -96,6 +96,9 @@ def lib():
             "pa_layernorm_ws_floats": (I64, [I64, I]),
             "pa_layernorm_fwd": (I, [P, P, P, P, P, P, I64, I, F, I, P]),
             "pa_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I64, I, I, F, U, P]),
+            "pa_layernorm_bwd_partial": (I, [P, P, P, P, P, P, P, I, P, I64, I, I, F, U, P]),
+            "pa_layernorm_bwd_nparts": (I, [I64]),
+            "pa_layernorm_finish_many": (I, [P, I, I, P]),
             "pa_attn_fwd": (I, [P, P]),
             "pa_attn_bwd": (I, [P, P]),
             "pa_switch_fwd": (I, [P, P, I, P, P, I64, I, P]),

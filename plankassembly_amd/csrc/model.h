@@ -58,6 +58,7 @@ struct pa_model {
     void *gA, *gB, *gC, *gD, *gE, *gF, *gQ3, *gKV, *dmem, *dvlog, *dplog; float *dsw, *delta, *partial, *splitws;
     size_t splitws_floats = 0;
     void* gBs[3] = {nullptr, nullptr, nullptr}; void* gCs[3] = {nullptr, nullptr, nullptr};   // per-site LN-backward outputs (ffn, cross, self)
+    float* lnp[3] = {nullptr, nullptr, nullptr}; pa_ln_finish_desc lnq[PA_MAX_LN_FINISH]; int nlnq = 0;   // queued LayerNorm-backward finishes
     pa_gemm_args dwq[PA_MAX_GROUP]; int ndwq = 0;                               // queued weight-gradient GEMMs of the current segment
     pa_colsum_desc cs[PA_MAX_COLSUM]; int ncs = 0; bool defer_ok = false;       // queued bias-gradient column sums of the current segment
     pa_reduce_desc defer[PA_MAX_REDUCE]; int ndefer = 0; size_t slab_used = 0;   // queued split-K reductions of the current segment

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(T* y, const T* z, co
     }
 }
 
-constexpr int LNB_ROWS = 32;   // rows per block in backward (8 per wave, two at a time for memory-level parallelism)
+constexpr int LNB_ROWS = 16;   // rows per block in backward (4 per wave, two at a time; ~500 blocks at 7 940 rows keep 2 blocks per CU in flight)
 
 // dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-block partial column sums of dy * xhat (dgamma),
 // dy (dbeta) and the (dropped) dz (dzsum) go to partial[block][3][d]; partial_finish_kernel adds them to the outputs.
@@ -329,6 +329,25 @@ __global__ __launch_bounds__(256) void partial_finish_kernel(const float* partia
         const float* p = partial + (size_t)qn * q_stride + c;
 #pragma unroll 8
         for (int i = pl; i < nparts; i += 4) s += p[(size_t)i * part_stride];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0 && c < ncols && o) o[c] += (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+}
+
+// the same for several LayerNorm backward passes at once (blockIdx.z = descriptor)
+struct LnFinishTab { pa_ln_finish_desc d[PA_MAX_LN_FINISH]; int n; };
+__global__ __launch_bounds__(256) void partial_finish_many_kernel(LnFinishTab t, int ncols) {
+    __shared__ float red[256];
+    const pa_ln_finish_desc d = t.d[blockIdx.z];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    const int qn = blockIdx.y;
+    float* o = qn == 0 ? d.dgamma : (qn == 1 ? d.dbeta : d.dzsum);
+    float s = 0.f;
+    if (c < ncols && o) {
+        const float* p = d.partial + (size_t)qn * ncols + c;
+#pragma unroll 8
+        for (int i = pl; i < d.nparts; i += 4) s += p[(size_t)i * 3 * ncols];
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -612,11 +631,10 @@ extern "C" int pa_layernorm_fwd(void* y, const void* z, const float* gamma, cons
     return 0;
 }
 
-extern "C" int pa_layernorm_bwd(void* dz, void* ddrop, const void* dy, const void* z, const float* gamma,
-                                const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dzsum,
-                                float* partial, int64_t rows, int32_t d, int32_t dtype,
-                                float drop_p, uint32_t drop_seed, void* stream) {
-    if (!dz || !dy || !z || !gamma || !mean || !rstd || !dgamma || !dbeta || !partial) return PA_EINVAL;
+extern "C" int pa_layernorm_bwd_partial(void* dz, void* ddrop, const void* dy, const void* z, const float* gamma,
+                                        const float* mean, const float* rstd, int32_t want_dzsum, float* partial,
+                                        int64_t rows, int32_t d, int32_t dtype, float drop_p, uint32_t drop_seed, void* stream) {
+    if (!dz || !dy || !z || !gamma || !mean || !rstd || !partial) return PA_EINVAL;
     if (rows <= 0 || (d & 3) || d > 256 * MAXV || drop_p < 0.f || drop_p >= 1.f) return PA_EINVAL;
     const uint32_t thr = (uint32_t)(drop_p * 65536.0f + 0.5f);
     if (thr && !ddrop) return PA_EINVAL;
@@ -624,14 +642,37 @@ extern "C" int pa_layernorm_bwd(void* dz, void* ddrop, const void* dy, const voi
     const int grid = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
     const size_t shm = (size_t)4 * 3 * d * sizeof(float);
 #define LNB_GO(T_, NV_) PA_LAUNCH((layernorm_bwd_kernel<T_, NV_>), dim3(grid), dim3(256), shm, ST(stream), (T_*)dz, (T_*)ddrop, \
-        (const T_*)dy, (const T_*)z, gamma, mean, rstd, partial, rows, d, thr, scale, drop_seed, dzsum ? 1 : 0)
+        (const T_*)dy, (const T_*)z, gamma, mean, rstd, partial, rows, d, thr, scale, drop_seed, want_dzsum ? 1 : 0)
 #define LNB_NV(T_) do { if (d <= 256) LNB_GO(T_, 1); else if (d <= 512) LNB_GO(T_, 2); else if (d <= 1024) LNB_GO(T_, 4); \
         else LNB_GO(T_, 8); } while (0)
     if (dtype == PA_BF16) LNB_NV(bf16); else LNB_NV(float);
 #undef LNB_NV
 #undef LNB_GO
-    PA_LAUNCH(partial_finish_kernel, dim3((d + 63) / 64, dzsum ? 3 : 2), dim3(256), 0, ST(stream), partial, grid, 3 * d, d, d, dgamma, dbeta, dzsum);
     return 0;
+}
+extern "C" int32_t pa_layernorm_bwd_nparts(int64_t rows) { return (int32_t)((rows + LNB_ROWS - 1) / LNB_ROWS); }
+extern "C" int pa_layernorm_finish_many(const pa_ln_finish_desc* descs, int32_t n, int32_t d, void* stream) {
+    if (!descs || n <= 0 || n > PA_MAX_LN_FINISH || d <= 0) return PA_EINVAL;
+    LnFinishTab t; t.n = n;
+    bool any3 = false;
+    for (int i = 0; i < n; ++i) {
+        if (!descs[i].partial || !descs[i].dgamma || !descs[i].dbeta || descs[i].nparts <= 0) return PA_EINVAL;
+        t.d[i] = descs[i];
+        any3 = any3 || descs[i].dzsum != nullptr;
+    }
+    PA_LAUNCH(partial_finish_many_kernel, dim3((d + 63) / 64, any3 ? 3 : 2, n), dim3(256), 0, ST(stream), t, d);
+    return 0;
+}
+extern "C" int pa_layernorm_bwd(void* dz, void* ddrop, const void* dy, const void* z, const float* gamma,
+                                const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dzsum,
+                                float* partial, int64_t rows, int32_t d, int32_t dtype,
+                                float drop_p, uint32_t drop_seed, void* stream) {
+    if (!dgamma || !dbeta) return PA_EINVAL;
+    int rc = pa_layernorm_bwd_partial(dz, ddrop, dy, z, gamma, mean, rstd, dzsum ? 1 : 0, partial, rows, d, dtype, drop_p, drop_seed, stream);
+    if (rc) return rc;
+    pa_ln_finish_desc fd; fd.partial = partial; fd.nparts = pa_layernorm_bwd_nparts(rows); fd.pad_ = 0;
+    fd.dgamma = dgamma; fd.dbeta = dbeta; fd.dzsum = dzsum;
+    return pa_layernorm_finish_many(&fd, 1, d, stream);
 }
 
 extern "C" int pa_switch_fwd(float* s, const void* h, int32_t dtype, const float* w, const float* b, int64_t rows,

@@ -99,6 +99,14 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
     }
     int ln_bwd(void* dz, void* ddrop, const void* dy, const void* z, const float* g, const float* mean, const float* rstd,
                float* dg, float* db, float* dzsum, int64_t rows, float drop_p, uint32_t seed) const {
+        if (m->defer_ok && m->nlnq < PA_MAX_LN_FINISH && m->nlnq < 3) {
+            // inside a layer segment: partial sums now (own buffer), one finishing launch for all of them at the end
+            float* part = m->lnp[m->nlnq];
+            RC(pa_layernorm_bwd_partial(dz, ddrop, dy, z, g, mean, rstd, dzsum ? 1 : 0, part, rows, m->cfg.d_model, dt(), drop_p, seed, st));
+            pa_ln_finish_desc& fd = m->lnq[m->nlnq++];
+            fd.partial = part; fd.nparts = pa_layernorm_bwd_nparts(rows); fd.pad_ = 0; fd.dgamma = dg; fd.dbeta = db; fd.dzsum = dzsum;
+            return 0;
+        }
         return pa_layernorm_bwd(dz, ddrop, dy, z, g, mean, rstd, dg, db, dzsum, m->partial, rows, m->cfg.d_model, dt(),
                                 drop_p, seed, st);
     }
@@ -168,6 +176,7 @@ size_t pa_train_layout(pa_model* m, char* base, int B, int S, int T) {
     const size_t cs = (size_t)pa_colsum_ws_floats((int)R, (int)(wide > (size_t)m->ldv ? wide : m->ldv));
     if (cs > part) part = cs;
     m->partial = (float*)a.take(part * 4);
+    for (int s_ = 0; s_ < 3; ++s_) m->lnp[s_] = (float*)a.take((size_t)pa_layernorm_ws_floats((int64_t)R, (int)d) * 4);   // queued LN-backward partials
     // split-K slabs of every weight gradient of one backward segment (they are reduced together at its end):
     // a decoder layer is the largest segment (self in/out, cross in/out, two FFN weights), <= 16 slices each
     const size_t wmax = (3 * d * d > d * ff ? 3 * d * d : d * ff);
@@ -394,7 +403,7 @@ int bwd_enc_layer(pa_model* m, int i, void* st) {
 
 int backward_segment_body(pa_model* m, int seg, float gscale, void* st);
 int backward_segment(pa_model* m, int seg, float gscale, void* st) {
-    m->ndefer = 0; m->slab_used = 0; m->ncs = 0; m->ndwq = 0;
+    m->ndefer = 0; m->slab_used = 0; m->ncs = 0; m->ndwq = 0; m->nlnq = 0;
     m->defer_ok = seg >= 1 && seg != m->cfg.n_dec + 1 && seg != m->cfg.n_dec + 2;     // layer segments (not the heads: they reuse buffers)
     RC(backward_segment_body(m, seg, gscale, st));
     m->defer_ok = false;
@@ -404,6 +413,7 @@ int backward_segment(pa_model* m, int seg, float gscale, void* st) {
         m->ndwq = 0;
         RC(rc);
     }
+    if (m->nlnq > 0) { RC(pa_layernorm_finish_many(m->lnq, m->nlnq, m->cfg.d_model, st)); m->nlnq = 0; }
     if (m->ncs > 0) { RC(pa_colsum_many(m->cs, m->ncs, m->cfg.dtype, st)); m->ncs = 0; }
     if (m->ndefer > 0) {                                   // one reduction launch for the segment's weight gradients
         RC(pa_splitk_reduce_many(m->defer, m->ndefer, st));
