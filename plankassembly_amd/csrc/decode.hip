@@ -112,27 +112,40 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int l
     float m = -INFINITY, l = 0.f, acc[EB];
 #pragma unroll
     for (int e = 0; e < EB; ++e) acc[e] = 0.f;
-    constexpr int UN = 4;                                // key groups per iteration: 2*UN 16-byte loads in flight per lane
+    // UN key groups per iteration; K and V rows travel as raw 16-byte vectors (one load each per lane and key) and are
+    // widened only when used, so 2*UN loads are in flight per lane at 2*UN*4 VGPRs
+    constexpr int UN = 8;
+    auto widen = [](const u32x4& raw, float* f) {
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { f[2 * w] = bf16_lo(raw[w]); f[2 * w + 1] = bf16_hi(raw[w]); }
+        } else {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) f[w] = __uint_as_float(raw[w]);
+        }
+    };
     for (int base0 = wave * KPW; base0 < Lk; base0 += 4 * KPW * UN) {
-        f32x4 kq[UN][EB / 4], vq[UN][EB / 4];
+        u32x4 kraw[UN], vraw[UN];
         bool okk[UN];
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
             const int key = base0 + j * 4 * KPW + slot;
             const bool in = key < Lk;
             okk[j] = in && !(mk && mk[in ? key : 0]);
-#pragma unroll
-            for (int e = 0; e < EB / 4; ++e) {
-                kq[j][e] = f32x4{0.f, 0.f, 0.f, 0.f}; vq[j][e] = kq[j][e];
-                if (in) { kq[j][e] = ld4<T>(kb + (int64_t)key * ldkv + 4 * e); vq[j][e] = ld4<T>(vb + (int64_t)key * ldkv + 4 * e); }
+            kraw[j] = u32x4{0u, 0u, 0u, 0u}; vraw[j] = kraw[j];
+            if (in) {
+                kraw[j] = *reinterpret_cast<const u32x4*>(kb + (int64_t)key * ldkv);
+                vraw[j] = *reinterpret_cast<const u32x4*>(vb + (int64_t)key * ldkv);
             }
         }
         float s[UN];
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
+            float kf[EB];
+            widen(kraw[j], kf);
             float a = 0.f;
 #pragma unroll
-            for (int e = 0; e < EB; ++e) a += qv[e] * kq[j][e >> 2][e & 3];
+            for (int e = 0; e < EB; ++e) a += qv[e] * kf[e];
 #pragma unroll
             for (int o = 1; o < LPR; o <<= 1) a += __shfl_xor(a, o);
             s[j] = okk[j] ? a * sl : -INFINITY;
@@ -149,8 +162,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int l
             for (int j = 0; j < UN; ++j) {
                 const float pj = exp2f(s[j] - mn);           // exp2(-inf) = 0 for masked / out-of-range keys
                 l += pj;
+                float vf[EB];
+                widen(vraw[j], vf);
 #pragma unroll
-                for (int e = 0; e < EB; ++e) acc[e] += pj * vq[j][e >> 2][e & 3];
+                for (int e = 0; e < EB; ++e) acc[e] += pj * vf[e];
             }
             m = mn;
         }

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(T* y, const T* z, co
     }
 }
 
-constexpr int LNB_ROWS = 16;   // rows per block in backward (4 per wave, two at a time; ~500 blocks at 7 940 rows keep 2 blocks per CU in flight)
+constexpr int LNB_ROWS = 8;    // rows per block in backward: one pair of rows per wave, ~1000 blocks at 7 940 rows (4 per CU in flight)
 
 // dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-block partial column sums of dy * xhat (dgamma),
 // dy (dbeta) and the (dropped) dz (dzsum) go to partial[block][3][d]; partial_finish_kernel adds them to the outputs.
