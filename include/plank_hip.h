@@ -334,6 +334,13 @@ int pa_model_train_fwd(pa_model* m, const pa_batch* batch, void* ws, int64_t ws_
  * last segment) - the host can launch their all-reduce on a side stream. */
 int pa_model_train_num_segments(const pa_model* m);
 int pa_model_train_bwd(pa_model* m, int32_t seg_lo, int32_t seg_hi, float gscale, void* stream);
+/* Gradient finality lag in segments.  With PA_SIDE_STREAM=1 (experimental, off by default: slower on MI355X) the model
+ * owns one extra HIP stream: the work queued at
+ * the end of a layer's backward segment (grouped weight-gradient GEMM, split-K reductions, bias column sums,
+ * LayerNorm finishes - all independent of the dX chain) runs there, fenced with events against `stream`, while
+ * `stream` continues with the next segment.  The gradients of segment s are then final, in `stream` order, once
+ * segment s+2 has been enqueued or the last segment has returned (which joins everything): returns 2; 0 otherwise. */
+int pa_model_grad_lag(const pa_model* m);
 /* introspection for parity tests: device pointer + element count of an activation of the last forward */
 int pa_model_tensor(pa_model* m, int32_t which, void** ptr, int64_t* numel);
 

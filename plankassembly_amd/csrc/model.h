@@ -63,6 +63,20 @@ struct pa_model {
     pa_colsum_desc cs[PA_MAX_COLSUM]; int ncs = 0; bool defer_ok = false;       // queued bias-gradient column sums of the current segment
     pa_reduce_desc defer[PA_MAX_REDUCE]; int ndefer = 0; size_t slab_used = 0;   // queued split-K reductions of the current segment
     bool dmem_written = false;
+    // Two copies ("parity sets") of every buffer the queued end-of-segment work reads: with the side stream on, that
+    // work of segment s runs concurrently with the main stream's segments s+1 (other set) and is joined before s+2.
+    struct SegSet { void* gBs[3]; void* gCs[3]; void *gE, *gF, *gQ3, *gKV; float* lnp[3]; float* splitws; };
+    SegSet seg_set[2];
+    void select_set(int par) {
+        const SegSet& s = seg_set[par];
+        for (int i = 0; i < 3; ++i) { gBs[i] = s.gBs[i]; gCs[i] = s.gCs[i]; lnp[i] = s.lnp[i]; }
+        gE = s.gE; gF = s.gF; gQ3 = s.gQ3; gKV = s.gKV; splitws = s.splitws;
+    }
+    bool side_on = false;                        // PA_SIDE_STREAM (default on): queued segment work goes to `side`
+    void* side = nullptr;                        // hipStream_t
+    void* ev_ready[2] = {nullptr, nullptr};      // main -> side: the segment's dY buffers are complete
+    void* ev_done[2] = {nullptr, nullptr};       // side -> main: the segment's queued work is complete
+    bool ev_pending[2] = {false, false};
     // ---- greedy decode state (decode.hip) ----
     struct DecodeLayout* dec = nullptr;
 

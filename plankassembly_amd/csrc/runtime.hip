@@ -169,6 +169,11 @@ size_t pa_train_layout(pa_model* m, char* base, int B, int S, int T) {
     for (int s_ = 1; s_ < 3; ++s_) { m->gBs[s_] = a.take(R * d * e); m->gCs[s_] = a.take(R * d * e); }
     m->gE = a.take(R * d * e); m->gF = a.take(R * ff * e); m->gQ3 = a.take(R * 3 * d * e);
     m->gKV = a.take(BS * 2 * d * e); m->dmem = a.take(BS * d * e);
+    {   // parity set 1 (set 0 = the buffers above)
+        pa_model::SegSet& s1 = m->seg_set[1];
+        for (int s_ = 0; s_ < 3; ++s_) { s1.gBs[s_] = a.take(R * d * e); s1.gCs[s_] = a.take(R * d * e); }
+        s1.gE = a.take(R * d * e); s1.gF = a.take(R * ff * e); s1.gQ3 = a.take(R * 3 * d * e); s1.gKV = a.take(BS * 2 * d * e);
+    }
     m->dvlog = a.take(BT * m->ldv * e); m->dplog = a.take(BT * T * e); m->dsw = (float*)a.take(BT * 4);
     m->delta = (float*)a.take((size_t)B * H * R * 4);
     size_t part = (size_t)pa_layernorm_ws_floats((int64_t)R, (int)d);
@@ -177,12 +182,19 @@ size_t pa_train_layout(pa_model* m, char* base, int B, int S, int T) {
     if (cs > part) part = cs;
     m->partial = (float*)a.take(part * 4);
     for (int s_ = 0; s_ < 3; ++s_) m->lnp[s_] = (float*)a.take((size_t)pa_layernorm_ws_floats((int64_t)R, (int)d) * 4);   // queued LN-backward partials
+    for (int s_ = 0; s_ < 3; ++s_) m->seg_set[1].lnp[s_] = (float*)a.take((size_t)pa_layernorm_ws_floats((int64_t)R, (int)d) * 4);
     // split-K slabs of every weight gradient of one backward segment (they are reduced together at its end):
     // a decoder layer is the largest segment (self in/out, cross in/out, two FFN weights), <= 16 slices each
     const size_t wmax = (3 * d * d > d * ff ? 3 * d * d : d * ff);
     const size_t wlayer = 8 * d * d + 2 * d * ff + (size_t)m->ldv * d;
     m->splitws_floats = 16 * (wlayer > wmax ? wlayer : wmax);
     m->splitws = (float*)a.take(m->splitws_floats * 4);
+    m->seg_set[1].splitws = (float*)a.take(m->splitws_floats * 4);
+    {   // record set 0 and make it current
+        pa_model::SegSet& s0 = m->seg_set[0];
+        for (int s_ = 0; s_ < 3; ++s_) { s0.gBs[s_] = m->gBs[s_]; s0.gCs[s_] = m->gCs[s_]; s0.lnp[s_] = m->lnp[s_]; }
+        s0.gE = m->gE; s0.gF = m->gF; s0.gQ3 = m->gQ3; s0.gKV = m->gKV; s0.splitws = m->splitws;
+    }
     return a.off;
 }
 namespace {
@@ -402,22 +414,51 @@ int bwd_enc_layer(pa_model* m, int i, void* st) {
 }
 
 int backward_segment_body(pa_model* m, int seg, float gscale, void* st);
-int backward_segment(pa_model* m, int seg, float gscale, void* st) {
-    m->ndefer = 0; m->slab_used = 0; m->ncs = 0; m->ndwq = 0; m->nlnq = 0;
-    m->defer_ok = seg >= 1 && seg != m->cfg.n_dec + 1 && seg != m->cfg.n_dec + 2;     // layer segments (not the heads: they reuse buffers)
-    RC(backward_segment_body(m, seg, gscale, st));
-    m->defer_ok = false;
+#define HC(x) do { hipError_t he_ = (x); if (he_ != hipSuccess) return (int)he_; } while (0)
+// enqueue the segment's queued work (grouped weight-gradient GEMM, split-K reductions, bias column sums, LayerNorm
+// finishes) on stream `q`
+int flush_segment(pa_model* m, void* q) {
     if (m->ndwq > 0) {                                     // all weight-gradient GEMMs of the segment: one ring-kernel launch
-        int rc = m->ndwq > 1 ? pa_gemm_group(m->dwq, m->ndwq, st) : PA_EINVAL;
-        if (rc == PA_EINVAL) { rc = 0; for (int i = 0; i < m->ndwq && !rc; ++i) rc = pa_gemm(&m->dwq[i], st); }
+        int rc = m->ndwq > 1 ? pa_gemm_group(m->dwq, m->ndwq, q) : PA_EINVAL;
+        if (rc == PA_EINVAL) { rc = 0; for (int i = 0; i < m->ndwq && !rc; ++i) rc = pa_gemm(&m->dwq[i], q); }
         m->ndwq = 0;
         RC(rc);
     }
-    if (m->nlnq > 0) { RC(pa_layernorm_finish_many(m->lnq, m->nlnq, m->cfg.d_model, st)); m->nlnq = 0; }
-    if (m->ncs > 0) { RC(pa_colsum_many(m->cs, m->ncs, m->cfg.dtype, st)); m->ncs = 0; }
+    if (m->nlnq > 0) { RC(pa_layernorm_finish_many(m->lnq, m->nlnq, m->cfg.d_model, q)); m->nlnq = 0; }
+    if (m->ncs > 0) { RC(pa_colsum_many(m->cs, m->ncs, m->cfg.dtype, q)); m->ncs = 0; }
     if (m->ndefer > 0) {                                   // one reduction launch for the segment's weight gradients
-        RC(pa_splitk_reduce_many(m->defer, m->ndefer, st));
+        RC(pa_splitk_reduce_many(m->defer, m->ndefer, q));
         m->ndefer = 0; m->slab_used = 0;
+    }
+    return 0;
+}
+// main stream waits for the side-stream work of parity `par` (if any is outstanding)
+int join_side(pa_model* m, int par, void* st) {
+    if (m->ev_pending[par]) {
+        HC(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)m->ev_done[par], 0));
+        m->ev_pending[par] = false;
+    }
+    return 0;
+}
+int backward_segment(pa_model* m, int seg, float gscale, void* st) {
+    const int par = seg & 1;
+    m->ndefer = 0; m->slab_used = 0; m->ncs = 0; m->ndwq = 0; m->nlnq = 0;
+    m->defer_ok = seg >= 1 && seg != m->cfg.n_dec + 1 && seg != m->cfg.n_dec + 2;     // layer segments (not the heads: they reuse buffers)
+    if (m->side_on) {
+        RC(join_side(m, par, st));             // segment seg-2 used this parity set: its queued work must be finished
+        m->select_set(par);
+    }
+    RC(backward_segment_body(m, seg, gscale, st));
+    m->defer_ok = false;
+    const bool queued = m->ndwq > 0 || m->nlnq > 0 || m->ncs > 0 || m->ndefer > 0;
+    if (queued && m->side_on) {
+        HC(hipEventRecord((hipEvent_t)m->ev_ready[par], (hipStream_t)st));
+        HC(hipStreamWaitEvent((hipStream_t)m->side, (hipEvent_t)m->ev_ready[par], 0));
+        RC(flush_segment(m, m->side));
+        HC(hipEventRecord((hipEvent_t)m->ev_done[par], (hipStream_t)m->side));
+        m->ev_pending[par] = true;
+    } else if (queued) {
+        RC(flush_segment(m, st));
     }
     return 0;
 }
@@ -469,12 +510,38 @@ extern "C" int pa_model_create(const pa_model_cfg* cfg, pa_model** out) {
     m->n_params = P_FIXED_HEAD + cfg->n_enc * E_COUNT + 2 + cfg->n_dec * D_COUNT + 2 + T_COUNT;
     m->pf.assign(m->n_params, nullptr); m->pl.assign(m->n_params, nullptr); m->gr.assign(m->n_params, nullptr);
     m->plT.assign(m->n_params, nullptr);
+    // Optional side stream for the queued end-of-segment backward work (PA_SIDE_STREAM=1).  Off by default: measured
+    // on MI355X the event fences cost more than the overlap gains (7.68 vs 7.49 ms/step, profiles/README.md).
+    const char* ss = getenv("PA_SIDE_STREAM");
+    if (ss && atoi(ss) != 0) {
+        hipStream_t q = nullptr;
+        bool ok = hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+        if (ok) {
+            m->side = q; m->ev_ready[0] = ev[0]; m->ev_ready[1] = ev[1]; m->ev_done[0] = ev[2]; m->ev_done[1] = ev[3];
+            m->side_on = true;
+        } else {
+            for (int i = 0; i < 4; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (q) (void)hipStreamDestroy(q);
+            (void)hipGetLastError();
+        }
+    }
     *out = m;
     return 0;
 }
 
 void pa_decode_free_layout(pa_model* m);   // decode.hip
-extern "C" void pa_model_destroy(pa_model* m) { if (m) { pa_decode_free_layout(m); delete m; } }
+extern "C" void pa_model_destroy(pa_model* m) {
+    if (!m) return;
+    for (int i = 0; i < 2; ++i) {
+        if (m->ev_ready[i]) (void)hipEventDestroy((hipEvent_t)m->ev_ready[i]);
+        if (m->ev_done[i]) (void)hipEventDestroy((hipEvent_t)m->ev_done[i]);
+    }
+    if (m->side) (void)hipStreamDestroy((hipStream_t)m->side);
+    pa_decode_free_layout(m);
+    delete m;
+}
 
 extern "C" int pa_model_num_params(const pa_model* m) { return m ? m->n_params : PA_EINVAL; }
 
@@ -531,8 +598,12 @@ extern "C" int pa_model_train_bwd(pa_model* m, int32_t seg_lo, int32_t seg_hi, f
     const int nseg = m->cfg.n_dec + m->cfg.n_enc + 4;
     if (seg_lo < 0 || seg_hi > nseg || seg_lo > seg_hi) return PA_EINVAL;
     for (int s = seg_lo; s < seg_hi; ++s) RC(backward_segment(m, s, gscale, stream));
+    if (seg_hi == nseg && m->side_on) { RC(join_side(m, 0, stream)); RC(join_side(m, 1, stream)); m->select_set(0); }
     return 0;
 }
+// Segments by which gradient finality lags behind pa_model_train_bwd: with the side stream on, the gradients of segment
+// s are final (in `stream` order) once segment s+2 has been enqueued, or after the last segment.  0 = immediately.
+extern "C" int pa_model_grad_lag(const pa_model* m) { return (m && m->side_on) ? 2 : 0; }
 
 extern "C" int pa_model_tensor(pa_model* m, int32_t which, void** ptr, int64_t* numel) {
     if (!m || !ptr || !numel || m->B == 0) return PA_EINVAL;

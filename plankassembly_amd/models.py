@@ -527,10 +527,15 @@ class PlankModel(nn.Module):
         stats[3:4].copy_(gloss.reshape(1).to(torch.float32), non_blocking=True)   # upstream grad, no host sync
         slices = self.segment_slices()
         hook = self._grad_hook if not accumulate else None
+        # with the library's side stream the gradients of segment s are final once segment s + lag is enqueued
+        lag = int(L.lib().pa_model_grad_lag(self._handle))
         for s in range(nseg):
             L.check(L.lib().pa_model_train_bwd(self._handle, s, s + 1, C.c_float(1.0), L.stream()),
                     "pa_model_train_bwd")
-            if hook is not None:
+            if hook is not None and s - lag >= 0:
+                hook(s - lag, *slices[s - lag])
+        if hook is not None:
+            for s in range(max(0, nseg - lag), nseg):       # the last segment joined everything
                 hook(s, *slices[s])
         if accumulate:
             self._gflat.add_(self._gtmp)
