@@ -17,8 +17,9 @@ import re
 import sys
 
 KEYS = [  # json key -> regex on the demangled kernel name
-    ("gemm_ring_tt", r"gemm3_kernel<true, true>"),
-    ("gemm_ring_nn", r"gemm3_kernel<false, false>"),
+    ("gemm_ring_tt", r"gemm3_kernel<true, true, .*GemmP>"),
+    ("gemm_ring_nn", r"gemm3_kernel<false, false, .*GemmP>"),
+    ("gemm_ring_nn_group", r"gemm3_kernel<false, false, .*GemmGroup>"),
     ("gemm_pair_tt", r"gemm_kernel<__bf16, 64, 2, true, true, true, true, false, 2>"),
     ("gemm_pair_nn", r"gemm_kernel<__bf16, 64, 2, false, false, true, true, true, 2>"),
     ("attn_fwd", r"attn_fwd_bf16_kernel<64>"),
@@ -27,6 +28,7 @@ KEYS = [  # json key -> regex on the demangled kernel name
     ("layernorm_bwd", r"layernorm_bwd_kernel<__bf16"),
     ("layernorm_fwd", r"layernorm_fwd_kernel<__bf16"),
     ("splitk_reduce", r"splitk_reduce_kernel"),
+    ("splitk_reduce_many", r"splitk_reduce_many_kernel"),
     ("adam", r"adam_kernel"),
 ]
 
