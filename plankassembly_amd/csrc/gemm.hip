@@ -1151,6 +1151,256 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
 #undef PA_MFMA
 }
 
+// -------------------------------------------------------------------------------------------------
+// Small-tile ring kernel: 64 x 64 x 64 tiles for launches whose 128 x 128 tiling would occupy a quarter of the CUs or
+// less (decoder-side Linears M = B*T = 2 048, every Linear of the greedy-decode step M = B).  Same structure as
+// gemm3_kernel - one block per CU, 4-stage ring of K tiles filled by direct-to-LDS DMA, k-steps that interleave the MFMA
+// with the next k-step's fragment reads - with one 32 x 32 MFMA tile per wave (2 x 2 waves), so a K tile costs a
+// quarter of the LDS / MFMA time and four times as many CUs share the problem.  bf16, both operands k-contiguous,
+// K % 64 == 0, one problem, no split-K.
+__global__ __launch_bounds__(NT, 1) void gemm3s_kernel(GemmP p) {
+    using T = bf16;
+    constexpr int TB = 64;                              // tile edge
+    constexpr int RB = 128, NCH = 8;                    // bytes / 16-byte chunks per LDS row (64 bf16)
+    constexpr int TILE_BYTES = TB * RB;                 // 8 KiB per operand
+    constexpr int NLD = TB * NCH / NT;                  // 2 chunks per thread per operand
+    constexpr int NSTG = 4, STAGE = 2 * TILE_BYTES, EPI = 32 * 32 * 4;    // EPI: 32 rows x 32 f32 per wave
+    __shared__ __attribute__((aligned(256))) char smem[NSTG * STAGE + 4 * EPI];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5;
+    constexpr int esz = 2;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // ---- DMA addressing ---------------------------------------------------------------------------------------
+    uint32_t offA[NLD], offB[NLD];
+    const char* kA = nullptr; const char* kB = nullptr;
+    auto setup = [&](const Unit& un, int t_begin) {
+        const char* baseA = reinterpret_cast<const char*>(p.A) + (size_t)un.b * p.sA * esz + (size_t)t_begin * 64 * esz;
+        const char* baseB = reinterpret_cast<const char*>(p.B) + (size_t)un.b * p.sB * esz + (size_t)t_begin * 64 * esz;
+        const int m0 = un.tile_m * TB, n0 = un.tile_n * TB;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int pidx = tid + i * NT, row = pidx / NCH, ch = ((pidx % NCH) ^ (row / 2)) & (NCH - 1);
+            offA[i] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)(p.lda * esz) + ch * 16;
+            offB[i] = (uint32_t)min(n0 + row, p.N - 1) * (uint32_t)(p.ldb * esz) + ch * 16;
+        }
+        kA = baseA; kB = baseB;
+    };
+    // one quarter of an item's DMA: Q = 0, 1 -> A chunk 0, 1; Q = 2, 3 -> B chunk 0, 1
+    auto fetch_q = [&](int stage, auto Q_) {
+        constexpr int Q = decltype(Q_)::value, i = Q & 1;
+        char* lx = smem + stage * STAGE + (Q >= 2 ? TILE_BYTES : 0);
+        const char* src = (Q < 2) ? kA + offA[i] : kB + offB[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            (__attribute__((address_space(3))) void*)(lx + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+    auto fetch_done = [&]() { kA += 64 * esz; kB += 64 * esz; };
+    using Q0 = std::integral_constant<int, 0>; using Q1 = std::integral_constant<int, 1>;
+    using Q2 = std::integral_constant<int, 2>; using Q3 = std::integral_constant<int, 3>;
+    auto fetch = [&](int stage) {
+        fetch_q(stage, Q0{}); fetch_q(stage, Q1{}); fetch_q(stage, Q2{}); fetch_q(stage, Q3{});
+        fetch_done();
+    };
+
+    // ---- fragment reads ------------------------------------------------------------------------------------------
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    const int sw = ((lane & 31) >> 1) & 7;
+    uint32_t xs[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) xs[s_] = (uint32_t)((((2 * s_ + half) ^ sw) & 7) << 4);
+    const uint32_t fa_off = (wm * 32 + (lane & 31)) * RB, fb_off = (wn * 32 + (lane & 31)) * RB + TILE_BYTES;
+#define PA_RD128(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+    auto frag = [&](u32x4 (&f)[2], uint32_t st, int s_) {
+        const uint32_t a0 = st + fa_off + xs[s_], b0 = st + fb_off + xs[s_];
+        PA_RD128(f[0], a0); PA_RD128(f[1], b0);
+    };
+    auto wait_frag = [&](u32x4 (&f)[2]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1])); };
+
+    // ---- epilogue: per-wave staging (32 x 32 f32), straight-line fast path ------------------------------------------
+    auto epilogue = [&](const Unit& un) {
+        char* stage = smem + NSTG * STAGE + wave * EPI;
+        const size_t cbase = (size_t)un.b * p.sC;
+        const int mw = un.tile_m * TB + wm * 32, nw = un.tile_n * TB + wn * 32;
+        const int chunk = lane & 7, rsub = lane >> 3;                     // 8 chunks of 4 columns, 8 rows per instruction
+        const int n = nw + chunk * 4;
+        const bool out_f32 = p.out_dtype == PA_F32;
+        const bool has_bias = p.bias != nullptr, has_aux = p.aux != nullptr, has_res = p.R != nullptr, has_drop = p.drop_thr != 0;
+        const bool fast = p.vec_ok && (nw + 32 <= p.N);                   // wave-uniform
+        constexpr int NIT = 4;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (has_bias) {
+            if (fast) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+            else { for (int e = 0; e < 4; ++e) if (n + e < p.N) bias[e] = p.bias[n + e]; }
+        }
+        {
+            const int lrow = lane & 31;                                   // accumulator: row (m) = lane & 31, value r <-> n
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[4 * g4 + e];
+                const int ch = 2 * g4 + half;
+                *reinterpret_cast<f32x4*>(stage + lrow * 128 + ((ch ^ (lrow & 7)) << 4)) = v;
+            }
+        }
+        f32x4 x[NIT];
+        const int mp = mw + rsub;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int lr = it * 8 + rsub;
+            x[it] = *reinterpret_cast<const f32x4*>(stage + lr * 128 + ((chunk ^ (lr & 7)) << 4));
+        }
+        if (fast) {
+            f32x4 res[NIT], gate[NIT];
+            if (has_res) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const size_t ro = (size_t)un.b * p.sR + (size_t)min(mp + it * 8, p.M - 1) * p.ldr + n;
+                    res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(p.R) + ro)
+                                      : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+                }
+            }
+            if (has_aux) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const size_t ao = (size_t)un.b * p.sAux + (size_t)min(mp + it * 8, p.M - 1) * p.ldaux + n;
+                    gate[it] = ld4<T>(reinterpret_cast<const T*>(p.aux) + ao);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y = x[it][e] * p.alpha + bias[e];
+                    if (p.relu) y = fmaxf(y, 0.f);
+                    if (has_aux) y = gate[it][e] > 0.f ? y * p.aux_scale : 0.f;
+                    if (has_drop) {
+                        const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + mp + it * 8) * p.N + n + e);
+                        y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
+                    }
+                    if (has_res) y += res[it][e];
+                    x[it][e] = y;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int m = mp + it * 8;
+                if (m < p.M) {
+                    const size_t co = cbase + (size_t)m * p.ldc + n;
+                    if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = x[it];
+                    else st4<bf16>(reinterpret_cast<bf16*>(p.C) + co, x[it]);
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < NIT; ++it) {
+                const int m = mp + it * 8;
+                if (m >= p.M) continue;
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= p.N) continue;
+                    float y = x[it][e] * p.alpha + bias[e];
+                    if (p.relu) y = fmaxf(y, 0.f);
+                    if (has_aux) {
+                        const float g = ld1(reinterpret_cast<const T*>(p.aux) + (size_t)un.b * p.sAux + (size_t)m * p.ldaux + n + e);
+                        y = g > 0.f ? y * p.aux_scale : 0.f;
+                    }
+                    if (has_drop) {
+                        const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + m) * p.N + n + e);
+                        y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
+                    }
+                    if (has_res) {
+                        const size_t ro = (size_t)un.b * p.sR + (size_t)m * p.ldr + n + e;
+                        y += out_f32 ? reinterpret_cast<const float*>(p.R)[ro] : (float)reinterpret_cast<const bf16*>(p.R)[ro];
+                    }
+                    const size_t co = cbase + (size_t)m * p.ldc + n + e;
+                    if (out_f32) reinterpret_cast<float*>(p.C)[co] = y;
+                    else reinterpret_cast<bf16*>(p.C)[co] = (bf16)y;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    };
+
+    // ---- item stream (as in gemm3_kernel; plain unit order, every unit valid, no split-K) ---------------------------------
+    const int ustride = gridDim.x, nt = p.K / 64;
+    auto unit_of = [&](int u, Unit& un) {
+        const int per_b = p.tiles_m * p.tiles_n;
+        un.b = u / per_b; un.z = un.b;
+        const int r = u - un.b * per_b;
+        un.tile_m = r / p.tiles_n; un.tile_n = r - un.tile_m * p.tiles_n;
+        un.t_begin = 0; un.t_end = nt;
+    };
+    int cd_u = blockIdx.x, cd_t = 0;            // DMA cursor
+    int cc_u = blockIdx.x, cc_t = 0;            // compute cursor
+    if (cc_u >= p.units) return;
+    Unit cun, dun;
+    unit_of(cc_u, cun);
+    unit_of(cd_u, dun); setup(dun, 0);
+    int sd = 0, pending = 0;
+    auto issue = [&]() {
+        fetch(sd);
+        sd = (sd + 1) & (NSTG - 1);
+        ++pending;
+        if (++cd_t >= nt) { cd_u += ustride; cd_t = 0; if (cd_u < p.units) { unit_of(cd_u, dun); setup(dun, 0); } }
+    };
+    auto wait_items = [&](int younger) {        // items are 4 DMA instructions each here
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) if (cd_u < p.units) issue();
+    wait_items(pending - 1);
+    __builtin_amdgcn_s_barrier();
+    int sc = 0;
+    u32x4 F0[2], F1[2];
+    frag(F0, lds0, 0);
+    auto item = [&](auto HOT_) -> bool {
+        constexpr bool HOT = decltype(HOT_)::value;
+        const uint32_t st = lds0 + sc * STAGE;
+        __builtin_amdgcn_s_barrier();           // barrier A: previous item's stage may be refilled
+        if constexpr (!HOT) { if (cd_u < p.units) issue(); }
+        wait_frag(F0); acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&F0[1]), *reinterpret_cast<const bf16x8*>(&F0[0]), acc, 0, 0, 0);
+        frag(F1, st, 1); if constexpr (HOT) { fetch_q(sd, Q0{}); fetch_q(sd, Q1{}); }
+        wait_frag(F1); acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&F1[1]), *reinterpret_cast<const bf16x8*>(&F1[0]), acc, 0, 0, 0);
+        frag(F0, st, 2); if constexpr (HOT) { fetch_q(sd, Q2{}); fetch_q(sd, Q3{}); fetch_done(); sd = (sd + 1) & (NSTG - 1); ++cd_t; }
+        wait_frag(F0); acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&F0[1]), *reinterpret_cast<const bf16x8*>(&F0[0]), acc, 0, 0, 0);
+        frag(F1, st, 3);
+        const bool has_next = HOT || pending >= 2;
+        wait_frag(F1);
+        if (has_next) {
+            if constexpr (HOT) wait_items(2); else wait_items(pending - 2);
+            __builtin_amdgcn_s_barrier();       // barrier B: the next item has landed for every wave
+            frag(F0, lds0 + ((sc + 1) & (NSTG - 1)) * STAGE, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&F1[1]), *reinterpret_cast<const bf16x8*>(&F1[0]), acc, 0, 0, 0);
+        sc = (sc + 1) & (NSTG - 1);
+        if constexpr (HOT) { ++cc_t; return true; }
+        else {
+            if (++cc_t >= nt) {
+                epilogue(cun);
+                cc_u += ustride; cc_t = 0;
+                if (cc_u < p.units) unit_of(cc_u, cun);
+            }
+            --pending;
+            return has_next;
+        }
+    };
+#pragma unroll 1
+    while (true) {
+        int hot = (pending == 3 && cd_u == cc_u) ? (nt - cd_t - 1) : 0;
+#pragma unroll 1
+        for (; hot > 0; --hot) item(std::true_type{});
+        if (!item(std::false_type{})) break;
+    }
+#undef PA_RD128
+}
+
 // split-K second pass: sum the slabs and apply the epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float* ws) {
@@ -1334,6 +1584,16 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     const int valid_units = p.tiles_m * p.tiles_n * a->batch * splitk;
     const bool go_v3 = use_v3 && (valid_units <= 256 || use_v3 == 2) && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds && is_aligned<bf16>(a) && v3_layout_ok;
     if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR); }
+    // small-tile ring kernel: plain k-contiguous Linears whose 128 x 128 tiling covers at most 64 CUs
+    static const int use_small = getenv("PA_GEMM_SMALL") ? atoi(getenv("PA_GEMM_SMALL")) : 1;
+    if (go_v3 && use_small && a->a_kcontig && a->b_kcontig && splitk == 1 && valid_units <= 64 && a->K % 64 == 0) {
+        GemmP ps = pk;
+        ps.tiles_m = (a->M + 63) / 64; ps.tiles_n = (a->N + 63) / 64; ps.tiles_m_pad = ps.tiles_m; ps.plain_order = 1;
+        ps.units = ps.tiles_m * ps.tiles_n * a->batch;
+        const int gs = ps.units < 256 ? ps.units : 256;
+        PA_LAUNCH(gemm3s_kernel, dim3(gs), dim3(NT), 0, st, ps);
+        rc = 0;
+    } else
     if (go_v3) {
         const int g3 = pk.units < 256 ? pk.units : 256;
         if (a->a_kcontig && a->b_kcontig) PA_LAUNCH((gemm3_kernel<true, true, GemmP>), dim3(g3), dim3(NT), 0, st, pk);
