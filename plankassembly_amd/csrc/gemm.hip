@@ -1584,9 +1584,10 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     const int valid_units = p.tiles_m * p.tiles_n * a->batch * splitk;
     const bool go_v3 = use_v3 && (valid_units <= 256 || use_v3 == 2) && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds && is_aligned<bf16>(a) && v3_layout_ok;
     if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR); }
-    // small-tile ring kernel: plain k-contiguous Linears whose 128 x 128 tiling covers at most 64 CUs
+    // small-tile ring kernel: plain k-contiguous Linears whose 128 x 128 tiling covers at most half of the CUs (measured: <= 128 units 7.05 ms/step, <= 64 7.11, <= 256 7.53)
     static const int use_small = getenv("PA_GEMM_SMALL") ? atoi(getenv("PA_GEMM_SMALL")) : 1;
-    if (go_v3 && use_small && a->a_kcontig && a->b_kcontig && splitk == 1 && valid_units <= 64 && a->K % 64 == 0) {
+    static const int small_max = getenv("PA_GEMM_SMALL_MAX") ? atoi(getenv("PA_GEMM_SMALL_MAX")) : 128;
+    if (go_v3 && use_small && a->a_kcontig && a->b_kcontig && splitk == 1 && valid_units <= small_max && a->K % 64 == 0) {
         GemmP ps = pk;
         ps.tiles_m = (a->M + 63) / 64; ps.tiles_n = (a->N + 63) / 64; ps.tiles_m_pad = ps.tiles_m; ps.plain_order = 1;
         ps.units = ps.tiles_m * ps.tiles_n * a->batch;
