@@ -144,6 +144,16 @@ int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* const* tables,
 int pa_embed_input_bwd(const void* dout, int32_t dtype, float* const* dtables, const int64_t* const* idx,
                        const int32_t* rowmap, const int32_t* table_rows, int32_t n_tables, int64_t n_tok, int32_t d,
                        void* stream);
+/* Embedding-table gradients by sorted segments: the token rows are grouped by table row once per batch - order[k] =
+ * row indices (into dout) sorted by id, seg[k][r] .. seg[k][r+1] = the rows that use table row r (int32, seg has
+ * table_rows[k] + 1 entries) - and each table row sums its segment: dtable[r] += sum (tables with few rows split
+ * their long segments over several blocks and combine with one atomic per column).  n_rows = rows of dout (sizes the
+ * splitting).  The grouping depends only on the batch, so it is built when the batch is prepared
+ * (PlankModel.prepare_batch); without it the atomic scatter-add kernels (pa_embed_input_bwd / _output_bwd) run. */
+#define PA_MAX_SEG_TABLES 5
+int pa_embed_segment_bwd(const void* dout, int32_t dtype, float* const* dtables, const int32_t* const* order,
+                         const int32_t* const* seg, const int32_t* table_rows, int32_t n_tables, int64_t n_rows,
+                         int32_t d, void* stream);
 /* Row packing ("unpadding"): mask uint8 [B][S] (1 = PAD) -> cu int32 [2B+1] (cu[b] = #valid rows before batch element
  * b, cu[B] = total; entries B+1..2B are scratch) and rowmap int32 [B*S] (rowmap[packed row] = b*S + s).  Padded
  * encoder positions never reach the loss (they are masked as keys everywhere), so the encoder stack can run on the
@@ -307,6 +317,11 @@ typedef struct {
     /* optional packed-encoder mode (pa_pack_rows): all three set, or cu_in == NULL for the dense path.  n_valid is the
      * host copy of cu_in[B] (the one device->host read of a training step). */
     const int32_t* cu_in; const int32_t* rowmap; int32_t n_valid;
+    /* optional grouping of the token rows by table row (pa_embed_segment_bwd; NULL = atomic scatter-add kernels):
+     * in_* for the five input tables over the (packed) encoder rows; out_* for the output embedding's value / coord /
+     * pos tables over the B*T decoder rows (row (b,t) uses token t-1; rows with t = 0 are left out) */
+    const int32_t* in_order[5]; const int32_t* in_seg[5];
+    const int32_t* out_order[3]; const int32_t* out_seg[3];
 } pa_batch;
 
 #define PA_T_MEMORY 0

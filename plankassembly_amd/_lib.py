@@ -90,6 +90,7 @@ def lib():
             "pa_colsum": (I, [P, I, I, I, I, P, I, P, P]),
             "pa_embed_input_fwd": (I, [P, I, P, P, P, I, I64, I, P]),
             "pa_embed_input_bwd": (I, [P, I, P, P, P, P, I, I64, I, P]),
+            "pa_embed_segment_bwd": (I, [P, I, P, P, P, P, I, I64, I, P]),
             "pa_pack_rows": (I, [P, I, I, P, P, P]),
             "pa_embed_output_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
             "pa_embed_output_bwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),

@@ -570,6 +570,56 @@ extern "C" int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* con
     return 0;
 }
 
+// Table gradients by sorted segments: the token rows were grouped by table row once when the batch was prepared
+// (order = rows sorted by id, seg[r] .. seg[r+1] = the rows that use table row r).  A block sums (a 64-row chunk
+// stride of) one segment in registers, 128 lanes x 4 columns, four token rows in flight.  Tables with few rows and
+// long segments are split over `ch` blocks per row, which then combine with one f32 atomic per column; otherwise
+// dtable[r] += sum with a plain read-modify-write.
+struct SegTab { float* t[PA_MAX_SEG_TABLES]; const int32_t* order[PA_MAX_SEG_TABLES]; const int32_t* seg[PA_MAX_SEG_TABLES];
+                int rows[PA_MAX_SEG_TABLES]; int ch[PA_MAX_SEG_TABLES]; int begin[PA_MAX_SEG_TABLES + 1]; int n; };
+template <typename T>
+__global__ __launch_bounds__(128) void embed_segment_bwd_kernel(const T* dout, SegTab tb, int d) {
+    int k = 0;
+    while (k + 1 < tb.n && (int)blockIdx.x >= tb.begin[k + 1]) ++k;
+    const int rel = blockIdx.x - tb.begin[k], ch = tb.ch[k];
+    const int r = rel / ch, j = rel - r * ch;
+    const int32_t* order = tb.order[k];
+    const int b0 = tb.seg[k][r], b1 = tb.seg[k][r + 1];
+    if (b0 + j * 64 >= b1) return;
+    for (int c = threadIdx.x << 2; c < d; c += 512) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = b0 + j * 64; s0 < b1; s0 += ch * 64) {
+            const int s1 = min(s0 + 64, b1);
+            int i = s0;
+            for (; i + 4 <= s1; i += 4) {
+                const f32x4 g0 = ld4<T>(dout + (int64_t)order[i] * d + c), g1 = ld4<T>(dout + (int64_t)order[i + 1] * d + c);
+                const f32x4 g2 = ld4<T>(dout + (int64_t)order[i + 2] * d + c), g3 = ld4<T>(dout + (int64_t)order[i + 3] * d + c);
+                acc += (g0 + g1) + (g2 + g3);
+            }
+            for (; i < s1; ++i) acc += ld4<T>(dout + (int64_t)order[i] * d + c);
+        }
+        float* dst = tb.t[k] + (int64_t)r * d + c;
+        if (ch == 1) *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + acc;
+        else { for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, acc[e]); }
+    }
+}
+extern "C" int pa_embed_segment_bwd(const void* dout, int32_t dtype, float* const* dtables, const int32_t* const* order,
+                                    const int32_t* const* seg, const int32_t* table_rows, int32_t n_tables, int64_t n_rows,
+                                    int32_t d, void* stream) {
+    if (!dout || !dtables || !order || !seg || !table_rows || n_tables < 1 || n_tables > PA_MAX_SEG_TABLES || (d & 3) || n_rows <= 0) return PA_EINVAL;
+    SegTab tb; tb.n = n_tables; tb.begin[0] = 0;
+    for (int k = 0; k < n_tables; ++k) {
+        tb.t[k] = dtables[k]; tb.order[k] = order[k]; tb.seg[k] = seg[k]; tb.rows[k] = table_rows[k];
+        if (!tb.t[k] || !tb.order[k] || !tb.seg[k] || tb.rows[k] <= 0) return PA_EINVAL;
+        int64_t ch = n_rows / ((int64_t)tb.rows[k] * 64);          // ~64-row chunks of an average segment
+        tb.ch[k] = (int)(ch < 1 ? 1 : (ch > 16 ? 16 : ch));
+        tb.begin[k + 1] = tb.begin[k] + tb.rows[k] * tb.ch[k];
+    }
+    if (dtype == PA_BF16) PA_LAUNCH(embed_segment_bwd_kernel<bf16>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const bf16*)dout, tb, d);
+    else PA_LAUNCH(embed_segment_bwd_kernel<float>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const float*)dout, tb, d);
+    return 0;
+}
+
 extern "C" int pa_embed_input_bwd(const void* dout, int32_t dtype, float* const* dtables, const int64_t* const* idx,
                                   const int32_t* rowmap, const int32_t* table_rows, int32_t n_tables, int64_t n_tok, int32_t d,
                                   void* stream) {

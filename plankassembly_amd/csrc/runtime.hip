@@ -470,8 +470,18 @@ int backward_segment_body(pa_model* m, int seg, float gscale, void* st) {
     if (seg == 0) { m->dmem_written = false; return bwd_heads(m, gscale, st); }
     if (seg <= c.n_dec) return bwd_dec_layer(m, c.n_dec - seg, st);
     if (seg == c.n_dec + 1)
+    {
+        const pa_batch& bt = m->batch;
+        if (bt.out_order[0] && bt.out_seg[0] && bt.out_order[1] && bt.out_seg[1] && bt.out_order[2] && bt.out_seg[2]) {
+            float* gt[3] = {G(P_IN_VALUE), G(P_Q_COORD), G(P_Q_POS)};
+            const int32_t* go[3] = {bt.out_order[0], bt.out_order[1], bt.out_order[2]};
+            const int32_t* gs[3] = {bt.out_seg[0], bt.out_seg[1], bt.out_seg[2]};
+            int32_t gr[3] = {c.in_table_rows[0], c.out_dof, (T + c.out_dof - 1) / c.out_dof};
+            return pa_embed_segment_bwd(m->gA, c.dtype, gt, go, gs, gr, 3, (int64_t)B * T, d, st);
+        }
         return pa_embed_output_bwd(m->gA, c.dtype, G(P_IN_VALUE), G(P_Q_COORD), G(P_Q_POS), m->batch.output_value, T, B, T, d,
                                    c.out_dof, st);
+    }
     if (seg == c.n_dec + 2) {
         if (!m->dmem_written) {       // no decoder layers: memory got no gradient
             hipError_t he = hipMemsetAsync(m->dmem, 0, (size_t)BS * d * m->esz, (hipStream_t)st);
@@ -489,6 +499,25 @@ int backward_segment_body(pa_model* m, int seg, float gscale, void* st) {
     if (es < c.n_enc) return bwd_enc_layer(m, c.n_enc - 1 - es, st);
     if (es == c.n_enc) {
         float* dt[5] = {G(P_IN_VALUE), G(P_IN_POS), G(P_IN_COORD), G(P_IN_VIEW), G(P_IN_TYPE)};
+        const pa_batch& bt = m->batch;
+        {   // tables with a per-batch grouping: segment sums; the rest: scatter-add kernel
+            float* gt[5]; const int32_t* go[5]; const int32_t* gs[5]; int32_t gr[5]; int ng = 0;
+            const int64_t* idx2[5];
+            bool any = false;
+            for (int j = 0; j < 5; ++j) {
+                idx2[j] = bt.input_idx[j];
+                if (bt.input_idx[j] && bt.in_order[j] && bt.in_seg[j]) {
+                    gt[ng] = dt[j]; go[ng] = bt.in_order[j]; gs[ng] = bt.in_seg[j]; gr[ng] = c.in_table_rows[j]; ++ng;
+                    idx2[j] = nullptr;
+                }
+                any = any || idx2[j] != nullptr;
+            }
+            if (ng > 0) {
+                RC(pa_embed_segment_bwd(m->gA, c.dtype, gt, go, gs, gr, ng, (int64_t)BS, d, st));
+                if (!any) return 0;
+                return pa_embed_input_bwd(m->gA, c.dtype, dt, idx2, bt.rowmap, c.in_table_rows, 5, (int64_t)BS, d, st);
+            }
+        }
         return pa_embed_input_bwd(m->gA, c.dtype, dt, m->batch.input_idx, m->batch.rowmap, c.in_table_rows, 5, (int64_t)BS, d, st);
     }
     return PA_EINVAL;

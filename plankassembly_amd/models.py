@@ -50,7 +50,9 @@ class _Batch(C.Structure):
     _fields_ = [("input_idx", C.c_void_p * 5), ("input_mask", C.c_void_p), ("output_value", C.c_void_p),
                 ("output_label", C.c_void_p), ("output_mask", C.c_void_p),
                 ("B", C.c_int32), ("S", C.c_int32), ("T", C.c_int32),
-                ("cu_in", C.c_void_p), ("rowmap", C.c_void_p), ("n_valid", C.c_int32)]
+                ("cu_in", C.c_void_p), ("rowmap", C.c_void_p), ("n_valid", C.c_int32),
+                ("in_order", C.c_void_p * 5), ("in_seg", C.c_void_p * 5),
+                ("out_order", C.c_void_p * 3), ("out_seg", C.c_void_p * 3)]
 
 
 INPUT_KEYS = ("input_value", "input_pos", "input_coord", "input_view", "input_type")
@@ -444,6 +446,17 @@ class PlankModel(nn.Module):
             keep += [cu, rowmap]
             b.cu_in, b.rowmap, b.n_valid = cu.data_ptr(), rowmap.data_ptr(), n_valid
             self._last_pack = (cu, rowmap, n_valid, B, S)
+            groups = batch.get("_groups")
+            if groups is not None and with_output:
+                for j, grp in enumerate(groups["in"]):      # encoder rows grouped by table row, per input table
+                    if grp is not None and grp[0].device == m.device:
+                        keep += [grp[0], grp[1]]
+                        b.in_order[j], b.in_seg[j] = grp[0].data_ptr(), grp[1].data_ptr()
+                og = groups.get("out")
+                if og is not None and og[0][0].device == m.device and groups.get("out_T") == batch["output_value"].shape[1]:
+                    for j, grp in enumerate(og):            # decoder rows grouped by value / coord / pos table row
+                        keep += [grp[0], grp[1]]
+                        b.out_order[j], b.out_seg[j] = grp[0].data_ptr(), grp[1].data_ptr()
         else:
             self._last_pack = None
         T = self.max_output_length
@@ -477,6 +490,37 @@ class PlankModel(nn.Module):
             msk = out["input_mask"].contiguous()
             msk = msk.view(torch.uint8) if msk.dtype == torch.bool else msk.to(torch.uint8)
             out["_pack"] = self._pack(msk)
+            # group the token rows by embedding-table row: the table gradients then are segment sums instead of millions
+            # of atomics (pa_embed_segment_bwd).  Batch-only information, like the packing.
+            cu, rowmap, n_valid = out["_pack"]
+
+            def group(ids, rows, row_index=None):
+                order = torch.argsort(ids, stable=True)
+                if row_index is not None:
+                    order = row_index[order]
+                seg = torch.zeros(rows + 1, dtype=torch.int32, device=dev)
+                seg[1:] = torch.cumsum(torch.bincount(ids, minlength=rows)[:rows], 0).to(torch.int32)
+                return order.to(torch.int32).contiguous(), seg
+
+            gin = []
+            sel = rowmap[:n_valid].long()
+            for key in INPUT_KEYS:
+                t = out.get(key)
+                rows = self._shapes.get(f"input_embeddings.{key}.weight", (None,))[0]
+                gin.append(None if (t is None or rows is None) else group(t.reshape(-1)[sel], rows))
+            groups = {"in": gin}
+            ov = out.get("output_value")
+            if ov is not None:
+                Bq, Tq = ov.shape
+                dof = self.num_output_dof
+                tpos = torch.arange(1, Tq, device=dev)                              # decoder row (b, t) embeds token t-1
+                rows_bt = (torch.arange(Bq, device=dev)[:, None] * Tq + tpos[None, :]).reshape(-1)
+                prev = (tpos - 1)[None, :].expand(Bq, -1).reshape(-1)
+                groups["out"] = [group(ov[:, :-1].reshape(-1), self._shapes["input_embeddings.input_value.weight"][0], rows_bt),
+                                 group(prev % dof, dof, rows_bt),
+                                 group(prev // dof, (Tq + dof - 1) // dof, rows_bt)]      # the rows the runtime walks
+                groups["out_T"] = Tq
+            out["_groups"] = groups
         return out
 
     def _workspace(self, B, S, T):

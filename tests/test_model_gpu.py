@@ -69,6 +69,25 @@ def test_g3_fused_adam_step(small_fixture):
             assert float(diff[solid].max()) < 2e-6, (k, float(diff[solid].max()))
 
 
+@pytest.mark.parametrize("fixture_name", ["small_fixture", "ragged_fixture"])
+def test_prepared_batch_matches_golden_gradients(fixture_name, request):
+    """prepare_batch() attaches the encoder packing and the per-table row groupings (segment-sum embedding gradients
+    instead of atomics): every gradient must still match the reference's (G2)."""
+    sd, batch, g = request.getfixturevalue(fixture_name)
+    m = make(sd).train()
+    pb = m.prepare_batch(batch)
+    assert "_groups" in pb and pb["_groups"]["out"] is not None
+    out = m(pb)
+    assert abs(out["loss"].item() - float(g["g1::loss"])) < 1e-4
+    out["loss"].backward()
+    for k, p in m.named_parameters():
+        if ("g2::" + k) not in g:
+            continue
+        ref = torch.from_numpy(g["g2::" + k])
+        err = float((p.grad.cpu() - ref).abs().max())
+        assert err <= 1e-5 + 1e-4 * float(ref.abs().max()), (k, err)
+
+
 def test_g7_ragged_sideface_f32(ragged_fixture):
     sd, batch, g = ragged_fixture
     m = make(sd).train()
