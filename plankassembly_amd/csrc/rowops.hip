@@ -571,36 +571,63 @@ extern "C" int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* con
 }
 
 // Table gradients by sorted segments: the token rows were grouped by table row once when the batch was prepared
-// (order = rows sorted by id, seg[r] .. seg[r+1] = the rows that use table row r).  A block sums (a 64-row chunk
-// stride of) one segment in registers, 128 lanes x 4 columns, four token rows in flight.  Tables with few rows and
-// long segments are split over `ch` blocks per row, which then combine with one f32 atomic per column; otherwise
-// dtable[r] += sum with a plain read-modify-write.
+// (order = rows sorted by id, seg[r] .. seg[r+1] = the rows that use table row r).  Sums run in registers, 128 lanes x 4
+// columns, four token rows in flight.
 struct SegTab { float* t[PA_MAX_SEG_TABLES]; const int32_t* order[PA_MAX_SEG_TABLES]; const int32_t* seg[PA_MAX_SEG_TABLES];
                 int rows[PA_MAX_SEG_TABLES]; int ch[PA_MAX_SEG_TABLES]; int begin[PA_MAX_SEG_TABLES + 1]; int n; };
+constexpr int SEG_CHUNK = 128;
+template <typename T>
+__device__ __forceinline__ f32x4 seg_sum(const T* dout, const int32_t* order, int lo, int hi, int d, int c) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int i = lo;
+    for (; i + 8 <= hi; i += 8) {                 // eight independent index loads, then eight row loads in flight
+        int o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = order[i + j];
+        f32x4 g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = ld4<T>(dout + (int64_t)o[j] * d + c);
+        acc += ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
+    }
+    if (i < hi) {
+        int o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = order[min(i + j, hi - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const f32x4 g = ld4<T>(dout + (int64_t)o[j] * d + c); if (i + j < hi) acc += g; }
+    }
+    return acc;
+}
+// ch[k] == 1: one block per table row (plain read-modify-write, no atomics) - tables with many rows / short segments.
+// ch[k] == 0: one block per SEG_CHUNK consecutive entries of the sorted order, whatever rows they belong to (a table with a
+// handful of rows has segments of thousands of tokens); per overlapped row one atomic per column.
 template <typename T>
 __global__ __launch_bounds__(128) void embed_segment_bwd_kernel(const T* dout, SegTab tb, int d) {
     int k = 0;
     while (k + 1 < tb.n && (int)blockIdx.x >= tb.begin[k + 1]) ++k;
-    const int rel = blockIdx.x - tb.begin[k], ch = tb.ch[k];
-    const int r = rel / ch, j = rel - r * ch;
+    const int rel = blockIdx.x - tb.begin[k];
     const int32_t* order = tb.order[k];
-    const int b0 = tb.seg[k][r], b1 = tb.seg[k][r + 1];
-    if (b0 + j * 64 >= b1) return;
-    for (int c = threadIdx.x << 2; c < d; c += 512) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s0 = b0 + j * 64; s0 < b1; s0 += ch * 64) {
-            const int s1 = min(s0 + 64, b1);
-            int i = s0;
-            for (; i + 4 <= s1; i += 4) {
-                const f32x4 g0 = ld4<T>(dout + (int64_t)order[i] * d + c), g1 = ld4<T>(dout + (int64_t)order[i + 1] * d + c);
-                const f32x4 g2 = ld4<T>(dout + (int64_t)order[i + 2] * d + c), g3 = ld4<T>(dout + (int64_t)order[i + 3] * d + c);
-                acc += (g0 + g1) + (g2 + g3);
-            }
-            for (; i < s1; ++i) acc += ld4<T>(dout + (int64_t)order[i] * d + c);
+    const int32_t* seg = tb.seg[k];
+    if (tb.ch[k] == 1) {
+        const int b0 = seg[rel], b1 = seg[rel + 1];
+        if (b0 >= b1) return;
+        for (int c = threadIdx.x << 2; c < d; c += 512) {
+            float* dst = tb.t[k] + (int64_t)rel * d + c;
+            *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + seg_sum<T>(dout, order, b0, b1, d, c);
         }
-        float* dst = tb.t[k] + (int64_t)r * d + c;
-        if (ch == 1) *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + acc;
-        else { for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, acc[e]); }
+    } else {
+        const int c0 = rel * SEG_CHUNK, c1 = min(c0 + SEG_CHUNK, seg[tb.rows[k]]);
+        if (c0 >= c1) return;
+        for (int r = 0; r < tb.rows[k]; ++r) {
+            const int lo = max(seg[r], c0), hi = min(seg[r + 1], c1);
+            if (lo >= hi) continue;
+            for (int c = threadIdx.x << 2; c < d; c += 512) {
+                const f32x4 acc = seg_sum<T>(dout, order, lo, hi, d, c);
+                float* dst = tb.t[k] + (int64_t)r * d + c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, acc[e]);
+            }
+        }
     }
 }
 extern "C" int pa_embed_segment_bwd(const void* dout, int32_t dtype, float* const* dtables, const int32_t* const* order,
@@ -611,9 +638,8 @@ extern "C" int pa_embed_segment_bwd(const void* dout, int32_t dtype, float* cons
     for (int k = 0; k < n_tables; ++k) {
         tb.t[k] = dtables[k]; tb.order[k] = order[k]; tb.seg[k] = seg[k]; tb.rows[k] = table_rows[k];
         if (!tb.t[k] || !tb.order[k] || !tb.seg[k] || tb.rows[k] <= 0) return PA_EINVAL;
-        int64_t ch = n_rows / ((int64_t)tb.rows[k] * 64);          // ~64-row chunks of an average segment
-        tb.ch[k] = (int)(ch < 1 ? 1 : (ch > 16 ? 16 : ch));
-        tb.begin[k + 1] = tb.begin[k] + tb.rows[k] * tb.ch[k];
+        tb.ch[k] = tb.rows[k] > 64 ? 1 : 0;
+        tb.begin[k + 1] = tb.begin[k] + (tb.ch[k] ? tb.rows[k] : (int)((n_rows + SEG_CHUNK - 1) / SEG_CHUNK));
     }
     if (dtype == PA_BF16) PA_LAUNCH(embed_segment_bwd_kernel<bf16>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const bf16*)dout, tb, d);
     else PA_LAUNCH(embed_segment_bwd_kernel<float>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const float*)dout, tb, d);
