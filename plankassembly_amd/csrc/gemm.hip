@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
 // with the next k-step's fragment reads - with one 32 x 32 MFMA tile per wave (2 x 2 waves), so a K tile costs a
 // quarter of the LDS / MFMA time and four times as many CUs share the problem.  bf16, both operands k-contiguous,
 // K % 64 == 0, one problem, no split-K.
-__global__ __launch_bounds__(NT, 1) void gemm3s_kernel(GemmP p) {
+__global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
     using T = bf16;
     constexpr int TB = 64;                              // tile edge
     constexpr int RB = 128, NCH = 8;                    // bytes / 16-byte chunks per LDS row (64 bf16)
@@ -1591,7 +1591,7 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         GemmP ps = pk;
         ps.tiles_m = (a->M + 63) / 64; ps.tiles_n = (a->N + 63) / 64; ps.tiles_m_pad = ps.tiles_m; ps.plain_order = 1;
         ps.units = ps.tiles_m * ps.tiles_n * a->batch;
-        const int gs = ps.units < 256 ? ps.units : 256;
+        const int gs = ps.units < 512 ? ps.units : 512;       // two 80 KB blocks fit a CU
         PA_LAUNCH(gemm3s_kernel, dim3(gs), dim3(NT), 0, st, ps);
         rc = 0;
     } else

@@ -158,7 +158,8 @@ size_t pa_train_layout(pa_model* m, char* base, int B, int S, int T) {
         t.r2 = (float*)a.take(BT * 4); t.m3 = (float*)a.take(BT * 4); t.r3 = (float*)a.take(BT * 4);
     }
     m->hid = a.take(BT * d * e); m->hid_m = (float*)a.take(BT * 4); m->hid_r = (float*)a.take(BT * 4);
-    m->ldv = (c.vocab + 7) / 8 * 8;
+    m->ldv = (c.vocab + 63) / 64 * 64;     // logits / d(logits) rows padded to a whole K tile: the pad columns are written as zeros
+                                           // (mixture_nll_bwd), so dX = d(logits) x W runs as an aligned GEMM with K = ldv
     m->vlog = (float*)a.take(BT * m->ldv * 4); m->pfeat = a.take(BT * d * e);
     m->plog = (float*)a.take(BT * T * 4); m->sw = (float*)a.take(BT * 4); m->row_lse = (float*)a.take(BT * 2 * 4);
     // backward temporaries
@@ -294,7 +295,11 @@ int bwd_heads(pa_model* m, float gscale, void* st) {
     RC(pa_mixture_nll_bwd(m->dvlog, m->dplog, c.dtype, m->dsw, m->stats, m->row_lse, m->vlog, m->ldv, m->plog, m->sw,
                           m->batch.output_label, B, T, c.vocab, c.pad, gscale, st));
     // vocab head
-    RC(k.linear_dx(m->dvlog, m->ldv, m->pl[tl + T_VOCAB_W], d, m->gA, d, BT, c.vocab, d));
+    if (m->plT[tl + T_VOCAB_W])       // padded W^T shadow [d][ldv] (pad columns zero): contraction over the padded width, both k-contiguous
+        RC(k.linear_dx(m->dvlog, m->ldv, m->pl[tl + T_VOCAB_W], d, m->gA, d, BT, m->ldv, d, nullptr, 0, nullptr, 0, 1.f,
+                       m->plT[tl + T_VOCAB_W], m->ldv));
+    else
+        RC(k.linear_dx(m->dvlog, m->ldv, m->pl[tl + T_VOCAB_W], d, m->gA, d, BT, c.vocab, d));
     RC(k.linear_dw(m->dvlog, m->ldv, m->hid, d, G(tl + T_VOCAB_W), G(tl + T_VOCAB_B), BT, c.vocab, d));
     // pointer head: plog[b] = pfeat[b] hid[b]^T / d
     {

@@ -378,6 +378,16 @@ class PlankModel(nn.Module):
         for i, k in enumerate(self._order):
             s = self._shapes[k]
             is_linear_w = len(s) == 2 and ("proj" in k or "linear" in k or k == "pointer_head.weight")
+            if k == "vocab_head.weight" and s[1] % 8 == 0:
+                # [vocab][d] -> W^T [d][ldv] with the vocabulary padded to a whole K tile (pad columns stay zero): the
+                # runtime contracts d(logits) [rows][ldv] with it (csrc/runtime.hip bwd_heads)
+                ldv = (s[0] + 63) // 64 * 64
+                self._vocabT = torch.zeros(s[1] * ldv, dtype=torch.bfloat16, device=dev)
+                tab[i] = self._vocabT.data_ptr()
+                d = _TrDesc(self._shadow.data_ptr() + self._offsets[k] * 2, self._vocabT.data_ptr(), s[0], s[1], s[1], ldv, tiles, 0)
+                tiles += ((s[0] + 63) // 64) * ((s[1] + 63) // 64)
+                descs.append(d)
+                continue
             if not is_linear_w or s[0] % 8 or s[1] % 8:
                 tab[i] = None
                 continue
