@@ -135,7 +135,7 @@ def gemm_census(model, batch, train_step):
         ev[1].synchronize()
         t = ev[0].elapsed_time(ev[1]) * 1e-3 / reps
         lay = "tt" if (a.a_kcontig and a.b_kcontig) else ("nn" if not (a.a_kcontig or a.b_kcontig) else "mixed")
-        key = ("ring" if (i < nk and kinds[i] == 1) else "pair") + "_" + lay
+        key = ({1: "ring", 2: "wide"}.get(kinds[i] if i < nk else 0, "pair")) + "_" + lay
         f = fam.setdefault(key, dict(launches=0, flops=0.0, seconds=0.0))
         f["launches"] += 1
         f["flops"] += 2.0 * a.M * a.N * a.K * a.batch
@@ -385,7 +385,8 @@ def main():
             c = census[key]
             names = {"ring_tt": "gemm3_kernel<true,true> (bf16, 128x128x64 tiles, one block per CU, 4-stage LDS ring)",
                      "ring_nn": "gemm3_kernel<false,false> (bf16 dW, split-K, incl. splitk_reduce_kernel)",
-                     "pair_tt": "gemm_kernel<bf16,64,2,true,true,...> (two blocks per CU)"}
+                     "pair_tt": "gemm_kernel<bf16,64,2,true,true,...> (two blocks per CU)",
+                     "wide_tt": "gemm3w_kernel<2,4> (bf16, 128x256x64 tiles, one block per CU, 3-stage LDS ring)"}
             ach = c["flops"] / c["seconds"] / 1e12
             line["roofline"] = {"kernel": names.get(key, key) + " - every launch of it in one train step, replayed under HIP events",
                                 "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

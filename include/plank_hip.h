@@ -83,6 +83,7 @@ int pa_gemm_recorded(pa_gemm_args* out, int32_t cap);
  * PA_GEMM_KIND_PAIR = gemm_kernel (two blocks per CU; everything else). */
 #define PA_GEMM_KIND_PAIR 0
 #define PA_GEMM_KIND_RING 1
+#define PA_GEMM_KIND_WIDE 2   /* gemm3w_kernel: 128 x 256 tiles for the large multi-round Linears */
 int pa_gemm_recorded_kinds(int32_t* out, int32_t cap);
 
 /* Several weight-gradient GEMMs (dW = dY^T X: bf16 operands, contraction index strided in both, f32 output, no

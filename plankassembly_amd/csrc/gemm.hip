@@ -21,6 +21,7 @@
 #include <mutex>
 #include <vector>
 #include <type_traits>
+#include <utility>
 #include "common.cuh"
 #include <mutex>
 #include <vector>
@@ -1401,6 +1402,297 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
 #undef PA_RD128
 }
 
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [LO, HI)
+template <int LO, int... I, typename F>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, LO + I>{}), ...); }
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl<LO>(f, std::make_integer_sequence<int, (HI > LO ? HI - LO : 0)>{}); }
+
+// -------------------------------------------------------------------------------------------------
+// Wide-tile ring kernel: (64*FM) x (64*FN) x 64 tiles, 2 x 2 waves with FM x FN 32x32 MFMA tiles each, for the large
+// multi-round Linears (N >= 1024).  With FM = 2, FN = 4 (128 x 256) a k-step is 8 MFMAs against 6 fragment reads, so the
+// LDS traffic per flop drops by a third against the 128 x 128 kernels and the MFMA pipe, not LDS, bounds the K loop.
+// 3-stage ring (3 x 48 KB) + 4 KB staging per wave.  bf16, both operands k-contiguous, K % 64 == 0, no split-K.
+template <int FM, int FN>
+__global__ __launch_bounds__(NT, 1) void gemm3w_kernel(GemmP p) {
+    using T = bf16;
+    constexpr int TBM = 64 * FM, TBN = 64 * FN;
+    constexpr int RB = 128, NCH = 8;
+    constexpr int A_BYTES = TBM * RB, B_BYTES = TBN * RB;
+    constexpr int NLA = TBM * NCH / NT, NLB = TBN * NCH / NT, NLD = NLA + NLB;      // 16-byte DMA chunks per thread per item
+    constexpr int NSTG = 3, STAGE = A_BYTES + B_BYTES, EPI = 32 * 32 * 4;
+    static_assert(NSTG * STAGE + 4 * EPI <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(256))) char smem[NSTG * STAGE + 4 * EPI];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5;
+    constexpr int esz = 2;
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint32_t offA[NLA], offB[NLB];
+    const char* kA = nullptr; const char* kB = nullptr;
+    auto setup = [&](const Unit& un) {
+        kA = reinterpret_cast<const char*>(p.A) + (size_t)un.b * p.sA * esz;
+        kB = reinterpret_cast<const char*>(p.B) + (size_t)un.b * p.sB * esz;
+        const int m0 = un.tile_m * TBM, n0 = un.tile_n * TBN;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int pidx = tid + i * NT, row = pidx / NCH, ch = ((pidx % NCH) ^ (row / 2)) & (NCH - 1);
+            offA[i] = (uint32_t)min(m0 + row, p.M - 1) * (uint32_t)(p.lda * esz) + ch * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const int pidx = tid + i * NT, row = pidx / NCH, ch = ((pidx % NCH) ^ (row / 2)) & (NCH - 1);
+            offB[i] = (uint32_t)min(n0 + row, p.N - 1) * (uint32_t)(p.ldb * esz) + ch * 16;
+        }
+    };
+    // chunk c of an item's DMA: c < NLA -> A chunk c, else B chunk c - NLA
+    auto fetch_c = [&](int stage, auto C_) {
+        constexpr int c = decltype(C_)::value;
+        char* lx = smem + stage * STAGE + (c < NLA ? 0 : A_BYTES);
+        constexpr int i = c < NLA ? c : c - NLA;
+        const char* src = (c < NLA) ? kA + offA[i] : kB + offB[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            (__attribute__((address_space(3))) void*)(lx + (i * NT + wave * 64) * 16), 16, 0, 0);
+    };
+    auto fetch_done = [&]() { kA += 64 * esz; kB += 64 * esz; };
+    auto fetch_range = [&](int stage, auto LO_, auto HI_) {
+        constexpr int LO = decltype(LO_)::value, HI = decltype(HI_)::value;
+        static_for<LO, HI>([&](auto I_) { fetch_c(stage, I_); });
+    };
+    auto fetch = [&](int stage) {
+        fetch_range(stage, std::integral_constant<int, 0>{}, std::integral_constant<int, NLD>{});
+        fetch_done();
+    };
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    const int sw = ((lane & 31) >> 1) & 7;
+    uint32_t xs[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) xs[s_] = (uint32_t)((((2 * s_ + half) ^ sw) & 7) << 4);
+    const uint32_t fa_off = (wm * 32 * FM + (lane & 31)) * RB, fb_off = (wn * 32 * FN + (lane & 31)) * RB + A_BYTES;
+#define PA_RD128O(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+    // fragment W of k-step s: W < FM -> A row group W, else B row group W - FM
+    auto rd1 = [&](u32x4 (&f)[FM + FN], uint32_t st, int s_, auto W_) {
+        constexpr int W = decltype(W_)::value;
+        if constexpr (W < FM) { const uint32_t ad = st + fa_off + xs[s_]; PA_RD128O(f[W], ad, W * 32 * RB); }
+        else { const uint32_t ad = st + fb_off + xs[s_]; PA_RD128O(f[W], ad, (W - FM) * 32 * RB); }
+    };
+    auto frag = [&](u32x4 (&f)[FM + FN], uint32_t st, int s_) {
+        static_for<0, FM + FN>([&](auto I_) { rd1(f, st, s_, I_); });
+    };
+    auto wait_frag = [&](u32x4 (&f)[FM + FN]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < FM + FN; ++i) asm volatile("" : "+v"(f[i]));
+    };
+
+    // ---- epilogue: one 32 x 32 accumulator tile at a time through a 4 KB per-wave staging slice ------------------------
+    auto epilogue = [&](const Unit& un) {
+        char* stage = smem + NSTG * STAGE + wave * EPI;
+        const size_t cbase = (size_t)un.b * p.sC;
+        const int chunk = lane & 7, rsub = lane >> 3;
+        const bool out_f32 = p.out_dtype == PA_F32;
+        const bool has_bias = p.bias != nullptr, has_aux = p.aux != nullptr, has_res = p.R != nullptr, has_drop = p.drop_thr != 0;
+        constexpr int NIT = 4;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int nw = un.tile_n * TBN + (wn * FN + fn) * 32;
+            const int n = nw + chunk * 4;
+            const bool fast = p.vec_ok && (nw + 32 <= p.N);
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            if (has_bias) {
+                if (fast) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+                else { for (int e = 0; e < 4; ++e) if (n + e < p.N) bias[e] = p.bias[n + e]; }
+            }
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int mw = un.tile_m * TBM + (wm * FM + fm) * 32;
+                {
+                    const int lrow = lane & 31;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[fn][fm][4 * g4 + e];
+                        const int ch = 2 * g4 + half;
+                        *reinterpret_cast<f32x4*>(stage + lrow * 128 + ((ch ^ (lrow & 7)) << 4)) = v;
+                    }
+                }
+                f32x4 x[NIT];
+                const int mp = mw + rsub;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int lr = it * 8 + rsub;
+                    x[it] = *reinterpret_cast<const f32x4*>(stage + lr * 128 + ((chunk ^ (lr & 7)) << 4));
+                }
+                if (fast) {
+                    f32x4 res[NIT], gate[NIT];
+                    if (has_res) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const size_t ro = (size_t)un.b * p.sR + (size_t)min(mp + it * 8, p.M - 1) * p.ldr + n;
+                            res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(p.R) + ro)
+                                              : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+                        }
+                    }
+                    if (has_aux) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const size_t ao = (size_t)un.b * p.sAux + (size_t)min(mp + it * 8, p.M - 1) * p.ldaux + n;
+                            gate[it] = ld4<T>(reinterpret_cast<const T*>(p.aux) + ao);
+                        }
+                    }
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float y = x[it][e] * p.alpha + bias[e];
+                            if (p.relu) y = fmaxf(y, 0.f);
+                            if (has_aux) y = gate[it][e] > 0.f ? y * p.aux_scale : 0.f;
+                            if (has_drop) {
+                                const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + mp + it * 8) * p.N + n + e);
+                                y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
+                            }
+                            if (has_res) y += res[it][e];
+                            x[it][e] = y;
+                        }
+                    }
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int m = mp + it * 8;
+                        if (m < p.M) {
+                            const size_t co = cbase + (size_t)m * p.ldc + n;
+                            if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = x[it];
+                            else st4<bf16>(reinterpret_cast<bf16*>(p.C) + co, x[it]);
+                        }
+                    }
+                } else {
+#pragma unroll 1
+                    for (int it = 0; it < NIT; ++it) {
+                        const int m = mp + it * 8;
+                        if (m >= p.M) continue;
+                        for (int e = 0; e < 4; ++e) {
+                            if (n + e >= p.N) continue;
+                            float y = x[it][e] * p.alpha + bias[e];
+                            if (p.relu) y = fmaxf(y, 0.f);
+                            if (has_aux) {
+                                const float g = ld1(reinterpret_cast<const T*>(p.aux) + (size_t)un.b * p.sAux + (size_t)m * p.ldaux + n + e);
+                                y = g > 0.f ? y * p.aux_scale : 0.f;
+                            }
+                            if (has_drop) {
+                                const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + m) * p.N + n + e);
+                                y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
+                            }
+                            if (has_res) {
+                                const size_t ro = (size_t)un.b * p.sR + (size_t)m * p.ldr + n + e;
+                                y += out_f32 ? reinterpret_cast<const float*>(p.R)[ro] : (float)reinterpret_cast<const bf16*>(p.R)[ro];
+                            }
+                            const size_t co = cbase + (size_t)m * p.ldc + n + e;
+                            if (out_f32) reinterpret_cast<float*>(p.C)[co] = y;
+                            else reinterpret_cast<bf16*>(p.C)[co] = (bf16)y;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
+            }
+        }
+    };
+
+    // ---- item stream: DMA cursor NSTG - 1 = 2 items ahead; units in XCD-interleaved order over the row tiles ------------
+    const int ustride = gridDim.x, nt = p.K / 64;
+    auto unit_of = [&](int u, Unit& un) -> bool {
+        const int per_b = p.tiles_m_pad * p.tiles_n;
+        un.b = u / per_b; un.z = un.b;
+        const int r = u - un.b * per_b;
+        const int xcd = r & 7, i = r >> 3, q = i / p.tiles_n;
+        un.tile_n = i - q * p.tiles_n; un.tile_m = q * 8 + xcd;
+        un.t_begin = 0; un.t_end = nt;
+        return un.tile_m < p.tiles_m;
+    };
+    auto seek = [&](int u, Unit& un) -> int { while (u < p.units && !unit_of(u, un)) u += ustride; return u; };
+    Unit cun, dun;
+    int cc_u = seek(blockIdx.x, cun), cc_t = 0;
+    if (cc_u >= p.units) return;
+    int cd_u = seek(blockIdx.x, dun), cd_t = 0;
+    setup(dun);
+    int sd = 0, pending = 0;
+    auto issue = [&]() {
+        fetch(sd);
+        sd = sd + 1 == NSTG ? 0 : sd + 1;
+        ++pending;
+        if (++cd_t >= nt) { cd_u = seek(cd_u + ustride, dun); cd_t = 0; if (cd_u < p.units) setup(dun); }
+    };
+    auto wait_items = [&](int younger) {        // items are NLD DMA instructions each
+        if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#pragma unroll 1
+    for (int k = 0; k < NSTG - 1; ++k) if (cd_u < p.units) issue();
+    wait_items(pending - 1);
+    __builtin_amdgcn_s_barrier();
+    int sc = 0;
+    u32x4 F0[FM + FN], F1[FM + FN];
+    frag(F0, lds0, 0);
+    auto mma_all = [&](u32x4 (&f)[FM + FN]) {
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) mma16B<T>(acc[fn][fm], f[FM + fn], f[fm]);
+    };
+    auto item = [&](auto HOT_) -> bool {
+        constexpr bool HOT = decltype(HOT_)::value;
+        const uint32_t st = lds0 + sc * STAGE;
+        __builtin_amdgcn_s_barrier();           // barrier A: the previous item's stage may be refilled
+        if constexpr (!HOT) { if (cd_u < p.units) issue(); }
+        constexpr int Q = (NLD + 2) / 3;        // DMA chunks per k-step in the hot loop (all issued by the end of k-step 2)
+        wait_frag(F0); frag(F1, st, 1); mma_all(F0);
+        if constexpr (HOT) fetch_range(sd, std::integral_constant<int, 0>{}, std::integral_constant<int, Q>{});
+        wait_frag(F1); frag(F0, st, 2); mma_all(F1);
+        if constexpr (HOT) fetch_range(sd, std::integral_constant<int, Q>{}, std::integral_constant<int, (2 * Q < NLD ? 2 * Q : NLD)>{});
+        wait_frag(F0); frag(F1, st, 3); mma_all(F0);
+        if constexpr (HOT) {
+            fetch_range(sd, std::integral_constant<int, (2 * Q < NLD ? 2 * Q : NLD)>{}, std::integral_constant<int, NLD>{});
+            fetch_done(); sd = sd + 1 == NSTG ? 0 : sd + 1; ++cd_t;
+        }
+        const bool has_next = HOT || pending >= 2;
+        wait_frag(F1);
+        if (has_next) {
+            if constexpr (HOT) wait_items(1); else wait_items(pending - 2);
+            __builtin_amdgcn_s_barrier();       // barrier B: the next item has landed for every wave
+            frag(F0, lds0 + (sc + 1 == NSTG ? 0 : sc + 1) * STAGE, 0);
+        }
+        mma_all(F1);
+        sc = sc + 1 == NSTG ? 0 : sc + 1;
+        if constexpr (HOT) { ++cc_t; return true; }
+        else {
+            if (++cc_t >= nt) {
+                epilogue(cun);
+                cc_t = 0;
+                if (has_next) cc_u = seek(cc_u + ustride, cun);
+            }
+            --pending;
+            return has_next;
+        }
+    };
+#pragma unroll 1
+    while (true) {
+        int hot = (pending == NSTG - 1 && cd_u == cc_u) ? (nt - cd_t - 1) : 0;
+#pragma unroll 1
+        for (; hot > 0; --hot) item(std::true_type{});
+        if (!item(std::false_type{})) break;
+    }
+#undef PA_RD128O
+}
+
 // split-K second pass: sum the slabs and apply the epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float* ws) {
@@ -1583,7 +1875,23 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     // with more rounds the two-blocks-per-CU kernel overlaps better.  PA_GEMM_V3=2 forces v3 for every eligible launch.
     const int valid_units = p.tiles_m * p.tiles_n * a->batch * splitk;
     const bool go_v3 = use_v3 && (valid_units <= 256 || use_v3 == 2) && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds && is_aligned<bf16>(a) && v3_layout_ok;
-    if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR); }
+    // 128 x 256 kernel: opt-in (PA_GEMM_WIDE=1).  Measured on MI355X: 0.73 us per K tile (0.37 per 128 x 128 equivalent, the best
+    // of the four kernels) but 14.8 us fixed cost against 11.9 us (eight staged 32 x 32 epilogue passes), so at the model's
+    // K = 512 it loses to the two-blocks-per-CU kernel (20.4 vs 18.5 us at 7 940 x 1 024) and only wins from K ~ 2 048 on.
+    static const int use_wide = getenv("PA_GEMM_WIDE") ? atoi(getenv("PA_GEMM_WIDE")) : 0;
+    const bool go_wide = use_v3 && use_wide && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds && is_aligned<bf16>(a) && a->a_kcontig &&
+                         a->b_kcontig && splitk == 1 && a->K % 64 == 0 && a->N >= 1024 && valid_units > 256;
+    if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_wide ? PA_GEMM_KIND_WIDE : (go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR)); }
+    // wide-tile ring kernel: large multi-round k-contiguous Linears (N >= 1024): 128 x 256 tiles
+    if (go_wide) {
+        GemmP pw = pk;
+        pw.tiles_m = (a->M + 127) / 128; pw.tiles_n = (a->N + 255) / 256;
+        pw.tiles_m_pad = (pw.tiles_m + 7) / 8 * 8; pw.plain_order = 0;
+        pw.units = pw.tiles_m_pad * pw.tiles_n * a->batch;
+        const int gw = pw.units < 256 ? pw.units : 256;
+        PA_LAUNCH((gemm3w_kernel<2, 4>), dim3(gw), dim3(NT), 0, st, pw);
+        return 0;
+    }
     // small-tile ring kernel: plain k-contiguous Linears whose 128 x 128 tiling covers at most half of the CUs (measured: <= 128 units 7.05 ms/step, <= 64 7.11, <= 256 7.53)
     static const int use_small = getenv("PA_GEMM_SMALL") ? atoi(getenv("PA_GEMM_SMALL")) : 1;
     static const int small_max = getenv("PA_GEMM_SMALL_MAX") ? atoi(getenv("PA_GEMM_SMALL_MAX")) : 128;

@@ -471,3 +471,20 @@ def test_attention_varlen_matches_masked_dense(dtype, B, H, dh, Lq, Lk, self_att
     assert rel_err(dq, qr.grad.reshape(B * Lq, dm)[sel_q]) < t
     assert rel_err(dk, kr.grad.reshape(B * Lk, dm)[sel_k]) < t
     assert rel_err(dv, vr.grad.reshape(B * Lk, dm)[sel_k]) < t
+
+
+def test_gemm_wide_tile_bf16():
+    """Large multi-round Linears: ragged M, N not a multiple of 256, every epilogue.  Runs on the two-blocks-per-CU kernel
+    by default and on the 128 x 256 tile kernel under PA_GEMM_WIDE=1 (both were validated with this test)."""
+    M, K = 7940, 512
+    for N in (1024, 1536, 1100):
+        a, b = rnd(M, K, dtype=torch.bfloat16, seed=70, scale=0.3), rnd(N, K, dtype=torch.bfloat16, seed=71 + N, scale=0.3)
+        bias, res = rnd(N, seed=72), rnd(M, N, dtype=torch.bfloat16, seed=73)
+        acc = a.float() @ b.float().t()
+        out = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), relu=True)
+        assert rel_err(out, torch.relu(acc + bias)) < 2.5e-2, N
+        out = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=res.to(DEV), out_dtype=torch.bfloat16)
+        assert rel_err(out, acc + bias + res.float()) < 2.5e-2, N
+    a, b = rnd(4096, 1024, dtype=torch.bfloat16, seed=74, scale=0.3), rnd(2048, 1024, dtype=torch.bfloat16, seed=75, scale=0.3)
+    out = ops.gemm(a.to(DEV), b.to(DEV), out_dtype=torch.float32)
+    assert rel_err(out, a.float() @ b.float().t()) < 1e-2
