@@ -103,11 +103,14 @@ def kernel_rooflines(B):
 
 
 def gemm_census(model, batch, train_step):
-    """Per-launch census of the GEMM kernels over ONE training step: the library records every pa_gemm() argument
-    block of the step and the kernel it dispatched to (pa_gemm_record), then each recorded launch is replayed on the
-    same buffers under HIP events.  Returns {family: {launches, flops, seconds}}; family = kernel + operand layout:
-    'ring' = gemm3_kernel (one block per CU, 4-stage LDS ring), 'pair' = gemm_kernel (two blocks per CU);
-    'tt' both operands k-contiguous (forward and dX Linears), 'nn' neither (dW, split-K, incl. its reduce pass)."""
+    """Per-launch census of the GEMM kernels over ONE training step: the library records every GEMM argument block of
+    the step, the kernel it dispatched to and - for the weight gradients - the grouped launch it was a member of
+    (pa_gemm_record); then every launch is replayed on the same buffers under HIP events, grouped launches as groups
+    (pa_gemm_group).  Returns {family: {launches, flops, seconds}}; family = kernel + operand layout:
+    'ring' gemm3_kernel (128x128 tiles, one block per CU, 4-stage LDS ring), 'small' gemm3s_kernel (64x64 tiles),
+    'pair' gemm_kernel (two blocks per CU), 'wide' gemm3w_kernel (128x256, opt-in), 'group' one pa_gemm_group launch
+    of several weight-gradient GEMMs (flops = sum of its members); 'tt' both operands k-contiguous (forward and dX
+    Linears), 'nn' neither (dW; the split-K slab reductions run as separate batched launches and are not included)."""
     import ctypes as C
     from plankassembly_amd import _lib as L
     lib = L.lib()
@@ -118,28 +121,39 @@ def gemm_census(model, batch, train_step):
     n = lib.pa_gemm_record(0)
     rec = (L.GemmArgs * n)()
     kinds = (C.c_int32 * n)()
-    n = lib.pa_gemm_recorded(C.cast(rec, C.c_void_p), n)
+    groups = (C.c_int32 * n)()
     nk = lib.pa_gemm_recorded_kinds(C.cast(kinds, C.c_void_p), n)
+    ng = lib.pa_gemm_recorded_groups(C.cast(groups, C.c_void_p), n)
+    n = lib.pa_gemm_recorded(C.cast(rec, C.c_void_p), n)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fam = {}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     reps = 5
-    for i in range(n):
+    names = {0: "pair", 1: "ring", 2: "wide", 3: "small"}
+    i = 0
+    while i < n:
+        gid = groups[i] if i < ng else -1
+        j = i + 1
+        if gid >= 0:
+            while j < n and j < ng and groups[j] == gid:
+                j += 1
         a = rec[i]
-        ref = C.cast(C.byref(a), C.c_void_p)
-        lib.pa_gemm(ref, st)
+        first = C.cast(C.byref(rec, i * C.sizeof(L.GemmArgs)), C.c_void_p)
+        launch = (lambda: lib.pa_gemm_group(first, j - i, st)) if gid >= 0 else (lambda: lib.pa_gemm(first, st))
+        launch()
         ev[0].record()
         for _ in range(reps):
-            lib.pa_gemm(ref, st)
+            launch()
         ev[1].record()
         ev[1].synchronize()
         t = ev[0].elapsed_time(ev[1]) * 1e-3 / reps
         lay = "tt" if (a.a_kcontig and a.b_kcontig) else ("nn" if not (a.a_kcontig or a.b_kcontig) else "mixed")
-        key = ({1: "ring", 2: "wide"}.get(kinds[i] if i < nk else 0, "pair")) + "_" + lay
+        key = ("group" if gid >= 0 else names.get(kinds[i] if i < nk else 0, "pair")) + "_" + lay
         f = fam.setdefault(key, dict(launches=0, flops=0.0, seconds=0.0))
         f["launches"] += 1
-        f["flops"] += 2.0 * a.M * a.N * a.K * a.batch
+        f["flops"] += sum(2.0 * rec[q].M * rec[q].N * rec[q].K * rec[q].batch for q in range(i, j))
         f["seconds"] += t
+        i = j
     return fam
 
 
@@ -383,8 +397,11 @@ def main():
             # Linears whose tile count fits one round of the 256 CUs
             key = max(census, key=lambda k: census[k]["seconds"])
             c = census[key]
-            names = {"ring_tt": "gemm3_kernel<true,true> (bf16, 128x128x64 tiles, one block per CU, 4-stage LDS ring)",
-                     "ring_nn": "gemm3_kernel<false,false> (bf16 dW, split-K, incl. splitk_reduce_kernel)",
+            names = {"ring_tt": "gemm3_kernel<true,true,GemmP> (bf16, 128x128x64 tiles, one block per CU, 4-stage LDS ring)",
+                     "ring_nn": "gemm3_kernel<false,false,GemmP> (bf16 dW, split-K slabs)",
+                     "group_nn": "gemm3_kernel<false,false,GemmGroup> (all weight-gradient GEMMs of a backward segment in one "
+                                 "launch; bf16, 128x128x64 tiles, split-K slabs)",
+                     "small_tt": "gemm3s_kernel (bf16, 64x64x64 tiles, 4-stage LDS ring)",
                      "pair_tt": "gemm_kernel<bf16,64,2,true,true,...> (two blocks per CU)",
                      "wide_tt": "gemm3w_kernel<2,4> (bf16, 128x256x64 tiles, one block per CU, 3-stage LDS ring)"}
             ach = c["flops"] / c["seconds"] / 1e12

@@ -84,7 +84,10 @@ int pa_gemm_recorded(pa_gemm_args* out, int32_t cap);
 #define PA_GEMM_KIND_PAIR 0
 #define PA_GEMM_KIND_RING 1
 #define PA_GEMM_KIND_WIDE 2   /* gemm3w_kernel: 128 x 256 tiles for the large multi-round Linears */
+#define PA_GEMM_KIND_SMALL 3  /* gemm3s_kernel: 64 x 64 tiles for launches that cover at most half of the CUs */
 int pa_gemm_recorded_kinds(int32_t* out, int32_t cap);
+/* -1 for launches made by pa_gemm; members of one pa_gemm_group launch share an id >= 0 (consecutive entries). */
+int pa_gemm_recorded_groups(int32_t* out, int32_t cap);
 
 /* Several weight-gradient GEMMs (dW = dY^T X: bf16 operands, contraction index strided in both, f32 output, no
  * epilogue, batch 1; splitk > 1 only with splitk_defer) in one launch of the ring kernel: its unit stream runs through

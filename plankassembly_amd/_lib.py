@@ -84,6 +84,7 @@ def lib():
             "pa_gemm_record": (I, [I]),
             "pa_gemm_recorded": (I, [P, I]),
             "pa_gemm_recorded_kinds": (I, [P, I]),
+            "pa_gemm_recorded_groups": (I, [P, I]),
             "pa_splitk_reduce_many": (I, [P, I, P]),
             "pa_colsum_many": (I, [P, I, I, P]),
             "pa_colsum_ws_floats": (I64, [I, I]),

@@ -1775,6 +1775,8 @@ template <typename T> bool is_aligned(const pa_gemm_args* a) {
 namespace {
 std::vector<pa_gemm_args>* g_rec = nullptr;
 std::vector<int32_t>* g_rec_kind = nullptr;      // kernel each recorded launch was dispatched to (PA_GEMM_KIND_*)
+std::vector<int32_t>* g_rec_group = nullptr;     // -1: launched by pa_gemm; >= 0: member of that pa_gemm_group launch
+int g_rec_ngroups = 0;
 std::mutex g_rec_mu;
 }
 extern "C" int pa_gemm_record(int32_t enable) {
@@ -1782,6 +1784,7 @@ extern "C" int pa_gemm_record(int32_t enable) {
     if (enable) {
         delete g_rec; g_rec = new std::vector<pa_gemm_args>();
         delete g_rec_kind; g_rec_kind = new std::vector<int32_t>();
+        delete g_rec_group; g_rec_group = new std::vector<int32_t>(); g_rec_ngroups = 0;
         return 0;
     }
     return g_rec ? (int)g_rec->size() : 0;
@@ -1792,6 +1795,13 @@ extern "C" int pa_gemm_recorded(pa_gemm_args* out, int32_t cap) {
     const int n = (int)g_rec->size() < cap ? (int)g_rec->size() : cap;
     for (int i = 0; i < n; ++i) out[i] = (*g_rec)[i];
     delete g_rec; g_rec = nullptr;
+    return n;
+}
+extern "C" int pa_gemm_recorded_groups(int32_t* out, int32_t cap) {
+    std::lock_guard<std::mutex> lk(g_rec_mu);
+    if (!g_rec_group) return 0;
+    const int n = (int)g_rec_group->size() < cap ? (int)g_rec_group->size() : cap;
+    for (int i = 0; i < n; ++i) out[i] = (*g_rec_group)[i];
     return n;
 }
 extern "C" int pa_gemm_recorded_kinds(int32_t* out, int32_t cap) {
@@ -1878,10 +1888,13 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     // 128 x 256 kernel: opt-in (PA_GEMM_WIDE=1).  Measured on MI355X: 0.73 us per K tile (0.37 per 128 x 128 equivalent, the best
     // of the four kernels) but 14.8 us fixed cost against 11.9 us (eight staged 32 x 32 epilogue passes), so at the model's
     // K = 512 it loses to the two-blocks-per-CU kernel (20.4 vs 18.5 us at 7 940 x 1 024) and only wins from K ~ 2 048 on.
+    static const int use_small = getenv("PA_GEMM_SMALL") ? atoi(getenv("PA_GEMM_SMALL")) : 1;
+    static const int small_max = getenv("PA_GEMM_SMALL_MAX") ? atoi(getenv("PA_GEMM_SMALL_MAX")) : 128;
+    const bool go_small = go_v3 && use_small && a->a_kcontig && a->b_kcontig && splitk == 1 && valid_units <= small_max && a->K % 64 == 0;
     static const int use_wide = getenv("PA_GEMM_WIDE") ? atoi(getenv("PA_GEMM_WIDE")) : 0;
     const bool go_wide = use_v3 && use_wide && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds && is_aligned<bf16>(a) && a->a_kcontig &&
                          a->b_kcontig && splitk == 1 && a->K % 64 == 0 && a->N >= 1024 && valid_units > 256;
-    if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_wide ? PA_GEMM_KIND_WIDE : (go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR)); }
+    if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_wide ? PA_GEMM_KIND_WIDE : (go_small ? PA_GEMM_KIND_SMALL : (go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR))); if (g_rec && g_rec_group) g_rec_group->push_back(-1); }
     // wide-tile ring kernel: large multi-round k-contiguous Linears (N >= 1024): 128 x 256 tiles
     if (go_wide) {
         GemmP pw = pk;
@@ -1893,9 +1906,7 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         return 0;
     }
     // small-tile ring kernel: plain k-contiguous Linears whose 128 x 128 tiling covers at most half of the CUs (measured: <= 128 units 7.05 ms/step, <= 64 7.11, <= 256 7.53)
-    static const int use_small = getenv("PA_GEMM_SMALL") ? atoi(getenv("PA_GEMM_SMALL")) : 1;
-    static const int small_max = getenv("PA_GEMM_SMALL_MAX") ? atoi(getenv("PA_GEMM_SMALL_MAX")) : 128;
-    if (go_v3 && use_small && a->a_kcontig && a->b_kcontig && splitk == 1 && valid_units <= small_max && a->K % 64 == 0) {
+    if (go_small) {
         GemmP ps = pk;
         ps.tiles_m = (a->M + 63) / 64; ps.tiles_n = (a->N + 63) / 64; ps.tiles_m_pad = ps.tiles_m; ps.plain_order = 1;
         ps.units = ps.tiles_m * ps.tiles_n * a->batch;
@@ -1970,8 +1981,9 @@ extern "C" int pa_gemm_group(const pa_gemm_args* args, int32_t n, void* stream) 
         p.vec_ok = ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0 && (p.ldc & 3) == 0) ? 1 : 0;
         g.begin[i + 1] = g.begin[i] + p.units;
         valid += p.units;
-        if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec) { g_rec->push_back(*a); if (g_rec_kind) g_rec_kind->push_back(PA_GEMM_KIND_RING); } }
+        if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec) { g_rec->push_back(*a); if (g_rec_kind) g_rec_kind->push_back(PA_GEMM_KIND_RING); if (g_rec_group) g_rec_group->push_back(g_rec_ngroups); } }
     }
+    if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec) ++g_rec_ngroups; }
     const int grid = valid < 256 ? valid : 256;
     PA_LAUNCH((gemm3_kernel<false, false, GemmGroup>), dim3(grid), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), g);
     return 0;

@@ -19,7 +19,8 @@ import sys
 KEYS = [  # json key -> regex on the demangled kernel name
     ("gemm_ring_tt", r"gemm3_kernel<true, true, .*GemmP>"),
     ("gemm_ring_nn", r"gemm3_kernel<false, false, .*GemmP>"),
-    ("gemm_ring_nn_group", r"gemm3_kernel<false, false, .*GemmGroup>"),
+    ("gemm_group_nn", r"gemm3_kernel<false, false, .*GemmGroup>"),
+    ("gemm_small_tt", r"gemm3s_kernel"),
     ("gemm_pair_tt", r"gemm_kernel<__bf16, 64, 2, true, true, true, true, false, 2>"),
     ("gemm_pair_nn", r"gemm_kernel<__bf16, 64, 2, false, false, true, true, true, 2>"),
     ("attn_fwd", r"attn_fwd_bf16_kernel<64>"),
