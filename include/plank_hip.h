@@ -203,6 +203,11 @@ typedef struct {
     int32_t nparts, pad_;
 } pa_ln_finish_desc;
 int pa_layernorm_finish_many(const pa_ln_finish_desc* descs, int32_t n, int32_t d, void* stream);
+/* The three batched end-of-segment reductions (pa_layernorm_finish_many, pa_colsum_many, pa_splitk_reduce_many) in
+ * ONE launch: they are independent of each other, their blocks are concatenated.  Any of the three lists may be empty. */
+int pa_segment_tail(const pa_ln_finish_desc* ln, int32_t n_ln, int32_t d_model, const pa_colsum_desc* cs, int32_t n_cs,
+                    int32_t dtype, const pa_reduce_desc* rd, int32_t n_rd, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head attention core: softmax(Q K^T * scale + mask) V per (batch, head), flash-style

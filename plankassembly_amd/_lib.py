@@ -81,6 +81,7 @@ def lib():
             "pa_gemm": (I, [P, P]),
             "pa_gemm_effective_splitk": (I, [I, I, I]),
             "pa_gemm_group": (I, [P, I, P]),
+            "pa_segment_tail": (I, [P, I, I, P, I, I, P, I, P]),
             "pa_gemm_record": (I, [I]),
             "pa_gemm_recorded": (I, [P, I]),
             "pa_gemm_recorded_kinds": (I, [P, I]),

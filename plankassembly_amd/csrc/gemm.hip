@@ -1993,13 +1993,13 @@ extern "C" int pa_gemm_group(const pa_gemm_args* args, int32_t n, void* stream) 
 // deferred split-K reduction of several plain f32 outputs in one launch (include/plank_hip.h)
 namespace {
 struct ReduceTab { pa_reduce_desc d[PA_MAX_REDUCE]; int begin[PA_MAX_REDUCE + 1]; int n; };
-__global__ __launch_bounds__(256) void splitk_reduce_many_kernel(ReduceTab t) {
+__device__ __forceinline__ void reduce_block(const ReduceTab& t, int blk) {
     // block -> descriptor (few entries: linear scan), then 1024 consecutive floats of its output
     int di = 0;
-    while (di + 1 < t.n && (int)blockIdx.x >= t.begin[di + 1]) ++di;
+    while (di + 1 < t.n && blk >= t.begin[di + 1]) ++di;
     const pa_reduce_desc d = t.d[di];
     const size_t total = (size_t)d.rows * d.cols;
-    const size_t e0 = ((size_t)(blockIdx.x - t.begin[di]) * 256 + threadIdx.x) * 4;
+    const size_t e0 = ((size_t)(blk - t.begin[di]) * 256 + threadIdx.x) * 4;
     if (e0 >= total) return;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if ((d.cols & 3) == 0) {
@@ -2016,6 +2016,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_many_kernel(ReduceTab t) {
         }
     }
 }
+__global__ __launch_bounds__(256) void splitk_reduce_many_kernel(ReduceTab t) { reduce_block(t, blockIdx.x); }
 }  // namespace
 extern "C" int pa_splitk_reduce_many(const pa_reduce_desc* descs, int32_t n_desc, void* stream) {
     if (!descs || n_desc <= 0 || n_desc > PA_MAX_REDUCE) return PA_EINVAL;
@@ -2075,15 +2076,82 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, i
 // several matrices in one launch: block -> (descriptor, column block, row block)
 struct ColsumTab { pa_colsum_desc d[PA_MAX_COLSUM]; int begin[PA_MAX_COLSUM + 1]; int n; };
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_many_kernel(ColsumTab t) {
+__device__ __forceinline__ void colsum_many_block(const ColsumTab& t, int blk) {
     constexpr int EB = ET<T>::EB;
     int di = 0;
-    while (di + 1 < t.n && (int)blockIdx.x >= t.begin[di + 1]) ++di;
+    while (di + 1 < t.n && blk >= t.begin[di + 1]) ++di;
     const pa_colsum_desc d = t.d[di];
     const int nbx = (d.N + 64 * EB - 1) / (64 * EB);
-    const int rel = blockIdx.x - t.begin[di];
+    const int rel = blk - t.begin[di];
     colsum_block<T, true>(reinterpret_cast<const T*>(d.X), d.M, d.N, d.ldx, d.out, rel % nbx, rel / nbx);
 }
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_many_kernel(ColsumTab t) { colsum_many_block<T>(t, blockIdx.x); }
+
+// ---- the whole tail of a backward segment in ONE launch: LayerNorm gamma/beta finishes, bias column sums and split-K
+// slab reductions are independent of each other; their blocks are simply concatenated (every dependent launch saved
+// is ~5 us on this machine)
+struct LnTailTab { pa_ln_finish_desc d[PA_MAX_LN_FINISH]; int n; int ncols; int nbx; int nby; };
+__device__ __forceinline__ void ln_finish_block(const LnTailTab& t, int blk) {
+    __shared__ float red_ln[256];
+    const int bx = blk % t.nbx, by = (blk / t.nbx) % t.nby, bz = blk / (t.nbx * t.nby);
+    const pa_ln_finish_desc d = t.d[bz];
+    const int c = bx * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    float* o = by == 0 ? d.dgamma : (by == 1 ? d.dbeta : d.dzsum);
+    float sacc = 0.f;
+    if (c < t.ncols && o) {
+        const float* p = d.partial + (size_t)by * t.ncols + c;
+#pragma unroll 8
+        for (int i = pl; i < d.nparts; i += 4) sacc += p[(size_t)i * 3 * t.ncols];
+    }
+    red_ln[threadIdx.x] = sacc;
+    __syncthreads();
+    if (pl == 0 && c < t.ncols && o) o[c] += (red_ln[threadIdx.x] + red_ln[threadIdx.x + 64]) + (red_ln[threadIdx.x + 128] + red_ln[threadIdx.x + 192]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void segment_tail_kernel(LnTailTab ln, int n_ln_blocks, ColsumTab cs, int n_cs_blocks, ReduceTab rd) {
+    const int b = blockIdx.x;                      // block-uniform dispatch
+    if (b < n_ln_blocks) ln_finish_block(ln, b);
+    else if (b < n_ln_blocks + n_cs_blocks) colsum_many_block<T>(cs, b - n_ln_blocks);
+    else reduce_block(rd, b - n_ln_blocks - n_cs_blocks);
+}
+}  // namespace
+extern "C" int pa_segment_tail(const pa_ln_finish_desc* ln, int32_t n_ln, int32_t d_model, const pa_colsum_desc* cs, int32_t n_cs,
+                               int32_t dtype, const pa_reduce_desc* rd, int32_t n_rd, void* stream) {
+    if (n_ln < 0 || n_ln > PA_MAX_LN_FINISH || n_cs < 0 || n_cs > PA_MAX_COLSUM || n_rd < 0 || n_rd > PA_MAX_REDUCE) return PA_EINVAL;
+    if ((n_ln && !ln) || (n_cs && !cs) || (n_rd && !rd) || n_ln + n_cs + n_rd == 0) return PA_EINVAL;
+    if (dtype != PA_BF16 && dtype != PA_F32) return PA_EINVAL;
+    const int EB = dtype == PA_BF16 ? 8 : 4;
+    LnTailTab lt; lt.n = n_ln; lt.ncols = d_model; lt.nbx = (d_model + 63) / 64; lt.nby = 2;
+    for (int i = 0; i < n_ln; ++i) {
+        if (!ln[i].partial || !ln[i].dgamma || !ln[i].dbeta || ln[i].nparts <= 0 || d_model <= 0) return PA_EINVAL;
+        lt.d[i] = ln[i];
+        if (ln[i].dzsum) lt.nby = 3;
+    }
+    const int n_ln_blocks = n_ln ? lt.nbx * lt.nby * n_ln : 0;
+    ColsumTab ct; ct.n = n_cs; ct.begin[0] = 0;
+    for (int i = 0; i < n_cs; ++i) {
+        const pa_colsum_desc& d = cs[i];
+        if (!d.X || !d.out || d.M <= 0 || d.N <= 0) return PA_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(d.X) & 15) || d.ldx % EB || d.ldx < (d.N + EB - 1) / EB * EB) return PA_EALIGN;
+        ct.d[i] = d;
+        ct.begin[i + 1] = ct.begin[i] + ((d.N + 64 * EB - 1) / (64 * EB)) * ((d.M + CS_ROWS - 1) / CS_ROWS);
+    }
+    ReduceTab rt; rt.n = n_rd; rt.begin[0] = 0;
+    for (int i = 0; i < n_rd; ++i) {
+        const pa_reduce_desc& d = rd[i];
+        if (!d.ws || !d.out || d.rows <= 0 || d.cols <= 0 || d.splitk < 1 || d.ld_out < d.cols) return PA_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(d.ws) & 15) || (reinterpret_cast<uintptr_t>(d.out) & 15) || ((d.cols & 3) == 0 && (d.ld_out & 3))) return PA_EALIGN;
+        rt.d[i] = d;
+        rt.begin[i + 1] = rt.begin[i] + (int)(((size_t)d.rows * d.cols + 1023) / 1024);
+    }
+    const int total = n_ln_blocks + ct.begin[n_cs] + rt.begin[n_rd];
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == PA_BF16) PA_LAUNCH(segment_tail_kernel<bf16>, dim3(total), dim3(256), 0, st, lt, n_ln_blocks, ct, ct.begin[n_cs], rt);
+    else PA_LAUNCH(segment_tail_kernel<float>, dim3(total), dim3(256), 0, st, lt, n_ln_blocks, ct, ct.begin[n_cs], rt);
+    return 0;
+}
+namespace {
 }  // namespace
 extern "C" int pa_colsum_many(const pa_colsum_desc* descs, int32_t n_desc, int32_t dtype, void* stream) {
     if (!descs || n_desc <= 0 || n_desc > PA_MAX_COLSUM) return PA_EINVAL;

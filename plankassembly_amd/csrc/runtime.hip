@@ -432,11 +432,10 @@ int flush_segment(pa_model* m, void* q) {
         m->ndwq = 0;
         RC(rc);
     }
-    if (m->nlnq > 0) { RC(pa_layernorm_finish_many(m->lnq, m->nlnq, m->cfg.d_model, q)); m->nlnq = 0; }
-    if (m->ncs > 0) { RC(pa_colsum_many(m->cs, m->ncs, m->cfg.dtype, q)); m->ncs = 0; }
-    if (m->ndefer > 0) {                                   // one reduction launch for the segment's weight gradients
-        RC(pa_splitk_reduce_many(m->defer, m->ndefer, q));
-        m->ndefer = 0; m->slab_used = 0;
+    // LayerNorm gamma/beta finishes + bias column sums + split-K slab reductions of the segment: one launch
+    if (m->nlnq > 0 || m->ncs > 0 || m->ndefer > 0) {
+        RC(pa_segment_tail(m->lnq, m->nlnq, m->cfg.d_model, m->cs, m->ncs, m->cfg.dtype, m->defer, m->ndefer, q));
+        m->nlnq = 0; m->ncs = 0; m->ndefer = 0; m->slab_used = 0;
     }
     return 0;
 }
