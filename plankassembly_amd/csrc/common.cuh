@@ -106,7 +106,13 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t 
 // Attention-probability dropout: ONE hash yields the keep decisions of 4 consecutive keys of a query row
 // (8 bits each; the drop probability is quantised to thr8/256 and the survivors are scaled by 256/(256-thr8),
 // so the expectation is exact).  idx4 = row * ceil(Lk/4) + key/4, decision j = key & 3.
-__device__ __forceinline__ uint32_t drop_hash4(uint32_t seed, uint32_t idx4) { return mix32(idx4 * 0x9e3779b9u + seed); }
+// (two multiply / xor-shift rounds: the dK/dV kernel needs one hash per score, so the full 3-round mix32 was ~40 % of its
+// VALU work; the keep-rate / independence statistics are checked by tests/test_kernels_gpu.py)
+__device__ __forceinline__ uint32_t drop_hash4(uint32_t seed, uint32_t idx4) {
+    uint32_t x = idx4 * 0x9e3779b9u + seed;
+    x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 13;
+    return x;
+}
 __device__ __forceinline__ bool drop_keep4(uint32_t h, int j, uint32_t thr8) { return ((h >> (8 * j)) & 0xffu) >= thr8; }
 
 __device__ __forceinline__ float wave_sum(float v) {
