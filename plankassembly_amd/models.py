@@ -58,6 +58,18 @@ class _Batch(C.Structure):
 INPUT_KEYS = ("input_value", "input_pos", "input_coord", "input_view", "input_type")
 
 
+def group_rows_by_id(ids, rows, row_index=None):
+    """Group row indices by embedding-table row (pa_embed_segment_bwd's input).  ids[i] = table row used by the i-th
+    entry; row_index[i] = the gradient row that entry reads (default i).  Returns (order int32 [len(ids)] = gradient rows
+    sorted by id, seg int32 [rows + 1] with seg[r] .. seg[r+1] = the slice of `order` that uses table row r)."""
+    order = torch.argsort(ids, stable=True)
+    if row_index is not None:
+        order = row_index[order]
+    seg = torch.zeros(rows + 1, dtype=torch.int32, device=ids.device)
+    seg[1:] = torch.cumsum(torch.bincount(ids, minlength=rows)[:rows], 0).to(torch.int32)
+    return order.to(torch.int32).contiguous(), seg
+
+
 def param_order(n_enc: int, n_dec: int):
     """Canonical parameter order = the reference's state_dict order (csrc/runtime.hip enums)."""
     keys = [f"input_embeddings.{k}.weight" for k in INPUT_KEYS]
@@ -504,13 +516,7 @@ class PlankModel(nn.Module):
             # of atomics (pa_embed_segment_bwd).  Batch-only information, like the packing.
             cu, rowmap, n_valid = out["_pack"]
 
-            def group(ids, rows, row_index=None):
-                order = torch.argsort(ids, stable=True)
-                if row_index is not None:
-                    order = row_index[order]
-                seg = torch.zeros(rows + 1, dtype=torch.int32, device=dev)
-                seg[1:] = torch.cumsum(torch.bincount(ids, minlength=rows)[:rows], 0).to(torch.int32)
-                return order.to(torch.int32).contiguous(), seg
+            group = group_rows_by_id
 
             gin = []
             sel = rowmap[:n_valid].long()

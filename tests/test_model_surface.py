@@ -84,3 +84,25 @@ def test_c_abi_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in plank_hip.h but not exported"
     assert L.lib().pa_version() >= 1
+
+
+def test_group_rows_by_id_segments():
+    """Host side of the segment-sum embedding gradients: every entry lands in exactly the segment of its table row."""
+    import torch
+    from plankassembly_amd.models import group_rows_by_id
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 11, (257,), generator=g)
+    rows_idx = torch.arange(1000, 1257)
+    order, seg = group_rows_by_id(ids, 13, rows_idx)
+    assert seg[0] == 0 and seg[-1] == 257 and order.dtype == torch.int32 and seg.dtype == torch.int32
+    seen = torch.zeros(257, dtype=torch.bool)
+    for r in range(13):
+        sl = order[seg[r]:seg[r + 1]].long() - 1000
+        assert bool((ids[sl] == r).all())
+        seen[sl] = True
+    assert bool(seen.all())
+    # emulate the kernel: table gradient = sum of the gradient rows of each segment
+    dout = torch.randn(257, 8, generator=g)
+    ref = torch.zeros(13, 8).index_add_(0, ids, dout)
+    got = torch.stack([dout[order[seg[r]:seg[r + 1]].long() - 1000].sum(0) for r in range(13)])
+    assert torch.allclose(got, ref, atol=1e-5)
