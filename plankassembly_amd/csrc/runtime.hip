@@ -450,7 +450,9 @@ int join_side(pa_model* m, int par, void* st) {
 int backward_segment(pa_model* m, int seg, float gscale, void* st) {
     const int par = seg & 1;
     m->ndefer = 0; m->slab_used = 0; m->ncs = 0; m->ndwq = 0; m->nlnq = 0;
-    m->defer_ok = seg >= 1 && seg != m->cfg.n_dec + 1 && seg != m->cfg.n_dec + 2;     // layer segments (not the heads: they reuse buffers)
+    // heads and layer segments: every buffer the queued work reads (dY of the weight / bias gradients, LayerNorm partials)
+    // is written once per segment and stays untouched until its end
+    m->defer_ok = seg != m->cfg.n_dec + 1 && seg != m->cfg.n_dec + 2;
     if (m->side_on) {
         RC(join_side(m, par, st));             // segment seg-2 used this parity set: its queued work must be finished
         m->select_set(par);
