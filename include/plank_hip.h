@@ -343,6 +343,10 @@ void pa_model_destroy(pa_model* m);
 int pa_model_num_params(const pa_model* m);
 int pa_model_bind(pa_model* m, void* const* params_f32, void* const* params_lp, void* const* grads);
 int pa_model_bind_transposed(pa_model* m, void* const* params_lpT);
+/* Optional (bf16): the cross-attention K/V rows of every decoder layer's in_proj_weight, transposed and packed side by
+ * side: kvT_all[k][l * 2d + n] = in_proj_weight_l[d + n][k]  ([d][n_dec * 2d], low-precision dtype).  With it bound the
+ * backward pass forms d(memory) with ONE GEMM over all layers instead of n_dec accumulating ones.  NULL unbinds. */
+int pa_model_bind_cross_kv_t(pa_model* m, const void* kvT_all);
 int64_t pa_model_train_ws_bytes(pa_model* m, int32_t B, int32_t S, int32_t T);
 /* stats (device, f32[4]): [0] sum of -log p(label) over non-PAD labels, [1] #non-PAD, [2] #correct.
  * loss = stats[0]/stats[1] (reference models.py:221), accuracy = stats[2]/(stats[1]+1e-10) (:227);

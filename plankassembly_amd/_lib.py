@@ -115,6 +115,7 @@ def lib():
             "pa_model_num_params": (I, [P]),
             "pa_model_bind": (I, [P, P, P, P]),
             "pa_model_bind_transposed": (I, [P, P]),
+            "pa_model_bind_cross_kv_t": (I, [P, P]),
             "pa_transpose_many": (I, [P, I, I, I, P]),
             "pa_model_train_ws_bytes": (I64, [P, I, I, I]),
             "pa_model_train_fwd": (I, [P, P, P, I64, U, I, P, P]),

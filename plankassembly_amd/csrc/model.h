@@ -63,6 +63,7 @@ struct pa_model {
     pa_colsum_desc cs[PA_MAX_COLSUM]; int ncs = 0; bool defer_ok = false;       // queued bias-gradient column sums of the current segment
     pa_reduce_desc defer[PA_MAX_REDUCE]; int ndefer = 0; size_t slab_used = 0;   // queued split-K reductions of the current segment
     bool dmem_written = false;
+    void* gKV_all = nullptr; const void* kvT_all = nullptr;   // packed cross-attention K/V path (pa_model_bind_cross_kv_t)
     // Two copies ("parity sets") of every buffer the queued end-of-segment work reads: with the side stream on, that
     // work of segment s runs concurrently with the main stream's segments s+1 (other set) and is joined before s+2.
     struct SegSet { void* gBs[3]; void* gCs[3]; void *gE, *gF, *gQ3, *gKV; float* lnp[3]; float* splitws; };

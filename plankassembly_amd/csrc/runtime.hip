@@ -173,6 +173,7 @@ size_t pa_train_layout(pa_model* m, char* base, int B, int S, int T) {
     for (int s_ = 1; s_ < 3; ++s_) { m->gBs[s_] = a.take(R * d * e); m->gCs[s_] = a.take(R * d * e); }
     m->gE = a.take(R * d * e); m->gF = a.take(R * ff * e); m->gQ3 = a.take(R * 3 * d * e);
     m->gKV = a.take(BS * 2 * d * e); m->dmem = a.take(BS * d * e);
+    m->gKV_all = a.take(BS * 2 * d * e * (c.n_dec > 0 ? c.n_dec : 1));     // d(K|V) of every decoder layer side by side (packed K/V shadow mode)
     {   // parity set 1 (set 0 = the buffers above)
         pa_model::SegSet& s1 = m->seg_set[1];
         for (int s_ = 0; s_ < 3; ++s_) { s1.gBs[s_] = a.take(R * d * e); s1.gCs[s_] = a.take(R * d * e); }
@@ -369,17 +370,23 @@ int bwd_dec_layer(pa_model* m, int i, void* st) {
                 G(pb + D_N2_B), G(pb + D_CA_OUT_B), BT, p, site_seed(m->seed, sb + 3)));
     RC(k.linear_dw(ddrop, d, t.o_ca, d, G(pb + D_CA_OUT_W), nullptr, BT, d, d));
     RC(k.linear_dx(ddrop, d, m->pl[pb + D_CA_OUT_W], d, m->gD, d, BT, d, d, nullptr, 0, nullptr, 0, 1.f, m->plT[pb + D_CA_OUT_W], d));
+    // With the packed K/V weight shadow bound (bf16 mode) every layer writes d(K|V) into its column slice of one
+    // [BS][n_dec * 2d] matrix and d(memory) is ONE GEMM over all layers after the last decoder segment
+    // (backward_segment_body) instead of n_dec accumulating launches on the dX chain.
+    const bool kv_all = m->kvT_all != nullptr;
+    void* gKV = kv_all ? (void*)((char*)m->gKV_all + (size_t)i * 2 * d * e) : m->gKV;
+    const int ldg = kv_all ? c.n_dec * 2 * d : 2 * d;
     RC(k.attn(true, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, 2 * d, t.o_ca, t.lse_ca, in_mask, T, S, 0, p,
-              site_seed(m->seed, sb + 2), m->gD, m->gE, d, m->gKV, (char*)m->gKV + d * e, 2 * d, nullptr, cu));
+              site_seed(m->seed, sb + 2), m->gD, m->gE, d, gKV, (char*)gKV + d * e, ldg, nullptr, cu));
     float* dWin = G(pb + D_CA_IN_W); float* dbin = G(pb + D_CA_IN_B);
     RC(k.linear_dw(m->gE, d, t.y1, d, dWin, dbin, BT, d, d));
-    RC(k.linear_dw(m->gKV, 2 * d, memory, d, dWin + (size_t)d * d, dbin + d, BS, 2 * d, d));
-    {
+    RC(k.linear_dw(gKV, ldg, memory, d, dWin + (size_t)d * d, dbin + d, BS, 2 * d, d));
+    if (!kv_all) {
         const void* wt = m->plT[pb + D_CA_IN_W];                       // W_in^T is [d][3d]; K/V rows of W_in = its columns d..3d
-        RC(k.linear_dx(m->gKV, 2 * d, (const char*)m->pl[pb + D_CA_IN_W] + (size_t)d * d * e, d, m->dmem, d, BS, 2 * d, d,
+        RC(k.linear_dx(gKV, 2 * d, (const char*)m->pl[pb + D_CA_IN_W] + (size_t)d * d * e, d, m->dmem, d, BS, 2 * d, d,
                        m->dmem_written ? m->dmem : nullptr, d, nullptr, 0, 1.f, wt ? (const char*)wt + (size_t)d * e : nullptr, 3 * d));
+        m->dmem_written = true;
     }
-    m->dmem_written = true;
     RC(k.linear_dx(m->gE, d, m->pl[pb + D_CA_IN_W], d, m->gA, d, BT, d, d, gB, d, nullptr, 0, 1.f, m->plT[pb + D_CA_IN_W], 3 * d));
     // self attention block: z1 = Y[i] + drop(out_proj(attn(qkv(Y[i]))))
     gB = m->gBs[2]; gC = m->gCs[2]; ddrop = p > 0.f ? gC : gB;
@@ -492,6 +499,12 @@ int backward_segment_body(pa_model* m, int seg, float gscale, void* st) {
                                    c.out_dof, st);
     }
     if (seg == c.n_dec + 2) {
+        if (m->kvT_all && c.n_dec > 0) {
+            // d(memory) [BS][d] = d(K|V)_all [BS][n_dec*2d] x W_kv_all [n_dec*2d][d]; the packed shadow holds W_kv_all^T
+            const int kk = c.n_dec * 2 * d;
+            RC(k.linear_dx(m->gKV_all, kk, nullptr, 0, m->dmem, d, BS, kk, d, nullptr, 0, nullptr, 0, 1.f, m->kvT_all, kk));
+            m->dmem_written = true;
+        }
         if (!m->dmem_written) {       // no decoder layers: memory got no gradient
             hipError_t he = hipMemsetAsync(m->dmem, 0, (size_t)BS * d * m->esz, (hipStream_t)st);
             if (he != hipSuccess) return (int)he;
@@ -595,6 +608,12 @@ extern "C" int pa_model_bind(pa_model* m, void* const* params_f32, void* const* 
 extern "C" int pa_model_bind_transposed(pa_model* m, void* const* params_lpT) {
     if (!m) return PA_EINVAL;
     for (int i = 0; i < m->n_params; ++i) m->plT[i] = params_lpT ? params_lpT[i] : nullptr;
+    return 0;
+}
+
+extern "C" int pa_model_bind_cross_kv_t(pa_model* m, const void* kvT_all) {
+    if (!m) return PA_EINVAL;
+    m->kvT_all = kvT_all;
     return 0;
 }
 

@@ -408,10 +408,23 @@ class PlankModel(nn.Module):
             d = _TrDesc(self._shadow.data_ptr() + off, self._shadowT.data_ptr() + off, s[0], s[1], s[1], s[0], tiles, 0)
             tiles += ((s[0] + 63) // 64) * ((s[1] + 63) // 64)
             descs.append(d)
+        # cross-attention K/V weights of all decoder layers, transposed and packed: kvT[k][l*2d + n] = W_in_l[d + n][k]
+        nd, dm = self.num_decoder_layers, self.num_model
+        self._kvT = None
+        if nd > 0 and dm % 8 == 0 and os.environ.get("PLANK_CROSS_KV", "1") != "0":
+            self._kvT = torch.zeros(dm * nd * 2 * dm, dtype=torch.bfloat16, device=dev)
+            for li in range(nd):
+                k = f"decoder.layers.{li}.multihead_attn.in_proj_weight"
+                src = self._shadow.data_ptr() + (self._offsets[k] + dm * dm) * 2
+                dst = self._kvT.data_ptr() + li * 2 * dm * 2
+                descs.append(_TrDesc(src, dst, 2 * dm, dm, dm, nd * 2 * dm, tiles, 0))
+                tiles += ((2 * dm + 63) // 64) * ((dm + 63) // 64)
         arr = (_TrDesc * len(descs))(*descs)
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self._tr_descs = (host.to(dev), len(descs), tiles)
         L.check(L.lib().pa_model_bind_transposed(self._handle, tab), "pa_model_bind_transposed")
+        L.check(L.lib().pa_model_bind_cross_kv_t(self._handle, L.ptr(self._kvT) if self._kvT is not None else None),
+                "pa_model_bind_cross_kv_t")
 
     def refresh_transposed(self):
         """Re-derive the W^T shadow from the bf16 shadow (one batched transpose launch)."""

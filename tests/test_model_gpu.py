@@ -88,6 +88,27 @@ def test_prepared_batch_matches_golden_gradients(fixture_name, request):
         assert err <= 1e-5 + 1e-4 * float(ref.abs().max()), (k, err)
 
 
+def test_bf16_packed_cross_kv_matches_per_layer_path(small_fixture, monkeypatch):
+    """bf16 backward: d(memory) as one GEMM over the packed K/V shadow of all decoder layers vs the per-layer
+    accumulating GEMMs - every gradient (the encoder's depend on d(memory)) must agree to bf16 rounding."""
+    sd, batch, _ = small_fixture
+    grads = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PLANK_CROSS_KV", flag)
+        mdl = make(sd, dtype="bf16").train()
+        out = mdl(to_dev(batch))
+        out["loss"].backward()
+        assert (mdl._kvT is not None) == (flag == "1")
+        grads.append({k: p.grad.detach().float().cpu().clone() for k, p in mdl.named_parameters()})
+    num = den = 0.0
+    for k in grads[0]:
+        a, b = grads[0][k].flatten(), grads[1][k].flatten()
+        num += float((a * b).sum()); den += float(a.norm() * b.norm())
+        if k.startswith("encoder") or k.startswith("input_embeddings"):
+            assert float((a - b).abs().max()) <= 0.05 * float(b.abs().max()) + 1e-6, k
+    assert num / max(den, 1e-30) > 0.999
+
+
 def test_g7_ragged_sideface_f32(ragged_fixture):
     sd, batch, g = ragged_fixture
     m = make(sd).train()
