@@ -2151,8 +2151,6 @@ extern "C" int pa_segment_tail(const pa_ln_finish_desc* ln, int32_t n_ln, int32_
     else PA_LAUNCH(segment_tail_kernel<float>, dim3(total), dim3(256), 0, st, lt, n_ln_blocks, ct, ct.begin[n_cs], rt);
     return 0;
 }
-namespace {
-}  // namespace
 extern "C" int pa_colsum_many(const pa_colsum_desc* descs, int32_t n_desc, int32_t dtype, void* stream) {
     if (!descs || n_desc <= 0 || n_desc > PA_MAX_COLSUM) return PA_EINVAL;
     const int EB = dtype == PA_BF16 ? 8 : 4;

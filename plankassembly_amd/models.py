@@ -219,7 +219,7 @@ class PlankModel(nn.Module):
         self._gflat = None
         self._gtmp = None
         self._shadow = None
-        self._shadowT = None
+        self._shadowT = self._vocabT = self._kvT = None
         self._tr_descs = None
         self._shadow_version = -1
         self._handle = None
@@ -270,7 +270,7 @@ class PlankModel(nn.Module):
                 p.data = view
                 p.grad = None
         self._flat = flat
-        self._gflat = self._gtmp = self._shadow = self._shadowT = None
+        self._gflat = self._gtmp = self._shadow = self._shadowT = self._vocabT = self._kvT = None
         self._tr_descs = None
         self._shadow_version = -1
         self._drop_handle()
