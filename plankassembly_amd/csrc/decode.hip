@@ -230,8 +230,11 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(const float* vlog, int 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = *t_dev, sz = t + 1, i = t;
     const T* hb = h + (int64_t)b * d;
-    T* cache = hid_cache + (int64_t)b * Tmax * d;
-    for (int c = tid; c < d; c += 256) cache[(int64_t)t * d + c] = hb[c];
+    // hidden-state cache laid out [Tmax][B][d]: the 256 blocks walk the rows j in step, and with a per-sequence
+    // [B][Tmax][d] layout (1 MB apart) they would all hit the same HBM channel at the same time
+    const int64_t nb = gridDim.x;
+    T* cache = hid_cache + (int64_t)b * d;                          // row j of this sequence: cache + j * nb * d
+    for (int c = tid; c < d; c += 256) cache[(int64_t)t * nb * d + c] = hb[c];
     const float* vr = vlog + (int64_t)b * ldv;
     // vocab softmax statistics
     float vmax = -INFINITY;
@@ -245,15 +248,48 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(const float* vlog, int 
         for (int k = tid; k < V; k += 256) best = better(best, ArgMax{expf(vr[k] - vmax) / vsum, k});
     } else {
         // pointer logits over the hidden prefix (row j = t is written above but masked: j >= i)
+        // each wave takes 8 cached rows at a time, all their loads issued (unconditionally: rows clamped, tail discarded)
+        // before the first reduction; the pointer-feature row stays in registers.  Per row the arithmetic order is the
+        // one-row-at-a-time order (chunk by chunk per lane, then the wave sum): logits and greedy tokens are unchanged.
         const T* pf = pfeat + (int64_t)b * d;
-        for (int j = wave; j < t; j += 4) {
-            float s = 0.f;
-            for (int c = lane << 2; c < d; c += 256) {
-                const f32x4 a = ld4<T>(pf + c), hh = ld4<T>(cache + (int64_t)j * d + c);
-                s += a[0] * hh[0] + a[1] * hh[1] + a[2] * hh[2] + a[3] * hh[3];
+        auto ptr_logits = [&](auto NCH_) {
+            constexpr int NCH = decltype(NCH_)::value, PUN = 8;           // NCH = d / 256 chunks of 4 columns per lane
+            f32x4 pa[NCH];
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) pa[q] = ld4<T>(pf + (lane << 2) + q * 256);
+            for (int j0 = wave * PUN; j0 < t; j0 += 4 * PUN) {
+                f32x4 hh[PUN][NCH];
+#pragma unroll
+                for (int u = 0; u < PUN; ++u) {
+                    const T* row = cache + (int64_t)min(j0 + u, t - 1) * nb * d + (lane << 2);
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q) hh[u][q] = ld4<T>(row + q * 256);
+                }
+#pragma unroll
+                for (int u = 0; u < PUN; ++u) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q)
+                        sacc += pa[q][0] * hh[u][q][0] + pa[q][1] * hh[u][q][1] + pa[q][2] * hh[u][q][2] + pa[q][3] * hh[u][q][3];
+                    sacc = wave_sum(sacc);
+                    if (lane == 0 && j0 + u < t) plog[j0 + u] = sacc / (float)d;
+                }
             }
-            s = wave_sum(s);
-            if (lane == 0) plog[j] = s / (float)d;
+        };
+        if (d == 512) ptr_logits(std::integral_constant<int, 2>{});
+        else if (d == 256) ptr_logits(std::integral_constant<int, 1>{});
+        else if (d == 768) ptr_logits(std::integral_constant<int, 3>{});
+        else if (d == 1024) ptr_logits(std::integral_constant<int, 4>{});
+        else {
+            for (int j = wave; j < t; j += 4) {
+                float s = 0.f;
+                for (int c = lane << 2; c < d; c += 256) {
+                    const f32x4 a = ld4<T>(pf + c), hh = ld4<T>(cache + (int64_t)j * nb * d + c);
+                    s += a[0] * hh[0] + a[1] * hh[1] + a[2] * hh[2] + a[3] * hh[3];
+                }
+                s = wave_sum(s);
+                if (lane == 0) plog[j] = s / (float)d;
+            }
         }
         if (wave == 0) {
             float s = 0.f;
