@@ -436,36 +436,60 @@ __device__ __forceinline__ RowStat wave_merge(RowStat a) {
     return a;
 }
 
+constexpr int NLL_ROWS = 4;      // rows per block (one per wave); the three statistics leave a block as ONE atomic each
+constexpr int NLL_VSLOTS = 16;   // a lane holds up to 16 vocabulary logits (V <= 1024) / 4 pointer logits (T <= 256) of its row:
+constexpr int NLL_PSLOTS = 4;    // all loads are issued up front, unconditionally (clamped index), then reduced in order
 __global__ __launch_bounds__(256) void mixture_nll_fwd_kernel(float* stats, float* row_lse, const float* vocab, int ldv,
                                                               const float* ptr, const float* sw, const int64_t* label,
                                                               int B, int Tn, int V, int pad) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= (int64_t)B * Tn) return;
-    const int i = (int)(row % Tn);
-    const float* vr = vocab + row * ldv;
-    const float* pr = ptr + row * Tn;
-    RowStat sv{-INFINITY, 0.f, 0x7fffffff}, sp{-INFINITY, 0.f, 0x7fffffff};
-    for (int k = lane; k < V; k += 64) online(sv, vr[k], k);
-    for (int j = lane; j < Tn; j += 64) online(sp, (j >= i) ? 1e-6f : pr[j], j);
-    sv = wave_merge(sv);
-    sp = wave_merge(sp);
-    const float lse_v = sv.m + logf(sv.s), lse_p = sp.m + logf(sp.s);
-    const float prob = 1.0f / (1.0f + expf(-sw[row]));
-    const float lv = logf(fmaxf(1.0f - prob, 1e-6f)), lp = logf(fmaxf(prob, 1e-6f));
-    if (lane == 0) {
-        row_lse[row * 2] = lse_v; row_lse[row * 2 + 1] = lse_p;
-        const int64_t lab = label[row];
-        if (lab != pad) {
-            float logp;
-            if (lab < V) logp = vr[lab] - lse_v + lv;
-            else { const int j = (int)(lab - V); logp = ((j >= i) ? 1e-6f : pr[j]) - lse_p + lp; }
-            const float best_v = sv.m - lse_v + lv, best_p = sp.m - lse_p + lp;
-            const int64_t pred = (best_p > best_v) ? (int64_t)V + sp.arg : (int64_t)sv.arg;
-            atomicAdd(stats + 0, -logp);
-            atomicAdd(stats + 1, 1.0f);
-            if (pred == lab) atomicAdd(stats + 2, 1.0f);
+    __shared__ float red[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a_nll = 0.f, a_cnt = 0.f, a_hit = 0.f;
+    for (int rr = wave; rr < NLL_ROWS; rr += 4) {
+        const int64_t row = (int64_t)blockIdx.x * NLL_ROWS + rr;
+        if (row >= (int64_t)B * Tn) break;
+        const int i = (int)(row % Tn);
+        const float* vr = vocab + row * ldv;
+        const float* pr = ptr + row * Tn;
+        RowStat sv{-INFINITY, 0.f, 0x7fffffff}, sp{-INFINITY, 0.f, 0x7fffffff};
+        if (V <= 64 * NLL_VSLOTS && Tn <= 64 * NLL_PSLOTS) {
+            float xv[NLL_VSLOTS], xp[NLL_PSLOTS];
+#pragma unroll
+            for (int q = 0; q < NLL_VSLOTS; ++q) xv[q] = vr[min(lane + 64 * q, V - 1)];
+#pragma unroll
+            for (int q = 0; q < NLL_PSLOTS; ++q) xp[q] = pr[min(lane + 64 * q, Tn - 1)];
+#pragma unroll
+            for (int q = 0; q < NLL_VSLOTS; ++q) { const int k = lane + 64 * q; if (k < V) online(sv, xv[q], k); }
+#pragma unroll
+            for (int q = 0; q < NLL_PSLOTS; ++q) { const int j = lane + 64 * q; if (j < Tn) online(sp, (j >= i) ? 1e-6f : xp[q], j); }
+        } else {
+            for (int k = lane; k < V; k += 64) online(sv, vr[k], k);
+            for (int j = lane; j < Tn; j += 64) online(sp, (j >= i) ? 1e-6f : pr[j], j);
         }
+        sv = wave_merge(sv);
+        sp = wave_merge(sp);
+        const float lse_v = sv.m + logf(sv.s), lse_p = sp.m + logf(sp.s);
+        const float prob = 1.0f / (1.0f + expf(-sw[row]));
+        const float lv = logf(fmaxf(1.0f - prob, 1e-6f)), lp = logf(fmaxf(prob, 1e-6f));
+        if (lane == 0) {
+            row_lse[row * 2] = lse_v; row_lse[row * 2 + 1] = lse_p;
+            const int64_t lab = label[row];
+            if (lab != pad) {
+                float logp;
+                if (lab < V) logp = vr[lab] - lse_v + lv;
+                else { const int j = (int)(lab - V); logp = ((j >= i) ? 1e-6f : pr[j]) - lse_p + lp; }
+                const float best_v = sv.m - lse_v + lv, best_p = sp.m - lse_p + lp;
+                const int64_t pred = (best_p > best_v) ? (int64_t)V + sp.arg : (int64_t)sv.arg;
+                a_nll -= logp; a_cnt += 1.0f;
+                if (pred == lab) a_hit += 1.0f;
+            }
+        }
+    }
+    if (lane == 0) { red[wave][0] = a_nll; red[wave][1] = a_cnt; red[wave][2] = a_hit; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (v != 0.f) atomicAdd(stats + threadIdx.x, v);
     }
 }
 
@@ -777,7 +801,7 @@ extern "C" int pa_mixture_nll_fwd(float* stats, float* row_lse, const float* voc
                                   const float* sw, const int64_t* label, int32_t B, int32_t T, int32_t V, int32_t pad,
                                   void* stream) {
     if (!stats || !row_lse || !vocab || !ptr || !sw || !label || B <= 0 || T <= 0 || V <= 0 || ldv < V) return PA_EINVAL;
-    const int grid = (int)(((int64_t)B * T + 3) / 4);
+    const int grid = (int)(((int64_t)B * T + NLL_ROWS - 1) / NLL_ROWS);
     PA_LAUNCH(mixture_nll_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad);
     return 0;
 }
