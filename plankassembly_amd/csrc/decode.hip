@@ -132,11 +132,11 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int l
             const int key = base0 + j * 4 * KPW + slot;
             const bool in = key < Lk;
             okk[j] = in && !(mk && mk[in ? key : 0]);
-            kraw[j] = u32x4{0u, 0u, 0u, 0u}; vraw[j] = kraw[j];
-            if (in) {
-                kraw[j] = *reinterpret_cast<const u32x4*>(kb + (int64_t)key * ldkv);
-                vraw[j] = *reinterpret_cast<const u32x4*>(vb + (int64_t)key * ldkv);
-            }
+            // unconditional loads (clamped row; out-of-range keys are discarded through okk): a branch around the loads
+            // would put a wait between them
+            const int64_t kc_ = (int64_t)min(key, Lk - 1) * ldkv;
+            kraw[j] = *reinterpret_cast<const u32x4*>(kb + kc_);
+            vraw[j] = *reinterpret_cast<const u32x4*>(vb + kc_);
         }
         float s[UN];
 #pragma unroll
