@@ -241,13 +241,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(T* dz, T* ddrop, con
             mu[u] = 0.f; rs[u] = 0.f;
             const int64_t row = r0 + rr + 4 * u;
             ok[u] = (rr + 4 * u < LNB_ROWS) && row < rows;
-            if (ok[u]) {
-                mu[u] = mean[row]; rs[u] = rstd[row];
+            // unconditional loads (row and column clamped; the surplus is discarded through ok / c < d below): a branch
+            // around them would put a wait between the loads of the two rows
+            const int64_t rowc = row < rows ? row : rows - 1;
+            mu[u] = mean[rowc]; rs[u] = rstd[rowc];
 #pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    const int c = (lane + i * 64) << 2;
-                    if (c < d) { zz[u][i] = ld4<T>(z + row * d + c); dd[u][i] = ld4<T>(dy + row * d + c); }
-                }
+            for (int i = 0; i < NV; ++i) {
+                const int c = min((lane + i * 64) << 2, d - 4);
+                zz[u][i] = ld4<T>(z + rowc * d + c); dd[u][i] = ld4<T>(dy + rowc * d + c);
             }
         }
 #pragma unroll
