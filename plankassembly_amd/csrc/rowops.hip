@@ -168,42 +168,45 @@ __global__ __launch_bounds__(256) void pack_fill_kernel(const uint8_t* mask, int
 }
 
 // ================================================================================ LayerNorm
-template <typename T>
+template <typename T, int NV>   // NV = ceil(d / 256): 4-wide vectors per lane per row
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(T* y, const T* z, const float* gamma, const float* beta,
                                                             float* mean, float* rstd, int64_t rows, int d, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T* zr = z + row * d;
-    f32x4 v[MAXV];
+    // every load of the row (and of gamma / beta) is issued up front, unconditionally (column clamped; lanes past d are
+    // masked in the arithmetic)
+    f32x4 v[NV], g[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = min((lane + i * 64) << 2, d - 4);
+        v[i] = ld4<T>(zr + c);
+        g[i] = *reinterpret_cast<const f32x4*>(gamma + c);
+        b[i] = *reinterpret_cast<const f32x4*>(beta + c);
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (lane + i * 64) << 2;
-        if (c < d) { v[i] = ld4<T>(zr + c); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
-    }
+    for (int i = 0; i < NV; ++i)
+        if (((lane + i * 64) << 2) < d) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     const float mu = wave_sum(s) / d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (lane + i * 64) << 2;
-        if (c < d) {
+    for (int i = 0; i < NV; ++i)
+        if (((lane + i * 64) << 2) < d) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const float t = v[i][j] - mu; q += t * t; }
         }
-    }
     const float rs = 1.0f / sqrtf(wave_sum(q) / d + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     T* yr = y + row * d;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (lane + i * 64) << 2;
         if (c < d) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
             f32x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[i][j] + b[i][j];
             st4<T>(yr + c, o);
         }
     }
@@ -727,8 +730,11 @@ extern "C" int pa_layernorm_fwd(void* y, const void* z, const float* gamma, cons
                                 int64_t rows, int32_t d, float eps, int32_t dtype, void* stream) {
     if (!y || !z || !gamma || !beta || !mean || !rstd || rows <= 0 || (d & 3) || d > 256 * MAXV) return PA_EINVAL;
     const int grid = (int)((rows + 3) / 4);
-    if (dtype == PA_BF16) PA_LAUNCH(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)y, (const bf16*)z, gamma, beta, mean, rstd, rows, d, eps);
-    else PA_LAUNCH(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)y, (const float*)z, gamma, beta, mean, rstd, rows, d, eps);
+#define LNF_GO(T_, NV_) PA_LAUNCH((layernorm_fwd_kernel<T_, NV_>), dim3(grid), dim3(256), 0, ST(stream), (T_*)y, (const T_*)z, gamma, beta, mean, rstd, rows, d, eps)
+#define LNF_NV(T_) do { if (d <= 256) LNF_GO(T_, 1); else if (d <= 512) LNF_GO(T_, 2); else if (d <= 1024) LNF_GO(T_, 4); else LNF_GO(T_, 8); } while (0)
+    if (dtype == PA_BF16) LNF_NV(bf16); else LNF_NV(float);
+#undef LNF_NV
+#undef LNF_GO
     return 0;
 }
 
