@@ -2091,22 +2091,29 @@ __global__ __launch_bounds__(256) void colsum_many_kernel(ColsumTab t) { colsum_
 // ---- the whole tail of a backward segment in ONE launch: LayerNorm gamma/beta finishes, bias column sums and split-K
 // slab reductions are independent of each other; their blocks are simply concatenated (every dependent launch saved
 // is ~5 us on this machine)
+// LN_CHUNKS blocks share the partial rows of one (LayerNorm, statistic, 64-column block): with 8-row LayerNorm-backward
+// blocks there are ~1 000 partial rows per LayerNorm, and 24 blocks walking them 4 at a time were the longest part of the
+// tail.  The chunk sums are combined with one f32 atomic per column.
+constexpr int LN_CHUNKS = 8;
 struct LnTailTab { pa_ln_finish_desc d[PA_MAX_LN_FINISH]; int n; int ncols; int nbx; int nby; };
 __device__ __forceinline__ void ln_finish_block(const LnTailTab& t, int blk) {
     __shared__ float red_ln[256];
+    const int ch = blk % LN_CHUNKS; blk /= LN_CHUNKS;
     const int bx = blk % t.nbx, by = (blk / t.nbx) % t.nby, bz = blk / (t.nbx * t.nby);
     const pa_ln_finish_desc d = t.d[bz];
     const int c = bx * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
     float* o = by == 0 ? d.dgamma : (by == 1 ? d.dbeta : d.dzsum);
+    const int per = (d.nparts + LN_CHUNKS - 1) / LN_CHUNKS, i0 = ch * per, i1 = min(d.nparts, i0 + per);
     float sacc = 0.f;
     if (c < t.ncols && o) {
         const float* p = d.partial + (size_t)by * t.ncols + c;
 #pragma unroll 8
-        for (int i = pl; i < d.nparts; i += 4) sacc += p[(size_t)i * 3 * t.ncols];
+        for (int i = i0 + pl; i < i1; i += 4) sacc += p[(size_t)i * 3 * t.ncols];
     }
     red_ln[threadIdx.x] = sacc;
     __syncthreads();
-    if (pl == 0 && c < t.ncols && o) o[c] += (red_ln[threadIdx.x] + red_ln[threadIdx.x + 64]) + (red_ln[threadIdx.x + 128] + red_ln[threadIdx.x + 192]);
+    if (pl == 0 && c < t.ncols && o && i0 < i1)
+        unsafeAtomicAdd(o + c, (red_ln[threadIdx.x] + red_ln[threadIdx.x + 64]) + (red_ln[threadIdx.x + 128] + red_ln[threadIdx.x + 192]));
 }
 template <typename T>
 __global__ __launch_bounds__(256) void segment_tail_kernel(LnTailTab ln, int n_ln_blocks, ColsumTab cs, int n_cs_blocks, ReduceTab rd) {
@@ -2128,7 +2135,7 @@ extern "C" int pa_segment_tail(const pa_ln_finish_desc* ln, int32_t n_ln, int32_
         lt.d[i] = ln[i];
         if (ln[i].dzsum) lt.nby = 3;
     }
-    const int n_ln_blocks = n_ln ? lt.nbx * lt.nby * n_ln : 0;
+    const int n_ln_blocks = n_ln ? lt.nbx * lt.nby * n_ln * LN_CHUNKS : 0;
     ColsumTab ct; ct.n = n_cs; ct.begin[0] = 0;
     for (int i = 0; i < n_cs; ++i) {
         const pa_colsum_desc& d = cs[i];
