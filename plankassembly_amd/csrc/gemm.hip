@@ -2192,9 +2192,53 @@ __global__ __launch_bounds__(256) void transpose_many_kernel(const pa_tr_desc* d
     const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
     const T* src = reinterpret_cast<const T*>(d.src);
     T* dst = reinterpret_cast<T*>(d.dst);
+    if constexpr (sizeof(T) == 2) {
+        // 8-byte accesses: thread -> (row = t/16 + 16k, 4 columns).  Needs 4-element aligned rows on both sides;
+        // loads are unconditional (clamped), stores are predicated per element at the edges (padding stays untouched).
+        const bool wide = ((d.ld_src | d.ld_dst | d.cols) & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 7) == 0 &&
+                          (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
+        if (wide) {
+            const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;
+            u32x2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rr = min(r0 + tr + 16 * k, d.rows - 1), cc = min(c0 + tc, d.cols - 4);
+                v[k] = *reinterpret_cast<const u32x2*>(src + (size_t)rr * d.ld_src + cc);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint16_t* row = reinterpret_cast<uint16_t*>(&tile[tr + 16 * k][tc]);
+                row[0] = (uint16_t)(v[k][0] & 0xffffu); row[1] = (uint16_t)(v[k][0] >> 16);
+                row[2] = (uint16_t)(v[k][1] & 0xffffu); row[3] = (uint16_t)(v[k][1] >> 16);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int oc = c0 + tr + 16 * k;                 // destination row = source column
+                const int orow = r0 + tc;                         // destination columns orow .. orow + 3 = source rows
+                if (oc >= d.cols || orow >= d.rows) continue;
+                const uint16_t* tp = reinterpret_cast<const uint16_t*>(&tile[0][0]);
+                uint16_t e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = tp[(tc + q) * 65 + tr + 16 * k];
+                T* o = dst + (size_t)oc * d.ld_dst + orow;
+                if (orow + 3 < d.rows) {
+                    u32x2 w; w[0] = (uint32_t)e[0] | ((uint32_t)e[1] << 16); w[1] = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+                    *reinterpret_cast<u32x2*>(o) = w;
+                } else {
+                    for (int q = 0; q < 4 && orow + q < d.rows; ++q) reinterpret_cast<uint16_t*>(o)[q] = e[q];
+                }
+            }
+            return;
+        }
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4)
-        if (r0 + i < d.rows && c0 + tx < d.cols) tile[i][tx] = src[(size_t)(r0 + i) * d.ld_src + c0 + tx];
+    const int cc = min(c0 + tx, d.cols - 1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rr = ty + 4 * i;
+        tile[rr][tx] = src[(size_t)min(r0 + rr, d.rows - 1) * d.ld_src + cc];
+    }
     __syncthreads();
     for (int i = ty; i < 64; i += 4)
         if (c0 + i < d.cols && r0 + tx < d.rows) dst[(size_t)(c0 + i) * d.ld_dst + r0 + tx] = tile[tx][i];

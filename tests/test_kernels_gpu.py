@@ -488,3 +488,27 @@ def test_gemm_wide_tile_bf16():
     a, b = rnd(4096, 1024, dtype=torch.bfloat16, seed=74, scale=0.3), rnd(2048, 1024, dtype=torch.bfloat16, seed=75, scale=0.3)
     out = ops.gemm(a.to(DEV), b.to(DEV), out_dtype=torch.float32)
     assert rel_err(out, a.float() @ b.float().t()) < 1e-2
+
+
+def test_transpose_many_bf16_edges():
+    """pa_transpose_many: 8-byte path (aligned matrices, ragged row count, padded / offset destination whose padding
+    must stay untouched) and the scalar path (unaligned shapes), all in one launch."""
+    import ctypes as C
+    from plankassembly_amd import _lib as L
+    from plankassembly_amd.models import _TrDesc
+    specs = [(514, 512, 576, 0), (1024, 512, 6144, 2048), (96, 40, 96, 0), (30, 18, 30, 0)]   # rows, cols, ld_dst, dst column offset
+    srcs, dsts, descs, tiles = [], [], [], 0
+    for i, (r, c, ldd, off) in enumerate(specs):
+        src = rnd(r, c, dtype=torch.bfloat16, seed=80 + i).to(DEV)
+        dst = torch.full((c, ldd), 7.0, dtype=torch.bfloat16, device=DEV)
+        srcs.append(src); dsts.append(dst)
+        descs.append(_TrDesc(src.data_ptr(), dst.data_ptr() + off * 2, r, c, c, ldd, tiles, 0))
+        tiles += ((r + 63) // 64) * ((c + 63) // 64)
+    arr = (_TrDesc * len(descs))(*descs)
+    dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    L.check(L.lib().pa_transpose_many(L.ptr(dev), len(descs), tiles, L.PA_BF16, L.stream()), "pa_transpose_many")
+    torch.cuda.synchronize()
+    for (r, c, ldd, off), src, dst in zip(specs, srcs, dsts):
+        assert torch.equal(dst[:, off:off + r].cpu(), src.t().cpu())
+        pad = torch.cat([dst[:, :off], dst[:, off + r:]], 1)
+        assert bool((pad == 7.0).all())                      # nothing written outside the transposed block
