@@ -151,7 +151,8 @@ int pa_embed_input_bwd(const void* dout, int32_t dtype, float* const* dtables, c
 /* Embedding-table gradients by sorted segments: the token rows are grouped by table row once per batch - order[k] =
  * row indices (into dout) sorted by id, seg[k][r] .. seg[k][r+1] = the rows that use table row r (int32, seg has
  * table_rows[k] + 1 entries) - and each table row sums its segment: dtable[r] += sum (tables with few rows split
- * their long segments over several blocks and combine with one atomic per column).  n_rows = rows of dout (sizes the
+ * their long segments over several blocks and combine with one atomic per column; in larger tables a row used by more
+ * than 64 tokens is split over 8 blocks the same way).  n_rows = rows of dout (sizes the
  * splitting).  The grouping depends only on the batch, so it is built when the batch is prepared
  * (PlankModel.prepare_batch); without it the atomic scatter-add kernels (pa_embed_input_bwd / _output_bwd) run. */
 #define PA_MAX_SEG_TABLES 5

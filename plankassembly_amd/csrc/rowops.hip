@@ -604,6 +604,7 @@ extern "C" int pa_embed_input_fwd(void* out, int32_t out_dtype, const float* con
 struct SegTab { float* t[PA_MAX_SEG_TABLES]; const int32_t* order[PA_MAX_SEG_TABLES]; const int32_t* seg[PA_MAX_SEG_TABLES];
                 int rows[PA_MAX_SEG_TABLES]; int ch[PA_MAX_SEG_TABLES]; int begin[PA_MAX_SEG_TABLES + 1]; int n; };
 constexpr int SEG_CHUNK = 128;
+constexpr int SEG_SPLIT = 8, SEG_LONG = 64;
 template <typename T>
 __device__ __forceinline__ f32x4 seg_sum(const T* dout, const int32_t* order, int lo, int hi, int d, int c) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -637,11 +638,24 @@ __global__ __launch_bounds__(128) void embed_segment_bwd_kernel(const T* dout, S
     const int32_t* order = tb.order[k];
     const int32_t* seg = tb.seg[k];
     if (tb.ch[k] == 1) {
-        const int b0 = seg[rel], b1 = seg[rel + 1];
-        if (b0 >= b1) return;
+        // SEG_SPLIT blocks per table row: a row used by at most SEG_LONG tokens is summed by its first block alone (plain
+        // read-modify-write); a heavily used row (skewed token distributions: thousands of tokens on one value) is spread
+        // over all of them, which then combine with atomics.
+        const int r = rel / SEG_SPLIT, j = rel - r * SEG_SPLIT;
+        const int b0 = seg[r], b1 = seg[r + 1], len = b1 - b0;
+        if (len <= 0 || (len <= SEG_LONG && j > 0)) return;
+        const bool multi = len > SEG_LONG;
+        const int per = multi ? (len + SEG_SPLIT - 1) / SEG_SPLIT : len;
+        const int lo = b0 + j * per, hi = min(b1, lo + per);
+        if (lo >= hi) return;
         for (int c = threadIdx.x << 2; c < d; c += 512) {
-            float* dst = tb.t[k] + (int64_t)rel * d + c;
-            *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + seg_sum<T>(dout, order, b0, b1, d, c);
+            float* dst = tb.t[k] + (int64_t)r * d + c;
+            const f32x4 acc = seg_sum<T>(dout, order, lo, hi, d, c);
+            if (!multi) *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + acc;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, acc[e]);
+            }
         }
     } else {
         const int c0 = rel * SEG_CHUNK, c1 = min(c0 + SEG_CHUNK, seg[tb.rows[k]]);
@@ -667,7 +681,7 @@ extern "C" int pa_embed_segment_bwd(const void* dout, int32_t dtype, float* cons
         tb.t[k] = dtables[k]; tb.order[k] = order[k]; tb.seg[k] = seg[k]; tb.rows[k] = table_rows[k];
         if (!tb.t[k] || !tb.order[k] || !tb.seg[k] || tb.rows[k] <= 0) return PA_EINVAL;
         tb.ch[k] = tb.rows[k] > 64 ? 1 : 0;
-        tb.begin[k + 1] = tb.begin[k] + (tb.ch[k] ? tb.rows[k] : (int)((n_rows + SEG_CHUNK - 1) / SEG_CHUNK));
+        tb.begin[k + 1] = tb.begin[k] + (tb.ch[k] ? tb.rows[k] * SEG_SPLIT : (int)((n_rows + SEG_CHUNK - 1) / SEG_CHUNK));
     }
     if (dtype == PA_BF16) PA_LAUNCH(embed_segment_bwd_kernel<bf16>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const bf16*)dout, tb, d);
     else PA_LAUNCH(embed_segment_bwd_kernel<float>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const float*)dout, tb, d);

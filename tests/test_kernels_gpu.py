@@ -512,3 +512,34 @@ def test_transpose_many_bf16_edges():
         assert torch.equal(dst[:, off:off + r].cpu(), src.t().cpu())
         pad = torch.cat([dst[:, :off], dst[:, off + r:]], 1)
         assert bool((pad == 7.0).all())                      # nothing written outside the transposed block
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_segment_bwd_skewed_rows(dtype):
+    """pa_embed_segment_bwd with a skewed id distribution: one table row used by thousands of tokens (split over several
+    blocks), rows used by exactly the single-block limit, unused rows, and a small table on the chunked path; the
+    gradients accumulate onto the existing table contents."""
+    import ctypes as C
+    from plankassembly_amd import _lib as L
+    from plankassembly_amd.models import group_rows_by_id
+    n, d = 6000, 512
+    g = torch.Generator().manual_seed(91)
+    big = torch.randint(0, 300, (n,), generator=g)
+    big[:3000] = 7                                     # heavy row
+    big[3000:3064] = 11                                # exactly 64 more users of one row
+    big[big == 5] = 6                                  # row 5 unused
+    small = torch.randint(0, 6, (n,), generator=g)
+    dout = rnd(n, d, dtype=dtype, seed=92).to(DEV)
+    tabs = [torch.full((300, d), 0.5, device=DEV), torch.full((6, d), -0.25, device=DEV)]
+    ids = [big.to(DEV), small.to(DEV)]
+    groups = [group_rows_by_id(i, t.shape[0]) for i, t in zip(ids, tabs)]
+    PP = C.c_void_p * 2
+    rows = (C.c_int32 * 2)(300, 6)
+    L.check(L.lib().pa_embed_segment_bwd(L.ptr(dout), L.dt(dout), PP(*[t.data_ptr() for t in tabs]),
+                                         PP(*[o.data_ptr() for o, _ in groups]), PP(*[s.data_ptr() for _, s in groups]),
+                                         rows, 2, n, d, L.stream()), "pa_embed_segment_bwd")
+    torch.cuda.synchronize()
+    for t, i, base in zip(tabs, ids, (0.5, -0.25)):
+        ref = torch.full(t.shape, base, dtype=torch.float64).index_add_(0, i.cpu(), dout.double().cpu())
+        assert rel_err(t, ref.float()) < 2e-6
+    assert bool((tabs[0][5] == 0.5).all())
