@@ -57,6 +57,14 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
         const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
         const int ktile = dt() == PA_BF16 ? 64 : 16;
         const int nkt = (M + ktile - 1) / ktile;
+        static const bool plan = !(getenv("PA_DW_PLAN") && atoi(getenv("PA_DW_PLAN")) == 0);
+        if (plan && m->defer_ok && tiles < 256 && m->ndwq < PA_MAX_GROUP) {
+            // member of the segment's grouped launch: its split is chosen at the flush, when all members are known
+            // (plan_group: one round of the one-block-per-CU kernel with the longest K slice as short as possible)
+            g.splitk = 0; g.ws = nullptr;
+            m->dwq[m->ndwq++] = g;
+            return queue_bias(dY, lddy, db, M, N);
+        }
         int sk = 1;
         if (tiles < 256) {
             // a lone launch wants one round of the one-block-per-CU kernel (256 tiles x slices); the members of a grouped
@@ -84,6 +92,10 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
         } else {
             RC(pa_gemm(&g, st));
         }
+        return queue_bias(dY, lddy, db, M, N);
+    }
+    // db[N] += colsum(dY[M][N])  (queued for the segment tail when the buffer stays untouched until then)
+    int queue_bias(const void* dY, int lddy, float* db, int M, int N) const {
         if (db) {   // gradients are zero-initialised by the caller: accumulate
             const int EB = dt() == PA_BF16 ? 8 : 4;
             const bool vec = (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && lddy % EB == 0 && lddy >= (N + EB - 1) / EB * EB;
@@ -432,8 +444,56 @@ int backward_segment_body(pa_model* m, int seg, float gscale, void* st);
 #define HC(x) do { hipError_t he_ = (x); if (he_ != hipSuccess) return (int)he_; } while (0)
 // enqueue the segment's queued work (grouped weight-gradient GEMM, split-K reductions, bias column sums, LayerNorm
 // finishes) on stream `q`
+// Split-K plan for the queued weight-gradient GEMMs of a segment (members queued with splitk == 0).  The grouped launch
+// runs one block per CU and a unit is (128x128 tile, K slice), so its duration is the longest K slice: starting from no
+// split, the member with the longest slice gets one more slice for as long as the launch still fits one round of the CUs.
+// Encoder layer (K = 7 940 rows, 128 tiles): every member split in two -> 256 units of 63 K tiles; decoder layer: only the
+// cross-attention K/V gradient (K = encoder rows) is split.  Slabs of the split members are reduced by the segment tail.
+void plan_group(pa_model* m) {
+    const int n = m->ndwq;
+    int tiles[PA_MAX_GROUP], nkt[PA_MAX_GROUP], cap[PA_MAX_GROUP], sk[PA_MAX_GROUP];
+    const int ktile = m->cfg.dtype == PA_BF16 ? 64 : 16;
+    int total = 0, planned = 0;
+    for (int i = 0; i < n; ++i) {
+        const pa_gemm_args& g = m->dwq[i];
+        tiles[i] = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+        nkt[i] = (g.K + ktile - 1) / ktile;
+        sk[i] = g.splitk > 0 ? g.splitk : 1;
+        cap[i] = g.splitk > 0 ? sk[i] : ((g.N & 3) ? 1 : (nkt[i] / 4 < 16 ? (nkt[i] / 4 > 0 ? nkt[i] / 4 : 1) : 16));
+        total += tiles[i] * sk[i];
+        planned += g.splitk == 0;
+    }
+    if (!planned) return;
+    static const int budget_env = getenv("PA_DW_BUDGET") ? atoi(getenv("PA_DW_BUDGET")) : 0;
+    const int budget = budget_env > 0 ? budget_env : 256;
+    for (;;) {
+        int best = -1, len = 0;
+        for (int i = 0; i < n; ++i) {
+            const int li = (nkt[i] + sk[i] - 1) / sk[i];
+            if (li > len) { len = li; best = i; }
+        }
+        if (best < 0 || sk[best] >= cap[best] || total + tiles[best] > budget) break;
+        ++sk[best]; total += tiles[best];
+    }
+    for (int i = 0; i < n; ++i) {
+        pa_gemm_args& g = m->dwq[i];
+        if (g.splitk > 0) continue;
+        int s = pa_gemm_effective_splitk(g.K, g.in_dtype, sk[i]);
+        const size_t need = (size_t)s * g.M * g.N;
+        if (s > 1 && !(m->ndefer < PA_MAX_REDUCE && m->slab_used + need <= m->splitws_floats)) s = 1;
+        g.splitk = s; g.ws = m->splitws; g.splitk_defer = 0;
+        if (s > 1) {
+            g.ws = m->splitws + m->slab_used;
+            g.splitk_defer = 1;
+            pa_reduce_desc& rd = m->defer[m->ndefer++];
+            rd.ws = (const float*)g.ws; rd.out = (float*)g.C; rd.rows = g.M; rd.cols = g.N; rd.ld_out = g.ldc; rd.splitk = s;
+            m->slab_used += (need + 3) / 4 * 4;
+        }
+    }
+}
 int flush_segment(pa_model* m, void* q) {
     if (m->ndwq > 0) {                                     // all weight-gradient GEMMs of the segment: one ring-kernel launch
+        plan_group(m);
         int rc = m->ndwq > 1 ? pa_gemm_group(m->dwq, m->ndwq, q) : PA_EINVAL;
         if (rc == PA_EINVAL) { rc = 0; for (int i = 0; i < m->ndwq && !rc; ++i) rc = pa_gemm(&m->dwq[i], q); }
         m->ndwq = 0;
