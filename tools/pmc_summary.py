@@ -21,8 +21,9 @@ KEYS = [  # json key -> regex on the demangled kernel name
     ("gemm_ring_nn", r"gemm3_kernel<false, false, .*GemmP>"),
     ("gemm_group_nn", r"gemm3_kernel<false, false, .*GemmGroup>"),
     ("gemm_small_tt", r"gemm3s_kernel"),
-    ("gemm_pair_tt", r"gemm_kernel<__bf16, 64, 2, true, true, true, true, false, 2>"),
-    ("gemm_pair_nn", r"gemm_kernel<__bf16, 64, 2, false, false, true, true, true, 2>"),
+    # (rocprofv3's demangler leaves names with the __bf16 template argument mangled)
+    ("gemm_pair_tt", r"gemm_kernel<__bf16, 64, 2, true, true, true, true, false, 2>|gemm_kernelIDF16bLi64ELi2ELb1ELb1ELb1ELb1ELb0ELi2E"),
+    ("gemm_pair_nn", r"gemm_kernel<__bf16, 64, 2, false, false, true, true, true, 2>|gemm_kernelIDF16bLi64ELi2ELb0ELb0ELb1ELb1ELb1ELi2E"),
     ("attn_fwd", r"attn_fwd_bf16_kernel<64>"),
     ("attn_bwd_dq", r"attn_bwd_dq_bf16_kernel<64>"),
     ("attn_bwd_dkv", r"attn_bwd_dkv_bf16_kernel<64>"),
