@@ -465,7 +465,8 @@ void plan_group(pa_model* m) {
     }
     if (!planned) return;
     static const int budget_env = getenv("PA_DW_BUDGET") ? atoi(getenv("PA_DW_BUDGET")) : 0;
-    const int budget = budget_env > 0 ? budget_env : 256;
+    // whole rounds of the 256 CUs: one round for the benchmark model, more when the unsplit tiles already exceed it
+    const int budget = budget_env > 0 ? budget_env : (total + 255) / 256 * 256;
     for (;;) {
         int best = -1, len = 0;
         for (int i = 0; i < n; ++i) {
