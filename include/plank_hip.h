@@ -160,7 +160,8 @@ int pa_embed_segment_bwd(const void* dout, int32_t dtype, float* const* dtables,
                          const int32_t* const* seg, const int32_t* table_rows, int32_t n_tables, int64_t n_rows,
                          int32_t d, void* stream);
 /* Row packing ("unpadding"): mask uint8 [B][S] (1 = PAD) -> cu int32 [2B+1] (cu[b] = #valid rows before batch element
- * b, cu[B] = total; entries B+1..2B are scratch) and rowmap int32 [B*S] (rowmap[packed row] = b*S + s).  Padded
+ * b, cu[B] = total; entries B+1..2B = the batch elements by descending row count, the dispatch order of the
+ * variable-length attention launches, pa_attn_args.order) and rowmap int32 [B*S] (rowmap[packed row] = b*S + s).  Padded
  * encoder positions never reach the loss (they are masked as keys everywhere), so the encoder stack can run on the
  * packed rows only; rowmap (optional, NULL = identity) lets the embedding kernels gather / scatter packed rows. */
 int pa_pack_rows(const uint8_t* mask, int32_t B, int32_t S, int32_t* cu, int32_t* rowmap, void* stream);
@@ -243,6 +244,11 @@ typedef struct {
      * element, or NULL for the dense [B][L] layout.  With offsets, Lq/Lk are the per-batch maxima (grid size and
      * layout of lse/delta [B][H][Lq]); no padding mask is needed because padded tokens are simply not there. */
     const int32_t* cu_q; const int32_t* cu_k;
+    /* optional dispatch order: int32 [B], a permutation of the batch elements by descending length (pa_pack_rows
+     * leaves it in cu[B+1 .. 2B]).  All blocks of a launch start together, a few per CU, so a variable-length launch
+     * lasts as long as the CU that drew the longest elements; in this order every CU gets a long, a medium and a short
+     * block.  Results do not depend on it.  NULL = batch order. */
+    const int32_t* order;
 } pa_attn_args;
 int pa_attn_fwd(const pa_attn_args* a, void* stream);
 int pa_attn_bwd(const pa_attn_args* a, void* stream);
@@ -324,7 +330,8 @@ typedef struct {
     const int64_t* output_label;   /* [B][T] */
     const uint8_t* output_mask;    /* [B][T] */
     int32_t B, S, T;
-    /* optional packed-encoder mode (pa_pack_rows): all three set, or cu_in == NULL for the dense path.  n_valid is the
+    /* optional packed-encoder mode: cu_in (int32 [2B+1]) and rowmap exactly as pa_pack_rows wrote them (the runtime also
+     * reads the dispatch order it leaves in cu_in[B+1 .. 2B]), or cu_in == NULL for the dense path.  n_valid is the
      * host copy of cu_in[B] (the one device->host read of a training step). */
     const int32_t* cu_in; const int32_t* rowmap; int32_t n_valid;
     /* optional grouping of the token rows by table row (pa_embed_segment_bwd; NULL = atomic scatter-add kernels):

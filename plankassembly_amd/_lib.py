@@ -45,7 +45,7 @@ class AttnArgs(C.Structure):
                 ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
                 ("delta", C.c_void_p),
                 ("lddo", C.c_int32), ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32),
-                ("cu_q", C.c_void_p), ("cu_k", C.c_void_p)]
+                ("cu_q", C.c_void_p), ("cu_k", C.c_void_p), ("order", C.c_void_p)]
 
 
 _lib = None

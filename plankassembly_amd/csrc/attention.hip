@@ -39,6 +39,7 @@ struct AttnP {
     const void* dout; void* dq; void* dk; void* dv; float* delta;
     int lddo, lddq, lddk, lddv;
     const int32_t* cu_q; const int32_t* cu_k;     // packed (variable-length) row offsets per batch element, or NULL
+    const int32_t* order;                         // batch elements in dispatch order (longest first), or NULL
 };
 
 // Variable-length ("unpadded") batches: with cu_q / cu_k given, batch element b owns rows [cu[b], cu[b+1]) of the
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(NTH) void attn_fwd_kernel(AttnP pin) {
     using A = AT<T, DH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
+    const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
     if (q0 >= p.Lq) return;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP pin) {
     using A = AT<T, DH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
+    const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
     if (q0 >= p.Lq) return;
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP pin) {
     using A = AT<T, DH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * BOWN;
+    const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * BOWN;
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
     if (key0 >= p.Lk) return;
@@ -664,6 +665,10 @@ __device__ __forceinline__ void decode_block(int ntiles, int H, int Bn, int& til
     h = pair % H;
     b = pair / H;
 }
+// Variable-length batches: all blocks of a launch start together (a few per CU), so the launch lasts as long as the CU
+// that drew the most work.  With `order` (batch elements by descending length) consecutive blocks carry descending work
+// and the round-robin placement gives every CU one long, one medium and one short block.
+__device__ __forceinline__ int dispatch_batch(const int32_t* order, int b) { return order ? order[b] : b; }
 
 template <int DH> struct BT {
     static constexpr int RBN = DH * 2;                 // natural row bytes
@@ -736,6 +741,7 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP pin) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b;
     decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b);
+    b = dispatch_batch(pin.order, b);
     const int q0 = tile_ * BOWN;
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
@@ -866,6 +872,7 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP pin) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b;
     decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b);
+    b = dispatch_batch(pin.order, b);
     const int q0 = tile_ * BOWN;
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
@@ -978,6 +985,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b;
     decode_block((pin.Lk + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b);
+    b = dispatch_batch(pin.order, b);
     const int key0 = tile_ * BOWN;
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
@@ -1083,7 +1091,7 @@ AttnP make_params(const pa_attn_args* a) {
     p.drop_seed = a->drop_seed;
     p.dout = a->dout; p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.delta = a->delta;
     p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
-    p.cu_q = a->cu_q; p.cu_k = a->cu_k;
+    p.cu_q = a->cu_q; p.cu_k = a->cu_k; p.order = a->order;
     return p;
 }
 

@@ -145,6 +145,19 @@ __global__ __launch_bounds__(256) void pack_count_kernel(const uint8_t* mask, in
 __global__ void pack_scan_kernel(const int32_t* cnt, int B, int32_t* cu) {
     if (threadIdx.x == 0) { int a = 0; for (int b = 0; b < B; ++b) { cu[b] = a; a += cnt[b]; } cu[B] = a; }
 }
+__global__ void pack_iota_kernel(int32_t* out, int B) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < B) out[i] = i; }
+// cnt[B] (rows per batch element) -> in place: the batch elements by descending row count (ties: batch order)
+__global__ __launch_bounds__(256) void pack_order_kernel(int32_t* cnt, int B) {
+    extern __shared__ int len_s[];
+    for (int i = threadIdx.x; i < B; i += 256) len_s[i] = cnt[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const int li = len_s[i];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) rank += (len_s[j] > li || (len_s[j] == li && j < i)) ? 1 : 0;
+        cnt[rank] = i;
+    }
+}
 __global__ __launch_bounds__(256) void pack_fill_kernel(const uint8_t* mask, int S, const int32_t* cu, int32_t* rowmap) {
     __shared__ int wsum[4];
     __shared__ int base;
@@ -733,6 +746,8 @@ extern "C" int pa_pack_rows(const uint8_t* mask, int32_t B, int32_t S, int32_t* 
     PA_LAUNCH(pack_count_kernel, dim3(B), dim3(256), 0, ST(stream), mask, S, cu + B + 1);
     PA_LAUNCH(pack_scan_kernel, dim3(1), dim3(64), 0, ST(stream), cu + B + 1, B, cu);
     PA_LAUNCH(pack_fill_kernel, dim3(B), dim3(256), 0, ST(stream), mask, S, cu, rowmap);
+    if (B <= 8192) PA_LAUNCH(pack_order_kernel, dim3(1), dim3(256), (size_t)B * sizeof(int), ST(stream), cu + B + 1, B);
+    else PA_LAUNCH(pack_iota_kernel, dim3((B + 255) / 256), dim3(256), 0, ST(stream), cu + B + 1, B);
     return 0;
 }
 

@@ -131,6 +131,9 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
              int lddkv = 0, const int32_t* cu_q = nullptr, const int32_t* cu_k = nullptr) const {
         pa_attn_args a; memset(&a, 0, sizeof(a));
         a.cu_q = cu_q; a.cu_k = cu_k;
+        // packed encoder rows: dispatch the batch elements longest first (pa_pack_rows left that order behind cu_in)
+        static const bool use_order = !(getenv("PA_ATTN_ORDER") && atoi(getenv("PA_ATTN_ORDER")) == 0);
+        if (use_order && cu_k && cu_k == m->batch.cu_in) a.order = cu_k + m->B + 1;
         const int d = m->cfg.d_model, H = m->cfg.n_head;
         a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.kpm = kpm;
         a.B = m->B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = d / H;

@@ -153,7 +153,8 @@ def embed_input_fwd(tables, idx, dtype=torch.float32, rowmap=None, n_rows=None):
 
 
 def pack_rows(mask):
-    """mask: bool/uint8 [B, S] (True = PAD).  Returns (cu int32 [B+1], rowmap int32 [n_valid], n_valid)."""
+    """mask: bool/uint8 [B, S] (True = PAD).  Returns (cu int32 [B+1], rowmap int32 [n_valid], n_valid); cu is a view of
+    the [2B+1] buffer whose tail holds the batch elements by descending row count (``pack_order(cu)``)."""
     B, S = mask.shape
     m8 = mask.to(torch.uint8).contiguous()
     cu = torch.empty(2 * B + 1, dtype=torch.int32, device=mask.device)
@@ -161,6 +162,13 @@ def pack_rows(mask):
     L.check(L.lib().pa_pack_rows(L.ptr(m8), B, S, L.ptr(cu), L.ptr(rowmap), L.stream()), "pa_pack_rows")
     n = int(cu[B])
     return cu[: B + 1], rowmap[:n], n
+
+
+def pack_order(cu):
+    """The dispatch order pa_pack_rows left behind cu (int32 [B]: batch elements, longest first)."""
+    B = cu.numel() - 1
+    base = cu._base if cu._base is not None else cu
+    return base[B + 1: 2 * B + 1]
 
 
 def embed_input_bwd(dout, dtables, idx, rowmap=None):
@@ -206,7 +214,7 @@ def layernorm_bwd(dy, z, gamma, mean, rstd, dgamma, dbeta, dzsum=None, drop_p=0.
     return dz, ddrop
 
 
-def _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H, cu_q=None, cu_k=None, B=None, Lq=None, Lk=None):
+def _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H, cu_q=None, cu_k=None, B=None, Lq=None, Lk=None, order=None):
     if B is None:
         B, Lq = q.shape[0], q.shape[1]
         Lk = k.shape[1]
@@ -218,6 +226,7 @@ def _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H, cu_q=N
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(-2), k.stride(-2), v.stride(-2), o.stride(-2)
     a.cu_q = cu_q.data_ptr() if cu_q is not None else None
     a.cu_k = cu_k.data_ptr() if cu_k is not None else None
+    a.order = order.data_ptr() if order is not None else None        # int32 [B] dispatch order (pa_pack_rows)
     a.causal = int(causal)
     a.scale = scale if scale is not None else 1.0 / math.sqrt(dh)
     a.drop_p, a.drop_seed = drop_p, drop_seed
@@ -306,18 +315,18 @@ def cast(src, dtype):
     return dst
 
 
-def attn_varlen_fwd(q, k, v, H, cu_q, cu_k, B, Lq_max, Lk_max, causal=False, scale=None, drop_p=0.0, drop_seed=0):
+def attn_varlen_fwd(q, k, v, H, cu_q, cu_k, B, Lq_max, Lk_max, causal=False, scale=None, drop_p=0.0, drop_seed=0, order=None):
     """Packed ("unpadded") attention: q [Nq, H*dh], k/v [Nk, H*dh] with int32 row offsets cu_q / cu_k [B+1]
     (either may be None = dense [B*L] rows).  Returns (o [Nq, H*dh], lse [B, H, Lq_max])."""
     o = torch.empty(q.shape[0], q.shape[1], dtype=q.dtype, device=q.device)
     lse = _f32(B, H, Lq_max, device=q.device)
-    a = _attn_args(q, k, v, o, lse, None, causal, scale, drop_p, drop_seed, H, cu_q, cu_k, B, Lq_max, Lk_max)
+    a = _attn_args(q, k, v, o, lse, None, causal, scale, drop_p, drop_seed, H, cu_q, cu_k, B, Lq_max, Lk_max, order)
     L.check(L.lib().pa_attn_fwd(C.byref(a), L.stream()), "pa_attn_fwd")
     return o, lse
 
 
-def attn_varlen_bwd(dout, q, k, v, o, lse, H, cu_q, cu_k, B, Lq_max, Lk_max, causal=False, scale=None, drop_p=0.0, drop_seed=0):
-    a = _attn_args(q, k, v, o, lse, None, causal, scale, drop_p, drop_seed, H, cu_q, cu_k, B, Lq_max, Lk_max)
+def attn_varlen_bwd(dout, q, k, v, o, lse, H, cu_q, cu_k, B, Lq_max, Lk_max, causal=False, scale=None, drop_p=0.0, drop_seed=0, order=None):
+    a = _attn_args(q, k, v, o, lse, None, causal, scale, drop_p, drop_seed, H, cu_q, cu_k, B, Lq_max, Lk_max, order)
     dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
     dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
     dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)

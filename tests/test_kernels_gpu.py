@@ -436,6 +436,8 @@ def test_pack_rows_matches_nonzero():
     assert torch.equal(rowmap.cpu().long(), valid)
     cnt = (~mask).sum(1)
     assert torch.equal(cu.cpu().long(), torch.cat((torch.zeros(1, dtype=torch.long), cnt.cumsum(0))))
+    order = ops.pack_order(cu).cpu().long()                 # batch elements by descending row count, ties in batch order
+    assert torch.equal(order, torch.sort(cnt, descending=True, stable=True).indices)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -471,6 +473,13 @@ def test_attention_varlen_matches_masked_dense(dtype, B, H, dh, Lq, Lk, self_att
     assert rel_err(dq, qr.grad.reshape(B * Lq, dm)[sel_q]) < t
     assert rel_err(dk, kr.grad.reshape(B * Lk, dm)[sel_k]) < t
     assert rel_err(dv, vr.grad.reshape(B * Lk, dm)[sel_k]) < t
+    # a dispatch order (longest first, as pa_pack_rows provides) changes which block does what, not the results
+    order = torch.sort(lens, descending=True, stable=True).indices.to(torch.int32).to(DEV)
+    o2, lse2 = ops.attn_varlen_fwd(qp, kp, vp, H, cu_q, cu_k, B, Lq, Lk, order=order)
+    rows_ok = qvalid[:, None, :].expand(B, H, Lq).to(DEV)     # lse rows past a packed element's length are never written
+    assert torch.equal(o2, o) and torch.equal(lse2[rows_ok], lse[rows_ok])
+    dq2, dk2, dv2 = ops.attn_varlen_bwd(dop, qp, kp, vp, o, lse, H, cu_q, cu_k, B, Lq, Lk, order=order)
+    assert torch.equal(dq2, dq) and torch.equal(dk2, dk) and torch.equal(dv2, dv)
 
 
 def test_gemm_wide_tile_bf16():
