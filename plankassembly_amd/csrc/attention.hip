@@ -40,6 +40,7 @@ struct AttnP {
     int lddo, lddq, lddk, lddv;
     const int32_t* cu_q; const int32_t* cu_k;     // packed (variable-length) row offsets per batch element, or NULL
     const int32_t* order;                         // batch elements in dispatch order (longest first), or NULL
+    int balanced;                                 // self-attention over packed rows with `order`: decode_block_balanced
 };
 
 // Variable-length ("unpadded") batches: with cu_q / cu_k given, batch element b owns rows [cu[b], cu[b+1]) of the
@@ -669,6 +670,30 @@ __device__ __forceinline__ void decode_block(int ntiles, int H, int Bn, int& til
 // that drew the most work.  With `order` (batch elements by descending length) consecutive blocks carry descending work
 // and the round-robin placement gives every CU one long, one medium and one short block.
 __device__ __forceinline__ int dispatch_batch(const int32_t* order, int b) { return order ? order[b] : b; }
+// Packed self-attention with H == 8 (XCD x = head x): the (element, tile) blocks of a head, sorted by descending work
+// (= element length; `order` + the tile counts from cu), are dealt to the XCD's 32 CUs boustrophedon - row 0 left to
+// right, row 1 right to left, ... - so the CU that got the longest block of one row gets the shortest of the next.
+// Blocks past the last valid one exit.  Every wave computes the same mapping from B <= 64 lanes (no LDS, no barrier).
+__device__ __forceinline__ bool decode_block_balanced(const AttnP& pin, const int32_t* cu, int& tile, int& h, int& b) {
+    const int L = blockIdx.x, x = L & 7, j = L >> 3;
+    const int lane = threadIdx.x & 63;
+    int o = 0, t = 0;
+    if (lane < pin.B) { o = pin.order[lane]; t = (cu[o + 1] - cu[o] + BOWN - 1) / BOWN; }
+    int inc = t;                                             // inclusive prefix of the tile counts over the ranks
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+    const int n = __shfl(inc, 63);
+    const int row = j >> 5, pos = j & 31, left = n - (row << 5);
+    if (left <= 0) return false;
+    const int rowlen = left < 32 ? left : 32;
+    if (pos >= rowlen) return false;
+    const int k = (row << 5) + ((row & 1) ? rowlen - 1 - pos : pos);
+    const int rank = __popcll(__ballot(inc <= k));           // elements whose blocks all come before block k
+    tile = __builtin_amdgcn_readfirstlane(k - (__shfl(inc, rank) - __shfl(t, rank)));
+    b = __builtin_amdgcn_readfirstlane(__shfl(o, rank));
+    h = x;
+    return true;
+}
 
 template <int DH> struct BT {
     static constexpr int RBN = DH * 2;                 // natural row bytes
@@ -740,8 +765,8 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP pin) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b;
-    decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b);
-    b = dispatch_batch(pin.order, b);
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b)) return; }
+    else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
     const int q0 = tile_ * BOWN;
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
@@ -871,8 +896,8 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP pin) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b;
-    decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b);
-    b = dispatch_batch(pin.order, b);
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b)) return; }
+    else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
     const int q0 = tile_ * BOWN;
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
@@ -984,8 +1009,8 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b;
-    decode_block((pin.Lk + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b);
-    b = dispatch_batch(pin.order, b);
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_k, tile_, h, b)) return; }
+    else { decode_block((pin.Lk + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
     const int key0 = tile_ * BOWN;
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
@@ -1092,6 +1117,8 @@ AttnP make_params(const pa_attn_args* a) {
     p.dout = a->dout; p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.delta = a->delta;
     p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
     p.cu_q = a->cu_q; p.cu_k = a->cu_k; p.order = a->order;
+    static const bool bal_env = !(getenv("PA_ATTN_BALANCED") && atoi(getenv("PA_ATTN_BALANCED")) == 0);
+    p.balanced = (bal_env && a->order && a->cu_q && a->cu_k && a->H == 8 && a->B <= 64) ? 1 : 0;
     return p;
 }
 

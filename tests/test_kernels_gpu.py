@@ -441,7 +441,8 @@ def test_pack_rows_matches_nonzero():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,dh,Lq,Lk,self_attn", [(3, 4, 16, 70, 70, True), (4, 8, 64, 128, 300, False), (2, 8, 64, 260, 260, True)])
+@pytest.mark.parametrize("B,H,dh,Lq,Lk,self_attn", [(3, 4, 16, 70, 70, True), (4, 8, 64, 128, 300, False), (2, 8, 64, 260, 260, True),
+                                                    (14, 8, 64, 450, 450, True)])
 def test_attention_varlen_matches_masked_dense(dtype, B, H, dh, Lq, Lk, self_attn):
     """Packed K/V (and Q for self-attention) without any mask == dense attention with a key-padding mask."""
     dm = H * dh
