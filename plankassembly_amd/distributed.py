@@ -61,7 +61,9 @@ class GradSync:
         self._pending = None
         if hi <= lo:
             return
-        g = self.model.flat_grads
+        g = getattr(self.model, "grad_sync_buffer", None)
+        if g is None:
+            g = self.model.flat_grads
         # ProcessGroupNCCL (= RCCL on ROCm) orders the collective after the work already enqueued on
         # the current stream and runs it on its own stream: the remaining backward kernels overlap.
         self._works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -75,13 +77,21 @@ class GradSync:
     def broadcast_parameters(self, src=0):
         """DDP constructor semantics: every rank starts from rank ``src``'s parameters."""
         dist.broadcast(self.model.flat_params, src=src, group=self.group)
-        if getattr(self.model, "_shadow_version", None) is not None:
-            self.model._shadow_version = -1
+        if hasattr(self.model, "invalidate_shadow"):
+            self.model.invalidate_shadow()
 
 
 def allreduce_metric_sums(values, group=None):
     """Sum a small vector of metric accumulators over ranks (reference plankassembly/metric.py:13-16,
     ``dist_reduce_fx='sum'``; trainer_complete.py:87-89 ``sync_dist=True``)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
+        backend = str(dist.get_backend(group)).lower()
+        if values.device.type == "cpu" and "nccl" in backend and "gloo" not in backend:
+            # the trainer / bench initialise an RCCL-only group: it has no CPU backend, so the (CPU, float64) metric
+            # accumulators travel through the current device
+            dev = values.to(torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(dev, op=dist.ReduceOp.SUM, group=group)
+            values.copy_(dev.cpu())
+        else:
+            dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
     return values

@@ -132,8 +132,6 @@ class PlankModel(nn.Module):
         super().__init__()
         if activation != "relu":
             raise ValueError("only ACTIVATION: relu is implemented (all reference configs use it)")
-        if num_input_dof != 4 or num_view < 1:
-            pass
         # run the encoder on the valid (non-PAD) rows only; PLANK_UNPAD=0 keeps the dense layout
         self.unpad = os.environ.get("PLANK_UNPAD", "1") != "0"
         compute_dtype = compute_dtype or os.environ.get("PLANK_COMPUTE_DTYPE", "f32")
@@ -302,6 +300,13 @@ class PlankModel(nn.Module):
         self._ensure_grads()
         return self._gflat
 
+    @property
+    def grad_sync_buffer(self):
+        """The flat buffer the running backward writes (what a grad-ready hook must exchange): the accumulation
+        scratch while gradients are being accumulated, else ``flat_grads``."""
+        t = getattr(self, "_sync_target", None)
+        return t if t is not None else self.flat_grads
+
     def segment_slices(self):
         """[(lo, hi)] element ranges of the flat gradient buffer that become final after each backward
         segment, in execution order (heads, decoder layers last->first, output embedding, encoder.norm,
@@ -437,10 +442,23 @@ class PlankModel(nn.Module):
         if self._gflat is None:
             self._gflat = torch.zeros(self._numel, dtype=torch.float32, device=self._flat.device)
 
+    def _param_version(self):
+        """Staleness stamp of the low-precision shadows.  After .cuda()/.to() every parameter is re-pointed at the flat
+        buffer with ``p.data = view`` and owns its version counter, so in-place updates through the parameters
+        (torch.optim.Adam, load_state_dict, p.add_()) never touch ``_flat._version``: the stamp is the sum over all of
+        them.  Updates through the C ABI (FusedAdam) bump nothing and call mark_shadow_fresh()/invalidate_shadow()."""
+        v = self._flat._version
+        for p in self._params.values():
+            v += p._version
+        return v
+
+    def invalidate_shadow(self):
+        self._shadow_version = -1
+
     def _refresh_shadow(self):
         if self.compute_dtype != "bf16":
             return
-        v = self._flat._version
+        v = self._param_version()
         if v != self._shadow_version:
             L.check(L.lib().pa_cast(L.ptr(self._shadow), L.PA_BF16, L.ptr(self._flat), L.PA_F32,
                                     C.c_int64(self._numel), L.stream()), "pa_cast")
@@ -449,7 +467,7 @@ class PlankModel(nn.Module):
 
     def mark_shadow_fresh(self):
         """Called by the fused optimizer, which refreshes the bf16 shadow inside its own kernel."""
-        self._shadow_version = self._flat._version
+        self._shadow_version = self._param_version()
         self.refresh_transposed()
 
     # ---------------------------------------------------------------------------------- batches
@@ -599,7 +617,10 @@ class PlankModel(nn.Module):
         stats = self._live[2]
         stats[3:4].copy_(gloss.reshape(1).to(torch.float32), non_blocking=True)   # upstream grad, no host sync
         slices = self.segment_slices()
-        hook = self._grad_hook if not accumulate else None
+        # gradient accumulation: the fresh micro-batch contribution (target = _gtmp) is what gets exchanged - the
+        # buffer accumulated so far was already summed over the ranks - and is added to _gflat after the last slice
+        hook = self._grad_hook
+        self._sync_target = target
         # with the library's side stream the gradients of segment s are final once segment s + lag is enqueued
         lag = int(L.lib().pa_model_grad_lag(self._handle))
         for s in range(nseg):
@@ -611,10 +632,8 @@ class PlankModel(nn.Module):
             for s in range(max(0, nseg - lag), nseg):       # the last segment joined everything
                 hook(s, *slices[s])
         if accumulate:
-            self._gflat.add_(self._gtmp)
-            if self._grad_hook is not None:
-                for s in range(nseg):
-                    self._grad_hook(s, *slices[s])
+            self._gflat.add_(self._gtmp)        # (the hook of the last segment waited for every collective)
+        self._sync_target = None
         for k, p in self._params.items():
             if p.grad is None and p.requires_grad:
                 n = p.numel()

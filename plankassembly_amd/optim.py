@@ -45,15 +45,25 @@ class FusedAdam(torch.optim.Optimizer):
                                      C.c_int64(flat.numel()), C.c_float(grp["lr"]), C.c_float(grp["betas"][0]),
                                      C.c_float(grp["betas"][1]), C.c_float(grp["eps"]), self._step,
                                      C.c_float(self.grad_scale), L.stream()), "pa_adam_step")
-        flat._version  # (in-place update through the C ABI does not bump torch's version counter)
+        # (the in-place update through the C ABI does not bump torch's version counters)
         if shadow is not None:
             m.mark_shadow_fresh()
         else:
-            m._shadow_version = -1
+            m.invalidate_shadow()
         return loss
 
     def state_dict(self):
-        return {"step": self._step, "m": self._m, "v": self._v, "param_groups": self.param_groups}
+        """Flat moments + step (CPU tensors: checkpoint payload)."""
+        cpu = lambda t: None if t is None else t.detach().cpu()
+        return {"step": self._step, "m": cpu(self._m), "v": cpu(self._v),
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
-        self._step, self._m, self._v = sd["step"], sd["m"], sd["v"]
+        dev = self.model.flat_params.device
+        self._step = int(sd["step"])
+        self._m = None if sd.get("m") is None else sd["m"].to(dev, torch.float32).clone()
+        self._v = None if sd.get("v") is None else sd["v"].to(dev, torch.float32).clone()
+        for g, sg in zip(self.param_groups, sd.get("param_groups", [])):
+            for k in ("lr", "betas", "eps"):
+                if k in sg:
+                    g[k] = tuple(sg[k]) if k == "betas" else sg[k]
