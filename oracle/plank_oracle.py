@@ -313,10 +313,12 @@ def greedy_decode_recompute(p, cfg: OracleCfg, batch, max_steps=None, early_stop
     return out, att
 
 
-def greedy_decode_cached(p, cfg: OracleCfg, batch, max_steps=None, early_stop=True):
+def greedy_decode_cached(p, cfg: OracleCfg, batch, max_steps=None, early_stop=True, return_margins=False):
     """Same result as :func:`greedy_decode_recompute` with a K/V cache (causal decoder in
     eval mode => row t only depends on rows <= t).  This is the form the HIP decode path
-    implements and the form timed as the ``cached`` CPU baseline."""
+    implements and the form timed as the ``cached`` CPU baseline.  ``return_margins`` also
+    returns [B, steps] = (largest - second largest) / largest probability of every sampled row: how
+    far each argmax is from flipping (diagnostics for reduced-precision comparisons)."""
     d, H = cfg.d_model, cfg.n_head
     dh = d // H
     memory = encode(p, cfg, batch)
@@ -336,6 +338,7 @@ def greedy_decode_cached(p, cfg: OracleCfg, batch, max_steps=None, early_stop=Tr
     out = torch.empty(B, 0, dtype=torch.long)
     att = torch.empty(B, 0, dtype=torch.long)
     scale = 1.0 / math.sqrt(dh)
+    margins = []
     x_in = torch.zeros(B, d)                                         # BOS zero row
     for t in range(steps):
         x = x_in
@@ -363,6 +366,9 @@ def greedy_decode_cached(p, cfg: OracleCfg, batch, max_steps=None, early_stop=Tr
         x = layer_norm(x, p["decoder.norm.weight"], p["decoder.norm.bias"], 1e-5)
         hid[:, t] = x
         dist = last_row_dist(p, cfg, hid[:, :t + 1])
+        if return_margins:
+            top2 = dist.topk(2, dim=-1).values
+            margins.append((top2[:, 0] - top2[:, 1]) / top2[:, 0])
         tok, ptr = sample(cfg, dist, out)
         out = torch.cat((out, tok[:, None]), dim=1)
         att = torch.cat((att, ptr[:, None]), dim=1)
@@ -372,6 +378,8 @@ def greedy_decode_cached(p, cfg: OracleCfg, batch, max_steps=None, early_stop=Tr
         x_in = (p["input_embeddings.input_value.weight"][tok]
                 + p["query_coord_embedding.weight"][t % cfg.out_dof]
                 + p["query_pos_embedding.weight"][t // cfg.out_dof])
+    if return_margins:
+        return out, att, torch.stack(margins, dim=1)
     return out, att
 
 

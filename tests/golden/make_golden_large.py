@@ -1,0 +1,111 @@
+"""Golden vectors at the BENCHMARKED shapes (d_model 512, 8 heads of 64, d_ff 1024, 6+6 layers) from the REAL
+reference model, plus a small fixture with a live (untrained) loss.
+
+Runs only in the build container (needs /root/reference; only inputs/outputs are stored as data):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_large.py
+
+The 32.5 M weights are not stored: both sides re-create them from a seed (tests/seeded.py).  Stored per case:
+loss / accuracy, row norms + a slice of `memory` and of the decoder `hiddens`, and for EVERY parameter the gradient's
+L2 norm, sum and leading slice; for the headline case additionally the greedy tokens / attach of the reference's own
+(recompute) eval loop with the relative top-2 probability margin of every step.
+
+  fixture_headline.npz  S=1024 (MAX_INPUT_LENGTH 1025), T=128, B=2 train; B=4 greedy decode, 128 steps
+  fixture_visible.npz   S=999, B=2 (train_visible.yaml lengths)
+  fixture_sideface.npz  S=299, B=16, no `input_type`, two empty rows [END, PAD, ...] (train_sideface.yaml)
+  fixture_live.npz      d=64 fixture config, untrained seeded weights (loss ~ log 514): all gradients
+"""
+import os
+import sys
+import time
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import numpy as np
+import torch
+
+from plankassembly.models import PlankModel          # the reference (namespace package)
+from plankassembly_amd.data import SynthSpec, spec_for, synth_batch
+from seeded import seeded_state_dict
+from large_cases import CASES, GAINS, SLICE, case_batch, grad_summary, make_empty_rows   # shared with the tests
+
+TOKEN = types.SimpleNamespace(END=512, PAD=513)
+
+
+def ref_model(c):
+    m = PlankModel(c["d"], c["h"], c["ff"], 0.0, "relu", True, c["ne"], c["nd"], 3, 2, 4, 6, c["max_in"], c["max_out"],
+                   514, TOKEN)
+    sd = seeded_state_dict(((k, v.shape) for k, v in m.state_dict().items()), c["wseed"], c["gains"])
+    m.load_state_dict(sd)
+    return m, sd
+
+
+def capture_train(m, batch):
+    m.train()
+    m.zero_grad()
+    inputs = {k: v for k, v in batch.items() if k[:5] == "input"}
+    emb_in = m._embed_input(inputs)
+    emb_out = m._embed_output(batch["output_value"][:, :-1])
+    with torch.no_grad():
+        memory = m.encoder(emb_in, src_key_padding_mask=batch["input_mask"])
+        hid = m.decoder(emb_out, memory, tgt_mask=m._generate_square_subsequent_mask(emb_out.size(1)),
+                        tgt_key_padding_mask=batch["output_mask"], memory_key_padding_mask=batch["input_mask"])
+    out = m(batch)
+    out["loss"].backward()
+    res = {"loss": np.float64(out["loss"].item()), "accuracy": np.float64(float(out["accuracy"])),
+           "memory_norm": memory.norm(dim=-1).numpy().astype(np.float32),
+           "memory_slice": memory[:, :, :SLICE[1]].numpy()[:, ::37][:, :24].copy(),      # 24 rows spread over the sequence
+           "hiddens_norm": hid.norm(dim=-1).numpy().astype(np.float32),
+           "hiddens_slice": hid[:, :, :64].numpy().copy()}
+    grads = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()}
+    res.update(grad_summary(grads))
+    return res, grads
+
+
+def main():
+    torch.set_num_threads(8)
+    only = sys.argv[1:]
+    for name, c in CASES.items():
+        if only and name not in only:
+            continue
+        t0 = time.time()
+        m, sd = ref_model(c)
+        batch = case_batch(c)
+        res, grads = capture_train(m, batch)
+        out = {"g::" + k: v for k, v in res.items()}
+        if c.get("all_grads"):
+            for k, g in grads.items():
+                out["gfull::" + k] = g.numpy().copy()
+        print(f"{name}: loss {res['loss']:.6f} acc {res['accuracy']:.4f} ({time.time() - t0:.1f}s)")
+        if c.get("decode_b"):
+            from oracle import plank_oracle as O
+            db = case_batch(c, decode=True)
+            m.eval()
+            t1 = time.time()
+            with torch.no_grad():
+                ev = m(db)                                     # the reference's own O(T^2) eval loop
+            cfg = O.OracleCfg(d_model=c["d"], n_head=c["h"], d_ff=c["ff"], n_enc=c["ne"], n_dec=c["nd"],
+                              max_input_length=c["max_in"], max_output_length=c["max_out"])
+            with torch.no_grad():
+                s2, a2, marg = O.greedy_decode_cached(sd, cfg, db, early_stop=True, return_margins=True)
+            assert torch.equal(ev["samples"], s2) and torch.equal(ev["attach"], a2), "oracle decode != reference decode"
+            out["d::samples"] = ev["samples"].numpy()
+            out["d::attach"] = ev["attach"].numpy()
+            out["d::margins"] = marg.numpy().astype(np.float32)
+            print(f"  decode {tuple(ev['samples'].shape)} in {time.time() - t1:.1f}s; pointers fired "
+                  f"{int((ev['attach'] >= 0).sum())}; distinct tokens {len(np.unique(out['d::samples']))}; "
+                  f"min relative top-2 margin {float(marg.min()):.3e}")
+            print("  samples[0][:24]", out["d::samples"][0][:24].tolist())
+        np.savez_compressed(os.path.join(HERE, f"fixture_{name}.npz"), **out)
+        print(f"  wrote fixture_{name}.npz {os.path.getsize(os.path.join(HERE, f'fixture_{name}.npz')) // 1024} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""Case definitions shared by tests/golden/make_golden_large.py (which runs the real reference) and the parity
+tests (oracle on the CPU, HIP model on the GPU): shapes, seeds, batches and the gradient summary format."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from plankassembly_amd.data import SynthSpec, synth_batch
+
+# gains applied on top of the seeded xavier / normal init (tests/seeded.py).  A plain random-init model collapses:
+# attention averages put the same large vector into every row, the token-dependent part of the residual stream decays
+# layer by layer and greedy decoding repeats one token.  Damped attention/FFN output
+# projections and larger embeddings / heads keep the rows distinct, so the decode fixture has diverse tokens, firing
+# pointers and wide top-2 margins.
+GAINS = {"input_embeddings.": 8.0, "query_": 16.0, "vocab_head.weight": 6.0, "pointer_head.weight": 24.0,
+         "switch_head.weight": 1.0, ".bias": 0.2, "out_proj.weight": 0.15, "multihead_attn.out_proj.weight": 3.0,
+         "linear2.weight": 0.5}
+SLICE = (8, 32)      # leading rows x cols of every gradient kept in the fixtures
+
+BIG = dict(d=512, h=8, ff=1024, ne=6, nd=6, gains=GAINS)
+CASES = {
+    "headline": dict(BIG, max_in=1025, max_out=128, B=2, wseed=58, bseed=5, lines=(8, 255), with_type=True,
+                     decode_b=4, decode_seed=6),
+    "visible": dict(BIG, max_in=1000, max_out=128, B=2, wseed=12, bseed=7, lines=(8, 249), with_type=True),
+    "sideface": dict(BIG, max_in=300, max_out=128, B=16, wseed=13, bseed=9, lines=(0, 74), with_type=False, empty_rows=(3, 11)),
+    "live": dict(d=64, h=4, ff=128, ne=2, nd=2, gains={}, max_in=65, max_out=36, B=4, wseed=3, bseed=2022,
+                 lines=(3, 15), planks=(2, 5), with_type=True, all_grads=True),
+}
+
+
+def make_empty_rows(batch, rows):
+    """Turn the given samples into the side-face 'nothing detected' input: [END, PAD, PAD, ...] with zero ids
+    (reference sideface_data.py:137-213 with no faces)."""
+    for r in rows:
+        for k in batch:
+            if k.startswith("input") and k != "input_mask":
+                batch[k][r] = 0
+        batch["input_value"][r] = 513
+        batch["input_value"][r, 0] = 512
+        batch["input_mask"][r] = batch["input_value"][r] == 513
+    return batch
+
+
+def case_batch(c, decode=False, batch_size=None):
+    spec = SynthSpec(c["max_in"], c["max_out"], c["lines"], c.get("planks", (2, 21)), c["with_type"])
+    B = batch_size or (c["decode_b"] if decode else c["B"])
+    b = synth_batch(B, spec, seed=c["decode_seed"] if decode else c["bseed"])
+    b.pop("name")
+    if c.get("empty_rows") and not decode:
+        make_empty_rows(b, [r for r in c["empty_rows"] if r < B])
+    return b
+
+
+def grad_summary(grads):
+    """{name: tensor} -> flat dict of per-parameter L2 norm / sum (float64) and the leading SLICE."""
+    res = {}
+    for n, g in grads.items():
+        g = g.detach().to(torch.float32).cpu()
+        g2 = g.reshape(g.shape[0], -1) if g.dim() > 1 else g.reshape(1, -1)
+        res["gnorm::" + n] = np.float64(g.double().norm().item())
+        res["gsum::" + n] = np.float64(g.double().sum().item())
+        res["gmax::" + n] = np.float64(g.abs().max().item())
+        res["gslice::" + n] = g2[:SLICE[0], :SLICE[1]].numpy().copy()
+    return res
+
+
+def case_shapes(c):
+    """(name, shape) of every state_dict entry of the case's model (from the drop-in module's own layout, which
+    tests/test_model_surface.py pins to the reference's key names, shapes and order)."""
+    import types
+    from plankassembly_amd.models import PlankModel
+    m = PlankModel(c["d"], c["h"], c["ff"], 0.0, "relu", True, c["ne"], c["nd"], 3, 2, 4, 6, c["max_in"], c["max_out"],
+                   514, types.SimpleNamespace(END=512, PAD=513))
+    return [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+
+
+def case_state_dict(c):
+    from seeded import seeded_state_dict
+    return seeded_state_dict(case_shapes(c), c["wseed"], c["gains"])
+
+
+def case_oracle_cfg(c):
+    from oracle import plank_oracle as O
+    return O.OracleCfg(d_model=c["d"], n_head=c["h"], d_ff=c["ff"], n_enc=c["ne"], n_dec=c["nd"],
+                       max_input_length=c["max_in"], max_output_length=c["max_out"])
+
+
+def load_large(name):
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"fixture_{name}.npz"))
+    return {k: z[k] for k in z.files}
