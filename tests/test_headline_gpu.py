@@ -1,0 +1,217 @@
+"""Model-level parity AT THE BENCHMARKED SHAPES on the GPU (d_model 512, 8 heads of 64, d_ff 1024, 6+6 layers):
+the HIP model (through the C ABI, with prepare_batch = packed encoder rows + grouped embedding gradients, grouped
+weight-gradient launches, and in bf16 the transposed / packed cross-K/V weight shadows) against
+
+* the golden vectors of the REAL reference model (tests/golden/fixture_{headline,visible,sideface,live}.npz), and
+* the CPU oracle run live on the same seeded weights and batches (full tensors, every gradient).
+
+Tolerances: f32 path = north star (1e-4 on loss / memory / hiddens, 1e-5 + 1e-4*scale on every gradient, greedy
+tokens bit-exact); bf16 path = per-tensor cosine and relative L2 against the f32 oracle, greedy agreement with the
+oracle's top-2 margin reported at every mismatch.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import large_cases as LC
+
+pytestmark = pytest.mark.gpu
+TOKEN = types.SimpleNamespace(END=512, PAD=513)
+
+_oracle_cache = {}
+
+
+def hip_model(c, dtype, sd):
+    from plankassembly_amd.models import PlankModel
+    m = PlankModel(c["d"], c["h"], c["ff"], 0.0, "relu", True, c["ne"], c["nd"], 3, 2, 4, 6, c["max_in"], c["max_out"],
+                   514, TOKEN, compute_dtype=dtype)
+    m.load_state_dict(sd)
+    return m.cuda()
+
+
+def oracle_train(name, batch_size=None):
+    """loss / memory / hiddens / all gradients of the CPU oracle (cached per case: shared by the f32 and bf16 tests)."""
+    key = (name, batch_size)
+    if key not in _oracle_cache:
+        from oracle import plank_oracle as O
+        c = LC.CASES[name]
+        sd = LC.case_state_dict(c)
+        batch = LC.case_batch(c, batch_size=batch_size)
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        out = O.train_forward(p, LC.case_oracle_cfg(c), batch, return_all=True)
+        out["loss"].backward()
+        grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
+        _oracle_cache[key] = (sd, batch, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}, grads)
+    return _oracle_cache[key]
+
+
+def run_hip_train(m, batch, prepared=True):
+    m.train()
+    pb = m.prepare_batch(batch) if prepared else {k: v.cuda() for k, v in batch.items()}
+    out = m(pb)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    B, S = batch["input_value"].shape
+    mem = m.debug_tensor("memory").float().view(B, S, -1).cpu()
+    hid = m.debug_tensor("hiddens").float().view(B, -1, m.num_model).cpu()
+    grads = {k: p.grad.detach().float().cpu() for k, p in m.named_parameters()}
+    return out, mem, hid, grads
+
+
+@pytest.mark.parametrize("name", ["headline", "visible", "sideface", "live"])
+def test_f32_train_step_matches_reference_and_oracle(name):
+    c = LC.CASES[name]
+    g = LC.load_large(name)
+    sd, batch, ref, rgrads = oracle_train(name)
+    m = hip_model(c, "f32", sd)
+    out, mem, hid, grads = run_hip_train(m, batch)
+    # --- against the real reference's golden vectors
+    assert abs(out["loss"].item() - float(g["g::loss"])) < 1e-4, (out["loss"].item(), float(g["g::loss"]))
+    assert abs(out["accuracy"].item() - float(g["g::accuracy"])) < 1e-6
+    valid = ~batch["input_mask"]
+    rows = torch.arange(0, mem.shape[1], 37)[:24]
+    assert float((mem[:, rows, :LC.SLICE[1]] - torch.from_numpy(g["g::memory_slice"]))[valid[:, rows]].abs().max()) < 1e-4
+    assert float((hid[:, :, :64] - torch.from_numpy(g["g::hiddens_slice"])).abs().max()) < 1e-4
+    got = LC.grad_summary(grads)
+    for k in grads:
+        scale = float(g["g::gmax::" + k])
+        err = float(np.abs(got["gslice::" + k] - g["g::gslice::" + k]).max())
+        assert err <= 1e-5 + 1e-4 * scale, (k, err, scale)
+        n_ref = float(g["g::gnorm::" + k])
+        assert abs(float(got["gnorm::" + k]) - n_ref) <= 1e-6 + 2e-4 * n_ref, (k, float(got["gnorm::" + k]), n_ref)
+    # --- against the oracle: full tensors
+    assert float((mem - ref["memory"])[valid].abs().max()) < 1e-4
+    assert float((hid - ref["hiddens"]).abs().max()) < 1e-4
+    worst = ("", 0.0)
+    for k, gr in grads.items():
+        r = rgrads[k]
+        err, scale = float((gr - r).abs().max()), float(r.abs().max())
+        if err / max(scale, 1e-6) > worst[1]:
+            worst = (k, err / max(scale, 1e-6))
+        assert err <= 1e-5 + 1e-4 * scale, (k, err, scale)
+    print(f"[{name}] f32 worst relative gradient error {worst[1]:.2e} ({worst[0]})")
+    if name == "sideface":
+        gt = grads["input_embeddings.input_type.weight"]
+        assert not gt.any()                                  # unused table: zero gradient (no DDP-style error)
+
+
+@pytest.mark.parametrize("name", ["headline", "sideface"])
+def test_f32_unprepared_batch_same_result(name):
+    """forward() also accepts batches that did not go through prepare_batch (packing computed in the step,
+    atomic scatter-add embedding gradients): same loss and gradients."""
+    c = LC.CASES[name]
+    sd, batch, ref, rgrads = oracle_train(name)
+    m = hip_model(c, "f32", sd)
+    out, mem, hid, grads = run_hip_train(m, batch, prepared=False)
+    assert abs(out["loss"].item() - float(ref["loss"])) < 1e-4
+    for k in ("input_embeddings.input_value.weight", "input_embeddings.input_pos.weight", "query_pos_embedding.weight",
+              "encoder.layers.0.self_attn.in_proj_weight"):
+        r = rgrads[k]
+        assert float((grads[k] - r).abs().max()) <= 1e-5 + 1e-4 * float(r.abs().max()), k
+
+
+def test_f32_sideface_full_batch_64():
+    """train_sideface.yaml's batch (64 samples of S = 299, no input_type, empty rows) against the oracle."""
+    c = LC.CASES["sideface"]
+    sd, batch, ref, rgrads = oracle_train("sideface", batch_size=64)
+    assert bool(batch["input_mask"][3, 1:].all())             # the [END, PAD, ...] rows are in
+    m = hip_model(c, "f32", sd)
+    out, mem, hid, grads = run_hip_train(m, batch)
+    assert abs(out["loss"].item() - float(ref["loss"])) < 1e-4
+    assert float((hid - ref["hiddens"]).abs().max()) < 1e-4
+    for k, gr in grads.items():
+        r = rgrads[k]
+        assert float((gr - r).abs().max()) <= 1e-5 + 1e-4 * float(r.abs().max()), k
+
+
+@pytest.mark.parametrize("name", ["headline", "visible", "sideface", "live"])
+def test_bf16_train_step_per_tensor(name):
+    """The benchmarked bf16 path against the f32 oracle, tensor by tensor: cosine and relative L2 of every gradient
+    (weighted summary printed), loss, memory and hiddens."""
+    c = LC.CASES[name]
+    sd, batch, ref, rgrads = oracle_train(name)
+    m = hip_model(c, "bf16", sd)
+    out, mem, hid, grads = run_hip_train(m, batch)
+    loss_ref = float(ref["loss"])
+    assert abs(out["loss"].item() - loss_ref) < 2e-2 * abs(loss_ref), (out["loss"].item(), loss_ref)
+    valid = ~batch["input_mask"]
+
+    def rel(a, b):
+        return float((a - b).double().norm() / (b.double().norm() + 1e-30))
+
+    r_mem, r_hid = rel(mem[valid], ref["memory"][valid]), rel(hid, ref["hiddens"])
+    assert r_mem < 2e-2 and r_hid < 3e-2, (r_mem, r_hid)
+    rows = []
+    for k, gr in grads.items():
+        r = rgrads[k].double().flatten()
+        a = gr.double().flatten()
+        nr = float(r.norm())
+        if nr == 0.0:
+            assert float(a.norm()) == 0.0, k
+            continue
+        cos = float(a @ r) / (float(a.norm()) * nr + 1e-300)
+        rows.append((k, cos, float((a - r).norm()) / nr, nr))
+    rows.sort(key=lambda t: t[1])
+    tot = sum(t[3] ** 2 for t in rows) ** 0.5
+    print(f"[{name}] bf16: loss {out['loss'].item():.5f} vs {loss_ref:.5f}; rel-L2 memory {r_mem:.2e} hiddens {r_hid:.2e}")
+    for k, cos, rl2, nr in rows[:5]:
+        print(f"    worst cosine {cos:.5f} rel-L2 {rl2:.3f} |g| share {nr / tot:.2e}  {k}")
+    for k, cos, rl2, nr in rows:
+        # tensors that carry a visible share of the gradient must be accurate; tiny ones (bf16 noise floor) looser
+        big = nr / tot > 1e-3
+        assert cos > (0.99 if big else 0.9), (k, cos, rl2, nr / tot)
+        assert rl2 < (0.15 if big else 0.5), (k, cos, rl2, nr / tot)
+
+
+def _decode(m, db, **kw):
+    import plankassembly_amd.decode as D
+    m.eval()
+    m._ensure_handle()
+    m._refresh_shadow()
+    dec = D.GreedyDecoder(m, **kw)
+    with torch.no_grad():
+        s, a = dec.run(m.prepare_batch(db))
+    return s.cpu(), a.cpu()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_f32_greedy_decode_token_exact_at_headline_shape(graph):
+    c = LC.CASES["headline"]
+    g = LC.load_large("headline")
+    sd = LC.case_state_dict(c)
+    db = LC.case_batch(c, decode=True)
+    m = hip_model(c, "f32", sd)
+    s, a = _decode(m, db, use_graph=graph)
+    assert np.array_equal(s.numpy(), g["d::samples"]), "greedy tokens differ from the reference's"
+    assert np.array_equal(a.numpy(), g["d::attach"])
+
+
+def test_f32_greedy_decode_batch8_vs_oracle_and_bf16_agreement():
+    from oracle import plank_oracle as O
+    c = LC.CASES["headline"]
+    sd = LC.case_state_dict(c)
+    db = LC.case_batch(c, decode=True, batch_size=8)
+    with torch.no_grad():
+        s_ref, a_ref, marg = O.greedy_decode_cached(sd, LC.case_oracle_cfg(c), db, early_stop=True, return_margins=True)
+    m = hip_model(c, "f32", sd)
+    s, a = _decode(m, db)
+    assert torch.equal(s, s_ref) and torch.equal(a, a_ref)
+    # bf16: greedy decoding is chaotic after the first flip, so agreement is measured on the prefix before each row's
+    # first mismatch and the oracle's margin at that step is reported (a flip at a wide margin would be a bug)
+    mb = hip_model(c, "bf16", sd)
+    sb, ab = _decode(mb, db)
+    n = min(sb.shape[1], s_ref.shape[1])
+    first = []
+    for i in range(s_ref.shape[0]):
+        neq = (sb[i, :n] != s_ref[i, :n]) | (ab[i, :n] != a_ref[i, :n])
+        t = int(neq.nonzero()[0]) if bool(neq.any()) else n
+        first.append(t)
+        if t < n:
+            print(f"    bf16 row {i}: first mismatch at step {t}: got {int(sb[i, t])}/{int(ab[i, t])} want "
+                  f"{int(s_ref[i, t])}/{int(a_ref[i, t])}, oracle relative top-2 margin {float(marg[i, t]):.3e}")
+            assert float(marg[i, t]) < 0.25, "bf16 flipped an argmax that was not close"
+    agree = sum(first) / (len(first) * n)
+    print(f"    bf16 greedy: exact-prefix agreement {agree:.3f} (rows fully exact: {sum(t == n for t in first)}/{len(first)})")
+    assert agree > 0.5, agree

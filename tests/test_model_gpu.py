@@ -260,3 +260,35 @@ def test_greedy_decode_bf16_mostly_agrees(small_fixture):
     n = min(ref.shape[1], out["samples"].shape[1])
     agree = (out["samples"].cpu()[:, :n] == ref[:, :n]).float().mean().item()
     assert agree > 0.9, agree
+
+
+# ------------------------------------------------------------------------------------------ bf16 shadow staleness
+def test_bf16_shadow_follows_torch_adam_and_load_state_dict(small_fixture):
+    """The bf16 GEMM-operand shadows (weights, W^T, packed cross K/V) must follow parameter updates that do not go
+    through FusedAdam: torch.optim.Adam steps and load_state_dict after a first forward (INTEGRATION.md drop-in path)."""
+    sd, batch, _ = small_fixture
+    gb = to_dev(batch)
+    m = make(sd, dtype="bf16").train()
+    opt = torch.optim.Adam(m.parameters(), lr=5e-3)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        out = m(gb)
+        out["loss"].backward()
+        opt.step()
+        losses.append(out["loss"].item())
+    # a model that keeps computing on the initial weights reports the same loss every step
+    assert max(losses) - min(losses) > 1e-3, losses
+    # the loss of the updated weights, seen by a fresh module that casts its shadow from scratch
+    fresh = make({k: v.detach().cpu() for k, v in m.state_dict().items()}, dtype="bf16").train()
+    a, b = m(gb)["loss"].item(), fresh(gb)["loss"].item()
+    assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (a, b)
+    # load_state_dict after a forward: the next forward must see the loaded weights
+    m.load_state_dict(sd)
+    ref = make(sd, dtype="bf16").train()
+    a, b = m(gb)["loss"].item(), ref(gb)["loss"].item()
+    assert abs(a - b) <= 1e-3 * max(1.0, abs(b)), (a, b)
+    m.eval()
+    with torch.no_grad():
+        m.vocab_head.bias.add_(0.0)                      # in-place touch through the parameter also invalidates
+    assert m._param_version() != m._shadow_version
