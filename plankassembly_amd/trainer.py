@@ -25,6 +25,7 @@ import torch.distributed as dist
 
 from .config import CfgNode, load_cli_config
 from .data import SynthSpec, synth_sample
+from .datasets import LineDataset, SidefaceDataset, parse_splits_list  # noqa: F401  (parse_splits_list re-exported)
 from .metric import build_criterion, build_matcher
 from .models import build_model
 
@@ -47,12 +48,6 @@ class SyntheticDrawings(torch.utils.data.Dataset):
         return out
 
 
-def parse_splits_list(path):
-    """reference dataset/data_utils.py:28-46: a split file lists one info json per line."""
-    with open(path) as f:
-        return [ln.strip() for ln in f if ln.strip()]
-
-
 class _Logger:
     def __init__(self, root="lightning_logs"):
         v = 0
@@ -70,6 +65,8 @@ class Trainer(torch.nn.Module):
 
     with_type = True
     default_lines = (8, 299)
+    dataset_cls = LineDataset
+    train_augmentation = True
 
     def __init__(self, hparams):
         super().__init__()
@@ -97,22 +94,28 @@ class Trainer(torch.nn.Module):
         return SynthSpec(d.MAX_INPUT_LENGTH, d.MAX_OUTPUT_LENGTH, (min(self.default_lines[0], hi), hi),
                          (2, (d.MAX_OUTPUT_LENGTH - 1) // d.NUM_OUTPUT_DOF), self.with_type)
 
-    def _loader(self, split_key, n_default, shuffle, drop_last, seed):
+    def _dataset(self, split_key, n_default, seed, augmentation):
+        """The reference's dataset over ``ROOT`` + split file when both exist on disk (trainer_complete.py:35-61),
+        else the seeded synthetic generator (there is no network to fetch the real dataset here)."""
         split = self.cfg.get(split_key)
-        if split and os.path.exists(split) and os.path.isdir(str(self.cfg.get("ROOT", ""))):
-            raise NotImplementedError(
-                "reading the real infos/*.json (reference line_data.py) is the next scope row (SURVEY 8f rank 2); "
-                "this round trains on the seeded synthetic generator")
-        ds = SyntheticDrawings(int(self.cfg.get("SYNTHETIC_SAMPLES", n_default)), self._spec(), seed)
+        root = str(self.cfg.get("ROOT", ""))
+        have_split = bool(split) and all(os.path.exists(s) for s in str(split).split())
+        if have_split and os.path.isdir(root):
+            return self.dataset_cls(root, parse_splits_list(split), self.cfg.TOKEN, self.cfg.DATA, augmentation)
+        return SyntheticDrawings(int(self.cfg.get("SYNTHETIC_SAMPLES", n_default)), self._spec(), seed)
+
+    def _loader(self, split_key, n_default, shuffle, drop_last, seed, augmentation=False):
+        ds = self._dataset(split_key, n_default, seed, augmentation)
         sampler = None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(ds, shuffle=shuffle, drop_last=drop_last)
             shuffle = False
+        workers = int(self.cfg.get("NUM_WORKERS", 0)) if not isinstance(ds, SyntheticDrawings) else 0
         return torch.utils.data.DataLoader(ds, batch_size=self.cfg.BATCH_SIZE, shuffle=shuffle, drop_last=drop_last,
-                                           num_workers=0, sampler=sampler)
+                                           num_workers=workers, sampler=sampler)
 
     def train_dataloader(self):
-        return self._loader("DATASETS_TRAIN", 256, True, True, 2022)
+        return self._loader("DATASETS_TRAIN", 256, True, True, 2022, self.train_augmentation)
 
     def val_dataloader(self):
         return self._loader("DATASETS_VALID", 64, False, False, 9_000_000)
@@ -172,22 +175,49 @@ class Trainer(torch.nn.Module):
         return {"optimizer": FusedAdam(self.model, lr=self.cfg.LR, grad_scale=1.0 / world)}
 
     # ------------------------------------------------------------------ checkpoints (Lightning-shaped)
-    def checkpoint(self, epoch, optimizer=None):
-        return {"epoch": epoch, "global_step": self.global_step,
-                "state_dict": {"model." + k: v.detach().cpu() for k, v in self.model.state_dict().items()},
-                "hyper_parameters": {"hparams": self.hparams_dict}}
+    def checkpoint(self, epoch, optimizer=None, best_score=None):
+        """The dict pytorch_lightning 1.7's ModelCheckpoint writes for the reference (configs/train_complete.yaml:6-14):
+        `state_dict` with the `model.` prefix, `optimizer_states` in torch.optim.Adam's layout, `hyper_parameters`
+        (save_hyperparameters(hparams), trainer_complete.py:24), epoch / global_step, callbacks, loops - so that a file
+        written here loads in the reference's Lightning CLI and vice versa."""
+        ck = {"epoch": epoch, "global_step": self.global_step, "pytorch-lightning_version": "1.7.7",
+              "state_dict": {"model." + k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+              "loops": {"fit_loop": {"state_dict": {}, "epoch_progress": {"current": {"completed": epoch + 1}}}},
+              "callbacks": {"ModelCheckpoint": {"monitor": "val/fmeasure",
+                                                "best_model_score": None if best_score is None else torch.tensor(float(best_score))}},
+              "optimizer_states": [], "lr_schedulers": [],
+              "hparams_name": "hparams", "hyper_parameters": {"hparams": self.hparams_dict}}
+        if optimizer is not None:
+            ck["optimizer_states"] = [optimizer.torch_state_dict() if hasattr(optimizer, "torch_state_dict")
+                                      else optimizer.state_dict()]
+        return ck
 
-    def load_checkpoint(self, path):
-        ck = torch.load(path, map_location="cpu", weights_only=False)
+    def load_checkpoint(self, path, optimizer=None):
+        """Weights always; with ``optimizer`` also the Adam moments / step, epoch and global_step (what Lightning's
+        ``fit --ckpt_path`` resumes).  Returns the checkpoint dict."""
+        try:
+            ck = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception:                                           # pickled non-tensor payloads (older files)
+            ck = torch.load(path, map_location="cpu", weights_only=False)
         sd = ck.get("state_dict", ck)
         sd = {(k[6:] if k.startswith("model.") else k): v for k, v in sd.items()}
         self.model.load_state_dict(sd)
+        if optimizer is not None and ck.get("optimizer_states"):
+            optimizer.load_state_dict(ck["optimizer_states"][0])
+        if optimizer is not None:
+            self.global_step = int(ck.get("global_step", 0))
+            self.resume_epoch = int(ck.get("epoch", -1)) + 1
+            best = (ck.get("callbacks") or {})
+            for v in best.values():
+                if isinstance(v, dict) and v.get("best_model_score") is not None:
+                    self.resume_best = float(v["best_model_score"])
         return ck
 
 
 class VisibleTrainer(Trainer):
-    """reference trainer_visible.py: no augmentation in the train loader (a no-op for synthetic data)."""
+    """reference trainer_visible.py: no augmentation in the train loader."""
     default_lines = (8, 249)
+    train_augmentation = False
 
 
 class SidefaceTrainer(Trainer):
@@ -195,6 +225,7 @@ class SidefaceTrainer(Trainer):
     side faces (input = [END, PAD...]) scores 0 and writes an empty prediction (:46-52)."""
     with_type = False
     default_lines = (0, 74)
+    dataset_cls = SidefaceDataset
 
     def test_step(self, batch, batch_idx):
         outputs = self.model(batch)
@@ -237,10 +268,10 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
         torch.manual_seed(int(seed)); np.random.seed(int(seed))
     module = trainer_cls(hparams)
     module.logger = _Logger()
-    if ckpt_path:
-        module.load_checkpoint(ckpt_path)
     dev = torch.device("cuda", local)
     module.model.to(dev)
+    if ckpt_path and subcommand == "test":
+        module.load_checkpoint(ckpt_path)
     if subcommand == "test":
         module.model.eval()
         with torch.no_grad():
@@ -251,6 +282,11 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
             print({k: round(v, 4) for k, v in module._logged.items()})
         return module
     opt = module.configure_optimizers()["optimizer"]
+    start_epoch, best = 0, -1.0
+    if ckpt_path:                                  # fit --ckpt_path: weights + Adam state + counters, like Lightning
+        module.load_checkpoint(ckpt_path, optimizer=opt)
+        start_epoch = getattr(module, "resume_epoch", 0)
+        best = getattr(module, "resume_best", -1.0)
     sync = None
     if world > 1:
         from .distributed import GradSync
@@ -259,9 +295,8 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
     max_epochs = int(tkw.get("max_epochs", 1))
     every = int(tkw.get("check_val_every_n_epoch", 1))
     max_steps = int(tkw.get("max_steps", -1))
-    best = -1.0
     loader = module.train_dataloader()
-    for epoch in range(max_epochs):
+    for epoch in range(start_epoch, max_epochs):
         module.model.train()
         if hasattr(loader.sampler, "set_epoch"):
             loader.sampler.set_epoch(epoch)
@@ -282,6 +317,10 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
             print(f"epoch {epoch}: train/loss {float(l):.4f} train/accuracy {float(a):.4f} "
                   f"{n * world / (time.perf_counter() - t0):.1f} samples/s")
         if (epoch + 1) % every == 0:
+            ckdir = os.path.join(module.logger.log_dir, "checkpoints")
+            if rank == 0:                                              # save_last: before the metric exchange, so a failure
+                os.makedirs(ckdir, exist_ok=True)                      # in validation cannot lose the epoch's weights
+                torch.save(module.checkpoint(epoch, opt, best if best >= 0 else None), os.path.join(ckdir, "last.ckpt"))
             module.model.eval()
             with torch.no_grad():
                 for i, batch in enumerate(module.val_dataloader()):
@@ -289,9 +328,8 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
             module.validation_epoch_end()
             f1 = module._logged.get("val/fmeasure", 0.0)
             if rank == 0:
-                os.makedirs(os.path.join(module.logger.log_dir, "checkpoints"), exist_ok=True)
-                ck = module.checkpoint(epoch, opt)
-                torch.save(ck, os.path.join(module.logger.log_dir, "checkpoints", "last.ckpt"))
+                ck = module.checkpoint(epoch, opt, max(best, f1))
+                torch.save(ck, os.path.join(ckdir, "last.ckpt"))
                 if f1 > best:                                      # ModelCheckpoint(monitor=val/fmeasure, mode=max)
                     best = f1
                     name = (f"checkpoint_{epoch:03d}-precision={module._logged['val/precision']:.3f}-"
