@@ -11,7 +11,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libplank_hip.so")
+LIB_PATH = os.environ.get("PLANK_HIP_LIB") or os.path.join(HERE, "libplank_hip.so")   # (override: A/B runs of two builds)
 
 PA_F32, PA_BF16 = 0, 1
 _ERR = {-1: "PA_EINVAL (bad argument)", -2: "PA_EALIGN (misaligned pointer / leading dimension)",

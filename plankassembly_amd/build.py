@@ -33,7 +33,7 @@ def _digest(paths) -> str:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "common.cuh"),
+    deps = srcs + [os.path.join(CSRC, "pa_device.h"),
                    os.path.join(os.path.dirname(HERE), "include", "plank_hip.h")]
     deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".h"))]
     deps = sorted(set(deps))

@@ -15,7 +15,7 @@
 // [row][dh] image and/or a transposed [dh][row] image (4 x EB register blocks transposed in
 // flight).  LDS images are XOR-swizzled in 16-byte chunks.  Scores never touch HBM.
 // Softmax runs in the log2 domain (exp2), f32 statistics.
-#include "common.cuh"
+#include "pa_device.h"
 #include "../../include/plank_hip.h"
 
 namespace {
@@ -35,7 +35,7 @@ struct AttnP {
     int B, H, Lq, Lk;
     int ldq, ldk, ldv, ldo;
     int causal; float scale;
-    uint32_t drop_thr; float drop_scale; uint32_t drop_seed; int nk4;
+    uint32_t drop_thr; float drop_scale; uint32_t drop_seed;   // drop_thr = p * 2^32 (pa_device.h drop_keep2)
     const void* dout; void* dq; void* dk; void* dv; float* delta;
     int lddo, lddq, lddk, lddv;
     const int32_t* cu_q; const int32_t* cu_k;     // packed (variable-length) row offsets per batch element, or NULL
@@ -348,18 +348,19 @@ __global__ __launch_bounds__(NTH) void attn_fwd_kernel(AttnP pin) {
         }
         const float m_safe = (m_run == -INFINITY) ? 0.f : m_run;
         float lsum = 0.f;
-        const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qrow) * p.nk4);
+        const uint32_t arow = drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow));
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uint32_t hsh = 0;
-                if (p.drop_thr) hsh = drop_hash4(p.drop_seed, drow + ((k0 + kt * 32 + 8 * g + 4 * half) >> 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float pe = fast_exp2(sacc[kt][4 * g + e] - m_safe);
                     lsum += pe;
-                    if (p.drop_thr) pe = drop_keep4(hsh, e, p.drop_thr) ? pe * p.drop_scale : 0.f;
+                    if (p.drop_thr) {
+                        const uint32_t ck = drop_key_hash(p.drop_seed, (uint32_t)(k0 + kt * 32 + 8 * g + 4 * half + e));
+                        pe = drop_keep2(arow, ck, p.drop_thr) ? pe * p.drop_scale : 0.f;
+                    }
                     sacc[kt][4 * g + e] = pe;
                 }
             }
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP pin) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
     const float sl = p.scale * LOG2E;
-    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qrow) * p.nk4);
+    const uint32_t arow = drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow));
 
     u32x4 st[A::NITEM][4];
     uint8_t mreg = 0;
@@ -497,15 +498,14 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP pin) {
             for (int g = 0; g < 4; ++g) {
                 const int koff = kt * 32 + 8 * g + 4 * half;
                 const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
-                uint32_t hsh = 0;
-                if (p.drop_thr) hsh = drop_hash4(p.drop_seed, drow + ((k0 + koff) >> 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int key = k0 + koff + e;
                     const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
                     const float pe = masked ? 0.f : fast_exp2(sacc[4 * g + e] * sl - lse2);
                     float dp = dpacc[4 * g + e];
-                    if (p.drop_thr) dp = drop_keep4(hsh, e, p.drop_thr) ? dp * p.drop_scale : 0.f;
+                    if (p.drop_thr)
+                        dp = drop_keep2(arow, drop_key_hash(p.drop_seed, (uint32_t)key), p.drop_thr) ? dp * p.drop_scale : 0.f;
                     sacc[4 * g + e] = pe * (dp - dlt) * p.scale;          // dS^T
                 }
             }
@@ -620,8 +620,8 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP pin) {
                     float dp = dpacc[4 * g + e];
                     float pd = pe;
                     if (p.drop_thr) {
-                        const uint32_t idx4 = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qr) * p.nk4 + (krow >> 2));
-                        const bool keep = drop_keep4(drop_hash4(p.drop_seed, idx4), krow & 3, p.drop_thr);
+                        const uint32_t ar = drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qr));
+                        const bool keep = drop_keep2(ar, drop_key_hash(p.drop_seed, (uint32_t)krow), p.drop_thr);
                         dp = keep ? dp * p.drop_scale : 0.f;
                         pd = keep ? pe * p.drop_scale : 0.f;
                     }
@@ -724,6 +724,49 @@ __device__ __forceinline__ void glds_nat(char* lds, const bf16* base, int ld, in
     }
 }
 
+// The same tile DMA through a buffer resource (v3 kernels): `voff` is the per-thread byte offset of its first chunk inside a
+// tile (tile_voff, loop invariant: ONE VGPR for every tile of a matrix), and every round of a tile gets its own resource
+// descriptor (four SGPRs, scalar arithmetic only) whose base is the round's first row and whose size ends at the sample's
+// last row: rows past the end read as ZEROS through the hardware range check - no clamp, no 64-bit vector address
+// arithmetic in the loop.  (The scalar offset operand of buffer loads is excluded from the range check, which is why the
+// row offset moves the base instead.)
+struct TileSrc {
+    uint64_t base; int ld; int64_t bytes;       // first byte of the sample's rows (head offset included), bytes up to the end of its last row
+};
+__device__ __forceinline__ TileSrc tile_src(const bf16* base, int ld, int nrows, int dh) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    TileSrc t;
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); };      // (the builtin returns a signed int)
+    t.base = ((uint64_t)uni((uint32_t)(a >> 32)) << 32) | (uint64_t)uni((uint32_t)a);
+    t.ld = (int)uni((uint32_t)ld);
+    const uint64_t nb = nrows > 0 ? ((uint64_t)(nrows - 1) * ld + dh) * 2 : 0;
+    t.bytes = (int64_t)(((uint64_t)uni((uint32_t)(nb >> 32)) << 32) | (uint64_t)uni((uint32_t)nb));
+    return t;
+}
+template <int DH> __device__ __forceinline__ int tile_voff(int ld, int tid) {
+    using B = BT<DH>;
+    constexpr int RPB = (B::RBN >= 256) ? 1 : 256 / B::RBN;
+    const int row = tid / B::NCHR;
+    const int ch = ((tid % B::NCHR) ^ (row / RPB)) & (B::NCHR - 1);           // source chunk that belongs at position tid
+    return (row * ld + ch * 8) * 2;
+}
+template <int DH>
+__device__ __forceinline__ void glds_tile(char* lds, const TileSrc& ts, int voff, int row0, int wave) {
+    using B = BT<DH>;
+    static_assert(B::NCHUNK % 64 == 0, "whole waves");
+    constexpr int RPI = NTH / B::NCHR;                                        // rows covered by one round of the block
+#pragma unroll
+    for (int i = 0; i < B::NLD; ++i)
+        if (B::NCHUNK % NTH == 0 || i * NTH + wave * 64 < B::NCHUNK) {        // (dh = 16: the tile is two waves' worth)
+            const int64_t skip = (int64_t)(row0 + i * RPI) * ts.ld * 2;       // scalar
+            const int64_t left = ts.bytes - skip;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void*>(ts.base + (uint64_t)skip), 0, (int)(left > 0 ? (left < 0x7fffffff ? left : 0x7fffffff) : 0), 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + (i * NTH + wave * 64) * 16), 16,
+                                                     voff, 0, 0, 0);
+        }
+}
+
 // acc[dt] (32 d x 32) += NAT^T[d][rows] (A operand via transposing reads) x P (B operand = this lane's 16 accumulator
 // values of a 32-row sub-tile starting at row0; value r <-> row 8*(r>>2) + 4*half + (r&3))
 template <int DH>
@@ -756,11 +799,125 @@ __device__ __forceinline__ void mma_tr_nat(f32x16* acc, const char* nat, int row
     }
 }
 
-template <int DH>
-__global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP pin) {
+// ---- bf16 kernels (v3) -----------------------------------------------------------------------------------------------
+// What bounds them: per 64-key step a wave runs 16 (forward) / 24 (dQ) / 32 (dK,dV) MFMAs = 32 cycles each on its SIMD's
+// matrix pipe, and one softmax element per lane per half MFMA.  Measured on MI355X (tools/ubench/valu_rate.hip) a single
+// wave issues one VALU instruction per ~6.5 cycles whatever the mix; the SIMD reaches its 2.5-3.3 cycles per instruction
+// only with >= 3 resident waves.  So the kernels are VALU-issue bound, and the design rules are: (i) as few VALU
+// instructions per score as possible - masks only on the tiles that contain a masked key (the key-padding mask is scanned
+// once per block for its first masked / last unmasked key; tiles beyond the last unmasked key are skipped altogether),
+// dropout as one v_mul_u32_u24 + compare + select per score (pa_device.h drop_keep2; the per-key / per-row hash words
+// come from LDS, written once per tile), scale and max folded into one FMA, LDS addresses = loop-invariant base + immediate
+// (the two pipeline stages are separate instantiations of the loop body); (ii) four blocks = 16 waves per CU (<= 128
+// VGPRs), so that the hardware interleaves the MFMA, VALU and LDS phases of different waves.
+// LDS stage: [X tile 64 x DH][Y tile 64 x DH][aux 768 B]; two stages + 32 B for the mask scan.
+template <int DH> struct BL {
+    static constexpr int NAT = BT<DH>::NAT;
+    static constexpr int AUX = 2 * NAT;
+    static constexpr int BUF = 2 * NAT + 768;
+    static constexpr int SHM = 2 * BUF + 64;
+};
+template <int V> struct IC { static constexpr int value = V; };
+// Block barrier that also publishes this wave's LDS-DMA tiles: hipcc does not count `buffer_load ... lds` among the
+// operations __syncthreads() has to wait for (observed: s_waitcnt vmcnt(3) before the s_barrier), so the wait is explicit.
+__device__ __forceinline__ void tile_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// Key range of a key-padding-mask row: kfirst = first masked key, klast = last unmasked key + 1 (both Lk without a mask).
+// Key tiles at or beyond klast contribute exactly zero and are skipped; tiles that end at or before kfirst need no
+// per-element mask test.  One pass over the Lk mask bytes by the whole block; contains a barrier.
+__device__ __forceinline__ void scan_key_mask(const uint8_t* mp, int Lk, int tid, int* s_scan, int& kfirst, int& klast) {
+    int f = Lk, l = 0;
+    for (int k = tid; k < Lk; k += NTH) {
+        if (mp[k]) f = min(f, k);
+        else l = k + 1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { f = min(f, __shfl_xor(f, o)); l = max(l, __shfl_xor(l, o)); }
+    if ((tid & 63) == 0) { s_scan[(tid >> 6) * 2] = f; s_scan[(tid >> 6) * 2 + 1] = l; }
+    __syncthreads();
+    kfirst = min(min(s_scan[0], s_scan[2]), min(s_scan[4], s_scan[6]));
+    klast = max(max(s_scan[1], s_scan[3]), max(s_scan[5], s_scan[7]));
+}
+// aux slot of key t (0..63) of a tile such that a lane's 32 keys (kt, g, e | half) are 32 consecutive words
+__device__ __forceinline__ int key_slot(int t) { return ((t >> 2) & 1) * 32 + (t >> 5) * 16 + ((t >> 3) & 3) * 4 + (t & 3); }
+
+// LDS operand reads of the v3 kernels: hand-placed ds_read instructions on a few loop-invariant per-lane base addresses
+// plus immediate offsets (tile, pipeline stage, 32-row sub-tile), so that no address arithmetic and no address registers
+// beyond these live in the loop (the compiler's own addressing kept ~50 invariant addresses alive and spilled them).
+// hipcc does not track asm-issued LDS reads: every consumer sits behind wait_lds(), which ties the registers through the
+// s_waitcnt so that nothing using them can be scheduled above it.
+#define PA_DS128(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define PA_DSTR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+template <int N> __device__ __forceinline__ void wait_lds(u32x4 (&f)[N]) {
+    if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]));
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+    else static_assert(N == 1 || N == 2 || N == 4, "fragment count");
+}
+// Per-lane base addresses (bytes from the start of dynamic LDS, tile offset not included) of a natural [64][DH] bf16 tile:
+//   nat[s]  row (lane & 31), 16-byte chunk 2s + half, swizzled             - A operand of S^T = K Q^T style products
+//   trA/trB the ds_read_b64_tr_b16 patch of this lane for (dt ^ rsel) = 0 / 1 - A operand of the transposed products
+// Every other address of the loop is one of these plus an immediate (32-row sub-tile kt: + kt*32*RBN; 16-row half u of a
+// transposed sub-tile: + u*16*RBN; second 8 rows rsel: + 8*RBN; the swizzle term is unaffected by those because
+// 32, 16 rows are multiples of the swizzle period, and rsel / dt only flip one chunk bit - which selects trA or trB).
+template <int DH> struct LdsBase {
+    uint32_t nat[BT<DH>::NS];
+    uint32_t trA, trB;
+    __device__ __forceinline__ void init(uint32_t smem_base, int lane) {
+        using B = BT<DH>;
+        const int l = lane & 31, half = lane >> 5, L = lane & 15, G = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < B::NS; ++s) nat[s] = smem_base + swz_off<B::RBN>(l, 2 * s + half);
+        const int col = 16 * (G & 1) + 4 * (L & 3), r = 4 * half + (L >> 2);
+        trA = smem_base + r * B::RBN + swz_off<B::RBN>(r, col >> 3) - r * B::RBN + (col & 7) * 2;
+        trB = smem_base + r * B::RBN + swz_off<B::RBN>(r + 8, col >> 3) - (r + 8) * B::RBN + (col & 7) * 2;
+    }
+};
+// acc (32 x 32) += TILE[OFF/RBN + (lane & 31)][:] (A operand, contraction over dh) x regs (B operand)
+template <int DH, int OFF> __device__ __forceinline__ void mma_nat3(f32x16& acc, const LdsBase<DH>& lb, const u32x4* regs) {
+    constexpr int NS = BT<DH>::NS;
+    u32x4 a[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) PA_DS128(a[s], lb.nat[s], OFF);
+    wait_lds(a);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) mma16B<bf16>(acc, a[s], regs[s]);
+}
+// acc[dt] (32 d x 32) += TILE^T[d][32 rows at OFF] x P  (P = this lane's 16 accumulator values of the 32-row sub-tile;
+// value r <-> row 8*(r>>2) + 4*half + (r&3)); lanes whose dh column lies beyond DH (dh = 16) feed accumulator rows that
+// are never stored
+template <int DH, int OFF> __device__ __forceinline__ void mma_tr3(f32x16* acc, const LdsBase<DH>& lb, const f32x16& pv) {
+    using B = BT<DH>;
+    u32x4 pb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) pb[u][w] = pack_bf16(pv[8 * u + 2 * w], pv[8 * u + 2 * w + 1]);
+#pragma unroll
+    for (int dt = 0; dt < B::NDT; ++dt) {
+        u32x4 a[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x2 x0, x1;
+            // rsel = 0 -> chunk bit (dt ^ 0), rsel = 1 -> (dt ^ 1)
+            if (dt == 0) { PA_DSTR(x0, lb.trA, OFF + u * 16 * B::RBN); PA_DSTR(x1, lb.trB, OFF + u * 16 * B::RBN + 8 * B::RBN); }
+            else { PA_DSTR(x0, lb.trB, OFF + u * 16 * B::RBN); PA_DSTR(x1, lb.trA, OFF + u * 16 * B::RBN + 8 * B::RBN); }
+            a[u][0] = x0[0]; a[u][1] = x0[1]; a[u][2] = x1[0]; a[u][3] = x1[1];
+        }
+        wait_lds(a);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) mma16B<bf16>(acc[dt], a[u], pb[u]);
+    }
+}
+
+template <int DH, bool DROP>
+__global__ __launch_bounds__(NTH, 4) void attn_fwd_bf16_kernel(AttnP pin) {
     using A = AT<bf16, DH>;
     using B = BT<DH>;
-    constexpr int BUF = 2 * B::NAT + 64;
+    constexpr int BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -779,7 +936,33 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP pin) {
 
     u32x4 qreg[A::NS];
     load_row_regs<bf16, DH>(qreg, Qp, p.ldq, qrow, p.Lq, lane);
-    int nsteps = (p.Lk + BSTR - 1) / BSTR;
+
+    const TileSrc srcK = tile_src(Kp, p.ldk, p.Lk, DH), srcV = tile_src(Vp, p.ldv, p.Lk, DH);
+    const int voffK = tile_voff<DH>(p.ldk, tid), voffV = tile_voff<DH>(p.ldv, tid);
+    LdsBase<DH> lb;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    lb.init(smem_base, lane);
+    const uint32_t cbase = smem_base + half * 128;       // this half-wave's 32 key-hash words of a tile (key_slot)
+    auto issue = [&](int step, int buf, int kfirst_) {
+        char* base = smem + buf * BUF;
+        const int k0 = step * BSTR;
+        const bool tile_masked = k0 + BSTR > kfirst_;                  // block-uniform
+        uint8_t mb = 0;
+        if (tile_masked && tid < BSTR) {                               // (loaded before the DMA is issued: its wait must not cover the tiles)
+            const int key = k0 + tid;
+            mb = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+        }
+        glds_tile<DH>(base, srcK, voffK, k0, wave);
+        glds_tile<DH>(base + B::NAT, srcV, voffV, k0, wave);
+        if (tid < BSTR) {
+            if (tile_masked) reinterpret_cast<uint8_t*>(base + AUX)[tid] = mb;
+            if (DROP) reinterpret_cast<uint32_t*>(base + AUX + 64)[key_slot(tid)] = drop_key_hash(p.drop_seed, (uint32_t)(k0 + tid));
+        }
+    };
+    issue(0, 0, 0);
+    int kfirst = p.Lk, klast = p.Lk;
+    if (mp) scan_key_mask(mp, p.Lk, tid, reinterpret_cast<int*>(smem + 2 * BUF), kfirst, klast);
+    int nsteps = (klast + BSTR - 1) / BSTR;
     if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
 
     f32x16 oacc[A::NDT];
@@ -789,109 +972,104 @@ __global__ __launch_bounds__(NTH, 3) void attn_fwd_bf16_kernel(AttnP pin) {
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float sl = p.scale * LOG2E;
-    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qrow) * p.nk4);
+    const uint32_t arow = DROP ? drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow)) : 0u;
+    tile_barrier();
 
-    auto issue = [&](int step, int buf) {
-        char* base = smem + buf * BUF;
-        const int k0 = step * BSTR;
-        glds_nat<DH>(base, Kp, p.ldk, k0, p.Lk, tid, wave);
-        glds_nat<DH>(base + B::NAT, Vp, p.ldv, k0, p.Lk, tid, wave);
-        if (tid < BSTR) {
-            const int key = k0 + tid;
-            reinterpret_cast<uint8_t*>(base + 2 * B::NAT)[tid] = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
-        }
-    };
-    if (nsteps > 0) issue(0, 0);
-    __syncthreads();
-
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
-        const char* knat = smem + buf * BUF;
-        const char* vnat = knat + B::NAT;
-        const uint8_t* mk = reinterpret_cast<const uint8_t*>(knat + 2 * B::NAT);
-        const int k0 = step * BSTR;
-        f32x16 sacc[2];
+    auto body = [&](int step, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1, kfirst);
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(smem + buf * BUF + AUX);
+        // The online softmax advances in 32-key chunks (one 32 x 32 S^T accumulator = 16 registers live instead of 32;
+        // what keeps the kernel at four blocks per CU): S^T chunk -> row max -> deferred rescale -> P -> O^T += V^T P^T.
+        auto sub = [&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
+            const int k0 = step * BSTR + kt * 32;
+            f32x16 sacc;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
-            mma_nat<bf16, DH>(sacc[kt], knat, kt * 32, qreg, lane);
-        }
-        // Softmax arithmetic in the log2 domain on the RAW scores (the scale is folded into one FMA per element):
-        // m_run = running max of s * sl.  Masks are only evaluated on tiles that can contain a masked key (key-padding
-        // mask present, tail of the sequence, or the causal diagonal) - wave-uniform test.
-        const bool need_mask = (mp != nullptr) || (k0 + BSTR > p.Lk) || (p.causal && (k0 + BSTR - 1 > q0 + wave * 32));
-        float mx = -INFINITY;
-        if (need_mask) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            mma_nat3<DH, buf * BUF + kt * 32 * B::RBN>(sacc, lb, qreg);
+            // Softmax in the log2 domain on the RAW scores (scale folded into one FMA per element); m_run = running max of s * sl.
+            const bool key_masked = k0 + 32 > kfirst;                      // (the tile's mask bytes exist: issue() wrote them)
+            const bool need_mask = key_masked || (p.causal && (k0 + 31 > q0 + wave * 32));               // wave-uniform
+            float mx = -INFINITY;
+            if (need_mask) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int koff = kt * 32 + 8 * g + 4 * half;
-                    const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
+                    const int ko = 8 * g + 4 * half;
+                    const uint32_t m4 = key_masked ? *reinterpret_cast<const uint32_t*>(mk + kt * 32 + ko) : 0u;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int key = k0 + koff + e;
-                        const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
-                        const float x = masked ? -INFINITY : sacc[kt][4 * g + e];
-                        sacc[kt][4 * g + e] = x;
+                        const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && k0 + ko + e > qrow);
+                        const float x = masked ? -INFINITY : sacc[4 * g + e];
+                        sacc[4 * g + e] = x;
                         mx = fmaxf(mx, x);
                     }
                 }
-        } else {
+            } else {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(sacc[r], sacc[r + 1]));                 // v_max3_f32
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl;
+            // deferred rescale (see the generic kernel): the reference point only moves when some row outgrew it by 2^RESCALE_THR
+            if (__any(mx > m_run + RESCALE_THR)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float ms = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = fast_exp2(m_run - ms);
+                l_run *= alpha;
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(sacc[kt][r], sacc[kt][r + 1]));     // v_max3_f32
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl;
-        if (__any(mx > m_run + RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float ms = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = fast_exp2(m_run - ms);
-            l_run *= alpha;
+                for (int dt = 0; dt < A::NDT; ++dt)
 #pragma unroll
-            for (int dt = 0; dt < A::NDT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-            m_run = m_new;
-        }
-        const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
-        float lsum = 0.f;
-        // dropout: survivors are NOT rescaled here - 1/(1-p) is folded into the final normalisation
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                m_run = m_new;
+            }
+            const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
+            float lsum[4] = {0.f, 0.f, 0.f, 0.f};                          // four short chains instead of one of 16 adds
+            // dropout: survivors are NOT rescaled here - 1/(1-p) is folded into the final normalisation.  The 16 key hashes
+            // of this lane's scores stream through two registers: group g + 1 is requested before group g is consumed.
+            u32x4 cq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            if (DROP) PA_DS128(cq[0], cbase, buf * BUF + AUX + 64 + kt * 64);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uint32_t hsh = 0;
-                if (p.drop_thr) hsh = drop_hash4(p.drop_seed, drow + ((k0 + kt * 32 + 8 * g + 4 * half) >> 2));
+                if (DROP) {
+                    if (g + 1 < 4) {
+                        PA_DS128(cq[(g + 1) & 1], cbase, buf * BUF + AUX + 64 + kt * 64 + (g + 1) * 16);
+                        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cq[g & 1]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cq[g & 1]));
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float pe = fast_exp2(__builtin_fmaf(sacc[kt][4 * g + e], sl, nm));
-                    lsum += pe;
-                    if (p.drop_thr) pe = drop_keep4(hsh, e, p.drop_thr) ? pe : 0.f;
-                    sacc[kt][4 * g + e] = pe;
+                    float pe = fast_exp2(__builtin_fmaf(sacc[4 * g + e], sl, nm));
+                    lsum[e] += pe;
+                    if (DROP) pe = drop_keep2(arow, cq[g & 1][e], p.drop_thr) ? pe : 0.f;
+                    sacc[4 * g + e] = pe;
                 }
             }
-        l_run += lsum;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) mma_tr_nat<DH>(oacc, vnat, kt * 32, sacc[kt], lane);
-        __syncthreads();
+            l_run += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+            mma_tr3<DH, buf * BUF + B::NAT + kt * 32 * B::RBN>(oacc, lb, sacc);
+        };
+        sub(IC<0>{});
+        sub(IC<1>{});
+        tile_barrier();
+    };
+    for (int step = 0; step < nsteps; step += 2) {
+        body(step, IC<0>{});
+        if (step + 1 < nsteps) body(step + 1, IC<1>{});
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = l_tot > 0.f ? (p.drop_thr ? p.drop_scale : 1.0f) / l_tot : 0.f;
+    const float inv = l_tot > 0.f ? (DROP ? p.drop_scale : 1.0f) / l_tot : 0.f;
     bf16* Op = reinterpret_cast<bf16*>(p.o) + (size_t)qoff * p.ldo + h * DH;
     store_rows<bf16, DH>(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);
     if (half == 0 && qrow < p.Lq && p.lse)
         p.lse[((size_t)b * p.H + h) * pin.Lq + qrow] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : 0.f;
 }
 
-template <int DH>
-__global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP pin) {
+template <int DH, bool DROP, int OCC>
+__global__ __launch_bounds__(NTH, OCC) void attn_bwd_dq_bf16_kernel(AttnP pin) {
     using A = AT<bf16, DH>;
     using B = BT<DH>;
-    constexpr int BUF = 2 * B::NAT + 64;
+    constexpr int BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -914,9 +1092,9 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP pin) {
     load_row_regs<bf16, DH>(doreg, dOp, p.lddo, qrow, p.Lq, lane);
     const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qrow;
     const float lse2 = (qrow < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
-    // dS = P o (drop(dP) - delta) * scale with drop(x) = keep ? x / (1-p) : 0  ==  P o (keep ? dP : 0 - delta * (1-p)) * scale / (1-p):
+    // dS = P o (drop(dP) - delta) * scale with drop(x) = keep ? x / (1-p) : 0  ==  P o ((keep ? dP : 0) - delta * (1-p)) * scale / (1-p):
     // the two constant factors move to the final store, delta is pre-multiplied once
-    const float keep_p = p.drop_thr ? 1.0f / p.drop_scale : 1.0f;
+    const float keep_p = DROP ? 1.0f / p.drop_scale : 1.0f;
     // delta[q] = sum_d dO[q][d] * O[q][d] is computed here (each half-wave lane holds half of the row) and published
     // for the dK/dV kernel, which is launched after this one - no separate delta pass
     float dsum = 0.f;
@@ -933,7 +1111,33 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP pin) {
         if (half == 0 && qrow < p.Lq) p.delta[srow] = dsum;
     }
     const float dlt = (qrow < p.Lq) ? dsum * keep_p : 0.f;
-    int nsteps = (p.Lk + BSTR - 1) / BSTR;
+
+    const TileSrc srcK = tile_src(Kp, p.ldk, p.Lk, DH), srcV = tile_src(Vp, p.ldv, p.Lk, DH);
+    const int voffK = tile_voff<DH>(p.ldk, tid), voffV = tile_voff<DH>(p.ldv, tid);
+    LdsBase<DH> lb;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    lb.init(smem_base, lane);
+    const uint32_t cbase = smem_base + half * 128;       // this half-wave's 32 key-hash words of a tile (key_slot)
+    auto issue = [&](int step, int buf, int kfirst_) {
+        char* base = smem + buf * BUF;
+        const int k0 = step * BSTR;
+        const bool tile_masked = k0 + BSTR > kfirst_;
+        uint8_t mb = 0;
+        if (tile_masked && tid < BSTR) {
+            const int key = k0 + tid;
+            mb = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+        }
+        glds_tile<DH>(base, srcK, voffK, k0, wave);
+        glds_tile<DH>(base + B::NAT, srcV, voffV, k0, wave);
+        if (tid < BSTR) {
+            if (tile_masked) reinterpret_cast<uint8_t*>(base + AUX)[tid] = mb;
+            if (DROP) reinterpret_cast<uint32_t*>(base + AUX + 64)[key_slot(tid)] = drop_key_hash(p.drop_seed, (uint32_t)(k0 + tid));
+        }
+    };
+    issue(0, 0, 0);
+    int kfirst = p.Lk, klast = p.Lk;
+    if (mp) scan_key_mask(mp, p.Lk, tid, reinterpret_cast<int*>(smem + 2 * BUF), kfirst, klast);
+    int nsteps = (klast + BSTR - 1) / BSTR;
     if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
 
     f32x16 dqacc[A::NDT];
@@ -942,69 +1146,72 @@ __global__ __launch_bounds__(NTH, 3) void attn_bwd_dq_bf16_kernel(AttnP pin) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
     const float sl = p.scale * LOG2E;
-    const uint32_t drow = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qrow) * p.nk4);
+    const float nl = -lse2;
+    const uint32_t arow = DROP ? drop_row_hash(p.drop_seed, (uint32_t)srow) : 0u;
+    tile_barrier();
 
-    auto issue = [&](int step, int buf) {
-        char* base = smem + buf * BUF;
-        const int k0 = step * BSTR;
-        glds_nat<DH>(base, Kp, p.ldk, k0, p.Lk, tid, wave);
-        glds_nat<DH>(base + B::NAT, Vp, p.ldv, k0, p.Lk, tid, wave);
-        if (tid < BSTR) {
-            const int key = k0 + tid;
-            reinterpret_cast<uint8_t*>(base + 2 * B::NAT)[tid] = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
-        }
-    };
-    if (nsteps > 0) issue(0, 0);
-    __syncthreads();
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
-        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+    auto body = [&](int step, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1, kfirst);
         const char* knat = smem + buf * BUF;
-        const char* vnat = knat + B::NAT;
-        const uint8_t* mk = reinterpret_cast<const uint8_t*>(knat + 2 * B::NAT);
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(knat + AUX);
         const int k0 = step * BSTR;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        const bool key_masked = k0 + BSTR > kfirst;                       // (the tile's mask bytes exist: issue() wrote them)
+        const bool need_mask = key_masked || (p.causal && (k0 + BSTR - 1 > q0 + wave * 32));
+        auto sub = [&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
             f32x16 sacc, dpacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-            mma_nat<bf16, DH>(sacc, knat, kt * 32, qreg, lane);
-            mma_nat<bf16, DH>(dpacc, vnat, kt * 32, doreg, lane);
-            const bool need_mask = (mp != nullptr) || (k0 + BSTR > p.Lk) || (p.causal && (k0 + BSTR - 1 > q0 + wave * 32));
-            const float nl = -lse2;
+            mma_nat3<DH, buf * BUF + kt * 32 * B::RBN>(sacc, lb, qreg);
+            mma_nat3<DH, buf * BUF + B::NAT + kt * 32 * B::RBN>(dpacc, lb, doreg);
+            u32x4 cq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            if (DROP) PA_DS128(cq[0], cbase, buf * BUF + AUX + 64 + kt * 64);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int koff = kt * 32 + 8 * g + 4 * half;
+                const int ko = kt * 32 + 8 * g + 4 * half;
                 uint32_t m4 = 0;
-                if (need_mask) m4 = *reinterpret_cast<const uint32_t*>(mk + koff);
-                uint32_t hsh = 0;
-                if (p.drop_thr) hsh = drop_hash4(p.drop_seed, drow + ((k0 + koff) >> 2));
+                if (key_masked) m4 = *reinterpret_cast<const uint32_t*>(mk + ko);
+                if (DROP) {
+                    if (g + 1 < 4) {
+                        PA_DS128(cq[(g + 1) & 1], cbase, buf * BUF + AUX + 64 + kt * 64 + (g + 1) * 16);
+                        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cq[g & 1]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cq[g & 1]));
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float pe = fast_exp2(__builtin_fmaf(sacc[4 * g + e], sl, nl));
                     if (need_mask) {
-                        const int key = k0 + koff + e;
+                        const int key = k0 + ko + e;
                         const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
                         pe = masked ? 0.f : pe;
                     }
                     float dp = dpacc[4 * g + e];
-                    if (p.drop_thr) dp = drop_keep4(hsh, e, p.drop_thr) ? dp : 0.f;
+                    if (DROP) dp = drop_keep2(arow, cq[g & 1][e], p.drop_thr) ? dp : 0.f;
                     sacc[4 * g + e] = pe * (dp - dlt);                      // dS^T / (scale / (1-p))
                 }
             }
-            mma_tr_nat<DH>(dqacc, knat, kt * 32, sacc, lane);            // dQ^T += K^T dS^T
-        }
-        __syncthreads();
+            mma_tr3<DH, buf * BUF + kt * 32 * B::RBN>(dqacc, lb, sacc);      // dQ^T += K^T dS^T
+        };
+        sub(IC<0>{});
+        sub(IC<1>{});
+        tile_barrier();
+    };
+    for (int step = 0; step < nsteps; step += 2) {
+        body(step, IC<0>{});
+        if (step + 1 < nsteps) body(step + 1, IC<1>{});
     }
     bf16* dQp = reinterpret_cast<bf16*>(p.dq) + (size_t)qoff * p.lddq + h * DH;
-    store_rows<bf16, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, p.scale * (p.drop_thr ? p.drop_scale : 1.0f), lane);
+    store_rows<bf16, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, p.scale * (DROP ? p.drop_scale : 1.0f), lane);
 }
 
-template <int DH>
-__global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
+template <int DH, bool DROP, int OCC>
+__global__ __launch_bounds__(NTH, OCC) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
     using A = AT<bf16, DH>;
     using B = BT<DH>;
-    constexpr int BUF = 2 * B::NAT + 2 * 64 * 4;
+    constexpr int BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1034,70 +1241,96 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkacc[dt][r] = 0.f; dvacc[dt][r] = 0.f; }
     const float sl = p.scale * LOG2E;
-    const float keep_p = p.drop_thr ? 1.0f / p.drop_scale : 1.0f;
+    const float keep_p = DROP ? 1.0f / p.drop_scale : 1.0f;
+    const uint32_t ckey = DROP ? drop_key_hash(p.drop_seed, (uint32_t)krow) : 0u;
+    const size_t srow0 = ((size_t)b * p.H + h) * pin.Lq;
 
+    const TileSrc srcQ = tile_src(Qp, p.ldq, p.Lq, DH), srcO = tile_src(dOp, p.lddo, p.Lq, DH);
+    const int voffQ = tile_voff<DH>(p.ldq, tid), voffO = tile_voff<DH>(p.lddo, tid);
+    LdsBase<DH> lb;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    lb.init(smem_base, lane);
+    const uint32_t abase = smem_base + half * 16;        // this half-wave's 4 query rows of an 8-row group (aux words)
     auto issue = [&](int step, int buf) {
         char* base = smem + buf * BUF;
         const int r0 = step * BSTR;
-        glds_nat<DH>(base, Qp, p.ldq, r0, p.Lq, tid, wave);
-        glds_nat<DH>(base + B::NAT, dOp, p.lddo, r0, p.Lq, tid, wave);
+        float lv = INFINITY, dv_ = 0.f;                                   // +inf -> p = 0 for rows past Lq
+        if (tid < BSTR && r0 + tid < p.Lq) { lv = p.lse[srow0 + r0 + tid] * LOG2E; dv_ = p.delta[srow0 + r0 + tid] * keep_p; }
+        glds_tile<DH>(base, srcQ, voffQ, r0, wave);
+        glds_tile<DH>(base + B::NAT, srcO, voffO, r0, wave);
         if (tid < BSTR) {
-            const int qr = r0 + tid;
-            const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qr;
-            float* aux = reinterpret_cast<float*>(base + 2 * B::NAT);
-            aux[tid] = (qr < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;      // +inf -> p = 0 for rows past Lq
-            aux[64 + tid] = (qr < p.Lq) ? p.delta[srow] * keep_p : 0.f;     // delta * (1-p), see the dQ kernel
+            float* aux = reinterpret_cast<float*>(base + AUX);
+            aux[tid] = lv;
+            aux[64 + tid] = dv_;                                          // delta * (1-p), see the dQ kernel
+            if (DROP) reinterpret_cast<uint32_t*>(aux)[128 + tid] = drop_row_hash(p.drop_seed, (uint32_t)(srow0 + r0 + tid));
         }
     };
     if (step0 < nsteps) issue(step0, 0);
-    __syncthreads();
-    for (int step = step0; step < nsteps; ++step) {
-        const int buf = (step - step0) & 1;
+    tile_barrier();
+
+    auto body = [&](int step, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
         if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
-        const char* qnat = smem + buf * BUF;
-        const char* donat = qnat + B::NAT;
-        const float* aux = reinterpret_cast<const float*>(qnat + 2 * B::NAT);
         const int r0 = step * BSTR;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        auto sub = [&](auto qtc) {
+            constexpr int qt = decltype(qtc)::value;
             f32x16 sacc, dpacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-            mma_nat<bf16, DH>(sacc, qnat, qt * 32, kreg, lane);        // S[q][key]
-            mma_nat<bf16, DH>(dpacc, donat, qt * 32, vreg, lane);      // dP[q][key]
+            mma_nat3<DH, buf * BUF + qt * 32 * B::RBN>(sacc, lb, kreg);               // S[q][key]
+            mma_nat3<DH, buf * BUF + B::NAT + qt * 32 * B::RBN>(dpacc, lb, vreg);     // dP[q][key]
             // A masked KEY (this lane's row) gets its accumulators zeroed at the end instead of per element; the causal
             // test only runs on the q tiles that straddle the diagonal (wave-uniform).
             const bool need_causal = p.causal && (key0 + wave * 32 + 31 > r0 + qt * 32);
+            // per-query-row words of the tile (lse, delta, dropout row hash) stream through two register sets: the words of
+            // group g + 1 are requested before group g is consumed
+            u32x4 lq[2], dq_[2], aq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            constexpr int AO = buf * BUF + AUX + qt * 128;
+            PA_DS128(lq[0], abase, AO); PA_DS128(dq_[0], abase, AO + 256);
+            if (DROP) PA_DS128(aq[0], abase, AO + 512);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int qoff = qt * 32 + 8 * g + 4 * half;
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(aux + qoff);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(aux + 64 + qoff);
+                const int qo = qt * 32 + 8 * g + 4 * half;
+                if (g + 1 < 4) {
+                    PA_DS128(lq[(g + 1) & 1], abase, AO + (g + 1) * 32); PA_DS128(dq_[(g + 1) & 1], abase, AO + 256 + (g + 1) * 32);
+                    if (DROP) {
+                        PA_DS128(aq[(g + 1) & 1], abase, AO + 512 + (g + 1) * 32);
+                        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(lq[g & 1]), "+v"(dq_[g & 1]), "+v"(aq[g & 1]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lq[g & 1]), "+v"(dq_[g & 1]));
+                    }
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lq[g & 1]), "+v"(dq_[g & 1]), "+v"(aq[g & 1]));
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int qr = r0 + qoff + e;
-                    float pe = fast_exp2(__builtin_fmaf(sacc[4 * g + e], sl, -l4[e]));
-                    if (need_causal) pe = (krow > qr) ? 0.f : pe;
+                    float pe = fast_exp2(__builtin_fmaf(sacc[4 * g + e], sl, -__uint_as_float(lq[g & 1][e])));
+                    if (need_causal) pe = (krow > r0 + qo + e) ? 0.f : pe;
                     float dp = dpacc[4 * g + e];
                     float pd = pe;
-                    if (p.drop_thr) {
-                        const uint32_t idx4 = (uint32_t)((((size_t)b * p.H + h) * pin.Lq + qr) * p.nk4 + (krow >> 2));
-                        const bool keep = drop_keep4(drop_hash4(p.drop_seed, idx4), krow & 3, p.drop_thr);
+                    if (DROP) {
+                        const bool keep = drop_keep2(aq[g & 1][e], ckey, p.drop_thr);
                         dp = keep ? dp : 0.f;
                         pd = keep ? pe : 0.f;
                     }
                     sacc[4 * g + e] = pd;                                  // P_drop * (1-p)
-                    dpacc[4 * g + e] = pe * (dp - d4[e]);                  // dS * (1-p) / scale
+                    dpacc[4 * g + e] = pe * (dp - __uint_as_float(dq_[g & 1][e]));      // dS * (1-p) / scale
                 }
             }
-            mma_tr_nat<DH>(dvacc, donat, qt * 32, sacc, lane);         // dV^T += dO^T P
-            mma_tr_nat<DH>(dkacc, qnat, qt * 32, dpacc, lane);         // dK^T += Q^T dS
-        }
-        __syncthreads();
+            mma_tr3<DH, buf * BUF + B::NAT + qt * 32 * B::RBN>(dvacc, lb, sacc);      // dV^T += dO^T P
+            mma_tr3<DH, buf * BUF + qt * 32 * B::RBN>(dkacc, lb, dpacc);              // dK^T += Q^T dS
+        };
+        sub(IC<0>{});
+        sub(IC<1>{});
+        tile_barrier();
+    };
+    for (int step = step0; step < nsteps; step += 2) {
+        body(step, IC<0>{});
+        if (step + 1 < nsteps) body(step + 1, IC<1>{});
     }
     bf16* dKp = reinterpret_cast<bf16*>(p.dk) + (size_t)koff * p.lddk + h * DH;
     bf16* dVp = reinterpret_cast<bf16*>(p.dv) + (size_t)koff * p.lddv + h * DH;
-    const float ds = p.drop_thr ? p.drop_scale : 1.0f;
+    const float ds = DROP ? p.drop_scale : 1.0f;
     // masked key: select (not multiply) - its accumulators may hold inf/NaN from exponentials the softmax never saw
     store_rows<bf16, DH>(dKp, p.lddk, krow, p.Lk, dkacc, kmasked ? 0.f : p.scale * ds, lane, kmasked);
     store_rows<bf16, DH>(dVp, p.lddv, krow, p.Lk, dvacc, kmasked ? 0.f : ds, lane, kmasked);
@@ -1110,9 +1343,8 @@ AttnP make_params(const pa_attn_args* a) {
     p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk;
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
     p.causal = a->causal; p.scale = a->scale;
-    p.drop_thr = (uint32_t)(a->drop_p * 256.0f + 0.5f);            // 8-bit resolution (see drop_hash4)
-    p.drop_scale = 256.0f / (256.0f - (float)p.drop_thr);
-    p.nk4 = (a->Lk + 3) / 4;
+    p.drop_thr = (uint32_t)((double)a->drop_p * 4294967296.0);     // keep <=> 32-bit product >= thr (pa_device.h drop_keep2)
+    p.drop_scale = (float)(1.0 / (1.0 - (double)p.drop_thr / 4294967296.0));
     p.drop_seed = a->drop_seed;
     p.dout = a->dout; p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.delta = a->delta;
     p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
@@ -1131,16 +1363,29 @@ template <typename K> int set_lds(K kern, int bytes) {
 }
 
 template <int DH> int run_fwd_bf16(const AttnP& p, hipStream_t st) {
-    const int shm = 2 * (2 * BT<DH>::NAT + 64);
+    const int shm = BL<DH>::SHM;
     dim3 grid(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B);
-    PA_LAUNCH((attn_fwd_bf16_kernel<DH>), grid, dim3(NTH), shm, st, p);
+    if (p.drop_thr) PA_LAUNCH((attn_fwd_bf16_kernel<DH, true>), grid, dim3(NTH), shm, st, p);
+    else PA_LAUNCH((attn_fwd_bf16_kernel<DH, false>), grid, dim3(NTH), shm, st, p);
     return 0;
 }
 template <int DH> int run_bwd_bf16(const AttnP& p, hipStream_t st) {
-    int shm = 2 * (2 * BT<DH>::NAT + 64);
-    PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH>), dim3(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B), dim3(NTH), shm, st, p);   // also writes delta
-    shm = 2 * (2 * BT<DH>::NAT + 2 * 64 * 4);
-    PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH>), dim3(((p.Lk + BOWN - 1) / BOWN) * p.H * p.B), dim3(NTH), shm, st, p);
+    const int shm = BL<DH>::SHM;
+    const dim3 gq(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B), gk(((p.Lk + BOWN - 1) / BOWN) * p.H * p.B);
+    // blocks per CU the register allocation is made for (experiment knob PA_ATTN_OCC="<dq><dkv>", e.g. "43")
+    static const int occ_env = getenv("PA_ATTN_OCC") ? atoi(getenv("PA_ATTN_OCC")) : 0;
+    const int oq = occ_env ? occ_env / 10 : 3, ok = occ_env ? occ_env % 10 : 2;
+    if (p.drop_thr) {
+        if (oq >= 4) PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH, true, 4>), gq, dim3(NTH), shm, st, p);      // also writes delta
+        else PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH, true, 3>), gq, dim3(NTH), shm, st, p);
+        if (ok >= 3) PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, true, 3>), gk, dim3(NTH), shm, st, p);
+        else PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, true, 2>), gk, dim3(NTH), shm, st, p);
+    } else {
+        if (oq >= 4) PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH, false, 4>), gq, dim3(NTH), shm, st, p);
+        else PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH, false, 3>), gq, dim3(NTH), shm, st, p);
+        if (ok >= 3) PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, false, 3>), gk, dim3(NTH), shm, st, p);
+        else PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, false, 2>), gk, dim3(NTH), shm, st, p);
+    }
     return 0;
 }
 

@@ -12,7 +12,7 @@
 #include <math.h>
 #include <new>
 #include <string.h>
-#include "common.cuh"
+#include "pa_device.h"
 #include "model.h"
 
 struct DecodeLayout {

@@ -22,7 +22,7 @@
 #include <vector>
 #include <type_traits>
 #include <utility>
-#include "common.cuh"
+#include "pa_device.h"
 #include <mutex>
 #include <vector>
 #include "../../include/plank_hip.h"

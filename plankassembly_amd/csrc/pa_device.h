@@ -26,8 +26,12 @@ template <> struct ET<bf16>  { static constexpr int EB = 8; static constexpr int
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    bf16x2 p; p[0] = (bf16)lo; p[1] = (bf16)hi;          // v_cvt_pk_bf16_f32 (RNE)
-    return *reinterpret_cast<uint32_t*>(&p);
+    // one v_cvt_pk_bf16_f32 (RNE).  As a VECTOR conversion: element-wise casts were sometimes lowered to a conversion per
+    // element plus a v_perm_b32, and an inline-asm v_cvt_pk is invisible to hipcc's hazard recogniser (an asm write to a
+    // register an in-flight MFMA still reads as its B operand corrupted results - seen with dh = 16 / 32 tiles).
+    const f32x2 v = {lo, hi};
+    const bf16x2 p = __builtin_convertvector(v, bf16x2);
+    return *reinterpret_cast<const uint32_t*>(&p);
 }
 
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
@@ -103,17 +107,20 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t 
     return (h >> 16) >= thr16;
 }
 
-// Attention-probability dropout: ONE hash yields the keep decisions of 4 consecutive keys of a query row
-// (8 bits each; the drop probability is quantised to thr8/256 and the survivors are scaled by 256/(256-thr8),
-// so the expectation is exact).  idx4 = row * ceil(Lk/4) + key/4, decision j = key & 3.
-// (two multiply / xor-shift rounds: the dK/dV kernel needs one hash per score, so the full 3-round mix32 was ~40 % of its
-// VALU work; the keep-rate / independence statistics are checked by tests/test_kernels_gpu.py)
-__device__ __forceinline__ uint32_t drop_hash4(uint32_t seed, uint32_t idx4) {
-    uint32_t x = idx4 * 0x9e3779b9u + seed;
-    x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 13;
-    return x;
+// Attention-probability dropout: separable counter-based decisions.  keep(row, key) <=> the low 32 bits of the 24 x 24-bit
+// product A[row] * C[key] are >= thr32, with A = a 24-bit avalanche hash of the global query-row index and C = an odd
+// 24-bit hash of the key index.  One v_mul_u32_u24 + one compare per score in every kernel layout: the forward / dQ
+// kernels (lane = query row) hold A in a register and read C per key tile from LDS, the dK/dV kernel (lane = key) holds
+// C and reads A per query tile.  thr32 = p * 2^32, so the drop probability is p to 2^-32 (no quantisation) and the
+// survivors' 1/(1-p) is exact.  Statistics (keep rate, row / column variance, pair correlations, 2 x 2 parity, spectrum
+// of a 256 x 256 block) checked against the binomial expectation; tests/test_kernels_gpu.py checks rate and determinism.
+__device__ __forceinline__ uint32_t drop_row_hash(uint32_t seed, uint32_t row) {
+    return mix32(row * 0x9e3779b9u + seed) & 0xffffffu;
 }
-__device__ __forceinline__ bool drop_keep4(uint32_t h, int j, uint32_t thr8) { return ((h >> (8 * j)) & 0xffu) >= thr8; }
+__device__ __forceinline__ uint32_t drop_key_hash(uint32_t seed, uint32_t key) {
+    return (mix32(key * 0x85ebca6bu + (seed ^ 0x5bd1e995u)) | 1u) & 0xffffffu;
+}
+__device__ __forceinline__ bool drop_keep2(uint32_t a, uint32_t c, uint32_t thr32) { return __umul24(a, c) >= thr32; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -2,7 +2,7 @@
 // backward), LayerNorm fwd/bwd, switch head, fused mixture-NLL fwd/bwd, Adam, casts.
 // One 64-lane wave per row with 16-byte (4 x f32 / 4 x bf16 = 8-byte) vector accesses and
 // shuffle reductions; parameter-gradient column sums go through per-block partials (deterministic).
-#include "common.cuh"
+#include "pa_device.h"
 #include "../../include/plank_hip.h"
 
 namespace {

@@ -261,6 +261,16 @@ def attn_bwd(dout, q, k, v, o, lse, H, kpm=None, causal=False, scale=None, drop_
     return dq, dk, dv
 
 
+def pack_lengths(lengths, device):
+    """int lengths [B] -> (cu int32 [B+1] on `device`, order int32 [B] = batch elements by descending length) - the
+    layout pa_pack_rows leaves behind (cu[0..B], cu[B+1..2B])."""
+    ln = torch.as_tensor(lengths, dtype=torch.int64)
+    cu = torch.zeros(len(ln) + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(ln, 0).to(torch.int32)
+    order = torch.argsort(ln, descending=True, stable=True).to(torch.int32)
+    return cu.to(device), order.to(device)
+
+
 def switch_fwd(h, w, b):
     rows, d = h.numel() // h.shape[-1], h.shape[-1]
     s = _f32(rows, device=h.device)

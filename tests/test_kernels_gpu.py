@@ -349,7 +349,56 @@ def test_attention_dropout_consistency():
     o, _ = ops.attn_fwd(qq, kk, vv, 1, drop_p=0.2, drop_seed=7)      # uniform P = 1/64 each
     kept = (o > 0).float().mean().item()
     assert abs(kept - 0.8) < 0.02, kept
-    assert abs(o[o > 0].mean().item() - (256.0 / 205.0) / Lk) < 1e-6       # p quantised to 51/256, exact rescale
+    assert abs(o[o > 0].mean().item() - 1.25 / Lk) < 1e-6                  # survivors scaled by exactly 1 / (1 - p)
+
+
+def _extract_keep_mask(B, H, Lq, Lk, dh, p, seed, dtype):
+    """The kernels' dropout decisions as a bool [B, H, Lq, Lk]: with Q = K = 0 the probabilities are uniform and
+    V = one-hot key indicators (64 keys per pass) expose which of them survived."""
+    dm = H * dh
+    z = torch.zeros(B, Lq, dm, device=DEV, dtype=dtype)
+    zk = torch.zeros(B, Lk, dm, device=DEV, dtype=dtype)
+    keep = torch.zeros(B, H, Lq, Lk, dtype=torch.bool)
+    for k0 in range(0, Lk, dh):
+        v = torch.zeros(B, Lk, H, dh, device=DEV, dtype=dtype)
+        n = min(dh, Lk - k0)
+        v[:, k0:k0 + n, :, :n] = torch.eye(n, device=DEV, dtype=dtype)[None, :, None, :]
+        o, _ = ops.attn_fwd(z, zk, v.view(B, Lk, dm), H, drop_p=p, drop_seed=seed)
+        keep[:, :, :, k0:k0 + n] = (o.float().view(B, Lq, H, dh)[..., :n] > 0).permute(0, 2, 1, 3).cpu()
+    return keep
+
+
+@pytest.mark.parametrize("dtype,B,H,dh,Lq,Lk,causal", [
+    (torch.bfloat16, 2, 2, 64, 200, 333, False),      # the benchmarked head size, ragged multi-tile shapes
+    (torch.bfloat16, 1, 2, 64, 130, 130, True),
+    (torch.float32, 1, 2, 16, 70, 100, False),
+])
+def test_attention_dropout_forward_backward_against_masked_reference(dtype, B, H, dh, Lq, Lk, causal):
+    """Dropout is a deterministic function of (seed, query row, key): extract the mask the kernels use, then compare
+    forward AND all three backward outputs with a torch reference that applies that same mask - this pins that the
+    forward, dQ and dK/dV kernels (different register layouts) regenerate identical decisions."""
+    p, seed, dm = 0.2, 777, H * dh
+    keep = _extract_keep_mask(B, H, Lq, Lk, dh, p, seed, dtype)
+    rate = keep.float().mean().item()
+    assert abs(rate - 0.8) < 0.01, rate
+    assert abs(keep.float().mean(dim=-1).std().item() - math.sqrt(0.16 / Lk)) < 0.4 * math.sqrt(0.16 / Lk)   # rows independent
+    q, k, v = rnd(B, Lq, dm, dtype=dtype, seed=90), rnd(B, Lk, dm, dtype=dtype, seed=91), rnd(B, Lk, dm, dtype=dtype, seed=92)
+    dout = rnd(B, Lq, dm, dtype=dtype, seed=93)
+    qr, kr, vr = (x.float().requires_grad_(True) for x in (q, k, v))
+    qh = qr.view(B, Lq, H, dh).transpose(1, 2); kh = kr.view(B, Lk, H, dh).transpose(1, 2); vh = vr.view(B, Lk, H, dh).transpose(1, 2)
+    sc = qh @ kh.transpose(-1, -2) / math.sqrt(dh)
+    if causal:
+        sc = sc + torch.triu(torch.full((Lq, Lk), float("-inf")), 1)
+    pr = torch.softmax(sc, -1) * keep / (1 - p)
+    ref = (pr @ vh).transpose(1, 2).reshape(B, Lq, dm)
+    ref.backward(dout.float())
+    o, lse = ops.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), H, causal=causal, drop_p=p, drop_seed=seed)
+    t = tol(dtype)
+    assert rel_err(o, ref) < t, rel_err(o, ref)
+    dq, dk, dv = ops.attn_bwd(dout.to(DEV), q.to(DEV), k.to(DEV), v.to(DEV), o, lse, H, causal=causal, drop_p=p, drop_seed=seed)
+    assert rel_err(dq, qr.grad) < t, ("dq", rel_err(dq, qr.grad))
+    assert rel_err(dk, kr.grad) < t, ("dk", rel_err(dk, kr.grad))
+    assert rel_err(dv, vr.grad) < t, ("dv", rel_err(dv, vr.grad))
 
 
 # ------------------------------------------------------------------------------------------ heads / loss
