@@ -34,8 +34,30 @@ T_START = time.perf_counter()
 D, H, FF, NE, ND, V = 512, 8, 1024, 6, 6, 514
 S_IN, T_OUT, B_TRAIN = 1024, 128, 16
 B_DEC, T_DEC = 256, 1024
+# Workloads (BASELINE.json `configs`).  The default - what the driver records - is the headline line.
+BIG = dict(d=512, h=8, ff=1024, ne=6, nd=6)
+CONFIGS = {
+    "headline": dict(BIG, max_in=1025, max_out=128, batch=16, spec="headline",
+                     name="train_complete.yaml model d_model=512 H=8 dff=1024 6+6 post-norm layers, dropout 0.2"),
+    "complete": dict(BIG, max_in=1200, max_out=128, batch=16, spec="complete", name="train_complete.yaml as shipped (C2)"),
+    "visible": dict(BIG, max_in=1000, max_out=128, batch=16, spec="visible", name="train_visible.yaml lengths (C4)"),
+    "sideface": dict(BIG, max_in=300, max_out=128, batch=64, spec="sideface",
+                     name="train_sideface.yaml lengths, no input_type, empty rows (C4)"),
+    "t1024": dict(BIG, max_in=1025, max_out=1024, batch=16, spec="headline", planks=(2, 170),
+                  name="headline encoder with decoder length 1024 (SURVEY 8d T=1024 variant)"),
+    "tiny": dict(d=128, h=8, ff=256, ne=2, nd=2, max_in=1200, max_out=128, batch=4, spec="complete",
+                 name="BASELINE config 0: d_model=128, 2+2 layers, batch 4 (the reference's CPU-runnable case, C1)"),
+}
 PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+
+
+def cfg_spec(c):
+    from plankassembly_amd.data import spec_for
+    sp = spec_for(c["spec"], max_input_length=c["max_in"], max_output_length=c["max_out"])
+    if "planks" in c:
+        sp.n_planks = c["planks"]
+    return sp
 
 
 def fwd_flops_per_sample(S, T, d=D, ff=FF, ne=NE, nd=ND, v=V):
@@ -46,10 +68,10 @@ def fwd_flops_per_sample(S, T, d=D, ff=FF, ne=NE, nd=ND, v=V):
     return ne * enc + nd * dec + heads
 
 
-def build(compute_dtype, max_in, max_out, dropout):
+def build(compute_dtype, max_in, max_out, dropout, c=BIG):
     from plankassembly_amd.models import PlankModel
     torch.manual_seed(2022)
-    m = PlankModel(D, H, FF, dropout, "relu", True, NE, ND, 3, 2, 4, 6, max_in, max_out, V, TOKEN,
+    m = PlankModel(c["d"], c["h"], c["ff"], dropout, "relu", True, c["ne"], c["nd"], 3, 2, 4, 6, max_in, max_out, V, TOKEN,
                    compute_dtype=compute_dtype)
     return m.cuda()
 
@@ -158,14 +180,16 @@ def gemm_census(model, batch, train_step):
 
 
 def pmc_traffic(kernel_key):
-    """HBM bytes per launch of one kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json,
+    """HBM bytes per launch of one kernel from the committed rocprofv3 PMC passes (profiles/r0N_pmc_traffic.json,
     made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(here, "profiles", name)) as f:
+                return json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def usable_cores():
@@ -188,20 +212,74 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(sample_b=2, budget_s=20.0):
+def attention_census(cfgd, batch, drop_p):
+    """The attention launches of ONE training step at the packed shapes of `batch`, timed under HIP events at the
+    step's own arguments (variable-length rows, longest-first dispatch order, dropout): {family: {launches, flops,
+    seconds}} with launches = per train step (one per layer).  flops = algorithmic 4*Lq*Lk*d per sample and layer for
+    the forward, 2.5x that for the backward (dQ + dK/dV kernels together)."""
+    from plankassembly_amd import ops
+    d, h, ne, nd = cfgd["d"], cfgd["h"], cfgd["ne"], cfgd["nd"]
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(3)
+
+    def rnd(*s_):
+        return torch.randn(*s_, device=dev, generator=g).to(torch.bfloat16)
+
+    cu, rowmap, n = batch["_pack"]
+    B = batch["input_value"].shape[0]
+    S = batch["input_value"].shape[1]
+    T = batch["output_value"].shape[1]
+    order = ops.pack_order(cu)
+    lens = (cu[1:B + 1] - cu[:B]).tolist()
+    kw = dict(drop_p=drop_p, drop_seed=5)
+    fam = {}
+    qkv = rnd(n, 3 * d)
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    do = rnd(n, d)
+    fl = sum(4.0 * l * l * d for l in lens)
+    o, lse = ops.attn_varlen_fwd(q, k, v, h, cu, cu, B, S, S, order=order, **kw)
+    t = time_kernel(lambda: ops.attn_varlen_fwd(q, k, v, h, cu, cu, B, S, S, order=order, **kw))
+    fam["attn_enc_self_fwd"] = dict(launches=ne, flops=fl * ne, seconds=t * ne)
+    t = time_kernel(lambda: ops.attn_varlen_bwd(do, q, k, v, o, lse, h, cu, cu, B, S, S, order=order, **kw), iters=10)
+    fam["attn_enc_self_bwd"] = dict(launches=2 * ne, flops=2.5 * fl * ne, seconds=t * ne)
+    qc, kvc, doc = rnd(B * T, d), rnd(n, 2 * d), rnd(B * T, d)
+    kc, vc = kvc[:, :d], kvc[:, d:]
+    flc = sum(4.0 * T * l * d for l in lens)
+    oc, lsec = ops.attn_varlen_fwd(qc, kc, vc, h, None, cu, B, T, S, **kw)
+    t = time_kernel(lambda: ops.attn_varlen_fwd(qc, kc, vc, h, None, cu, B, T, S, **kw))
+    fam["attn_cross_fwd"] = dict(launches=nd, flops=flc * nd, seconds=t * nd)
+    t = time_kernel(lambda: ops.attn_varlen_bwd(doc, qc, kc, vc, oc, lsec, h, None, cu, B, T, S, **kw), iters=10)
+    fam["attn_cross_bwd"] = dict(launches=2 * nd, flops=2.5 * flc * nd, seconds=t * nd)
+    qd = rnd(B, T, 3 * d)
+    q1, k1, v1 = qd[..., :d], qd[..., d:2 * d], qd[..., 2 * d:]
+    dod = rnd(B, T, d)
+    fld = 4.0 * T * T * d * B
+    od, lsed = ops.attn_fwd(q1, k1, v1, h, causal=True, **kw)
+    t = time_kernel(lambda: ops.attn_fwd(q1, k1, v1, h, causal=True, **kw))
+    fam["attn_dec_self_fwd"] = dict(launches=nd, flops=fld * nd, seconds=t * nd)
+    t = time_kernel(lambda: ops.attn_bwd(dod, q1, k1, v1, od, lsed, h, causal=True, **kw), iters=10)
+    fam["attn_dec_self_bwd"] = dict(launches=2 * nd, flops=2.5 * fld * nd, seconds=t * nd)
+    return fam
+
+
+def cpu_baseline(cfgd, sample_b=2, budget_s=20.0, fit_style=False):
     """The oracle (CPU restatement, fixture-pinned to the reference) timed on the host cores: full
-    train step (fwd + bwd + Adam) on a bounded sample of the same workload (time-boxed)."""
+    train step (fwd + bwd + Adam) on a bounded sample of the same workload (time-boxed).  fit_style (the tiny
+    BASELINE config 0): the whole batch, warm-up 2, time 10 steps."""
     from oracle import plank_oracle as O
-    from plankassembly_amd.data import spec_for, synth_batch
+    from plankassembly_amd.data import synth_batch
     from plankassembly_amd.models import PlankModel
     cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(2022)
-    m = PlankModel(D, H, FF, 0.0, "relu", True, NE, ND, 3, 2, 4, 6, S_IN + 1, T_OUT, V, TOKEN)
+    c = cfgd
+    m = PlankModel(c["d"], c["h"], c["ff"], 0.0, "relu", True, c["ne"], c["nd"], 3, 2, 4, 6, c["max_in"], c["max_out"], V, TOKEN)
     params = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    cfg = O.OracleCfg(d_model=D, n_head=H, d_ff=FF, n_enc=NE, n_dec=ND, max_input_length=S_IN + 1,
-                      max_output_length=T_OUT)
-    batch = synth_batch(sample_b, spec_for("headline"), seed=2022)
+    cfg = O.OracleCfg(d_model=c["d"], n_head=c["h"], d_ff=c["ff"], n_enc=c["ne"], n_dec=c["nd"], max_input_length=c["max_in"],
+                      max_output_length=c["max_out"])
+    if fit_style:
+        sample_b = c["batch"]
+    batch = synth_batch(sample_b, cfg_spec(c), seed=2022)
     batch.pop("name")
     mom = {k: torch.zeros_like(v) for k, v in params.items()}
     var = {k: torch.zeros_like(v) for k, v in params.items()}
@@ -212,20 +290,23 @@ def cpu_baseline(sample_b=2, budget_s=20.0):
         grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
         O.adam_step(params, grads, mom, var, i, lr=1e-4)
 
+    warm = 2 if fit_style else 1
     tw = time.perf_counter()
-    step(1)
+    for i in range(warm):
+        step(i + 1)
     tw = time.perf_counter() - tw
     steps = 0
     t0 = time.perf_counter()
     while True:
-        step(steps + 2)
+        step(steps + warm + 1)
         steps += 1
         dt = time.perf_counter() - t0
-        if dt + tw > budget_s or steps >= 10:
+        if steps >= 10 or (not fit_style and dt + tw > budget_s):
             break
     return dict(value=sample_b * steps / dt, unit="samples/s", cores=cores, kind="port",
-                sample=f"oracle train step (fwd+bwd+Adam, f32, torch CPU ops, {cores} threads), B={sample_b}, S={S_IN}, "
-                       f"T={T_OUT}, {steps} timed step(s) after 1 warm-up, {dt:.1f}s")
+                sample=f"oracle train step (fwd+bwd+Adam, f32, torch CPU ops, {cores} threads), B={sample_b}, "
+                       f"S={c['max_in'] - 1}, T={c['max_out']}, d_model={c['d']}, {c['ne']}+{c['nd']} layers, {steps} timed "
+                       f"step(s) after {warm} warm-up, {dt:.1f}s")
 
 
 def main():
@@ -234,90 +315,133 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--config", default="headline", choices=sorted(CONFIGS))
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
-    ap.add_argument("--batch", type=int, default=B_TRAIN)
+    ap.add_argument("--batch", type=int, default=0)
     args = ap.parse_args()
+    cfgd = CONFIGS[args.config]
+    headline = args.config == "headline"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    from plankassembly_amd.data import spec_for, synth_batch
+    from plankassembly_amd.data import DevicePrefetcher, synth_batch
     from plankassembly_amd.distributed import GradSync
     from plankassembly_amd.optim import FusedAdam
 
     # ------------------------------------------------------------------ training
-    B = args.batch
-    model = build(args.dtype, S_IN + 1, T_OUT, 0.2).train()
+    B = args.batch or cfgd["batch"]
+    S_in, T_out = cfgd["max_in"] - 1, cfgd["max_out"]
+    model = build(args.dtype, cfgd["max_in"], cfgd["max_out"], 0.2, cfgd).train()
     opt = FusedAdam(model, lr=1e-4, grad_scale=1.0 / world)
-    if world > 1:
-        sync = GradSync(model)
+    sync = None
+    if dist.is_initialized():
+        sync = GradSync(model)                      # (world size 1 under torchrun: the RCCL path still runs)
         sync.broadcast_parameters(0)
-    batches = []
-    for i in range(4):
-        b = synth_batch(B, spec_for("headline"), seed=2022 + 1000 * i + rank, device="cuda")
+    # Raw collated batches (what a dataloader hands over), resident in HBM before the timed region.  Every rank draws the
+    # SAME length distribution (seeds do not depend on the rank): weak scaling then measures the machine, not which rank
+    # happened to draw the longest drawings.
+    n_pool = 16
+    raw = []
+    for i in range(n_pool):
+        b = synth_batch(B, cfg_spec(cfgd), seed=2022 + 1000 * i, device="cuda")
         b.pop("name")
-        batches.append(model.prepare_batch(b))      # resident in HBM, encoder rows packed, before the timed region
+        raw.append(b)
+    prepared = [model.prepare_batch(b) for b in raw[:4]]
 
-    def train_step(i):
+    def step_on(batch):
         opt.zero_grad()
-        out = model(batches[i % len(batches)])
+        out = model(batch)
         out["loss"].backward()
         opt.step()
         return out
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"model + batches ready (rank {rank}/{world})")
-    for i in range(args.warmup):
-        out = train_step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = train_step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    def cycle(pool, n):
+        for i in range(n):
+            yield pool[i % len(pool)]
+
+    def timed(pool, fresh):
+        """args.warmup untimed + args.steps timed steps.  fresh: every step gets a batch that has not been prepared -
+        pa_pack_rows / pa_group_rows (and the host -> device copies when the pool lives on the host) run inside the timed
+        region, one step ahead on a side stream (DevicePrefetcher), as in trainer.run()."""
+        total = args.warmup + args.steps
+        it = DevicePrefetcher(model, cycle(pool, total)) if fresh else cycle(pool, total)
+        out = None
+        for _ in range(args.warmup):
+            out = step_on(next(it))
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step_on(next(it))
+        fence()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        if dist.is_initialized() and world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()), out
+
+    log(f"model + batches ready (rank {rank}/{world}, config {args.config})")
+    dt, out = timed(raw, fresh=True)                       # the headline figure: a fresh batch every step
     loss = float(out["loss"].detach())
     assert math.isfinite(loss), "training diverged"
+    samples_s = args.steps * B * world / dt
+    log(f"train: {samples_s:.1f} samples/s, {dt / args.steps * 1e3:.2f} ms/step, loss {loss:.4f} (fresh batch every step)")
+    dt_res, _ = timed(prepared, fresh=False)               # round-1 figure: four prepared batches cycled
+    resident = dict(value=args.steps * B * world / dt_res, unit="samples/s", ms_per_step=dt_res / args.steps * 1e3,
+                    note="four batches prepared before the timed region and cycled (what round 1 reported)")
+    log(f"       {resident['value']:.1f} samples/s, {resident['ms_per_step']:.2f} ms/step with prepared batches")
+    host_pool = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in raw]
+    dt_h, _ = timed(host_pool, fresh=True)
+    fresh_host = dict(value=args.steps * B * world / dt_h, unit="samples/s", ms_per_step=dt_h / args.steps * 1e3,
+                      note="batches start in pinned host memory: PCIe copy + preparation + step (never `value`)")
+    log(f"       {fresh_host['value']:.1f} samples/s, {fresh_host['ms_per_step']:.2f} ms/step from host batches")
+    del host_pool
+
+    def train_step(i):
+        return step_on(prepared[i % len(prepared)])
+
     census = None
     if rank == 0 and not args.no_kernels:
-        census = gemm_census(model, batches[0], train_step)
-        log("gemm census: " + ", ".join(f"{k}: {v['launches']} launches, {v['seconds'] / v['launches'] * 1e6:.1f} us avg, "
-                                         f"{v['flops'] / v['seconds'] / 1e12:.0f} TF" for k, v in census.items()))
-    samples_s = args.steps * B * world / dt
-    log(f"train: {samples_s:.1f} samples/s, {dt / args.steps * 1e3:.2f} ms/step, loss {loss:.4f}")
-    train_flops = 3.0 * fwd_flops_per_sample(S_IN, T_OUT) * B      # per GPU step, counted at the padded length (dense-equivalent)
+        census = gemm_census(model, prepared[0], train_step)
+        if args.dtype == "bf16":
+            census.update(attention_census(cfgd, prepared[0], 0.2))
+        log("kernel census: " + ", ".join(f"{k}: {v['launches']} launches, {v['seconds'] / v['launches'] * 1e6:.1f} us avg, "
+                                           f"{v['flops'] / v['seconds'] / 1e12:.0f} TF" for k, v in census.items()))
+    fw = fwd_flops_per_sample(S_in, T_out, cfgd["d"], cfgd["ff"], cfgd["ne"], cfgd["nd"])
+    train_flops = 3.0 * fw * B                                 # per GPU step, counted at the padded length (dense-equivalent)
     step_tflops = train_flops * args.steps / dt / 1e12
-    valid_rows = sum(bt["_pack"][2] for bt in batches) / len(batches) if model.unpad else B * S_IN
+    valid_rows = sum(bt["_pack"][2] for bt in prepared) / len(prepared) if model.unpad else B * S_in
+    # executed FLOPs: the encoder runs on the packed rows, its attention on the true lengths
+    exec_flops = 0.0
+    for bt in prepared:
+        cu = bt["_pack"][0]
+        lens = (cu[1:B + 1] - cu[:B]).tolist()
+        exec_flops += 3.0 * sum(fwd_flops_per_sample(l, T_out, cfgd["d"], cfgd["ff"], cfgd["ne"], cfgd["nd"]) for l in lens)
+    exec_tflops = exec_flops / len(prepared) * args.steps / dt / 1e12
 
     # secondary: the same step with the encoder left padded (what the reference computes row for row), rank 0, N=1 only
     dense = None
-    if rank == 0 and world == 1 and not args.no_kernels and model.unpad:
+    if rank == 0 and world == 1 and not args.no_kernels and model.unpad and headline:
         model.unpad = False
-        dbatches = [{k: v for k, v in bt.items() if k != "_pack"} for bt in batches]
-        def dense_step(i):
-            opt.zero_grad()
-            o = model(dbatches[i % len(dbatches)])
-            o["loss"].backward()
-            opt.step()
+        dbatches = [{k: v for k, v in bt.items() if not k.startswith("_")} for bt in prepared]
         for i in range(3):
-            dense_step(i)
+            step_on(dbatches[i % len(dbatches)])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(10):
-            dense_step(i)
+            step_on(dbatches[i % len(dbatches)])
         torch.cuda.synchronize()
         ddt = (time.perf_counter() - t1) / 10
         dense = dict(value=B / ddt, unit="samples/s", ms_per_step=ddt * 1e3,
@@ -327,74 +451,79 @@ def main():
 
     # ------------------------------------------------------------------ greedy decode
     decode = None
-    if not args.no_decode:
+    if not args.no_decode and headline:
         from plankassembly_amd.decode import GreedyDecoder
-        if world > 1:
-            del sync
-        del opt, model, batches, out
+        sync = None
+        model.register_grad_ready_hook(None)
+        del opt, model, prepared, raw, out
         torch.cuda.empty_cache()
-        dm = build(args.dtype, S_IN + 1, T_DEC, 0.0).eval()
-        dm._ensure_handle(); dm._refresh_shadow()
-        dec = GreedyDecoder(dm)
-        db = synth_batch(B_DEC, spec_for("decode"), seed=7 + rank, device="cuda")
-        db.pop("name")
-        db = dm.prepare_batch(db)
-        log("decode model + batch ready")
-        with torch.no_grad():
-            dec.run(db, max_len=T_DEC, early_stop=False)              # warm-up (captures the step graph)
-            log("decode warm-up done")
-            fence()
-            t0 = time.perf_counter()
-            toks, _ = dec.run(db, max_len=T_DEC, early_stop=False)
-            fence()
-            ddt = time.perf_counter() - t0
-        tt = torch.tensor([ddt], device="cuda", dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ddt = float(tt.item())
-        esz = 2 if args.dtype == "bf16" else 4
-        # algorithmic HBM bytes per step averaged over t: weights + cross K/V + self K/V
-        w_bytes = (ND * (4 * D * D + 4 * D * D + 2 * D * FF) + V * D + D * D) * esz
-        kv_bytes = 2 * ND * B_DEC * (S_IN + T_DEC / 2) * D * esz
-        decode = dict(value=B_DEC * T_DEC * world / ddt, unit="tokens/s", batch=B_DEC, max_len=T_DEC, seq_in=S_IN,
-                      ms_per_step=ddt / T_DEC * 1e3, graph=bool(dec.use_graph),
-                      hbm_gbs=(w_bytes + kv_bytes) * T_DEC / ddt / 1e9,
-                      hbm_frac=(w_bytes + kv_bytes) * T_DEC / ddt / 1e9 / PEAK_HBM_GBS,
-                      includes="encoder + cross-K/V projection + 1024 decode steps")
-        log(f"decode: {decode['value']:.0f} tokens/s, {decode['ms_per_step']:.3f} ms/step")
-        del dec, dm
-        torch.cuda.empty_cache()
+        decode = {}
+        for ddtype in ([args.dtype] if args.dtype == "f32" else ["bf16", "f32"]):
+            dm = build(ddtype, S_IN + 1, T_DEC, 0.0).eval()
+            dm._ensure_handle(); dm._refresh_shadow()
+            dec = GreedyDecoder(dm, use_graph=True, strict_graph=True)     # a failed capture is an error here, not a silent eager run
+            from plankassembly_amd.data import spec_for
+            db = synth_batch(B_DEC, spec_for("decode"), seed=7, device="cuda")
+            db.pop("name")
+            db = dm.prepare_batch(db)
+            with torch.no_grad():
+                dec.run(db, max_len=T_DEC, early_stop=False)              # warm-up (captures the step graph)
+                fence()
+                t0 = time.perf_counter()
+                toks, _ = dec.run(db, max_len=T_DEC, early_stop=False)
+                fence()
+                ddt = time.perf_counter() - t0
+            tt = torch.tensor([ddt], device="cuda", dtype=torch.float64)
+            if dist.is_initialized() and world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ddt = float(tt.item())
+            esz = 2 if ddtype == "bf16" else 4
+            # algorithmic HBM bytes per step averaged over t: weights + cross K/V + self K/V
+            w_bytes = (ND * (4 * D * D + 4 * D * D + 2 * D * FF) + V * D + D * D) * esz
+            kv_bytes = 2 * ND * B_DEC * (S_IN + T_DEC / 2) * D * esz
+            decode[ddtype] = dict(value=B_DEC * T_DEC * world / ddt, unit="tokens/s", batch=B_DEC, max_len=T_DEC, seq_in=S_IN,
+                                  ms_per_step=ddt / T_DEC * 1e3, graph=bool(dec.use_graph),
+                                  hbm_gbs=(w_bytes + kv_bytes) * T_DEC / ddt / 1e9,
+                                  hbm_frac=(w_bytes + kv_bytes) * T_DEC / ddt / 1e9 / PEAK_HBM_GBS,
+                                  token_exact=(ddtype == "f32"),
+                                  includes="encoder + cross-K/V projection + 1024 decode steps")
+            log(f"decode {ddtype}: {decode[ddtype]['value']:.0f} tokens/s, {decode[ddtype]['ms_per_step']:.3f} ms/step")
+            del dec, dm, db
+            torch.cuda.empty_cache()
 
     kern = None
-    if rank == 0 and not args.no_kernels:
+    if rank == 0 and not args.no_kernels and headline:
         kern = kernel_rooflines(B)
         log("kernel rooflines: " + ", ".join(f"{k} {v['tflops']:.0f} TF" for k, v in kern.items()))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(cfgd, fit_style=(args.config == "tiny"))
         log(f"cpu baseline: {cpu['value']:.3f} samples/s on {cpu['cores']} threads")
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     if rank == 0:
         line = {
-            "metric": "train samples/sec (fwd+bwd+all-reduce+Adam), d_model=512 seq=1024",
+            "metric": "train samples/sec (fwd+bwd+all-reduce+Adam), d_model=512 seq=1024" if headline else
+                      f"train samples/sec (fwd+bwd+all-reduce+Adam), config {args.config}",
             "value": samples_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic tokenised-drawing batches (SURVEY 8d), random-init weights",
-            "config": {"workload": "train_complete.yaml model d_model=512 H=8 dff=1024 6+6 post-norm layers, dropout 0.2, "
-                                   f"S={S_IN} (MAX_INPUT_LENGTH {S_IN + 1}), T={T_OUT}, batch {B}/GPU",
-                       "global_batch": B * world, "seq_len": S_IN, "parallelism": f"dp{world}"},
+            "dtype": args.dtype, "data": "synthetic tokenised-drawing batches (SURVEY 8d), random-init weights; collated "
+                                        "batches resident in HBM, a fresh one every step (row packing + embedding-row "
+                                        "grouping kernels inside the timed region)",
+            "config": {"workload": f"{cfgd['name']}, S={S_in} (MAX_INPUT_LENGTH {cfgd['max_in']}), T={T_out}, batch {B}/GPU",
+                       "global_batch": B * world, "seq_len": S_in, "parallelism": f"dp{world}"},
             "final_loss": loss,
-            "encoder_rows": {"padded": B * S_IN, "valid_avg": valid_rows,
+            "resident_prepared": resident, "fresh_host": fresh_host,
+            "encoder_rows": {"padded": B * S_in, "valid_avg": valid_rows,
                              "note": "padded encoder rows are packed away before the first layer (results identical: "
                                      "they never reach the loss); `dense_padded` is the same step without packing"},
             "dense_padded": dense,
             "train_dense_equiv_tflops_per_gpu": step_tflops, "train_dense_equiv_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
+            "train_executed_tflops_per_gpu": exec_tflops, "train_executed_mfma_frac": exec_tflops / PEAK_BF16_TFLOPS,
             "decode": decode,
         }
         if census:
-            # dominant kernel of the step by time: gemm3_kernel<A_KC, B_KC> (k-contiguous operands) = the forward and dX
-            # Linears whose tile count fits one round of the 256 CUs
+            # dominant kernel family of the step by time, over the GEMM families AND the attention launches
             key = max(census, key=lambda k: census[k]["seconds"])
             c = census[key]
             names = {"ring_tt": "gemm3_kernel<true,true,GemmP> (bf16, 128x128x64 tiles, one block per CU, 4-stage LDS ring)",
@@ -403,23 +532,33 @@ def main():
                                  "launch; bf16, 128x128x64 tiles, split-K slabs)",
                      "small_tt": "gemm3s_kernel (bf16, 64x64x64 tiles, 4-stage LDS ring)",
                      "pair_tt": "gemm_kernel<bf16,64,2,true,true,...> (two blocks per CU)",
-                     "wide_tt": "gemm3w_kernel<2,4> (bf16, 128x256x64 tiles, one block per CU, 3-stage LDS ring)"}
+                     "wide_tt": "gemm3w_kernel<2,4> (bf16, 128x256x64 tiles, one block per CU, 3-stage LDS ring)",
+                     "attn_enc_self_fwd": "attn_fwd_bf16_kernel<64,true> on the packed encoder rows (self-attention forward)",
+                     "attn_enc_self_bwd": "attn_bwd_dq_bf16_kernel + attn_bwd_dkv_bf16_kernel <64,true> on the packed encoder rows",
+                     "attn_cross_fwd": "attn_fwd_bf16_kernel<64,true>, decoder cross-attention forward",
+                     "attn_cross_bwd": "attn_bwd_dq / attn_bwd_dkv_bf16_kernel<64,true>, decoder cross-attention backward",
+                     "attn_dec_self_fwd": "attn_fwd_bf16_kernel<64,true>, decoder causal self-attention forward",
+                     "attn_dec_self_bwd": "attn_bwd_dq / attn_bwd_dkv_bf16_kernel<64,true>, decoder causal self-attention backward"}
             ach = c["flops"] / c["seconds"] / 1e12
-            line["roofline"] = {"kernel": names.get(key, key) + " - every launch of it in one train step, replayed under HIP events",
+            line["roofline"] = {"kernel": names.get(key, key) + " - every launch of it in one train step, timed under HIP events at "
+                                          "the step's own arguments",
                                 "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic("gemm_" + key),
+                                "frac": ach / PEAK_BF16_TFLOPS, "traffic": pmc_traffic(key if key.startswith("attn") else "gemm_" + key),
                                 "launches_per_step": c["launches"],
                                 "algorithmic_flops_per_launch": c["flops"] / c["launches"],
                                 "avg_launch_us": c["seconds"] / c["launches"] * 1e6}
-            line["gemm_census"] = {k: {"launches": v["launches"], "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
-                                       "tflops": round(v["flops"] / v["seconds"] / 1e12, 1)} for k, v in census.items()}
+            line["kernel_census"] = {k: {"launches": v["launches"], "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
+                                         "ms_per_step": round(v["seconds"] * 1e3, 3),
+                                         "tflops": round(v["flops"] / v["seconds"] / 1e12, 1),
+                                         "mfma_frac": round(v["flops"] / v["seconds"] / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                                     for k, v in census.items()}
         if kern:
             line["kernels"] = {k: {"ms": round(v["ms"], 4), "tflops": round(v["tflops"], 1),
                                    "mfma_frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4)} for k, v in kern.items()}
         if cpu:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -165,6 +165,23 @@ int pa_embed_segment_bwd(const void* dout, int32_t dtype, float* const* dtables,
  * encoder positions never reach the loss (they are masked as keys everywhere), so the encoder stack can run on the
  * packed rows only; rowmap (optional, NULL = identity) lets the embedding kernels gather / scatter packed rows. */
 int pa_pack_rows(const uint8_t* mask, int32_t B, int32_t S, int32_t* cu, int32_t* rowmap, void* stream);
+
+/* Token rows grouped by embedding-table row (the `order` / `seg` inputs of pa_embed_segment_bwd) for up to
+ * PA_MAX_GROUP_TABLES tables in ONE launch (one block per table; stable counting sort, so segment sums add in token order).
+ * Batch-only information like pa_pack_rows: belongs where the batch is built (the reference builds its batches in the
+ * dataloader, plankassembly/datasets/line_data.py:34-109; the gradients these groupings serve are those of
+ * models.py:103-138).  kind 0: an input table - entry i (0 <= i < n) uses table row idx[rowmap ? rowmap[i] : i] and
+ * reads gradient row i (the packed encoder rows).  kinds 1 / 2 / 3: the decoder's value / coordinate / position tables -
+ * entry i = b * (T-1) + t1 reads gradient row b*T + t1 + 1 (decoder row t embeds token t-1) and uses table row
+ * idx[b * tok_ld + t1] / t1 % dof / t1 / dof; n must be B * (T-1).
+ * Outputs: order int32 [n] (gradient rows sorted by table row, ties in entry order), seg int32 [rows + 1]. */
+#define PA_MAX_GROUP_TABLES 8
+typedef struct {
+    const int64_t* idx; const int32_t* rowmap;
+    int32_t n, rows, kind, T, dof, tok_ld;
+    int32_t* order; int32_t* seg;
+} pa_group_desc;
+int pa_group_rows(const pa_group_desc* descs, int32_t n_tables, void* stream);
 int pa_embed_output_fwd(void* out, int32_t out_dtype, const float* value, const float* coord, const float* pos,
                         const int64_t* tok, int32_t tok_ld, int32_t B, int32_t T, int32_t d, int32_t dof,
                         void* stream);

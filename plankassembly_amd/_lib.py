@@ -48,6 +48,12 @@ class AttnArgs(C.Structure):
                 ("cu_q", C.c_void_p), ("cu_k", C.c_void_p), ("order", C.c_void_p)]
 
 
+class GroupDesc(C.Structure):
+    _fields_ = [("idx", C.c_void_p), ("rowmap", C.c_void_p),
+                ("n", C.c_int32), ("rows", C.c_int32), ("kind", C.c_int32), ("T", C.c_int32), ("dof", C.c_int32),
+                ("tok_ld", C.c_int32), ("order", C.c_void_p), ("seg", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -94,6 +100,7 @@ def lib():
             "pa_embed_input_bwd": (I, [P, I, P, P, P, P, I, I64, I, P]),
             "pa_embed_segment_bwd": (I, [P, I, P, P, P, P, I, I64, I, P]),
             "pa_pack_rows": (I, [P, I, I, P, P, P]),
+            "pa_group_rows": (I, [P, I, P]),
             "pa_embed_output_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
             "pa_embed_output_bwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
             "pa_layernorm_ws_floats": (I64, [I64, I]),

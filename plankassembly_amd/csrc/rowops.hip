@@ -180,6 +180,135 @@ __global__ __launch_bounds__(256) void pack_fill_kernel(const uint8_t* mask, int
     }
 }
 
+// ---- batch preparation in one launch each -------------------------------------------------------------------------------
+// pack_rows_fused_kernel: everything pa_pack_rows produces (valid-row counts, their prefix sums, the packed row -> position map
+// and the batch elements by descending row count) from ONE block of 16 waves; wave w owns the batch rows w, w + 16, ...
+__global__ __launch_bounds__(1024) void pack_rows_fused_kernel(const uint8_t* mask, int B, int S, int32_t* cu, int32_t* rowmap) {
+    extern __shared__ int pk_s[];                    // [B] counts | [B + 1] offsets
+    int* cnt = pk_s;
+    int* off = pk_s + B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < B; b += 16) {
+        int c = 0;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            c += __popcll(__ballot(s < S && !mask[(size_t)b * S + s]));
+        }
+        if (lane == 0) cnt[b] = c;
+    }
+    __syncthreads();
+    if (wave == 0) {                                 // exclusive scan over the B counts, 64 at a time
+        int carry = 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int b = b0 + lane;
+            const int v = b < B ? cnt[b] : 0;
+            int inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+            if (b < B) off[b] = carry + inc - v;
+            carry += __shfl(inc, 63);
+        }
+        if (lane == 0) off[B] = carry;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= B; b += 1024) cu[b] = off[b];
+    for (int b = wave; b < B; b += 16) {
+        int base = off[b];
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            const bool v = s < S && !mask[(size_t)b * S + s];
+            const unsigned long long bal = __ballot(v);
+            if (v) rowmap[base + __popcll(bal & ((1ull << lane) - 1ull))] = b * S + s;
+            base += __popcll(bal);
+        }
+    }
+    for (int i = threadIdx.x; i < B; i += 1024) {    // dispatch order: descending count, ties in batch order
+        const int li = cnt[i];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) rank += (cnt[j] > li || (cnt[j] == li && j < i)) ? 1 : 0;
+        cu[B + 1 + rank] = i;
+    }
+}
+
+// group_rows_kernel: token rows grouped by embedding-table row for pa_embed_segment_bwd, one block per table - a STABLE
+// counting sort (ties keep token order, so the segment sums add in a fixed order and a training run is reproducible):
+// every wave owns a contiguous range of the tokens; per-(wave, id) counts by LDS atomics, an exclusive scan over the ids
+// gives seg[], per-wave cursors give each wave its slots inside every segment, and a second pass places the tokens in
+// order - the lanes of a 64-token batch that share an id are ranked with ballots.
+struct GroupTab { pa_group_desc d[PA_MAX_GROUP_TABLES]; };
+__device__ __forceinline__ int group_id(const pa_group_desc& g, int i, int& row) {
+    if (g.kind == 0) {
+        row = i;
+        return (int)g.idx[g.rowmap ? g.rowmap[i] : i];
+    }
+    const int b = i / (g.T - 1), t1 = i - b * (g.T - 1);            // decoder row (b, t1 + 1) embeds token t1
+    row = b * g.T + t1 + 1;
+    if (g.kind == 1) return (int)g.idx[(size_t)b * g.tok_ld + t1];
+    return g.kind == 2 ? t1 % g.dof : t1 / g.dof;
+}
+__global__ __launch_bounds__(1024) void group_rows_kernel(GroupTab tab) {
+    extern __shared__ int gr_s[];                                   // [16][R] per-wave counts / cursors | [R + 1] seg | [16] wave sums
+    const pa_group_desc& g = tab.d[blockIdx.x];
+    const int R = g.rows, n = g.n;
+    int* hist = gr_s;
+    int* seg = gr_s + 16 * R;
+    int* wsum = seg + R + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 16 * R; i += 1024) hist[i] = 0;
+    __syncthreads();
+    const int chunk = ((n + 15) / 16 + 63) / 64 * 64;
+    const int lo = wave * chunk, hi = min(n, lo + chunk);
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        int row;
+        const int id = i < hi ? group_id(g, i, row) : -1;
+        if (id >= 0 && id < R) atomicAdd(&hist[wave * R + id], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the per-id totals: thread t handles ids t, t + 1024, ... (R <= 1024 in practice: one round)
+    int carry = 0;
+    for (int r0 = 0; r0 < R; r0 += 1024) {
+        const int r = r0 + threadIdx.x;
+        int tot = 0;
+        if (r < R) for (int w = 0; w < 16; ++w) tot += hist[w * R + r];
+        int inc = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int wbase = carry;
+        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        if (r < R) {
+            int run = wbase + inc - tot;                            // segment start
+            seg[r] = run;
+            for (int w = 0; w < 16; ++w) { const int c = hist[w * R + r]; hist[w * R + r] = run; run += c; }   // wave cursors
+        }
+        int total = 0;
+        for (int w = 0; w < 16; ++w) total += wsum[w];
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) seg[R] = carry;
+    __syncthreads();
+    for (int r = threadIdx.x; r <= R; r += 1024) g.seg[r] = seg[r];
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        int row = 0;
+        int id = i < hi ? group_id(g, i, row) : -1;
+        if (id >= R) id = -1;
+        unsigned long long todo = __ballot(id >= 0);
+        while (todo) {
+            const int first = __ffsll((long long)todo) - 1;
+            const int lid = __shfl(id, first);
+            const unsigned long long m = __ballot(id == lid);
+            const int cur = hist[wave * R + lid];
+            if (id == lid) g.order[cur + __popcll(m & ((1ull << lane) - 1ull))] = row;
+            if (lane == first) hist[wave * R + lid] = cur + __popcll(m);
+            todo &= ~m;
+        }
+    }
+}
+
 // ================================================================================ LayerNorm
 template <typename T, int NV>   // NV = ceil(d / 256): 4-wide vectors per lane per row
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(T* y, const T* z, const float* gamma, const float* beta,
@@ -742,12 +871,38 @@ extern "C" int pa_embed_output_bwd(const void* dout, int32_t dtype, float* dvalu
 
 extern "C" int pa_pack_rows(const uint8_t* mask, int32_t B, int32_t S, int32_t* cu, int32_t* rowmap, void* stream) {
     if (!mask || !cu || !rowmap || B <= 0 || S <= 0) return PA_EINVAL;
+    if (B <= 1024) {                                  // one launch (the batch sizes of every shipped config)
+        PA_LAUNCH(pack_rows_fused_kernel, dim3(1), dim3(1024), (size_t)(2 * B + 1) * sizeof(int), ST(stream), mask, B, S, cu, rowmap);
+        return 0;
+    }
     // cu[B+1 .. 2B] doubles as scratch for the per-row counts (caller allocates 2B+1 ints)
     PA_LAUNCH(pack_count_kernel, dim3(B), dim3(256), 0, ST(stream), mask, S, cu + B + 1);
     PA_LAUNCH(pack_scan_kernel, dim3(1), dim3(64), 0, ST(stream), cu + B + 1, B, cu);
     PA_LAUNCH(pack_fill_kernel, dim3(B), dim3(256), 0, ST(stream), mask, S, cu, rowmap);
     if (B <= 8192) PA_LAUNCH(pack_order_kernel, dim3(1), dim3(256), (size_t)B * sizeof(int), ST(stream), cu + B + 1, B);
     else PA_LAUNCH(pack_iota_kernel, dim3((B + 255) / 256), dim3(256), 0, ST(stream), cu + B + 1, B);
+    return 0;
+}
+
+extern "C" int pa_group_rows(const pa_group_desc* descs, int32_t n_tables, void* stream) {
+    if (!descs || n_tables < 1 || n_tables > PA_MAX_GROUP_TABLES) return PA_EINVAL;
+    GroupTab tab;
+    int rmax = 0;
+    for (int k = 0; k < n_tables; ++k) {
+        const pa_group_desc& g = descs[k];
+        if (!g.order || !g.seg || g.n <= 0 || g.rows <= 0 || g.kind < 0 || g.kind > 3) return PA_EINVAL;
+        if (g.kind <= 1 && !g.idx) return PA_EINVAL;
+        if (g.kind >= 1 && (g.T < 2 || g.dof < 1 || g.n % (g.T - 1))) return PA_EINVAL;
+        if (g.rows > 2048) return PA_ESHAPE;                       // 16 x rows cursors live in LDS
+        tab.d[k] = g;
+        rmax = g.rows > rmax ? g.rows : rmax;
+    }
+    const size_t shm = (size_t)(16 * rmax + rmax + 1 + 16) * sizeof(int);
+    if (shm > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(group_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return (int)e;
+    }
+    PA_LAUNCH(group_rows_kernel, dim3(n_tables), dim3(1024), shm, ST(stream), tab);
     return 0;
 }
 

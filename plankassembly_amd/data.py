@@ -139,3 +139,56 @@ def spec_for(kind: str, max_input_length=None, max_output_length=None) -> SynthS
     if max_output_length is not None:
         s.max_output_length = max_output_length
     return s
+
+
+class DevicePrefetcher:
+    """Iterate prepared batches one step ahead of the training loop.
+
+    ``model.prepare_batch`` (host -> device copies, encoder row packing, embedding-row groupings; it ends with the one
+    device -> host read of a step, the number of valid encoder rows) runs for batch i + 1 on a side stream while step i
+    computes on the main stream, so that read never drains the main stream.  The reference gets the same overlap from
+    its DataLoader workers (trainer_complete.py:35-43); here the GPU-side part of batch preparation is overlapped too.
+    """
+
+    def __init__(self, model, batches):
+        self.model = model
+        self.it = iter(batches)
+        self.side = torch.cuda.Stream()
+        self.nxt = None
+        self._stage()
+
+    def _stage(self):
+        try:
+            raw = next(self.it)
+        except StopIteration:
+            self.nxt = None
+            return
+        self.side.wait_stream(torch.cuda.current_stream())       # (buffers the main stream may still be filling)
+        with torch.cuda.stream(self.side):
+            self.nxt = self.model.prepare_batch(raw)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.nxt is None:
+            raise StopIteration
+        main = torch.cuda.current_stream()
+        main.wait_stream(self.side)
+        cur = self.nxt
+        for t in _tensors_of(cur):
+            t.record_stream(main)                                # allocated on the side stream, consumed on the main one
+        self._stage()
+        return cur
+
+
+def _tensors_of(obj):
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)

@@ -16,9 +16,12 @@ from . import _lib as L
 
 
 class GreedyDecoder:
-    def __init__(self, model, use_graph=None, check_every=16):
+    def __init__(self, model, use_graph=None, check_every=16, strict_graph=False):
+        """``strict_graph``: a failed hipGraph capture raises instead of falling back to eager launches (benchmarks must
+        not silently measure the slow path; PLANK_DECODE_GRAPH=1 has the same effect)."""
         self.model = model
         self.check_every = check_every
+        self.strict_graph = strict_graph
         if use_graph is None:
             use_graph = os.environ.get("PLANK_DECODE_GRAPH", "1") != "0"
         self.use_graph = use_graph
@@ -89,7 +92,7 @@ class GreedyDecoder:
             try:
                 self._graph = self._capture()
             except Exception as exc:                                  # pragma: no cover
-                if os.environ.get("PLANK_DECODE_GRAPH") == "1":
+                if self.strict_graph or os.environ.get("PLANK_DECODE_GRAPH") == "1":
                     raise
                 print(f"[plankassembly_amd] hipGraph capture of the decode step failed ({exc}); running eagerly")
                 self.use_graph = False

@@ -59,7 +59,8 @@ INPUT_KEYS = ("input_value", "input_pos", "input_coord", "input_view", "input_ty
 
 
 def group_rows_by_id(ids, rows, row_index=None):
-    """Group row indices by embedding-table row (pa_embed_segment_bwd's input).  ids[i] = table row used by the i-th
+    """torch statement of what pa_group_rows computes (kept as the checker of tests/test_model_gpu.py; the product path
+    calls the HIP kernel).  Group row indices by embedding-table row (pa_embed_segment_bwd's input).  ids[i] = table row used by the i-th
     entry; row_index[i] = the gradient row that entry reads (default i).  Returns (order int32 [len(ids)] = gradient rows
     sorted by id, seg int32 [rows + 1] with seg[r] .. seg[r+1] = the slice of `order` that uses table row r)."""
     order = torch.argsort(ids, stable=True)
@@ -544,31 +545,52 @@ class PlankModel(nn.Module):
             msk = msk.view(torch.uint8) if msk.dtype == torch.bool else msk.to(torch.uint8)
             out["_pack"] = self._pack(msk)
             # group the token rows by embedding-table row: the table gradients then are segment sums instead of millions
-            # of atomics (pa_embed_segment_bwd).  Batch-only information, like the packing.
+            # of atomics (pa_embed_segment_bwd).  Batch-only information, like the packing: ONE launch for all eight
+            # tables (pa_group_rows, a stable counting sort per table), no torch op.
             cu, rowmap, n_valid = out["_pack"]
-
-            group = group_rows_by_id
-
-            gin = []
-            sel = rowmap[:n_valid].long()
-            for key in INPUT_KEYS:
-                t = out.get(key)
-                rows = self._shapes.get(f"input_embeddings.{key}.weight", (None,))[0]
-                gin.append(None if (t is None or rows is None) else group(t.reshape(-1)[sel], rows))
-            groups = {"in": gin}
-            ov = out.get("output_value")
-            if ov is not None:
-                Bq, Tq = ov.shape
-                dof = self.num_output_dof
-                tpos = torch.arange(1, Tq, device=dev)                              # decoder row (b, t) embeds token t-1
-                rows_bt = (torch.arange(Bq, device=dev)[:, None] * Tq + tpos[None, :]).reshape(-1)
-                prev = (tpos - 1)[None, :].expand(Bq, -1).reshape(-1)
-                groups["out"] = [group(ov[:, :-1].reshape(-1), self._shapes["input_embeddings.input_value.weight"][0], rows_bt),
-                                 group(prev % dof, dof, rows_bt),
-                                 group(prev // dof, (Tq + dof - 1) // dof, rows_bt)]      # the rows the runtime walks
-                groups["out_T"] = Tq
-            out["_groups"] = groups
+            out["_groups"] = self._group_rows(out, rowmap, n_valid)
+            return out
         return out
+
+    def _group_rows(self, batch, rowmap, n_valid):
+        """{'in': [(order, seg) | None] * 5, 'out': [(order, seg)] * 3 | None, 'out_T': T} on the model's device."""
+        dev = self._flat.device
+        descs, slots = [], []
+
+        def add(kind, idx, n, rows, T=0, dof=0, tok_ld=0, rmap=None):
+            order = torch.empty(n, dtype=torch.int32, device=dev)
+            seg = torch.empty(rows + 1, dtype=torch.int32, device=dev)
+            descs.append(L.GroupDesc(idx.data_ptr() if idx is not None else None, rmap.data_ptr() if rmap is not None else None,
+                                     n, rows, kind, T, dof, tok_ld, order.data_ptr(), seg.data_ptr()))
+            slots.append((order, seg))
+            return order, seg
+
+        keep = []
+        gin = []
+        for key in INPUT_KEYS:
+            t = batch.get(key)
+            if t is None or n_valid <= 0:
+                gin.append(None)
+                continue
+            t = t.to(device=dev, dtype=torch.int64).contiguous()
+            keep.append(t)
+            gin.append(add(0, t, n_valid, self._shapes[f"input_embeddings.{key}.weight"][0], rmap=rowmap))
+        groups = {"in": gin, "out": None}
+        ov = batch.get("output_value")
+        if ov is not None and ov.shape[1] >= 2:
+            ov = ov.to(device=dev, dtype=torch.int64).contiguous()
+            keep.append(ov)
+            Bq, Tq = ov.shape
+            dof, n = self.num_output_dof, Bq * (Tq - 1)
+            groups["out"] = [add(1, ov, n, self._shapes["input_embeddings.input_value.weight"][0], Tq, dof, Tq),
+                             add(2, None, n, dof, Tq, dof, Tq),
+                             add(3, None, n, (Tq + dof - 1) // dof, Tq, dof, Tq)]
+            groups["out_T"] = Tq
+        if descs:
+            arr = (L.GroupDesc * len(descs))(*descs)
+            L.check(L.lib().pa_group_rows(arr, len(descs), L.stream()), "pa_group_rows")
+        groups["_keep"] = keep
+        return groups
 
     def _workspace(self, B, S, T):
         need = int(L.lib().pa_model_train_ws_bytes(self._handle, B, S, T))

@@ -301,9 +301,10 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
         if hasattr(loader.sampler, "set_epoch"):
             loader.sampler.set_epoch(epoch)
         t0, n = time.perf_counter(), 0
-        for i, batch in enumerate(loader):
+        from .data import DevicePrefetcher
+        for i, batch in enumerate(DevicePrefetcher(module.model, loader)):     # batch i + 1 is prepared while step i runs
             opt.zero_grad()
-            loss = module.training_step(_to_device(batch, dev, module.model), i)
+            loss = module.training_step(batch, i)
             loss.backward()
             opt.step()
             module.global_step += 1

@@ -292,3 +292,40 @@ def test_bf16_shadow_follows_torch_adam_and_load_state_dict(small_fixture):
     with torch.no_grad():
         m.vocab_head.bias.add_(0.0)                      # in-place touch through the parameter also invalidates
     assert m._param_version() != m._shadow_version
+
+
+# ------------------------------------------------------------------------------------------ batch preparation kernels
+@pytest.mark.parametrize("kind", ["headline", "sideface"])
+def test_prepare_batch_groupings_match_the_torch_statement(kind):
+    """pa_pack_rows (one launch) + pa_group_rows (one launch, all eight tables) against argsort / bincount: identical
+    `order` (stable: ties in token order) and `seg` for every table, incl. the batch without input_type and empty rows."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import large_cases as LC
+    from plankassembly_amd.models import INPUT_KEYS, group_rows_by_id
+    c = LC.CASES[kind]
+    batch = LC.case_batch(c, batch_size=16)
+    from plankassembly_amd.models import PlankModel
+    m = PlankModel(64, 4, 128, 0.0, "relu", True, 1, 1, 3, 2, 4, 6, c["max_in"], c["max_out"], 514, TOKEN).cuda()
+    pb = m.prepare_batch(batch)
+    cu, rowmap, n_valid = pb["_pack"]
+    valid = (~batch["input_mask"]).flatten().nonzero().flatten()
+    assert n_valid == valid.numel() and torch.equal(rowmap[:n_valid].cpu().long(), valid)
+    sel = rowmap[:n_valid].long()
+    for j, key in enumerate(INPUT_KEYS):
+        grp = pb["_groups"]["in"][j]
+        if key not in batch:
+            assert grp is None
+            continue
+        rows = m._shapes[f"input_embeddings.{key}.weight"][0]
+        o_ref, s_ref = group_rows_by_id(pb[key].reshape(-1)[sel], rows)
+        assert torch.equal(grp[0], o_ref) and torch.equal(grp[1], s_ref), key
+    ov = pb["output_value"]
+    Bq, Tq = ov.shape
+    tpos = torch.arange(1, Tq, device="cuda")
+    rows_bt = (torch.arange(Bq, device="cuda")[:, None] * Tq + tpos[None, :]).reshape(-1)
+    prev = (tpos - 1)[None, :].expand(Bq, -1).reshape(-1)
+    refs = [group_rows_by_id(ov[:, :-1].reshape(-1), 514, rows_bt), group_rows_by_id(prev % 6, 6, rows_bt),
+            group_rows_by_id(prev // 6, (Tq + 5) // 6, rows_bt)]
+    for (o, s_), (o_ref, s_ref) in zip(pb["_groups"]["out"], refs):
+        assert torch.equal(o, o_ref) and torch.equal(s_, s_ref)
