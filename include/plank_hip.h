@@ -71,6 +71,11 @@ typedef struct {
     int32_t splitk_defer;   /* 1: only write the f32 slabs to `ws`; the caller reduces them later (pa_splitk_reduce_many) */
 } pa_gemm_args;
 int pa_gemm(const pa_gemm_args* a, void* stream);
+/* Leave `n` of the 256 CUs free in every persistent GEMM launch (0 <= n <= 192; default 0 or PA_RESERVE_CUS): room for the
+ * RCCL kernels that all-reduce finished gradient slices while the backward continues (the data-parallel exchange the
+ * reference gets from Lightning's `strategy: ddp`, configs/train_complete.yaml:18). */
+int pa_set_reserved_cus(int32_t n);
+int pa_get_reserved_cus(void);
 /* Slices pa_gemm really uses for a requested `splitk` (= number of slabs it writes; <= splitk). */
 int pa_gemm_effective_splitk(int32_t K, int32_t in_dtype, int32_t splitk);
 /* Measurement hook (bench.py's roofline census; no reference counterpart): pa_gemm_record(1) starts appending every

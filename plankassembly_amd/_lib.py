@@ -85,6 +85,8 @@ def lib():
         sig = {
             "pa_version": (I, []),
             "pa_gemm": (I, [P, P]),
+            "pa_set_reserved_cus": (I, [I]),
+            "pa_get_reserved_cus": (I, []),
             "pa_gemm_effective_splitk": (I, [I, I, I]),
             "pa_gemm_group": (I, [P, I, P]),
             "pa_segment_tail": (I, [P, I, I, P, I, I, P, I, P]),

@@ -18,6 +18,7 @@
 //    and writes whole 128/256-byte row segments with 8/16-byte vector stores (bias / ReLU / ReLU-backward gate /
 //    dropout / residual applied on the way).
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include <type_traits>
@@ -1824,6 +1825,29 @@ extern "C" int pa_gemm_effective_splitk(int32_t K, int32_t in_dtype, int32_t spl
     return (nt + per - 1) / per;
 }
 
+// CUs the persistent GEMM kernels occupy.  They launch one (or two) blocks per CU that hold the whole register file, so a
+// collective kernel enqueued on another stream (RCCL's all-reduce of a finished gradient slice) finds no CU to run on
+// until a GEMM launch drains.  pa_set_reserved_cus(n) (or PA_RESERVE_CUS=n) makes every persistent launch leave n CUs
+// alone; plankassembly_amd.distributed.GradSync sets it when the world is larger than one process.
+static std::atomic<int> g_reserved_cus{-1};
+static int cus_for_gemm() {
+    int r = g_reserved_cus.load(std::memory_order_relaxed);
+    if (r < 0) {
+        const char* e = getenv("PA_RESERVE_CUS");
+        r = e ? atoi(e) : 0;
+        if (r < 0) r = 0;
+        if (r > 192) r = 192;
+        g_reserved_cus.store(r, std::memory_order_relaxed);
+    }
+    return 256 - r;
+}
+extern "C" int pa_set_reserved_cus(int32_t n) {
+    if (n < 0 || n > 192) return PA_EINVAL;
+    g_reserved_cus.store(n, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int pa_get_reserved_cus(void) { return 256 - cus_for_gemm(); }
+
 extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return PA_EINVAL;
     if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec) g_rec->push_back(*a); }
@@ -1869,13 +1893,15 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         pk.vec_ok = ok(pk.C, pk.ldc, splitk > 1 ? (long long)a->M * a->N : a->sC, osz) && ok(a->R, a->ldr, a->sR, osz) &&
                     ok(a->aux, a->ldaux, a->sAux, isz) && ok(a->bias, 4, 0, 4);
     }
+    const int cus = cus_for_gemm();                 // 256 minus the CUs left to RCCL's kernels (pa_set_reserved_cus)
     // debug/ablation toggles (environment, read once): PA_GEMM_NOGLDS=1, PA_GEMM_GRID=<blocks> (0 = one block per unit)
     static const int dbg_noglds = getenv("PA_GEMM_NOGLDS") ? atoi(getenv("PA_GEMM_NOGLDS")) : 0;
     static const int dbg_grid = getenv("PA_GEMM_GRID") ? atoi(getenv("PA_GEMM_GRID")) :
                                 (getenv("PA_GEMM_NST") && atoi(getenv("PA_GEMM_NST")) == 1 ? 1024 : (bk32 ? 768 : 512));
     static const int dbg_bits = getenv("PA_GEMM_DBG") ? atoi(getenv("PA_GEMM_DBG")) : 0;   // v3 timing ablations (wrong results)
     pk.dbg = dbg_bits; p.dbg = dbg_bits;
-    int grid_x = (dbg_grid > 0 && pk.units > dbg_grid) ? dbg_grid : pk.units;
+    const int pair_cap = dbg_grid > 0 ? (dbg_grid / 256) * cus + dbg_grid % 256 : 0;      // (two blocks per CU by default)
+    int grid_x = (pair_cap > 0 && pk.units > pair_cap) ? pair_cap : pk.units;
     dim3 grid(grid_x);
     const bool glds = ((a->K % BK) == 0 || (!a->a_kcontig && !a->b_kcontig && a->in_dtype == PA_BF16 && !bk32)) && !dbg_noglds;
     int rc;
@@ -1901,7 +1927,7 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         pw.tiles_m = (a->M + 127) / 128; pw.tiles_n = (a->N + 255) / 256;
         pw.tiles_m_pad = (pw.tiles_m + 7) / 8 * 8; pw.plain_order = 0;
         pw.units = pw.tiles_m_pad * pw.tiles_n * a->batch;
-        const int gw = pw.units < 256 ? pw.units : 256;
+        const int gw = pw.units < cus ? pw.units : cus;
         PA_LAUNCH((gemm3w_kernel<2, 4>), dim3(gw), dim3(NT), 0, st, pw);
         return 0;
     }
@@ -1910,12 +1936,12 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         GemmP ps = pk;
         ps.tiles_m = (a->M + 63) / 64; ps.tiles_n = (a->N + 63) / 64; ps.tiles_m_pad = ps.tiles_m; ps.plain_order = 1;
         ps.units = ps.tiles_m * ps.tiles_n * a->batch;
-        const int gs = ps.units < 512 ? ps.units : 512;       // two 80 KB blocks fit a CU
+        const int gs = ps.units < 2 * cus ? ps.units : 2 * cus;       // two 80 KB blocks fit a CU
         PA_LAUNCH(gemm3s_kernel, dim3(gs), dim3(NT), 0, st, ps);
         rc = 0;
     } else
     if (go_v3) {
-        const int g3 = pk.units < 256 ? pk.units : 256;
+        const int g3 = pk.units < cus ? pk.units : cus;
         if (a->a_kcontig && a->b_kcontig) PA_LAUNCH((gemm3_kernel<true, true, GemmP>), dim3(g3), dim3(NT), 0, st, pk);
         else if (a->a_kcontig) PA_LAUNCH((gemm3_kernel<true, false, GemmP>), dim3(g3), dim3(NT), 0, st, pk);
         else if (a->b_kcontig) PA_LAUNCH((gemm3_kernel<false, true, GemmP>), dim3(g3), dim3(NT), 0, st, pk);
@@ -1984,7 +2010,8 @@ extern "C" int pa_gemm_group(const pa_gemm_args* args, int32_t n, void* stream) 
         if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec) { g_rec->push_back(*a); if (g_rec_kind) g_rec_kind->push_back(PA_GEMM_KIND_RING); if (g_rec_group) g_rec_group->push_back(g_rec_ngroups); } }
     }
     if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec) ++g_rec_ngroups; }
-    const int grid = valid < 256 ? valid : 256;
+    const int cus = cus_for_gemm();
+    const int grid = valid < cus ? valid : cus;
     PA_LAUNCH((gemm3_kernel<false, false, GemmGroup>), dim3(grid), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), g);
     return 0;
 }
