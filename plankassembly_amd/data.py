@@ -163,7 +163,8 @@ class DevicePrefetcher:
         except StopIteration:
             self.nxt = None
             return
-        self.side.wait_stream(torch.cuda.current_stream())       # (buffers the main stream may still be filling)
+        # (no wait on the main stream: a collated batch does not depend on the step in flight, and waiting would park
+        # prepare_batch's device -> host read behind that whole step)
         with torch.cuda.stream(self.side):
             self.nxt = self.model.prepare_batch(raw)
 
