@@ -359,6 +359,22 @@ class PlankModel(nn.Module):
         self._handle = h
         self._rebind()
 
+    def new_bound_handle(self):
+        """A second runtime handle over the SAME parameter buffers (its own batch / workspace / decode state): what lets
+        two halves of a decode batch run as independent kernel streams (decode.GreedyDecoder lanes).  The caller owns it
+        (pa_model_destroy)."""
+        self._ensure_handle()
+        rows = (C.c_int32 * 5)(*[self._shapes[f"input_embeddings.{k}.weight"][0] for k in INPUT_KEYS])
+        cfg = _ModelCfg(self.num_model, self.num_head, self.num_feedforward, self.num_encoder_layers,
+                        self.num_decoder_layers, self.vocab_size, self.num_output_dof, rows, self.eps_layer, 1e-5,
+                        int(self.has_enc_norm), self.dropout, int(self.token.PAD), int(self.token.END), self._pa_dtype())
+        h = C.c_void_p()
+        L.check(L.lib().pa_model_create(C.byref(cfg), C.byref(h)), "pa_model_create")
+        pf = self._ptr_table(self._flat, 4)
+        pl = self._ptr_table(self._shadow, 2) if self.compute_dtype == "bf16" else pf
+        L.check(L.lib().pa_model_bind(h, pf, pl, None), "pa_model_bind")
+        return h
+
     def _ptr_table(self, flat, esz):
         n = len(self._order)
         arr = (C.c_void_p * n)()
@@ -532,11 +548,12 @@ class PlankModel(nn.Module):
         L.check(L.lib().pa_pack_rows(L.ptr(mask_u8), B, S, L.ptr(cu), L.ptr(rowmap), L.stream()), "pa_pack_rows")
         return cu, rowmap, int(cu[B])
 
-    def prepare_batch(self, batch):
+    def prepare_batch(self, batch, groups=True):
         """Move a collated batch to the model's device and attach the encoder row packing (``_pack``: valid-row
-        offsets per sample, packed-row -> position map, number of valid rows).  Doing this when the batch is built
-        (dataloader / before the timed region) keeps the training loop free of device->host reads; forward() accepts
-        unprepared batches too."""
+        offsets per sample, packed-row -> position map, number of valid rows) and - for training (``groups``) - the
+        token rows grouped by embedding-table row (``_groups``).  Doing this when the batch is built (dataloader /
+        before the timed region) keeps the training loop free of device->host reads; forward() accepts unprepared
+        batches too."""
         self._require_gpu()
         dev = self._flat.device
         out = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -547,9 +564,9 @@ class PlankModel(nn.Module):
             # group the token rows by embedding-table row: the table gradients then are segment sums instead of millions
             # of atomics (pa_embed_segment_bwd).  Batch-only information, like the packing: ONE launch for all eight
             # tables (pa_group_rows, a stable counting sort per table), no torch op.
-            cu, rowmap, n_valid = out["_pack"]
-            out["_groups"] = self._group_rows(out, rowmap, n_valid)
-            return out
+            if groups:
+                cu, rowmap, n_valid = out["_pack"]
+                out["_groups"] = self._group_rows(out, rowmap, n_valid)
         return out
 
     def _group_rows(self, batch, rowmap, n_valid):

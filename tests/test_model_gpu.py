@@ -329,3 +329,28 @@ def test_prepare_batch_groupings_match_the_torch_statement(kind):
             group_rows_by_id(prev // 6, (Tq + 5) // 6, rows_bt)]
     for (o, s_), (o_ref, s_ref) in zip(pb["_groups"]["out"], refs):
         assert torch.equal(o, o_ref) and torch.equal(s_, s_ref)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_lane_decode_equals_single_lane(small_fixture, graph):
+    """Batches of >= 32 samples decode as two half-batches on two streams inside one graph (decode.GreedyDecoder lanes):
+    tokens and attach must equal the single-stream result bit for bit, with early stop and at full length."""
+    import plankassembly_amd.decode as D
+    from plankassembly_amd.data import SynthSpec, synth_batch
+    sd, _, _ = small_fixture
+    batch = synth_batch(40, SynthSpec(65, 36, (0, 15), (2, 5), True), seed=11)
+    batch.pop("name")
+    m = make(sd).eval()
+    m._ensure_handle()
+    gb = to_dev(batch)
+    for early in (True, False):
+        one = D.GreedyDecoder(m, use_graph=graph, lanes=1, strict_graph=True)
+        two = D.GreedyDecoder(m, use_graph=graph, lanes=2, strict_graph=True)
+        with torch.no_grad():
+            s1, a1 = one.run(gb, early_stop=early)
+            s2, a2 = two.run(gb, early_stop=early)
+            s3, a3 = two.run(m.prepare_batch(batch), early_stop=early)      # prepared input, graph reused
+        assert two._active == 2 and one._active == 1
+        assert torch.equal(s1, s2) and torch.equal(a1, a2)
+        assert torch.equal(s1, s3) and torch.equal(a1, a3)
+        del one, two
