@@ -1336,6 +1336,504 @@ __global__ __launch_bounds__(NTH, OCC) void attn_bwd_dkv_bf16_kernel(AttnP pin) 
     store_rows<bf16, DH>(dVp, p.lddv, krow, p.Lk, dvacc, kmasked ? 0.f : ds, lane, kmasked);
 }
 
+// ---- bf16 kernels, v4 (dh = 64): 16 rows of the owned side per WAVE, 8 waves per block ----------------------------------
+// Same algorithm, tiles, DMA, masks and dropout as v3; what changes is the MFMA shape: v_mfma_f32_16x16x32_bf16 gives a wave
+// 16 query (resp. key) rows instead of 32, so the same 128-row block is 8 waves and a launch has TWICE the waves.  The
+// packed encoder step is 7 924 rows x 8 heads = 1 981 32-row waves for 1 024 SIMDs - two per SIMD, where a lone wave pays
+// ~6.5 cycles per VALU instruction and every LDS / MFMA latency in full; with 16-row waves the same launch keeps ~4 per
+// SIMD and each wave's step is half as long (critical path of the longest sample).  Per-score VALU work and MFMA time are
+// unchanged (16 x 16 x 32: 8 passes, two per 32 x 32 x 16); LDS operand traffic per score doubles (13 % -> ~30 % of the
+// LDS cycles); registers per lane halve (<= 96 here), so three 512-thread blocks fit a CU.
+//   layouts (lane l: i = l & 15, g = l >> 4):  A[i][8g .. 8g+7], B[8g .. 8g+7][i], D[4g + r][i] (r = 0..3)
+//   S^T[key][q] = K Q^T   per 16-key block kb: A = K rows (LDS, chunk 4s + g), B = this lane's Q row (registers, s = 0, 1)
+//   O^T[d][q] += V^T P^T  per 16-d block db and 32-key block kk: B = the lane's own P values - slot 8g + 4c + r <-> key
+//                         32kk + 16c + 4g + r (kb = 2kk + c) - A = V^T through two ds_read_b64_tr_b16 with the same labelling
+constexpr int NT4 = 512;
+__device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
+}
+struct Lds4 {
+    uint32_t nat[2];          // natural rows: row (l & 15), chunk 4s + g               (+ kb * 16 * 128)
+    uint32_t tr[4];           // transposing patch of d block db: rows 4g + (L >> 2)    (+ (32kk + 16c) * 128)
+    __device__ __forceinline__ void init(uint32_t base, int lane) {
+        const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) nat[s] = base + swz_off<128>(i, 4 * s + g);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const int r = 4 * g + (i >> 2), col = 16 * db + 4 * (i & 3);
+            tr[db] = base + swz_off<128>(r, col >> 3) + (col & 7) * 2;
+        }
+    }
+};
+// sacc[kb] (16 x 16) = TILE rows 16kb + (l & 15) (A, contraction over dh = 64) x regs (B)
+template <int OFF> __device__ __forceinline__ void mma_nat4(f32x4 (&acc)[4], const Lds4& lb, const u32x4 (&regs)[2]) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        u32x4 a[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            PA_DS128(a[2 * j], lb.nat[0], OFF + (2 * h2 + j) * 2048);
+            PA_DS128(a[2 * j + 1], lb.nat[1], OFF + (2 * h2 + j) * 2048);
+        }
+        wait_lds(a);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            mma16(z, a[2 * j], regs[0]);
+            mma16(z, a[2 * j + 1], regs[1]);
+            acc[2 * h2 + j] = z;
+        }
+    }
+}
+// acc[db] (16 d x 16) += TILE^T[d][64 rows] x P  (P = the lane's 16 values p[kb][r] <-> row 16kb + 4g + r)
+template <int OFF> __device__ __forceinline__ void mma_tr4(f32x4 (&acc)[4], const Lds4& lb, const f32x4 (&p)[4]) {
+    u32x4 pb[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        pb[kk][0] = pack_bf16(p[2 * kk][0], p[2 * kk][1]); pb[kk][1] = pack_bf16(p[2 * kk][2], p[2 * kk][3]);
+        pb[kk][2] = pack_bf16(p[2 * kk + 1][0], p[2 * kk + 1][1]); pb[kk][3] = pack_bf16(p[2 * kk + 1][2], p[2 * kk + 1][3]);
+    }
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        u32x4 a[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x2 x0, x1;
+                PA_DSTR(x0, lb.tr[2 * h2 + j], OFF + (32 * kk) * 128);
+                PA_DSTR(x1, lb.tr[2 * h2 + j], OFF + (32 * kk + 16) * 128);
+                a[2 * j + kk][0] = x0[0]; a[2 * j + kk][1] = x0[1]; a[2 * j + kk][2] = x1[0]; a[2 * j + kk][3] = x1[1];
+            }
+        wait_lds(a);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            mma16(acc[2 * h2 + j], a[2 * j], pb[0]);
+            mma16(acc[2 * h2 + j], a[2 * j + 1], pb[1]);
+        }
+    }
+}
+__device__ __forceinline__ void load_row4(u32x4 (&regs)[2], const bf16* base, int ld, int row, int nrows, int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < nrows) v = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + 32 * s + 8 * g);
+        regs[s] = v;
+    }
+}
+// lane (row = l & 15, g) holds acc[db][r] = X^T[d = 16db + 4g + r][row]: four consecutive d per db
+__device__ __forceinline__ void store_rows4(bf16* base, int ld, int row, int nrows, const f32x4 (&acc)[4], float mul, int lane, bool zero = false) {
+    if (row >= nrows) return;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = zero ? 0.f : acc[db][e] * mul;
+        st4<bf16>(base + (size_t)row * ld + 16 * db + 4 * g, o);
+    }
+}
+__device__ __forceinline__ int tile_voff4(int ld, int tid) {
+    const int row = tid >> 3;
+    const int ch = ((tid & 7) ^ (row >> 1)) & 7;
+    return (row * ld + ch * 8) * 2;
+}
+__device__ __forceinline__ void glds_tile4(char* lds, const TileSrc& ts, int voff, int row0, int wave) {
+    const int64_t skip = (int64_t)row0 * ts.ld * 2;
+    const int64_t left = ts.bytes - skip;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void*>(ts.base + (uint64_t)skip), 0, (int)(left > 0 ? (left < 0x7fffffff ? left : 0x7fffffff) : 0), 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + wave * 1024), 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ void scan_key_mask4(const uint8_t* mp, int Lk, int tid, int* s_scan, int& kfirst, int& klast) {
+    int f = Lk, l = 0;
+    for (int k = tid; k < Lk; k += NT4) {
+        if (mp[k]) f = min(f, k);
+        else l = k + 1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { f = min(f, __shfl_xor(f, o)); l = max(l, __shfl_xor(l, o)); }
+    if ((tid & 63) == 0) { s_scan[(tid >> 6) * 2] = f; s_scan[(tid >> 6) * 2 + 1] = l; }
+    __syncthreads();
+    kfirst = Lk; klast = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { kfirst = min(kfirst, s_scan[2 * w]); klast = max(klast, s_scan[2 * w + 1]); }
+}
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+
+template <bool DROP>
+__global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
+    constexpr int DH = 64, NAT = BT<DH>::NAT, BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_, h, b;
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b)) return; }
+    else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
+    const int q0 = tile_ * BOWN;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (q0 >= p.Lq) return;
+    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
+    const int qw0 = q0 + wave * 16, qrow = qw0 + (lane & 15);
+
+    u32x4 qreg[2];
+    load_row4(qreg, Qp, p.ldq, qrow, p.Lq, lane);
+    const TileSrc srcK = tile_src(Kp, p.ldk, p.Lk, DH), srcV = tile_src(Vp, p.ldv, p.Lk, DH);
+    const int voffK = tile_voff4(p.ldk, tid), voffV = tile_voff4(p.ldv, tid);
+    Lds4 lb;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    lb.init(smem_base, lane);
+    const uint32_t cbase = smem_base + g * 16;            // this lane group's 4 keys of a 16-key block (aux words, natural order)
+    auto issue = [&](int step, int buf, int kfirst_) {
+        char* base = smem + buf * BUF;
+        const int k0 = step * BSTR;
+        const bool tile_masked = k0 + BSTR > kfirst_;
+        uint8_t mb = 0;
+        if (tile_masked && tid < BSTR) {
+            const int key = k0 + tid;
+            mb = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+        }
+        glds_tile4(base, srcK, voffK, k0, wave);
+        glds_tile4(base + NAT, srcV, voffV, k0, wave);
+        if (tid < BSTR) {
+            if (tile_masked) reinterpret_cast<uint8_t*>(base + AUX)[tid] = mb;
+            if (DROP) reinterpret_cast<uint32_t*>(base + AUX + 64)[tid] = drop_key_hash(p.drop_seed, (uint32_t)(k0 + tid));
+        }
+    };
+    issue(0, 0, 0);
+    int kfirst = p.Lk, klast = p.Lk;
+    if (mp) scan_key_mask4(mp, p.Lk, tid, reinterpret_cast<int*>(smem + 2 * BUF), kfirst, klast);
+    int nsteps = (klast + BSTR - 1) / BSTR;
+    if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+
+    f32x4 oacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl = p.scale * LOG2E;
+    const uint32_t arow = DROP ? drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow)) : 0u;
+    tile_barrier();
+
+    auto body = [&](int step, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1, kfirst);
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(smem + buf * BUF + AUX);
+        const int k0 = step * BSTR;
+        f32x4 sacc[4];
+        mma_nat4<buf * BUF>(sacc, lb, qreg);
+        const bool key_masked = k0 + BSTR > kfirst;
+        const bool need_mask = key_masked || (p.causal && (k0 + BSTR - 1 > qw0));           // wave-uniform
+        float mx = -INFINITY;
+        if (need_mask) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const int ko = 16 * kb + 4 * g;
+                const uint32_t m4 = key_masked ? *reinterpret_cast<const uint32_t*>(mk + ko) : 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && k0 + ko + e > qrow);
+                    const float x = masked ? -INFINITY : sacc[kb][e];
+                    sacc[kb][e] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) mx = fmaxf(mx, fmaxf(fmaxf(sacc[kb][0], sacc[kb][1]), fmaxf(sacc[kb][2], sacc[kb][3])));
+        }
+        mx = quad_max(mx) * sl;
+        if (__any(mx > m_run + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float ms = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2(m_run - ms);
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) oacc[db] *= alpha;
+            m_run = m_new;
+        }
+        const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
+        float lsum[4] = {0.f, 0.f, 0.f, 0.f};
+        u32x4 cq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+        if (DROP) PA_DS128(cq[0], cbase, buf * BUF + AUX + 64);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (DROP) {
+                if (kb + 1 < 4) {
+                    PA_DS128(cq[(kb + 1) & 1], cbase, buf * BUF + AUX + 64 + (kb + 1) * 64);
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cq[kb & 1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cq[kb & 1]));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = fast_exp2(__builtin_fmaf(sacc[kb][e], sl, nm));
+                lsum[e] += pe;
+                if (DROP) pe = drop_keep2(arow, cq[kb & 1][e], p.drop_thr) ? pe : 0.f;
+                sacc[kb][e] = pe;
+            }
+        }
+        l_run += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
+        mma_tr4<buf * BUF + NAT>(oacc, lb, sacc);
+        tile_barrier();
+    };
+    for (int step = 0; step < nsteps; step += 2) {
+        body(step, IC<0>{});
+        if (step + 1 < nsteps) body(step + 1, IC<1>{});
+    }
+    const float l_tot = quad_sum(l_run);
+    const float inv = l_tot > 0.f ? (DROP ? p.drop_scale : 1.0f) / l_tot : 0.f;
+    bf16* Op = reinterpret_cast<bf16*>(p.o) + (size_t)qoff * p.ldo + h * DH;
+    store_rows4(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);
+    if (g == 0 && qrow < p.Lq && p.lse)
+        p.lse[((size_t)b * p.H + h) * pin.Lq + qrow] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : 0.f;
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(NT4, 4) void attn4_bwd_dq_kernel(AttnP pin) {
+    constexpr int DH = 64, NAT = BT<DH>::NAT, BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_, h, b;
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b)) return; }
+    else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
+    const int q0 = tile_ * BOWN;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (q0 >= p.Lq) return;
+    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const bf16* dOp = reinterpret_cast<const bf16*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
+    const int qw0 = q0 + wave * 16, qrow = qw0 + (lane & 15);
+
+    u32x4 qreg[2], doreg[2];
+    load_row4(qreg, Qp, p.ldq, qrow, p.Lq, lane);
+    load_row4(doreg, dOp, p.lddo, qrow, p.Lq, lane);
+    const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qrow;
+    const float lse2 = (qrow < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
+    const float keep_p = DROP ? 1.0f / p.drop_scale : 1.0f;
+    float dsum = 0.f;
+    {
+        const bf16* Op = reinterpret_cast<const bf16*>(p.o) + (size_t)qoff * p.ldo + h * DH;
+        u32x4 oreg[2];
+        load_row4(oreg, Op, p.ldo, qrow, p.Lq, lane);
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                dsum += bf16_lo(oreg[s_][w]) * bf16_lo(doreg[s_][w]) + bf16_hi(oreg[s_][w]) * bf16_hi(doreg[s_][w]);
+        dsum = quad_sum(dsum);
+        if (g == 0 && qrow < p.Lq) p.delta[srow] = dsum;
+    }
+    const float dlt = (qrow < p.Lq) ? dsum * keep_p : 0.f;
+    const TileSrc srcK = tile_src(Kp, p.ldk, p.Lk, DH), srcV = tile_src(Vp, p.ldv, p.Lk, DH);
+    const int voffK = tile_voff4(p.ldk, tid), voffV = tile_voff4(p.ldv, tid);
+    Lds4 lb;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    lb.init(smem_base, lane);
+    const uint32_t cbase = smem_base + g * 16;
+    auto issue = [&](int step, int buf, int kfirst_) {
+        char* base = smem + buf * BUF;
+        const int k0 = step * BSTR;
+        const bool tile_masked = k0 + BSTR > kfirst_;
+        uint8_t mb = 0;
+        if (tile_masked && tid < BSTR) {
+            const int key = k0 + tid;
+            mb = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+        }
+        glds_tile4(base, srcK, voffK, k0, wave);
+        glds_tile4(base + NAT, srcV, voffV, k0, wave);
+        if (tid < BSTR) {
+            if (tile_masked) reinterpret_cast<uint8_t*>(base + AUX)[tid] = mb;
+            if (DROP) reinterpret_cast<uint32_t*>(base + AUX + 64)[tid] = drop_key_hash(p.drop_seed, (uint32_t)(k0 + tid));
+        }
+    };
+    issue(0, 0, 0);
+    int kfirst = p.Lk, klast = p.Lk;
+    if (mp) scan_key_mask4(mp, p.Lk, tid, reinterpret_cast<int*>(smem + 2 * BUF), kfirst, klast);
+    int nsteps = (klast + BSTR - 1) / BSTR;
+    if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+
+    f32x4 dqacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dqacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float sl = p.scale * LOG2E;
+    const float nl = -lse2;
+    const uint32_t arow = DROP ? drop_row_hash(p.drop_seed, (uint32_t)srow) : 0u;
+    tile_barrier();
+
+    auto body = [&](int step, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1, kfirst);
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(smem + buf * BUF + AUX);
+        const int k0 = step * BSTR;
+        const bool key_masked = k0 + BSTR > kfirst;
+        const bool need_mask = key_masked || (p.causal && (k0 + BSTR - 1 > qw0));
+        f32x4 sacc[4], dpacc[4];
+        mma_nat4<buf * BUF>(sacc, lb, qreg);
+        mma_nat4<buf * BUF + NAT>(dpacc, lb, doreg);
+        u32x4 cq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+        if (DROP) PA_DS128(cq[0], cbase, buf * BUF + AUX + 64);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int ko = 16 * kb + 4 * g;
+            uint32_t m4 = 0;
+            if (key_masked) m4 = *reinterpret_cast<const uint32_t*>(mk + ko);
+            if (DROP) {
+                if (kb + 1 < 4) {
+                    PA_DS128(cq[(kb + 1) & 1], cbase, buf * BUF + AUX + 64 + (kb + 1) * 64);
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cq[kb & 1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cq[kb & 1]));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = fast_exp2(__builtin_fmaf(sacc[kb][e], sl, nl));
+                if (need_mask) {
+                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && k0 + ko + e > qrow);
+                    pe = masked ? 0.f : pe;
+                }
+                float dp = dpacc[kb][e];
+                if (DROP) dp = drop_keep2(arow, cq[kb & 1][e], p.drop_thr) ? dp : 0.f;
+                sacc[kb][e] = pe * (dp - dlt);                         // dS^T / (scale / (1-p))
+            }
+        }
+        mma_tr4<buf * BUF>(dqacc, lb, sacc);                           // dQ^T += K^T dS^T
+        tile_barrier();
+    };
+    for (int step = 0; step < nsteps; step += 2) {
+        body(step, IC<0>{});
+        if (step + 1 < nsteps) body(step + 1, IC<1>{});
+    }
+    bf16* dQp = reinterpret_cast<bf16*>(p.dq) + (size_t)qoff * p.lddq + h * DH;
+    store_rows4(dQp, p.lddq, qrow, p.Lq, dqacc, p.scale * (DROP ? p.drop_scale : 1.0f), lane);
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
+    constexpr int DH = 64, NAT = BT<DH>::NAT, BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_, h, b;
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_k, tile_, h, b)) return; }
+    else { decode_block((pin.Lk + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
+    const int key0 = tile_ * BOWN;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (key0 >= p.Lk) return;
+    const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const bf16* dOp = reinterpret_cast<const bf16*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
+    const int kw0 = key0 + wave * 16, krow = kw0 + (lane & 15);
+    const bool kmasked = (krow >= p.Lk) || (p.kpm && p.kpm[(size_t)b * pin.Lk + krow]);
+
+    u32x4 kreg[2], vreg[2];
+    load_row4(kreg, Kp, p.ldk, krow, p.Lk, lane);
+    load_row4(vreg, Vp, p.ldv, krow, p.Lk, lane);
+    const int nsteps = (p.Lq + BSTR - 1) / BSTR;
+    const int step0 = p.causal ? (key0 / BSTR) : 0;
+
+    f32x4 dkacc[4], dvacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { dkacc[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dvacc[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float sl = p.scale * LOG2E;
+    const float keep_p = DROP ? 1.0f / p.drop_scale : 1.0f;
+    const uint32_t ckey = DROP ? drop_key_hash(p.drop_seed, (uint32_t)krow) : 0u;
+    const size_t srow0 = ((size_t)b * p.H + h) * pin.Lq;
+    const TileSrc srcQ = tile_src(Qp, p.ldq, p.Lq, DH), srcO = tile_src(dOp, p.lddo, p.Lq, DH);
+    const int voffQ = tile_voff4(p.ldq, tid), voffO = tile_voff4(p.lddo, tid);
+    Lds4 lb;
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    lb.init(smem_base, lane);
+    const uint32_t abase = smem_base + g * 16;            // this lane group's 4 query rows of a 16-row block (aux words)
+    auto issue = [&](int step, int buf) {
+        char* base = smem + buf * BUF;
+        const int r0 = step * BSTR;
+        float lv = INFINITY, dv_ = 0.f;
+        if (tid < BSTR && r0 + tid < p.Lq) { lv = p.lse[srow0 + r0 + tid] * LOG2E; dv_ = p.delta[srow0 + r0 + tid] * keep_p; }
+        glds_tile4(base, srcQ, voffQ, r0, wave);
+        glds_tile4(base + NAT, srcO, voffO, r0, wave);
+        if (tid < BSTR) {
+            float* aux = reinterpret_cast<float*>(base + AUX);
+            aux[tid] = lv;
+            aux[64 + tid] = dv_;
+            if (DROP) reinterpret_cast<uint32_t*>(aux)[128 + tid] = drop_row_hash(p.drop_seed, (uint32_t)(srow0 + r0 + tid));
+        }
+    };
+    if (step0 < nsteps) issue(step0, 0);
+    tile_barrier();
+
+    auto body = [&](int step, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        const int r0 = step * BSTR;
+        f32x4 sacc[4], dpacc[4];
+        mma_nat4<buf * BUF>(sacc, lb, kreg);                           // S[q][key]: rows q = 16qb + 4g + r, col key = l & 15
+        mma_nat4<buf * BUF + NAT>(dpacc, lb, vreg);                    // dP[q][key]
+        const bool need_causal = p.causal && (kw0 + 15 > r0);
+        // per-query-row words of the tile (lse, delta, dropout row hash): without dropout they stream through two register
+        // sets (group qb + 1 requested before qb is consumed); with dropout the third word would push the kernel past 128
+        // registers, so the three words of a group are read when it is processed (the other waves cover the latency)
+        u32x4 lq[2], dq_[2], aq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+        constexpr int AO = buf * BUF + AUX;
+        if (!DROP) { PA_DS128(lq[0], abase, AO); PA_DS128(dq_[0], abase, AO + 256); }
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            const int qo = 16 * qb + 4 * g;
+            constexpr int dummy = 0; (void)dummy;
+            if (DROP) {
+                PA_DS128(lq[0], abase, AO + qb * 64); PA_DS128(dq_[0], abase, AO + 256 + qb * 64); PA_DS128(aq[0], abase, AO + 512 + qb * 64);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lq[0]), "+v"(dq_[0]), "+v"(aq[0]));
+            } else if (qb + 1 < 4) {
+                PA_DS128(lq[(qb + 1) & 1], abase, AO + (qb + 1) * 64); PA_DS128(dq_[(qb + 1) & 1], abase, AO + 256 + (qb + 1) * 64);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lq[qb & 1]), "+v"(dq_[qb & 1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lq[qb & 1]), "+v"(dq_[qb & 1]));
+            }
+            const int cur = DROP ? 0 : (qb & 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = fast_exp2(__builtin_fmaf(sacc[qb][e], sl, -__uint_as_float(lq[cur][e])));
+                if (need_causal) pe = (krow > r0 + qo + e) ? 0.f : pe;
+                float dp = dpacc[qb][e];
+                float pd = pe;
+                if (DROP) {
+                    const bool keep = drop_keep2(aq[cur][e], ckey, p.drop_thr);
+                    dp = keep ? dp : 0.f;
+                    pd = keep ? pe : 0.f;
+                }
+                sacc[qb][e] = pd;                                                   // P_drop * (1-p)
+                dpacc[qb][e] = pe * (dp - __uint_as_float(dq_[cur][e]));         // dS * (1-p) / scale
+            }
+        }
+        mma_tr4<buf * BUF + NAT>(dvacc, lb, sacc);                     // dV^T += dO^T P
+        mma_tr4<buf * BUF>(dkacc, lb, dpacc);                          // dK^T += Q^T dS
+        tile_barrier();
+    };
+    for (int step = step0; step < nsteps; step += 2) {
+        body(step, IC<0>{});
+        if (step + 1 < nsteps) body(step + 1, IC<1>{});
+    }
+    bf16* dKp = reinterpret_cast<bf16*>(p.dk) + (size_t)koff * p.lddk + h * DH;
+    bf16* dVp = reinterpret_cast<bf16*>(p.dv) + (size_t)koff * p.lddv + h * DH;
+    const float ds = DROP ? p.drop_scale : 1.0f;
+    store_rows4(dKp, p.lddk, krow, p.Lk, dkacc, kmasked ? 0.f : p.scale * ds, lane, kmasked);
+    store_rows4(dVp, p.lddv, krow, p.Lk, dvacc, kmasked ? 0.f : ds, lane, kmasked);
+}
+
 // =====================================================================================================
 AttnP make_params(const pa_attn_args* a) {
     AttnP p;
@@ -1362,9 +1860,28 @@ template <typename K> int set_lds(K kern, int bytes) {
     return 0;
 }
 
+// 16-row waves (v4, dh = 64) for launches that cannot fill the SIMDs with 32-row waves: variable-length (packed) batches and
+// launches with fewer than four 32-row waves per SIMD.  Measured (tools/attn_bench.py): packed self-attention forward 35.9 ->
+// 32.9 us, cross-attention forward / backward 28.9 -> 23.5 / 57.1 -> 52.9 us, but the dense padded S = 1024 launch (4 096
+// 32-row waves, VALU-bound) 67.9 -> 75.0 us - twice the LDS operand reads and barriers for no extra occupancy.
+// PA_ATTN_V4=0 never, 2 always.
+static bool use_v4(const AttnP& p, int rows_owned) {
+    static const int mode = getenv("PA_ATTN_V4") ? atoi(getenv("PA_ATTN_V4")) : 1;
+    if (mode == 0) return false;
+    if (mode >= 2) return true;
+    const long long waves32 = (long long)p.B * p.H * ((rows_owned + 31) / 32);
+    return p.cu_q != nullptr || p.cu_k != nullptr || waves32 < 4 * 1024;
+}
 template <int DH> int run_fwd_bf16(const AttnP& p, hipStream_t st) {
     const int shm = BL<DH>::SHM;
     dim3 grid(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B);
+    if constexpr (DH == 64) {
+        if (use_v4(p, p.Lq)) {
+            if (p.drop_thr) PA_LAUNCH((attn4_fwd_kernel<true>), grid, dim3(NT4), shm, st, p);
+            else PA_LAUNCH((attn4_fwd_kernel<false>), grid, dim3(NT4), shm, st, p);
+            return 0;
+        }
+    }
     if (p.drop_thr) PA_LAUNCH((attn_fwd_bf16_kernel<DH, true>), grid, dim3(NTH), shm, st, p);
     else PA_LAUNCH((attn_fwd_bf16_kernel<DH, false>), grid, dim3(NTH), shm, st, p);
     return 0;
@@ -1372,6 +1889,18 @@ template <int DH> int run_fwd_bf16(const AttnP& p, hipStream_t st) {
 template <int DH> int run_bwd_bf16(const AttnP& p, hipStream_t st) {
     const int shm = BL<DH>::SHM;
     const dim3 gq(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B), gk(((p.Lk + BOWN - 1) / BOWN) * p.H * p.B);
+    if constexpr (DH == 64) {
+        if (use_v4(p, p.Lq > p.Lk ? p.Lq : p.Lk)) {
+            if (p.drop_thr) {
+                PA_LAUNCH((attn4_bwd_dq_kernel<true>), gq, dim3(NT4), shm, st, p);
+                PA_LAUNCH((attn4_bwd_dkv_kernel<true>), gk, dim3(NT4), shm, st, p);
+            } else {
+                PA_LAUNCH((attn4_bwd_dq_kernel<false>), gq, dim3(NT4), shm, st, p);
+                PA_LAUNCH((attn4_bwd_dkv_kernel<false>), gk, dim3(NT4), shm, st, p);
+            }
+            return 0;
+        }
+    }
     // blocks per CU the register allocation is made for (experiment knob PA_ATTN_OCC="<dq><dkv>", e.g. "43")
     static const int occ_env = getenv("PA_ATTN_OCC") ? atoi(getenv("PA_ATTN_OCC")) : 0;
     const int oq = occ_env ? occ_env / 10 : 3, ok = occ_env ? occ_env % 10 : 2;

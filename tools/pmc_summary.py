@@ -24,9 +24,9 @@ KEYS = [  # json key -> regex on the demangled kernel name
     # (rocprofv3's demangler leaves names with the __bf16 template argument mangled)
     ("gemm_pair_tt", r"gemm_kernel<__bf16, 64, 2, true, true, true, true, false, 2>|gemm_kernelIDF16bLi64ELi2ELb1ELb1ELb1ELb1ELb0ELi2E"),
     ("gemm_pair_nn", r"gemm_kernel<__bf16, 64, 2, false, false, true, true, true, 2>|gemm_kernelIDF16bLi64ELi2ELb0ELb0ELb1ELb1ELb1ELi2E"),
-    ("attn_fwd", r"attn_fwd_bf16_kernel<64>"),
-    ("attn_bwd_dq", r"attn_bwd_dq_bf16_kernel<64>"),
-    ("attn_bwd_dkv", r"attn_bwd_dkv_bf16_kernel<64>"),
+    ("attn_fwd", r"attn_fwd_bf16_kernel<64|attn4_fwd_kernel"),
+    ("attn_bwd_dq", r"attn_bwd_dq_bf16_kernel<64|attn4_bwd_dq_kernel"),
+    ("attn_bwd_dkv", r"attn_bwd_dkv_bf16_kernel<64|attn4_bwd_dkv_kernel"),
     ("layernorm_bwd", r"layernorm_bwd_kernel<__bf16"),
     ("layernorm_fwd", r"layernorm_fwd_kernel<__bf16"),
     ("splitk_reduce", r"splitk_reduce_kernel"),
@@ -75,6 +75,13 @@ def main():
         f1, w1 = tf / nf, tw / nw
         res[key] = dict(launches=nf, fetch_bytes_per_launch=f1, write_bytes_per_launch=w1, hbm_bytes_per_launch=f1 + w1)
         print(f"{key:16s} {nf:9d} {f1 / 1e6:10.3f} {w1 / 1e6:10.3f} {(f1 + w1) / 1e6:14.3f}")
+    # bench.py's attention families are forward / backward (dQ + dK,dV together): per-launch bytes of a family member
+    for fam, keys in (("attn_enc_self_fwd", ["attn_fwd"]), ("attn_enc_self_bwd", ["attn_bwd_dq", "attn_bwd_dkv"])):
+        if all(k in res for k in keys):
+            res[fam] = dict(launches=sum(res[k]["launches"] for k in keys),
+                            hbm_bytes_per_launch=sum(res[k]["hbm_bytes_per_launch"] * res[k]["launches"] for k in keys) /
+                            sum(res[k]["launches"] for k in keys),
+                            note="mean over ALL attention launches of these kernels in the step (self, cross and causal)")
     if len(sys.argv) > 3:
         json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB x 1024, per-launch mean",
                        calibration=dict(copy_fetch_bytes=cf[0], copy_write_bytes=cf[1]) if cf else None, kernels=res),
