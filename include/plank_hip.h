@@ -290,7 +290,7 @@ int pa_attn_bwd(const pa_attn_args* a, void* stream);
  * needs a host sync).
  * pa_switch_fwd: s[row] = h[row] . w + b (reference models.py:153), pa_switch_bwd its gradient
  * (dh += ds * w fused into the caller's GEMM epilogue is not possible, so dh_out is written
- * and dw/db accumulated).
+ * and dw/db accumulated).  `partial`: scratch of pa_layernorm_bwd_nparts(rows) x 2 x d floats.
  */
 int pa_switch_fwd(float* s, const void* h, int32_t dtype, const float* w, const float* b, int64_t rows,
                   int32_t d, void* stream);

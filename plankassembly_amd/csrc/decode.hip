@@ -135,8 +135,9 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int l
             // unconditional loads (clamped row; out-of-range keys are discarded through okk): a branch around the loads
             // would put a wait between them
             const int64_t kc_ = (int64_t)min(key, Lk - 1) * ldkv;
-            kraw[j] = *reinterpret_cast<const u32x4*>(kb + kc_);
-            vraw[j] = *reinterpret_cast<const u32x4*>(vb + kc_);
+            // (streamed once per step, never re-read by this CU: non-temporal, so the lines do not displace the weights in L2)
+            kraw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + kc_));
+            vraw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + kc_));
         }
         float s[UN];
 #pragma unroll

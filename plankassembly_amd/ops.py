@@ -284,7 +284,9 @@ def switch_bwd(ds, h, w, dw, db, dh=None):
     acc = dh is not None
     if dh is None:
         dh = torch.empty_like(h)
-    part = _f32(((rows + 31) // 32) * 2 * d, device=h.device)
+    # one [2][d] partial per backward block; the block height is the library's (it changed from 32 to 8 rows once
+    # and a hard-coded 32 here wrote past this buffer), so ask it
+    part = _f32(int(L.lib().pa_layernorm_bwd_nparts(C.c_int64(rows))) * 2 * d, device=h.device)
     L.check(L.lib().pa_switch_bwd(L.ptr(dh), int(acc), L.ptr(dw), L.ptr(db), L.ptr(ds), L.ptr(h), L.dt(h), L.ptr(w),
                                   L.ptr(part), C.c_int64(rows), d, L.stream()), "pa_switch_bwd")
     return dh

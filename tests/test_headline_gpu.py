@@ -72,7 +72,12 @@ def check_grads(name, grads, rgrads, batch_size=None):
     over thousands of rows with cancellation: LayerNorm affine / bias gradients, at B = 64 also some weight gradients)
     sit where the f32 reference's OWN rounding noise exceeds that bound (measured against float64: reference error
     1.5-2e-5, HIP error 5-6e-6 on the same entries); for those the HIP result must be within the same bound of the
-    float64 evaluation of the same computation, i.e. at least as close to the exact answer as the tolerance asks."""
+    float64 evaluation of the same computation, i.e. at least as close to the exact answer as the tolerance asks - or,
+    where float32 itself cannot get that close, within 4x the f32 reference's own distance from float64 (seen:
+    decoder.layers.5.linear1.weight in the sideface case, HIP and f32 oracle both 5.9e-4 from float64 and 2e-5 from
+    each other: both f32 computations take one ReLU branch and float64 the other).  HIP's f32 gradient sums use
+    atomics, so which tensors land in this list varies from run to run; at most 16 of ~190 may.  linear1 (the
+    ReLU-gated Linear) additionally tolerates a branch flip in at most two hidden units - see below."""
     worst, fallback = ("", 0.0), []
     for k, gr in grads.items():
         r = rgrads[k]
@@ -87,7 +92,18 @@ def check_grads(name, grads, rgrads, batch_size=None):
         e_ref = float((rgrads[k].double() - r64).abs().max())
         scale = float(r64.abs().max())
         print(f"    [{name}] {k}: vs f32 oracle beyond tolerance; vs float64: HIP {e_hip:.2e}, f32 oracle {e_ref:.2e} (scale {scale:.3f})")
-        assert e_hip <= 1e-5 + 1e-4 * scale, (k, e_hip, e_ref, scale)
+        bound = max(1e-5 + 1e-4 * scale, 4.0 * e_ref + 1e-6)
+        if e_hip > bound and k.endswith(("linear1.weight", "linear1.bias")):
+            # ReLU branch flip: a pre-activation within f32 rounding of zero is +tiny here and -tiny (or 0) in the
+            # reference, so ONE (row, unit) entry of the gated dY differs by its whole value; that shows up in exactly
+            # one hidden unit of this layer's dW / db (seen: decoder.layers.3.linear1, unit-local 5.4e-5 / 4.0e-5 at
+            # B = 64, identical in every run).  Allow at most two such units per tensor, everything else in bound.
+            per_unit = (grads[k].double() - r64).abs().reshape(r64.shape[0], -1).amax(dim=1)
+            flipped = torch.nonzero(per_unit > bound).flatten().tolist()
+            print(f"      ReLU branch flip in hidden unit(s) {flipped}: {per_unit[flipped].tolist()}")
+            assert len(flipped) <= 2 and float(per_unit.max()) <= 2e-3 * scale, (k, flipped, e_hip, scale)
+            continue
+        assert e_hip <= bound, (k, e_hip, e_ref, scale)
     assert len(fallback) <= 16, fallback
     return worst
 
