@@ -46,9 +46,11 @@ struct AttnP {
 // Variable-length ("unpadded") batches: with cu_q / cu_k given, batch element b owns rows [cu[b], cu[b+1]) of the
 // packed Q resp. K/V matrices; Lq / Lk in the launch parameters are then only the maxima (grid size, layout of the
 // per-row statistics lse/delta [B][H][Lq_max] and of the dropout counter).  Returns the per-batch view.
-__device__ __forceinline__ AttnP batch_view(const AttnP& pin, int b, int& qoff, int& koff) {
+// (off, len >= 0: the element's rows when the caller already knows them - balanced self-attention, cu_q == cu_k.)
+__device__ __forceinline__ AttnP batch_view(const AttnP& pin, int b, int& qoff, int& koff, int off = 0, int len = -1) {
     AttnP p = pin;
     qoff = b * pin.Lq; koff = b * pin.Lk;
+    if (len >= 0 && pin.cu_q == pin.cu_k) { qoff = koff = off; p.Lq = p.Lk = len; return p; }
     if (pin.cu_q) { qoff = pin.cu_q[b]; p.Lq = pin.cu_q[b + 1] - qoff; }
     if (pin.cu_k) { koff = pin.cu_k[b]; p.Lk = pin.cu_k[b + 1] - koff; }
     return p;
@@ -674,11 +676,13 @@ __device__ __forceinline__ int dispatch_batch(const int32_t* order, int b) { ret
 // (= element length; `order` + the tile counts from cu), are dealt to the XCD's 32 CUs boustrophedon - row 0 left to
 // right, row 1 right to left, ... - so the CU that got the longest block of one row gets the shortest of the next.
 // Blocks past the last valid one exit.  Every wave computes the same mapping from B <= 64 lanes (no LDS, no barrier).
-__device__ __forceinline__ bool decode_block_balanced(const AttnP& pin, const int32_t* cu, int& tile, int& h, int& b) {
+// `off` / `len`: the element's first row and row count in `cu`, from the lane that loaded them (saves the caller a second,
+// dependent round of loads - ~800 cycles of every block's prologue).
+__device__ __forceinline__ bool decode_block_balanced(const AttnP& pin, const int32_t* cu, int& tile, int& h, int& b, int& off, int& len) {
     const int L = blockIdx.x, x = L & 7, j = L >> 3;
     const int lane = threadIdx.x & 63;
-    int o = 0, t = 0;
-    if (lane < pin.B) { o = pin.order[lane]; t = (cu[o + 1] - cu[o] + BOWN - 1) / BOWN; }
+    int o = 0, t = 0, c0 = 0, cl = 0;
+    if (lane < pin.B) { o = pin.order[lane]; c0 = cu[o]; cl = cu[o + 1] - c0; t = (cl + BOWN - 1) / BOWN; }
     int inc = t;                                             // inclusive prefix of the tile counts over the ranks
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
@@ -691,9 +695,12 @@ __device__ __forceinline__ bool decode_block_balanced(const AttnP& pin, const in
     const int rank = __popcll(__ballot(inc <= k));           // elements whose blocks all come before block k
     tile = __builtin_amdgcn_readfirstlane(k - (__shfl(inc, rank) - __shfl(t, rank)));
     b = __builtin_amdgcn_readfirstlane(__shfl(o, rank));
+    off = __builtin_amdgcn_readfirstlane(__shfl(c0, rank));
+    len = __builtin_amdgcn_readfirstlane(__shfl(cl, rank));
     h = x;
     return true;
 }
+
 
 template <int DH> struct BT {
     static constexpr int RBN = DH * 2;                 // natural row bytes
@@ -921,12 +928,12 @@ __global__ __launch_bounds__(NTH, 4) void attn_fwd_bf16_kernel(AttnP pin) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile_, h, b;
-    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b)) return; }
+    int tile_, h, b, off_ = 0, len_ = -1;
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_)) return; }
     else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
-    const int q0 = tile_ * BOWN;
     int qoff, koff;
-    const AttnP p = batch_view(pin, b, qoff, koff);
+    const AttnP p = batch_view(pin, b, qoff, koff, off_, len_);
+    const int q0 = tile_ * BOWN;
     if (q0 >= p.Lq) return;
     const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
     const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
@@ -1073,12 +1080,12 @@ __global__ __launch_bounds__(NTH, OCC) void attn_bwd_dq_bf16_kernel(AttnP pin) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile_, h, b;
-    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b)) return; }
+    int tile_, h, b, off_ = 0, len_ = -1;
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_)) return; }
     else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
-    const int q0 = tile_ * BOWN;
     int qoff, koff;
-    const AttnP p = batch_view(pin, b, qoff, koff);
+    const AttnP p = batch_view(pin, b, qoff, koff, off_, len_);
+    const int q0 = tile_ * BOWN;
     if (q0 >= p.Lq) return;
     const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
     const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
@@ -1215,12 +1222,12 @@ __global__ __launch_bounds__(NTH, OCC) void attn_bwd_dkv_bf16_kernel(AttnP pin) 
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile_, h, b;
-    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_k, tile_, h, b)) return; }
+    int tile_, h, b, off_ = 0, len_ = -1;
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_k, tile_, h, b, off_, len_)) return; }
     else { decode_block((pin.Lk + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
-    const int key0 = tile_ * BOWN;
     int qoff, koff;
-    const AttnP p = batch_view(pin, b, qoff, koff);
+    const AttnP p = batch_view(pin, b, qoff, koff, off_, len_);
+    const int key0 = tile_ * BOWN;
     if (key0 >= p.Lk) return;
     const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
     const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
@@ -1464,19 +1471,28 @@ __device__ __forceinline__ void scan_key_mask4(const uint8_t* mp, int Lk, int ti
 __device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
 __device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
 
+#ifdef PA_ATTN_TRACE
+// debug build only (tools/attn_trace.py): per-block cycle stamps of the forward kernel
+__device__ unsigned long long pa_attn_trace[8192 * 8];
+#define PA_TR(i) do { if (tid == 0 && blockIdx.x < 8192) pa_attn_trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PA_TR(i) do { } while (0)
+#endif
 template <bool DROP>
 __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
     constexpr int DH = 64, NAT = BT<DH>::NAT, BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile_, h, b;
-    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b)) return; }
+    PA_TR(0);
+    int tile_, h, b, off_ = 0, len_ = -1;
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_)) return; }
     else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
-    const int q0 = tile_ * BOWN;
     int qoff, koff;
-    const AttnP p = batch_view(pin, b, qoff, koff);
+    const AttnP p = batch_view(pin, b, qoff, koff, off_, len_);
+    const int q0 = tile_ * BOWN;
     if (q0 >= p.Lq) return;
+    PA_TR(1);
     const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
     const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
     const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)koff * p.ldv + h * DH;
@@ -1520,6 +1536,7 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
     const float sl = p.scale * LOG2E;
     const uint32_t arow = DROP ? drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow)) : 0u;
     tile_barrier();
+    PA_TR(2);
 
     auto body = [&](int step, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
@@ -1588,12 +1605,18 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
         body(step, IC<0>{});
         if (step + 1 < nsteps) body(step + 1, IC<1>{});
     }
+    PA_TR(3);
     const float l_tot = quad_sum(l_run);
     const float inv = l_tot > 0.f ? (DROP ? p.drop_scale : 1.0f) / l_tot : 0.f;
     bf16* Op = reinterpret_cast<bf16*>(p.o) + (size_t)qoff * p.ldo + h * DH;
     store_rows4(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);
     if (g == 0 && qrow < p.Lq && p.lse)
         p.lse[((size_t)b * p.H + h) * pin.Lq + qrow] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : 0.f;
+#ifdef PA_ATTN_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PA_TR(4);
+    if (tid == 0 && blockIdx.x < 8192) { pa_attn_trace[blockIdx.x * 8 + 5] = nsteps; pa_attn_trace[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
+#endif
 }
 
 template <bool DROP>
@@ -1602,12 +1625,12 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dq_kernel(AttnP pin) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile_, h, b;
-    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b)) return; }
+    int tile_, h, b, off_ = 0, len_ = -1;
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_)) return; }
     else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
-    const int q0 = tile_ * BOWN;
     int qoff, koff;
-    const AttnP p = batch_view(pin, b, qoff, koff);
+    const AttnP p = batch_view(pin, b, qoff, koff, off_, len_);
+    const int q0 = tile_ * BOWN;
     if (q0 >= p.Lq) return;
     const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
     const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
@@ -1726,12 +1749,12 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile_, h, b;
-    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_k, tile_, h, b)) return; }
+    int tile_, h, b, off_ = 0, len_ = -1;
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_k, tile_, h, b, off_, len_)) return; }
     else { decode_block((pin.Lk + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
-    const int key0 = tile_ * BOWN;
     int qoff, koff;
-    const AttnP p = batch_view(pin, b, qoff, koff);
+    const AttnP p = batch_view(pin, b, qoff, koff, off_, len_);
+    const int key0 = tile_ * BOWN;
     if (key0 >= p.Lk) return;
     const bf16* Qp = reinterpret_cast<const bf16*>(p.q) + (size_t)qoff * p.ldq + h * DH;
     const bf16* Kp = reinterpret_cast<const bf16*>(p.k) + (size_t)koff * p.ldk + h * DH;
@@ -1982,3 +2005,9 @@ extern "C" int pa_attn_bwd(const pa_attn_args* a, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return a->dtype == PA_BF16 ? dispatch<bf16>(a, true, st) : dispatch<float>(a, true, st);
 }
+
+#ifdef PA_ATTN_TRACE
+extern "C" int pa_attn_trace_read(unsigned long long* out, int32_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_attn_trace), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
