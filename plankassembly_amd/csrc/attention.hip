@@ -1498,6 +1498,7 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
     const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)koff * p.ldv + h * DH;
     const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
     const int qw0 = q0 + wave * 16, qrow = qw0 + (lane & 15);
+    const bool wave_on = qw0 < p.Lq;                       // wave-uniform
 
     u32x4 qreg[2];
     load_row4(qreg, Qp, p.ldq, qrow, p.Lq, lane);
@@ -1541,6 +1542,7 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
     auto body = [&](int step, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         if (step + 1 < nsteps) issue(step + 1, buf ^ 1, kfirst);
+        if (!wave_on) { tile_barrier(); return; }      // this wave's 16 rows lie past the element's last row: DMA + barriers only
         const uint8_t* mk = reinterpret_cast<const uint8_t*>(smem + buf * BUF + AUX);
         const int k0 = step * BSTR;
         f32x4 sacc[4];
@@ -1638,6 +1640,7 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dq_kernel(AttnP pin) {
     const bf16* dOp = reinterpret_cast<const bf16*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
     const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
     const int qw0 = q0 + wave * 16, qrow = qw0 + (lane & 15);
+    const bool wave_on = qw0 < p.Lq;                       // wave-uniform
 
     u32x4 qreg[2], doreg[2];
     load_row4(qreg, Qp, p.ldq, qrow, p.Lq, lane);
@@ -1698,6 +1701,7 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dq_kernel(AttnP pin) {
     auto body = [&](int step, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         if (step + 1 < nsteps) issue(step + 1, buf ^ 1, kfirst);
+        if (!wave_on) { tile_barrier(); return; }      // this wave's 16 rows lie past the element's last row: DMA + barriers only
         const uint8_t* mk = reinterpret_cast<const uint8_t*>(smem + buf * BUF + AUX);
         const int k0 = step * BSTR;
         const bool key_masked = k0 + BSTR > kfirst;
@@ -1761,6 +1765,7 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
     const bf16* Vp = reinterpret_cast<const bf16*>(p.v) + (size_t)koff * p.ldv + h * DH;
     const bf16* dOp = reinterpret_cast<const bf16*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
     const int kw0 = key0 + wave * 16, krow = kw0 + (lane & 15);
+    const bool wave_on = kw0 < p.Lk;                       // wave-uniform
     const bool kmasked = (krow >= p.Lk) || (p.kpm && p.kpm[(size_t)b * pin.Lk + krow]);
 
     u32x4 kreg[2], vreg[2];
@@ -1802,6 +1807,7 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
     auto body = [&](int step, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
         if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        if (!wave_on) { tile_barrier(); return; }      // this wave's 16 keys lie past the element's last key
         const int r0 = step * BSTR;
         f32x4 sacc[4], dpacc[4];
         mma_nat4<buf * BUF>(sacc, lb, kreg);                           // S[q][key]: rows q = 16qb + 4g + r, col key = l & 15

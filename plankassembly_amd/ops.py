@@ -166,8 +166,10 @@ def pack_rows(mask):
 
 def pack_order(cu):
     """The dispatch order pa_pack_rows left behind cu (int32 [B]: batch elements, longest first)."""
-    B = cu.numel() - 1
-    base = cu._base if cu._base is not None else cu
+    base = cu._base if cu._base is not None else cu           # the [B+1] view pack_rows returns, or the whole buffer
+    if base.numel() % 2 == 0:
+        raise ValueError("pack_order needs the [2B+1] buffer of pa_pack_rows (or a view of it)")
+    B = (base.numel() - 1) // 2
     return base[B + 1: 2 * B + 1]
 
 

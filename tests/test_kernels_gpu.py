@@ -512,6 +512,7 @@ def test_pack_rows_matches_nonzero():
     assert torch.equal(cu.cpu().long(), torch.cat((torch.zeros(1, dtype=torch.long), cnt.cumsum(0))))
     order = ops.pack_order(cu).cpu().long()                 # batch elements by descending row count, ties in batch order
     assert torch.equal(order, torch.sort(cnt, descending=True, stable=True).indices)
+    assert torch.equal(ops.pack_order(cu._base).cpu().long(), order)     # the whole [2B+1] buffer (what prepare_batch keeps)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
