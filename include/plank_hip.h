@@ -94,6 +94,23 @@ int pa_gemm_recorded_kinds(int32_t* out, int32_t cap);
 /* -1 for launches made by pa_gemm; members of one pa_gemm_group launch share an id >= 0 (consecutive entries). */
 int pa_gemm_recorded_groups(int32_t* out, int32_t cap);
 
+/* Linear + bias (+ dropout) + residual + LayerNorm in one launch, for the post-norm sublayer tails of the reference's
+ * encoder / decoder layers (torch nn/modules/transformer.py `x = norm(x + dropout(sublayer(x)))`, used by
+ * plankassembly/models.py:76-112 through nn.TransformerEncoderLayer / nn.TransformerDecoderLayer):
+ *     Z[M][512] = R + drop(A[M][K] W[512][K]^T + bias),   Y = LayerNorm(Z; gamma, beta, eps),   mean / rstd per row.
+ * bf16 operands and outputs, f32 bias / gamma / beta / statistics; N must be 512, K a multiple of 64, rows 16-byte aligned.
+ * Z, R, bias, mean, rstd may be NULL (Z is what pa_layernorm_bwd needs; the greedy-decode step does not keep it).
+ * Bit-identical to pa_gemm (same arguments) followed by pa_layernorm_fwd.  One block per 32 rows: meant for
+ * M <= pa_gemm_ln_max_rows() (one round of blocks); beyond that the two separate launches are faster. */
+typedef struct {
+    const void* A; const void* W; const float* bias; const void* R;
+    void* Z; void* Y; const float* gamma; const float* beta; float* mean; float* rstd;
+    int32_t M, N, K, lda, ldw, ldr, ldz, ldy;
+    float eps, drop_p; uint32_t drop_seed; int32_t pad_;
+} pa_gemm_ln_args;
+int pa_gemm_ln(const pa_gemm_ln_args* a, void* stream);
+int pa_gemm_ln_max_rows(void);
+
 /* Several weight-gradient GEMMs (dW = dY^T X: bf16 operands, contraction index strided in both, f32 output, no
  * epilogue, batch 1; splitk > 1 only with splitk_defer) in one launch of the ring kernel: its unit stream runs through
  * all members.  PA_EINVAL when a member does not qualify - the caller then launches them one by one with pa_gemm. */

@@ -35,6 +35,15 @@ class GemmArgs(C.Structure):
                 ("splitk", C.c_int32), ("splitk_defer", C.c_int32)]
 
 
+class GemmLnArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p),
+                ("Z", C.c_void_p), ("Y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldw", C.c_int32),
+                ("ldr", C.c_int32), ("ldz", C.c_int32), ("ldy", C.c_int32),
+                ("eps", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("pad_", C.c_int32)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p),
                 ("lse", C.c_void_p), ("kpm", C.c_void_p),
@@ -85,6 +94,8 @@ def lib():
         sig = {
             "pa_version": (I, []),
             "pa_gemm": (I, [P, P]),
+            "pa_gemm_ln": (I, [P, P]),
+            "pa_gemm_ln_max_rows": (I, []),
             "pa_set_reserved_cus": (I, [I]),
             "pa_get_reserved_cus": (I, []),
             "pa_gemm_effective_splitk": (I, [I, I, I]),

@@ -349,6 +349,25 @@ int linear(pa_model* m, const void* A, const void* W, const float* bias, void* C
     return pa_gemm(&g, st);
 }
 
+// y = LayerNorm(R + A W^T + bias): pa_gemm into `z` followed by pa_layernorm_fwd.  PLANK_DECODE_FUSE_LN=1 swaps in the
+// one-launch row-block kernel (pa_gemm_ln; bf16, d_model 512, K = 512) to reproduce the measurement that keeps it OFF:
+// at 256 rows it is 8 blocks, each pulling the layer's whole 512 KB weight - cold, the step cycles through 38 MB of
+// them - with ~100 KB in flight: 1.317 ms / step against 1.239 for the two launches (32 blocks x 64 KB each).
+int linear_ln(pa_model* m, const void* A, const void* W, const float* bias, const void* R, void* z, void* y, const float* gamma,
+              const float* beta, float eps, int M, int K, void* st) {
+    const pa_model_cfg& c = m->cfg;
+    static const bool fuse = getenv("PLANK_DECODE_FUSE_LN") && atoi(getenv("PLANK_DECODE_FUSE_LN")) != 0;
+    if (fuse && c.dtype == PA_BF16 && c.d_model == 512 && K == 512 && M <= pa_gemm_ln_max_rows()) {
+        pa_gemm_ln_args g; memset(&g, 0, sizeof(g));
+        g.A = A; g.W = W; g.bias = bias; g.R = R; g.Z = nullptr; g.Y = y; g.gamma = gamma; g.beta = beta;
+        g.M = M; g.N = c.d_model; g.K = K; g.lda = K; g.ldw = K; g.ldr = c.d_model; g.ldz = c.d_model; g.ldy = c.d_model;
+        g.eps = eps;
+        return pa_gemm_ln(&g, st);
+    }
+    RC(linear(m, A, W, bias, z, c.d_model, M, c.d_model, K, 0, R, -1, st));
+    return pa_layernorm_fwd(y, z, gamma, beta, m->dec->mean, m->dec->rstd, M, c.d_model, eps, c.dtype, st);
+}
+
 size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tmax) {
     const pa_model_cfg& c = m->cfg;
     const size_t e = c.dtype == PA_BF16 ? 2 : 4, d = c.d_model, ff = c.d_ff;
@@ -409,16 +428,13 @@ int step_impl(pa_model* m, void* st) {
                            (const T*)L->qkv, L->t_dev, B, Tmax, d, c.n_head);
         RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->qkv, 3 * d, (const T*)L->self_k[i], (const T*)L->self_v[i], Tmax, nullptr, 0,
                           L->t_dev, B, st));
-        RC(linear(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), L->z, d, B, d, d, 0, x, -1, st));
-        RC(pa_layernorm_fwd(L->y, L->z, PF(pb + D_N1_W), PF(pb + D_N1_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
+        RC(linear_ln(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), x, L->z, L->y, PF(pb + D_N1_W), PF(pb + D_N1_B), c.eps_layer, B, d, st));
         RC(linear(m, L->y, PL(pb + D_CA_IN_W), PF(pb + D_CA_IN_B), L->q, d, B, d, d, 0, nullptr, -1, st));
         RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->q, d, (const T*)L->cross_k[i], (const T*)L->cross_v[i], S, L->cu ? nullptr : L->kpm, S,
                           L->t_dev, B, st, L->cu));
-        RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z, d, B, d, d, 0, L->y, -1, st));
-        RC(pa_layernorm_fwd(L->x, L->z, PF(pb + D_N2_W), PF(pb + D_N2_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
+        RC(linear_ln(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->y, L->z, L->x, PF(pb + D_N2_W), PF(pb + D_N2_B), c.eps_layer, B, d, st));
         RC(linear(m, L->x, PL(pb + D_L1_W), PF(pb + D_L1_B), L->ff, ff, B, ff, d, 1, nullptr, -1, st));
-        RC(linear(m, L->ff, PL(pb + D_L2_W), PF(pb + D_L2_B), L->z, d, B, d, ff, 0, L->x, -1, st));
-        RC(pa_layernorm_fwd(L->x, L->z, PF(pb + D_N3_W), PF(pb + D_N3_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
+        RC(linear_ln(m, L->ff, PL(pb + D_L2_W), PF(pb + D_L2_B), L->x, L->z, L->x, PF(pb + D_N3_W), PF(pb + D_N3_B), c.eps_layer, B, ff, st));
         (void)e;
     }
     RC(pa_layernorm_fwd(L->h, L->x, PF(m->dec_norm()), PF(m->dec_norm() + 1), L->mean, L->rstd, B, d, c.eps_final, c.dtype, st));

@@ -2060,6 +2060,215 @@ extern "C" int pa_splitk_reduce_many(const pa_reduce_desc* descs, int32_t n_desc
 }
 
 // -------------------------------------------------------------------------------------------------
+// Linear + bias (+ dropout) + residual + LayerNorm in ONE launch, for the post-norm sublayer tails
+//     z = r + drop(x W^T + b) ;  y = LN(z)           (reference torch transformer.py: x = norm(x + dropout(sublayer(x))))
+// whose N is the model width (512): LayerNorm needs whole rows, so a block owns 32 rows x all 512 columns and streams the
+// whole [512][K] weight through its CU (4-stage ring of 32-wide K tiles: 2 KB of A + 32 KB of W per stage, three tiles in
+// flight, direct-to-LDS DMA through buffer descriptors - rows past M read as zeros).  Eight waves (two per SIMD cover each other's LDS / barrier
+// waits), each 32 rows x 64 columns (two 32 x 32 MFMA tiles, the A fragment shared).  Epilogue: the f32 accumulators go through LDS (32 x 512 f32 = 64 KB, over the ring) into
+// the row-per-wave layout of layernorm_fwd_kernel; bias / dropout / residual are applied there in the order of the GEMM
+// epilogues, z is rounded to bf16 and the statistics are taken from the ROUNDED values in layernorm_fwd_kernel's summation
+// order - z, y, mean and rstd are bit-identical to pa_gemm followed by pa_layernorm_fwd (tests/test_kernels_gpu.py).
+// Per-CU arithmetic intensity is a quarter of the 128 x 128 tiling's (every block re-reads the whole weight from L2), so this
+// pays where the separate launches are latency-bound: 256 ... 8 192 rows.
+namespace {
+struct GemmLnP {
+    const void* A; const void* W; const float* bias; const void* R;
+    void* Z; void* Y; const float* gamma; const float* beta; float* mean; float* rstd;
+    int M, K, lda, ldw, ldr, ldz, ldy;
+    float eps;
+    uint32_t drop_thr; float drop_scale; uint32_t drop_seed;
+};
+constexpr int GL_N = 512, GL_BM = 32, GL_BK = 32, GL_NSTG = 4, GL_NT = 512;   // 8 waves: two per SIMD hide each other's waits
+constexpr int GL_A = GL_BM * GL_BK * 2, GL_STAGE = GL_A + GL_N * GL_BK * 2;   // 2 KB of A + 32 KB of W per stage
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gl_rsrc(const void* base, long long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes < 0x7fffffffLL ? (bytes > 0 ? bytes : 0) : 0x7fffffffLL), 0x00020000);
+}
+
+__global__ __launch_bounds__(GL_NT, 2) void gemm_ln_kernel(GemmLnP p) {
+    __shared__ __attribute__((aligned(256))) char smem[GL_NSTG * GL_STAGE];      // 136 KB; the epilogue's 64 KB overlay it
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                   // 0..7: columns 64 * wave .. + 63
+    const int m0 = blockIdx.x * GL_BM;
+    const int nt = p.K / GL_BK;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // ---- DMA: LDS rows are 64 bytes (32 bf16); a DMA instruction of a wave fills 16 rows.  Thread -> (row tid / 4 of a
+    // 128-row group, 16-byte slot tid % 4); the slot holds source chunk slot ^ ((row >> 2) & 3), which spreads the 16 rows
+    // a ds_read_b128 phase touches (64-byte stride) over all 16 bank groups.
+    const __amdgpu_buffer_rsrc_t rsA = gl_rsrc(reinterpret_cast<const char*>(p.A) + (size_t)m0 * p.lda * 2, (long long)(p.M - m0) * p.lda * 2);
+    const __amdgpu_buffer_rsrc_t rsW = gl_rsrc(p.W, (long long)GL_N * p.ldw * 2);
+    const int drow = tid >> 2, dch = ((tid & 3) ^ (drow >> 2)) & 3;
+    const int voffA = drow * p.lda * 2 + dch * 16, voffW = drow * p.ldw * 2 + dch * 16;
+    const int wstep = 128 * p.ldw * 2;                              // 128 weight rows further per DMA instruction
+    const bool a_wave = wave < 2;                                   // the 32 A rows are two waves' worth of chunks
+    auto issue = [&](int t) {
+        char* base = smem + (t & (GL_NSTG - 1)) * GL_STAGE;
+        const int k0 = t * (GL_BK * 2);                             // byte offset of the K tile inside a row
+        if (a_wave)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + wave * 1024), 16, voffA, k0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + GL_A + i * 8192 + wave * 1024), 16,
+                                                     voffW, k0 + i * wstep, 0, 0);
+    };
+    // wait until at most `younger` K tiles issued after the one needed are still in flight (5 DMA instructions per tile in
+    // the two waves that also carry A, 4 in the others)
+    auto wait_tiles = [&](int younger) {
+        if (a_wave) {
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+
+    // ---- fragment addresses: row lane & 31 of a 32-row tile, k-step s reads source chunk 2s + half (swizzled slot)
+    const int sw = ((lane & 31) >> 2) & 3;
+    int xs[2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) xs[s_] = (((2 * s_ + half) ^ sw) & 3) << 4;
+    const int fa = (lane & 31) * 64, fb = GL_A + (wave * 64 + (lane & 31)) * 64;
+
+    // three K tiles ahead: a tile's DMA has three tile-times to cover the L2 latency
+    int issued = 0;
+#pragma unroll 1
+    for (; issued < 3 && issued < nt; ++issued) issue(issued);
+#pragma unroll 1
+    for (int t = 0; t < nt; ++t) {
+        wait_tiles(issued - t - 1);
+        __builtin_amdgcn_s_barrier();                               // K tile t has landed for every wave, and every wave has
+                                                                    // finished tile t - 1: its stage is free for tile t + 3
+        if (issued < nt) { issue(issued); ++issued; }
+        const char* st = smem + (t & (GL_NSTG - 1)) * GL_STAGE;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(st + fa + xs[s_]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x4 b = *reinterpret_cast<const u32x4*>(st + fb + j * 2048 + xs[s_]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&b), *reinterpret_cast<const bf16x8*>(&a), acc[j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's LDS reads of the stage are complete
+    }
+    __syncthreads();                                                // all stages consumed: the epilogue may overlay them
+
+    // ---- accumulators -> LDS, [32][512] f32, 16-byte chunk c of row m at slot c ^ (m & 7) ------------------------------
+    {
+        const int m = lane & 31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * g4 + e];
+                const int c = wave * 16 + 8 * j + 2 * g4 + half;  // columns 4c .. 4c + 3
+                *reinterpret_cast<f32x4*>(smem + m * 2048 + ((c ^ (m & 7)) << 4)) = v;
+            }
+    }
+    __syncthreads();
+
+    // ---- row-per-wave tail: lane owns columns 4 * lane .. + 3 and 256 + 4 * lane .. + 3 (layernorm_fwd_kernel's mapping);
+    // wave w takes rows 4w .. 4w + 3
+    constexpr int RPW = GL_BM / (GL_NT / 64);
+    const int c0 = lane << 2, c1 = (lane + 64) << 2;
+    const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 b1 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + c1) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + c0), g1 = *reinterpret_cast<const f32x4*>(p.gamma + c1);
+    const f32x4 e0 = *reinterpret_cast<const f32x4*>(p.beta + c0), e1 = *reinterpret_cast<const f32x4*>(p.beta + c1);
+    const bf16* R = reinterpret_cast<const bf16*>(p.R);
+    bf16* Z = reinterpret_cast<bf16*>(p.Z);
+    bf16* Y = reinterpret_cast<bf16*>(p.Y);
+    f32x4 r0[RPW], r1[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int m = min(m0 + wave * RPW + i, p.M - 1);
+        r0[i] = R ? ld4<bf16>(R + (size_t)m * p.ldr + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        r1[i] = R ? ld4<bf16>(R + (size_t)m * p.ldr + c1) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int lr = wave * RPW + i, m = m0 + lr;
+        if (m >= p.M) break;                                        // wave-uniform
+        f32x4 x0 = *reinterpret_cast<const f32x4*>(smem + lr * 2048 + ((lane ^ (lr & 7)) << 4));
+        f32x4 x1 = *reinterpret_cast<const f32x4*>(smem + lr * 2048 + (((lane + 64) ^ (lr & 7)) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float y0 = x0[e] * 1.0f + b0[e], y1 = x1[e] * 1.0f + b1[e];
+            if (p.drop_thr) {
+                const uint32_t idx = (uint32_t)((size_t)m * GL_N + c0 + e);
+                y0 = drop_keep(p.drop_seed, idx, p.drop_thr) ? y0 * p.drop_scale : 0.f;
+                y1 = drop_keep(p.drop_seed, idx + 256u, p.drop_thr) ? y1 * p.drop_scale : 0.f;
+            }
+            if (R) { y0 += r0[i][e]; y1 += r1[i][e]; }
+            x0[e] = y0; x1[e] = y1;
+        }
+        // z in bf16 (what the backward reads); the statistics see exactly these rounded values
+        u32x2 z0, z1;
+        z0[0] = pack_bf16(x0[0], x0[1]); z0[1] = pack_bf16(x0[2], x0[3]);
+        z1[0] = pack_bf16(x1[0], x1[1]); z1[1] = pack_bf16(x1[2], x1[3]);
+        if (Z) {
+            *reinterpret_cast<u32x2*>(Z + (size_t)m * p.ldz + c0) = z0;
+            *reinterpret_cast<u32x2*>(Z + (size_t)m * p.ldz + c1) = z1;
+        }
+        f32x4 v0, v1;
+        v0[0] = bf16_lo(z0[0]); v0[1] = bf16_hi(z0[0]); v0[2] = bf16_lo(z0[1]); v0[3] = bf16_hi(z0[1]);
+        v1[0] = bf16_lo(z1[0]); v1[1] = bf16_hi(z1[0]); v1[2] = bf16_lo(z1[1]); v1[3] = bf16_hi(z1[1]);
+        float s = 0.f;
+        s += v0[0] + v0[1] + v0[2] + v0[3];
+        s += v1[0] + v1[1] + v1[2] + v1[3];
+        const float mu = wave_sum(s) / GL_N;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t_ = v0[e] - mu; q += t_ * t_; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t_ = v1[e] - mu; q += t_ * t_; }
+        const float rs = 1.0f / sqrtf(wave_sum(q) / GL_N + p.eps);
+        if (lane == 0) { if (p.mean) p.mean[m] = mu; if (p.rstd) p.rstd[m] = rs; }
+        f32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o0[e] = (v0[e] - mu) * rs * g0[e] + e0[e]; o1[e] = (v1[e] - mu) * rs * g1[e] + e1[e]; }
+        st4<bf16>(Y + (size_t)m * p.ldy + c0, o0);
+        st4<bf16>(Y + (size_t)m * p.ldy + c1, o1);
+    }
+}
+}  // namespace
+
+extern "C" int pa_gemm_ln_max_rows(void) { return 256 * GL_BM; }
+
+extern "C" int pa_gemm_ln(const pa_gemm_ln_args* a, void* stream) {
+    if (!a || !a->A || !a->W || !a->Y || !a->gamma || !a->beta) return PA_EINVAL;
+    if (a->M <= 0 || a->K <= 0 || a->N != GL_N || (a->K % 64) != 0) return PA_EINVAL;
+    if (a->drop_p < 0.f || a->drop_p >= 1.f) return PA_EINVAL;
+    auto al = [](const void* q, int bytes) { return !q || reinterpret_cast<uintptr_t>(q) % bytes == 0; };
+    if (!al(a->A, 16) || !al(a->W, 16) || (a->lda % 8) || (a->ldw % 8) || a->lda < a->K || a->ldw < a->K) return PA_EALIGN;
+    if (!al(a->R, 8) || !al(a->Z, 8) || !al(a->Y, 8) || (a->R && (a->ldr % 4)) || (a->Z && (a->ldz % 4)) || (a->ldy % 4)) return PA_EALIGN;
+    if (!al(a->bias, 16) || !al(a->gamma, 16) || !al(a->beta, 16)) return PA_EALIGN;
+    if ((long long)GL_N * a->ldw * 2 > 0x7fffffffLL) return PA_EINVAL;
+    GemmLnP p;
+    p.A = a->A; p.W = a->W; p.bias = a->bias; p.R = a->R; p.Z = a->Z; p.Y = a->Y;
+    p.gamma = a->gamma; p.beta = a->beta; p.mean = a->mean; p.rstd = a->rstd;
+    p.M = a->M; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldz = a->ldz; p.ldy = a->ldy;
+    p.eps = a->eps;
+    p.drop_thr = (uint32_t)(a->drop_p * 65536.0f + 0.5f);           // as pa_gemm
+    p.drop_scale = 1.0f / (1.0f - a->drop_p);
+    p.drop_seed = a->drop_seed;
+    const int grid = (a->M + GL_BM - 1) / GL_BM;
+    PA_LAUNCH(gemm_ln_kernel, dim3(grid), dim3(GL_NT), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
 // column sums (bias gradients): block = 64 sixteen-byte column chunks x 4 row lanes over CS_ROWS rows, partial rows
 // combined by a second small kernel.  HBM-bound: one coalesced pass over X.
 namespace {

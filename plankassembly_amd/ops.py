@@ -195,6 +195,28 @@ def embed_output_bwd(dout, dvalue, dcoord, dpos, tok, dof=6):
                                         L.ptr(tok), tok.stride(0), B, T, d, dof, L.stream()), "pa_embed_output_bwd")
 
 
+def gemm_ln(x, w, gamma, beta, eps, *, bias=None, residual=None, drop_p=0.0, drop_seed=0, want_z=True):
+    """z = residual + drop(x @ w.T + bias), y = LayerNorm(z) in one launch (bf16, w: [512, K]).  Returns (z | None, y, mean, rstd)
+    - bit-identical to gemm(..., bias, residual, drop_p) followed by layernorm_fwd."""
+    M, K = x.shape
+    assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
+    y = torch.empty(M, w.shape[0], dtype=x.dtype, device=x.device)
+    z = torch.empty_like(y) if want_z else None
+    mean, rstd = _f32(M, device=x.device), _f32(M, device=x.device)
+    g = L.GemmLnArgs()
+    g.A, g.W, g.Y, g.Z = x.data_ptr(), w.data_ptr(), y.data_ptr(), (z.data_ptr() if want_z else None)
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.R = residual.data_ptr() if residual is not None else None
+    g.gamma, g.beta, g.mean, g.rstd = gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    g.M, g.N, g.K = M, w.shape[0], K
+    g.lda, g.ldw, g.ldy = x.stride(0), w.stride(0), y.stride(0)
+    g.ldz = z.stride(0) if want_z else 0
+    g.ldr = residual.stride(0) if residual is not None else 0
+    g.eps, g.drop_p, g.drop_seed = eps, drop_p, drop_seed
+    L.check(L.lib().pa_gemm_ln(C.byref(g), L.stream()), "pa_gemm_ln")
+    return z, y, mean, rstd
+
+
 def layernorm_fwd(z, gamma, beta, eps):
     rows, d = z.numel() // z.shape[-1], z.shape[-1]
     y = torch.empty_like(z)

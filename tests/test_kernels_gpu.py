@@ -628,3 +628,26 @@ def test_embed_segment_bwd_skewed_rows(dtype):
         ref = torch.full(t.shape, base, dtype=torch.float64).index_add_(0, i.cpu(), dout.double().cpu())
         assert rel_err(t, ref.float()) < 2e-6
     assert bool((tabs[0][5] == 0.5).all())
+
+
+@pytest.mark.parametrize("M,K,drop,res", [(256, 512, 0.0, True), (2048, 1024, 0.2, True), (7940, 512, 0.2, True), (77, 512, 0.0, False),
+                                          (8192, 1024, 0.1, True)])
+def test_gemm_ln_fused_equals_separate_launches(M, K, drop, res):
+    """pa_gemm_ln (Linear + bias + dropout + residual + LayerNorm in one launch) against pa_gemm followed by
+    pa_layernorm_fwd: z, y, mean, rstd bit for bit, and against torch in f32 within the bf16 tolerance."""
+    x, w = rnd(M, K, dtype=torch.bfloat16, seed=300).to(DEV), (rnd(512, K, seed=301) * 0.05).to(torch.bfloat16).to(DEV)
+    bias, gamma, beta = rnd(512, seed=302).to(DEV), (1 + 0.1 * rnd(512, seed=303)).to(DEV), (0.1 * rnd(512, seed=304)).to(DEV)
+    r = rnd(M, 512, dtype=torch.bfloat16, seed=305).to(DEV) if res else None
+    z0 = ops.gemm(x, w, bias=bias, residual=r, drop_p=drop, drop_seed=77)
+    y0, m0, r0 = ops.layernorm_fwd(z0, gamma, beta, 1e-5)
+    z1, y1, m1, r1 = ops.gemm_ln(x, w, gamma, beta, 1e-5, bias=bias, residual=r, drop_p=drop, drop_seed=77)
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z0), float((z1.float() - z0.float()).abs().max())
+    assert torch.equal(m1, m0) and torch.equal(r1, r0)
+    assert torch.equal(y1, y0), float((y1.float() - y0.float()).abs().max())
+    _, y2, _, _ = ops.gemm_ln(x, w, gamma, beta, 1e-5, bias=bias, residual=r, drop_p=drop, drop_seed=77, want_z=False)
+    assert torch.equal(y2, y0)
+    if drop == 0.0:
+        zt = x.float() @ w.float().T + bias + (r.float() if res else 0.0)
+        yt = torch.nn.functional.layer_norm(zt, (512,), gamma, beta, 1e-5)
+        assert rel_err(y1, yt.cpu()) < tol(torch.bfloat16)
