@@ -1009,13 +1009,11 @@ __global__ __launch_bounds__(NTH, 4) void attn_fwd_bf16_kernel(AttnP pin) {
                         const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && k0 + ko + e > qrow);
                         const float x = masked ? -INFINITY : sacc[4 * g + e];
                         sacc[4 * g + e] = x;
-                        mx = fmaxf(mx, x);
                     }
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(sacc[r], sacc[r + 1]));                 // v_max3_f32
             }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mx = max3f(mx, sacc[r], sacc[r + 1]);
             mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl;
             // deferred rescale (see the generic kernel): the reference point only moves when some row outgrew it by 2^RESCALE_THR
             if (__any(mx > m_run + RESCALE_THR)) {
@@ -1560,13 +1558,11 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
                     const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && k0 + ko + e > qrow);
                     const float x = masked ? -INFINITY : sacc[kb][e];
                     sacc[kb][e] = x;
-                    mx = fmaxf(mx, x);
                 }
             }
-        } else {
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) mx = fmaxf(mx, fmaxf(fmaxf(sacc[kb][0], sacc[kb][1]), fmaxf(sacc[kb][2], sacc[kb][3])));
         }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) mx = max3f(max3f(mx, sacc[kb][0], sacc[kb][1]), sacc[kb][2], sacc[kb][3]);
         mx = quad_max(mx) * sl;
         if (__any(mx > m_run + RESCALE_THR)) {
             const float m_new = fmaxf(m_run, mx);

@@ -122,6 +122,15 @@ __device__ __forceinline__ uint32_t drop_key_hash(uint32_t seed, uint32_t key) {
 }
 __device__ __forceinline__ bool drop_keep2(uint32_t a, uint32_t c, uint32_t thr32) { return __umul24(a, c) >= thr32; }
 
+// max(a, b, c) as ONE v_max3_f32.  fmaxf() must quiet signalling NaNs, so hipcc canonicalises every operand that comes out
+// of an MFMA first (v_max_f32 x, x, x): 28 instructions for the row maximum of 16 scores instead of 8.  Scores are never
+// NaN (finite operands; masked entries are -inf, which v_max3 orders correctly).
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
