@@ -1212,7 +1212,10 @@ __global__ __launch_bounds__(NTH, OCC) void attn_bwd_dq_bf16_kernel(AttnP pin) {
     store_rows<bf16, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, p.scale * (DROP ? p.drop_scale : 1.0f), lane);
 }
 
-template <int DH, bool DROP, int OCC>
+// (CAUSAL as a template parameter: see attn4_bwd_dkv_kernel.  Not as two copies of the score loop behind a lambda: the
+// streamed lse / delta words are written by asynchronous ds_reads into registers the compiler must not move before the wait,
+// and by-reference captures let it.)
+template <int DH, bool DROP, int OCC, bool CAUSAL>
 __global__ __launch_bounds__(NTH, OCC) void attn_bwd_dkv_bf16_kernel(AttnP pin) {
     using A = AT<bf16, DH>;
     using B = BT<DH>;
@@ -1238,7 +1241,7 @@ __global__ __launch_bounds__(NTH, OCC) void attn_bwd_dkv_bf16_kernel(AttnP pin) 
     load_row_regs<bf16, DH>(kreg, Kp, p.ldk, krow, p.Lk, lane);
     load_row_regs<bf16, DH>(vreg, Vp, p.ldv, krow, p.Lk, lane);
     const int nsteps = (p.Lq + BSTR - 1) / BSTR;
-    const int step0 = p.causal ? (key0 / BSTR) : 0;
+    const int step0 = CAUSAL ? (key0 / BSTR) : 0;
 
     f32x16 dkacc[A::NDT], dvacc[A::NDT];
 #pragma unroll
@@ -1286,7 +1289,7 @@ __global__ __launch_bounds__(NTH, OCC) void attn_bwd_dkv_bf16_kernel(AttnP pin) 
             mma_nat3<DH, buf * BUF + B::NAT + qt * 32 * B::RBN>(dpacc, lb, vreg);     // dP[q][key]
             // A masked KEY (this lane's row) gets its accumulators zeroed at the end instead of per element; the causal
             // test only runs on the q tiles that straddle the diagonal (wave-uniform).
-            const bool need_causal = p.causal && (key0 + wave * 32 + 31 > r0 + qt * 32);
+            const bool need_causal = CAUSAL && (key0 + wave * 32 + 31 > r0 + qt * 32);
             // per-query-row words of the tile (lse, delta, dropout row hash) stream through two register sets: the words of
             // group g + 1 are requested before group g is consumed
             u32x4 lq[2], dq_[2], aq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
@@ -1310,16 +1313,12 @@ __global__ __launch_bounds__(NTH, OCC) void attn_bwd_dkv_bf16_kernel(AttnP pin) 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float pe = fast_exp2(__builtin_fmaf(sacc[4 * g + e], sl, -__uint_as_float(lq[g & 1][e])));
-                    if (need_causal) pe = (krow > r0 + qo + e) ? 0.f : pe;
-                    float dp = dpacc[4 * g + e];
+                    if (CAUSAL && need_causal) pe = (krow > r0 + qo + e) ? 0.f : pe;
                     float pd = pe;
-                    if (DROP) {
-                        const bool keep = drop_keep2(aq[g & 1][e], ckey, p.drop_thr);
-                        dp = keep ? dp : 0.f;
-                        pd = keep ? pe : 0.f;
-                    }
+                    if (DROP) pd = drop_keep2(aq[g & 1][e], ckey, p.drop_thr) ? pe : 0.f;
                     sacc[4 * g + e] = pd;                                  // P_drop * (1-p)
-                    dpacc[4 * g + e] = pe * (dp - __uint_as_float(dq_[g & 1][e]));      // dS * (1-p) / scale
+                    // dS * (1-p) / scale = P (keep * dP - delta) = P_drop dP - P delta: one select instead of two
+                    dpacc[4 * g + e] = __builtin_fmaf(pd, dpacc[4 * g + e], -(pe * __uint_as_float(dq_[g & 1][e])));
                 }
             }
             mma_tr3<DH, buf * BUF + B::NAT + qt * 32 * B::RBN>(dvacc, lb, sacc);      // dV^T += dO^T P
@@ -1743,7 +1742,9 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dq_kernel(AttnP pin) {
     store_rows4(dQp, p.lddq, qrow, p.Lq, dqacc, p.scale * (DROP ? p.drop_scale : 1.0f), lane);
 }
 
-template <bool DROP>
+// CAUSAL is a template parameter here: as a run-time flag the per-score causal select (index, compare, select) was executed
+// on every tile of the non-causal encoder / cross attention, and two copies of the score loop in one kernel spill at 128 VGPRs.
+template <bool DROP, bool CAUSAL>
 __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
     constexpr int DH = 64, NAT = BT<DH>::NAT, BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
     extern __shared__ __attribute__((aligned(256))) char smem[];
@@ -1768,7 +1769,7 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
     load_row4(kreg, Kp, p.ldk, krow, p.Lk, lane);
     load_row4(vreg, Vp, p.ldv, krow, p.Lk, lane);
     const int nsteps = (p.Lq + BSTR - 1) / BSTR;
-    const int step0 = p.causal ? (key0 / BSTR) : 0;
+    const int step0 = CAUSAL ? (key0 / BSTR) : 0;
 
     f32x4 dkacc[4], dvacc[4];
 #pragma unroll
@@ -1808,7 +1809,7 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
         f32x4 sacc[4], dpacc[4];
         mma_nat4<buf * BUF>(sacc, lb, kreg);                           // S[q][key]: rows q = 16qb + 4g + r, col key = l & 15
         mma_nat4<buf * BUF + NAT>(dpacc, lb, vreg);                    // dP[q][key]
-        const bool need_causal = p.causal && (kw0 + 15 > r0);
+        const bool need_causal = CAUSAL && (kw0 + 15 > r0);
         // per-query-row words of the tile (lse, delta, dropout row hash): without dropout they stream through two register
         // sets (group qb + 1 requested before qb is consumed); with dropout the third word would push the kernel past 128
         // registers, so the three words of a group are read when it is processed (the other waves cover the latency)
@@ -1832,16 +1833,12 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float pe = fast_exp2(__builtin_fmaf(sacc[qb][e], sl, -__uint_as_float(lq[cur][e])));
-                if (need_causal) pe = (krow > r0 + qo + e) ? 0.f : pe;
-                float dp = dpacc[qb][e];
+                if (CAUSAL && need_causal) pe = (krow > r0 + qo + e) ? 0.f : pe;
                 float pd = pe;
-                if (DROP) {
-                    const bool keep = drop_keep2(aq[cur][e], ckey, p.drop_thr);
-                    dp = keep ? dp : 0.f;
-                    pd = keep ? pe : 0.f;
-                }
+                if (DROP) pd = drop_keep2(aq[cur][e], ckey, p.drop_thr) ? pe : 0.f;
                 sacc[qb][e] = pd;                                                   // P_drop * (1-p)
-                dpacc[qb][e] = pe * (dp - __uint_as_float(dq_[cur][e]));         // dS * (1-p) / scale
+                // dS * (1-p) / scale = P (keep * dP - delta) = P_drop dP - P delta: one select instead of two
+                dpacc[qb][e] = __builtin_fmaf(pd, dpacc[qb][e], -(pe * __uint_as_float(dq_[cur][e])));
             }
         }
         mma_tr4<buf * BUF + NAT>(dvacc, lb, sacc);                     // dV^T += dO^T P
@@ -1918,10 +1915,12 @@ template <int DH> int run_bwd_bf16(const AttnP& p, hipStream_t st) {
         if (use_v4(p, p.Lq > p.Lk ? p.Lq : p.Lk)) {
             if (p.drop_thr) {
                 PA_LAUNCH((attn4_bwd_dq_kernel<true>), gq, dim3(NT4), shm, st, p);
-                PA_LAUNCH((attn4_bwd_dkv_kernel<true>), gk, dim3(NT4), shm, st, p);
+                if (p.causal) PA_LAUNCH((attn4_bwd_dkv_kernel<true, true>), gk, dim3(NT4), shm, st, p);
+                else PA_LAUNCH((attn4_bwd_dkv_kernel<true, false>), gk, dim3(NT4), shm, st, p);
             } else {
                 PA_LAUNCH((attn4_bwd_dq_kernel<false>), gq, dim3(NT4), shm, st, p);
-                PA_LAUNCH((attn4_bwd_dkv_kernel<false>), gk, dim3(NT4), shm, st, p);
+                if (p.causal) PA_LAUNCH((attn4_bwd_dkv_kernel<false, true>), gk, dim3(NT4), shm, st, p);
+                else PA_LAUNCH((attn4_bwd_dkv_kernel<false, false>), gk, dim3(NT4), shm, st, p);
             }
             return 0;
         }
@@ -1932,13 +1931,13 @@ template <int DH> int run_bwd_bf16(const AttnP& p, hipStream_t st) {
     if (p.drop_thr) {
         if (oq >= 4) PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH, true, 4>), gq, dim3(NTH), shm, st, p);      // also writes delta
         else PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH, true, 3>), gq, dim3(NTH), shm, st, p);
-        if (ok >= 3) PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, true, 3>), gk, dim3(NTH), shm, st, p);
-        else PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, true, 2>), gk, dim3(NTH), shm, st, p);
+        if (ok >= 3) { if (p.causal) PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, true, 3, true>), gk, dim3(NTH), shm, st, p); else PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, true, 3, false>), gk, dim3(NTH), shm, st, p); }
+        else { if (p.causal) PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, true, 2, true>), gk, dim3(NTH), shm, st, p); else PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, true, 2, false>), gk, dim3(NTH), shm, st, p); }
     } else {
         if (oq >= 4) PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH, false, 4>), gq, dim3(NTH), shm, st, p);
         else PA_LAUNCH((attn_bwd_dq_bf16_kernel<DH, false, 3>), gq, dim3(NTH), shm, st, p);
-        if (ok >= 3) PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, false, 3>), gk, dim3(NTH), shm, st, p);
-        else PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, false, 2>), gk, dim3(NTH), shm, st, p);
+        if (ok >= 3) { if (p.causal) PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, false, 3, true>), gk, dim3(NTH), shm, st, p); else PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, false, 3, false>), gk, dim3(NTH), shm, st, p); }
+        else { if (p.causal) PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, false, 2, true>), gk, dim3(NTH), shm, st, p); else PA_LAUNCH((attn_bwd_dkv_bf16_kernel<DH, false, 2, false>), gk, dim3(NTH), shm, st, p); }
     }
     return 0;
 }
