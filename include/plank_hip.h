@@ -437,6 +437,12 @@ int pa_model_tensor(pa_model* m, int32_t which, void** ptr, int64_t* numel);
 int64_t pa_decode_ws_bytes(pa_model* m, int32_t B, int32_t S, int32_t Tmax);
 int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t Tmax, void* stream);
 int pa_decode_step(pa_model* m, void* stream);
+/* One step of TWO half-batches of the same decode (two handles over the same parameters, each after its own
+ * pa_decode_begin) on two streams, attention launches strictly alternating between them so that one lane's K/V streaming
+ * overlaps the other lane's latency-bound launches.  Under stream capture stream_b must already belong to stream_a's
+ * capture (fork before, join after).  Host-side scheduling only: each lane computes exactly what pa_decode_step computes.
+ * Experimental: on MI355X / ROCm 7.2 the cross-queue event edges cost more than the overlap. */
+int pa_decode_step_pair(pa_model* a, pa_model* b, void* stream_a, void* stream_b);
 int pa_decode_buffers(pa_model* m, void** tokens, void** attach, void** first_end, void** t_dev);
 
 #ifdef __cplusplus

@@ -146,6 +146,7 @@ def lib():
             "pa_decode_ws_bytes": (I64, [P, I, I, I]),
             "pa_decode_begin": (I, [P, P, I64, I, P]),
             "pa_decode_step": (I, [P, P]),
+            "pa_decode_step_pair": (I, [P, P, P, P]),
             "pa_decode_buffers": (I, [P, P, P, P, P]),
         }
         for name, (res, args) in sig.items():

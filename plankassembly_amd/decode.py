@@ -116,6 +116,9 @@ class GreedyDecoder:
             use_graph = os.environ.get("PLANK_DECODE_GRAPH", "1") != "0"
         self.use_graph = use_graph
         self.max_lanes = int(lanes if lanes is not None else os.environ.get("PLANK_DECODE_LANES", "2"))
+        # PLANK_DECODE_ALTERNATE=1: the lanes' attention launches strictly alternate (pa_decode_step_pair).  OFF: measured
+        # 2.15 ms / step against 1.23 - 24 cross-queue event edges per step cost more than the overlap they arrange.
+        self.alternate = os.environ.get("PLANK_DECODE_ALTERNATE", "0") == "1"
         self._lanes = []
         self._graph = None
         self._side = None
@@ -165,11 +168,18 @@ class GreedyDecoder:
         main = torch.cuda.current_stream()
         if self._active == 2:
             self._side.wait_stream(main)               # fork
-            with torch.cuda.stream(self._side):
-                self._lanes[1].step()
-        self._lanes[0].step()
-        if self._active == 2:
+            if self.alternate:
+                # attention launches of the two lanes strictly alternate (pa_decode_step_pair): one lane streams its K/V
+                # caches while the other runs the latency-bound launches in between
+                L.check(L.lib().pa_decode_step_pair(self._lanes[0].h(), self._lanes[1].h(), C.c_void_p(main.cuda_stream),
+                                                    C.c_void_p(self._side.cuda_stream)), "pa_decode_step_pair")
+            else:
+                with torch.cuda.stream(self._side):
+                    self._lanes[1].step()
+                self._lanes[0].step()
             main.wait_stream(self._side)               # join
+        else:
+            self._lanes[0].step()
 
     def _capture(self):
         g = torch.cuda.CUDAGraph()
