@@ -75,6 +75,8 @@ def test_prepared_batch_matches_golden_gradients(fixture_name, request):
     instead of atomics): every gradient must still match the reference's (G2)."""
     sd, batch, g = request.getfixturevalue(fixture_name)
     m = make(sd).train()
+    if not m.unpad:
+        pytest.skip("PLANK_UNPAD=0: the dense path keeps no packing / groupings")
     pb = m.prepare_batch(batch)
     assert "_groups" in pb and pb["_groups"]["out"] is not None
     out = m(pb)
@@ -307,6 +309,8 @@ def test_prepare_batch_groupings_match_the_torch_statement(kind):
     batch = LC.case_batch(c, batch_size=16)
     from plankassembly_amd.models import PlankModel
     m = PlankModel(64, 4, 128, 0.0, "relu", True, 1, 1, 3, 2, 4, 6, c["max_in"], c["max_out"], 514, TOKEN).cuda()
+    if not m.unpad:
+        pytest.skip("PLANK_UNPAD=0: the dense path keeps no packing / groupings")
     pb = m.prepare_batch(batch)
     cu, rowmap, n_valid = pb["_pack"]
     valid = (~batch["input_mask"]).flatten().nonzero().flatten()
