@@ -357,4 +357,11 @@ def test_two_lane_decode_equals_single_lane(small_fixture, graph):
         assert two._active == 2 and one._active == 1
         assert torch.equal(s1, s2) and torch.equal(a1, a2)
         assert torch.equal(s1, s3) and torch.equal(a1, a3)
-        del one, two
+        # the experimental alternating schedule (pa_decode_step_pair: the lanes' attention launches take turns) computes
+        # the same thing
+        alt = D.GreedyDecoder(m, use_graph=graph, lanes=2, strict_graph=True)
+        alt.alternate = True
+        with torch.no_grad():
+            s4, a4 = alt.run(gb, early_stop=early)
+        assert alt._active == 2 and torch.equal(s1, s4) and torch.equal(a1, a4)
+        del one, two, alt
