@@ -734,6 +734,13 @@ __device__ __forceinline__ int total_units_of(const GemmGroup& g) { return g.beg
 // staging slice outside the ring (no block barrier) and straight-line code (no waits between stores).
 // PT = GemmP (one problem) or GemmGroup (several problems in one launch: the unit stream runs through all of them; used
 // for the weight gradients of a backward segment).  pd / pc = problem the DMA cursor / the compute cursor is in.
+#ifdef PA_GEMM_TRACE3
+// debug build only (tools/gemm_trace.py): per-block cycle stamps of the ring kernel
+__device__ unsigned long long pa_gemm3_trace[512 * 8];
+#define PA_TR3(i) do { if (threadIdx.x == 0 && blockIdx.x < 512) pa_gemm3_trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PA_TR3(i) do { } while (0)
+#endif
 template <bool A_KC, bool B_KC, typename PT>
 __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
     constexpr bool GROUP = std::is_same<PT, GemmGroup>::value;
@@ -747,6 +754,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
     __shared__ __attribute__((aligned(256))) char smem[NSTG * STAGE + 4 * EPI];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PA_TR3(0);
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5;
     constexpr int esz = 2;
@@ -912,9 +920,16 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
     };
     using NoQ = std::integral_constant<int, -1>;
 
+    // Residual / gate tiles of the block's FIRST unit, requested before its first K tile (see the prefetch below): in a
+    // single-round launch - most launches of the training step - every block would otherwise start these loads only after
+    // its K loop, with nothing left to hide their latency behind (measured: 5.9 k of a 15.5 k-cycle epilogue at K = 512).
+    u32x2 pre_res[2][8], pre_aux[2][8];
+    bool pre_live = false;
     // ---- epilogue ------------------------------------------------------------------------------------------------
     auto epilogue = [&](const Unit& un) {
         char* stage = smem + NSTG * STAGE + wave * EPI;
+        const bool pre = pre_live;
+        pre_live = false;
         const bool slab = pc.splitk > 1;
         const size_t cbase = slab ? (size_t)un.z * pc.M * pc.ldc : (size_t)un.b * pc.sC;
         const int mw = un.tile_m * BM + wm * 64, nw = un.tile_n * BN + wn * 64;
@@ -953,19 +968,30 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
             }
             if (fast) {
                 f32x4 res[NIT], gate[NIT];
+                auto widen = [](const u32x2& u) { f32x4 r; r[0] = bf16_lo(u[0]); r[1] = bf16_hi(u[0]); r[2] = bf16_lo(u[1]); r[3] = bf16_hi(u[1]); return r; };
                 if (has_res) {
+                    if (pre) {
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        const size_t ro = (size_t)un.b * pc.sR + (size_t)min(mp + it * 4, pc.M - 1) * pc.ldr + n;
-                        res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(pc.R) + ro)
-                                          : ld4<bf16>(reinterpret_cast<const bf16*>(pc.R) + ro);
+                        for (int it = 0; it < NIT; ++it) res[it] = widen(pre_res[pass][it]);
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const size_t ro = (size_t)un.b * pc.sR + (size_t)min(mp + it * 4, pc.M - 1) * pc.ldr + n;
+                            res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(pc.R) + ro)
+                                              : ld4<bf16>(reinterpret_cast<const bf16*>(pc.R) + ro);
+                        }
                     }
                 }
                 if (has_aux) {
+                    if (pre) {
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        const size_t ao = (size_t)un.b * pc.sAux + (size_t)min(mp + it * 4, pc.M - 1) * pc.ldaux + n;
-                        gate[it] = ld4<T>(reinterpret_cast<const T*>(pc.aux) + ao);
+                        for (int it = 0; it < NIT; ++it) gate[it] = widen(pre_aux[pass][it]);
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const size_t ao = (size_t)un.b * pc.sAux + (size_t)min(mp + it * 4, pc.M - 1) * pc.ldaux + n;
+                            gate[it] = ld4<T>(reinterpret_cast<const T*>(pc.aux) + ao);
+                        }
                     }
                 }
                 if (!slab) {
@@ -1077,6 +1103,24 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
     cmp_enter(blockIdx.x);
     if (cc_u >= total_units) return;
     dma_enter(blockIdx.x);
+    // Prefetch of the first unit's residual / gate tiles (bf16, vector path).  Issued BEFORE the first DMA instruction: loads
+    // return in order, so the hand-counted `vmcnt` waits of the K loop (which count DMA instructions only) stay exact - these
+    // loads are older than every DMA and are retired by the first of those waits, together with the first K tile.
+    if constexpr (!GROUP) {
+        const int nw0 = cun.tile_n * BN + wn * 64;
+        if (pc.splitk <= 1 && pc.vec_ok && nw0 + 64 <= pc.N && pc.out_dtype != PA_F32 && (pc.R != nullptr || pc.aux != nullptr)) {
+            pre_live = true;
+            const int mw0 = cun.tile_m * BM + wm * 64, n0 = nw0 + (lane & 15) * 4, rs = lane >> 4;
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = min(mw0 + pass * 32 + rs + it * 4, pc.M - 1);
+                    if (pc.R) pre_res[pass][it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(pc.R) + (size_t)cun.b * pc.sR + (size_t)m * pc.ldr + n0);
+                    if (pc.aux) pre_aux[pass][it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(pc.aux) + (size_t)cun.b * pc.sAux + (size_t)m * pc.ldaux + n0);
+                }
+        }
+    }
     int pending = 0;                            // items issued and not yet finished by the MFMAs
     auto issue = [&]() {
         DMA(fetch(sd));
@@ -1090,10 +1134,12 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+    PA_TR3(1);
 #pragma unroll 1
     for (int k = 0; k < 3; ++k) if (cd_u < total_units) issue();
     wait_items(pending - 1);
     __builtin_amdgcn_s_barrier();
+    PA_TR3(2);
     int sc = 0;
     u32x4 F0[4], F1[4];
     using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
@@ -1127,7 +1173,12 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
         if constexpr (HOT) { ++cc_t; return true; }
         else {
             if (++cc_t >= cc_end) {
+                PA_TR3(3);
                 epilogue(cun);
+#ifdef PA_GEMM_TRACE3
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                PA_TR3(4);
                 if (has_next) cmp_enter(cc_u + ustride);
             }
             --pending;
@@ -2514,3 +2565,9 @@ extern "C" int pa_colsum(const void* X, int32_t dtype, int32_t M, int32_t N, int
     }
     return 0;
 }
+
+#ifdef PA_GEMM_TRACE3
+extern "C" int pa_gemm3_trace_read(unsigned long long* out, int32_t n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_gemm3_trace), sizeof(unsigned long long) * (size_t)n);
+}
+#endif

@@ -24,5 +24,6 @@ if len(sys.argv) > 1:
             us = e0.elapsed_time(e1) / 40 * 1e3
             print(f"{sys.argv[1]:8s} N {N:5d} K {K:5d} M {M:5d}  {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.0f} TF", flush=True)
 else:
-    for tag, env in (("default", {}), ("ring", {"PA_GEMM_V3": "2"}), ("wide", {"PA_GEMM_WIDE": "1"})):
+    for tag, env in (("default", {}), ("ring", {"PA_GEMM_V3": "2"}), ("wide", {"PA_GEMM_WIDE": "1"}), ("small", {"PA_GEMM_SMALL_MAX": "256"}),
+                     ("pair", {"PA_GEMM_V3": "0"})):
         subprocess.run([sys.executable, __file__, tag], env={**os.environ, **env}, check=False)

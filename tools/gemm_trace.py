@@ -1,0 +1,44 @@
+"""Per-block cycle stamps of the ring GEMM (debug build with -DPA_GEMM_TRACE3, see csrc/gemm.hip):
+    PLANK_HIP_LIB=tools/ubench/libplank_trace.so python tools/gemm_trace.py
+mean cycles per block: kernel entry -> setup done -> first K tile landed -> K loop done -> epilogue done (stores retired)."""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from plankassembly_amd import ops, _lib as L
+
+
+def run(M, N, K, res=True, drop=0.0):
+    x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda")
+    r = torch.randn(M, N, device="cuda").to(torch.bfloat16) if res else None
+    for _ in range(3):
+        ops.gemm(x, w, bias=b, residual=r, drop_p=drop, drop_seed=1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.gemm(x, w, bias=b, residual=r, drop_p=drop, drop_seed=1)
+    e1.record(); torch.cuda.synchronize()
+    buf = np.zeros(512 * 8, dtype=np.uint64)
+    fn = L.lib().pa_gemm3_trace_read
+    fn.restype = C.c_int
+    assert fn(buf.ctypes.data_as(C.c_void_p), C.c_int32(buf.size)) == 0
+    t = buf.reshape(-1, 8).astype(np.int64)
+    nb = min(512, (M + 127) // 128 * ((N + 127) // 128))
+    t = t[:nb]
+    t = t[t[:, 4] > 0]
+    d = [t[:, i + 1] - t[:, i] for i in range(4)]
+    spread = t[:, 0].max() - t[:, 0].min()
+    span = t[:, 4].max() - t[:, 0].min()
+    print(f"M {M:5d} N {N:5d} K {K:5d} res {int(res)} drop {drop}: {e0.elapsed_time(e1) / 20 * 1e3:6.1f} us/launch | blocks {len(t)}  setup {d[0].mean():6.0f}  "
+          f"first tile {d[1].mean():6.0f}  K loop {d[2].mean():7.0f} ({d[2].mean() / (K // 64):5.0f}/tile)  epilogue {d[3].mean():6.0f}  "
+          f"block total {(t[:, 4] - t[:, 0]).mean():7.0f}  first entry -> last exit {span}  entry spread {spread}", flush=True)
+
+
+for K in (512, 1024, 1536):
+    run(7940, 512, K)
+run(7940, 512, 512, res=False)
+run(7940, 512, 1024, drop=0.2)
+run(7940, 1024, 512, res=False)
+run(2048, 2048, 4096, res=False)
