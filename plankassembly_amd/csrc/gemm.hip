@@ -1273,9 +1273,14 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
     };
     auto wait_frag = [&](u32x4 (&f)[2]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1])); };
 
+    // residual / gate tile of the block's first unit, requested before its first K tile (as in gemm3_kernel)
+    u32x2 pre_res[4], pre_aux[4];
+    bool pre_live = false;
     // ---- epilogue: per-wave staging (32 x 32 f32), straight-line fast path ------------------------------------------
     auto epilogue = [&](const Unit& un) {
         char* stage = smem + NSTG * STAGE + wave * EPI;
+        const bool pre = pre_live;
+        pre_live = false;
         const size_t cbase = (size_t)un.b * p.sC;
         const int mw = un.tile_m * TB + wm * 32, nw = un.tile_n * TB + wn * 32;
         const int chunk = lane & 7, rsub = lane >> 3;                     // 8 chunks of 4 columns, 8 rows per instruction
@@ -1309,19 +1314,30 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
         }
         if (fast) {
             f32x4 res[NIT], gate[NIT];
+            auto widen = [](const u32x2& u) { f32x4 r; r[0] = bf16_lo(u[0]); r[1] = bf16_hi(u[0]); r[2] = bf16_lo(u[1]); r[3] = bf16_hi(u[1]); return r; };
             if (has_res) {
+                if (pre) {
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const size_t ro = (size_t)un.b * p.sR + (size_t)min(mp + it * 8, p.M - 1) * p.ldr + n;
-                    res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(p.R) + ro)
-                                      : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+                    for (int it = 0; it < NIT; ++it) res[it] = widen(pre_res[it]);
+                } else {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const size_t ro = (size_t)un.b * p.sR + (size_t)min(mp + it * 8, p.M - 1) * p.ldr + n;
+                        res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(p.R) + ro)
+                                          : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+                    }
                 }
             }
             if (has_aux) {
+                if (pre) {
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const size_t ao = (size_t)un.b * p.sAux + (size_t)min(mp + it * 8, p.M - 1) * p.ldaux + n;
-                    gate[it] = ld4<T>(reinterpret_cast<const T*>(p.aux) + ao);
+                    for (int it = 0; it < NIT; ++it) gate[it] = widen(pre_aux[it]);
+                } else {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const size_t ao = (size_t)un.b * p.sAux + (size_t)min(mp + it * 8, p.M - 1) * p.ldaux + n;
+                        gate[it] = ld4<T>(reinterpret_cast<const T*>(p.aux) + ao);
+                    }
                 }
             }
 #pragma unroll
@@ -1393,6 +1409,19 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
     if (cc_u >= p.units) return;
     Unit cun, dun;
     unit_of(cc_u, cun);
+    {   // prefetch (bf16, vector path), before the first DMA instruction so that the in-order `vmcnt` counts stay exact
+        const int nw0 = cun.tile_n * TB + wn * 32;
+        if (p.vec_ok && nw0 + 32 <= p.N && p.out_dtype != PA_F32 && (p.R != nullptr || p.aux != nullptr)) {
+            pre_live = true;
+            const int mp0 = cun.tile_m * TB + wm * 32 + (lane >> 3), n0 = nw0 + (lane & 7) * 4;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int m = min(mp0 + it * 8, p.M - 1);
+                if (p.R) pre_res[it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.R) + (size_t)cun.b * p.sR + (size_t)m * p.ldr + n0);
+                if (p.aux) pre_aux[it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.aux) + (size_t)cun.b * p.sAux + (size_t)m * p.ldaux + n0);
+            }
+        }
+    }
     unit_of(cd_u, dun); setup(dun, 0);
     int sd = 0, pending = 0;
     auto issue = [&]() {
