@@ -973,12 +973,17 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
                     if (pre) {
 #pragma unroll
                         for (int it = 0; it < NIT; ++it) res[it] = widen(pre_res[pass][it]);
+                    } else if (out_f32) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const size_t ro = (size_t)un.b * pc.sR + (size_t)min(mp + it * 4, pc.M - 1) * pc.ldr + n;
+                            res[it] = ld4<float>(reinterpret_cast<const float*>(pc.R) + ro);
+                        }
                     } else {
 #pragma unroll
                         for (int it = 0; it < NIT; ++it) {
                             const size_t ro = (size_t)un.b * pc.sR + (size_t)min(mp + it * 4, pc.M - 1) * pc.ldr + n;
-                            res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(pc.R) + ro)
-                                              : ld4<bf16>(reinterpret_cast<const bf16*>(pc.R) + ro);
+                            res[it] = ld4<bf16>(reinterpret_cast<const bf16*>(pc.R) + ro);
                         }
                     }
                 }
@@ -995,29 +1000,63 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
                     }
                 }
                 if (!slab) {
+                    // one straight-line loop per optional stage, each behind its own (uniform) branch: as conditions inside one
+                    // per-element loop every stage cost its compare / select on every element whether it was enabled or not
+                    // (the epilogue of a plain Linear ran ~1 200 instructions per wave; a lone wave issues one per ~6.5 cycles)
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
+                    for (int it = 0; it < NIT; ++it)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float y = x[it][e] * alpha + bias[e];
-                            if (pc.relu) y = fmaxf(y, 0.f);
-                            if (has_aux) y = gate[it][e] > 0.f ? y * pc.aux_scale : 0.f;
-                            if (has_drop) {
+                        for (int e = 0; e < 4; ++e) x[it][e] = x[it][e] * alpha + bias[e];
+                    if (pc.relu) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[it][e] = fmaxf(x[it][e], 0.f);
+                    }
+                    if (has_aux) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[it][e] = gate[it][e] > 0.f ? x[it][e] * pc.aux_scale : 0.f;
+                    }
+                    if (has_drop) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
                                 const uint32_t idx = (uint32_t)(((size_t)un.b * pc.M + mp + it * 4) * pc.N + n + e);
-                                y = drop_keep(pc.drop_seed, idx, pc.drop_thr) ? y * pc.drop_scale : 0.f;
+                                x[it][e] = drop_keep(pc.drop_seed, idx, pc.drop_thr) ? x[it][e] * pc.drop_scale : 0.f;
                             }
-                            if (has_res) y += res[it][e];
-                            x[it][e] = y;
-                        }
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[it][e] += res[it][e];
                     }
                 }
+                // Stores: one running pointer, the output type and the "all 32 rows valid" test decided once per pass (as
+                // run-time conditions inside the loop they were a branch pair + 64-bit index arithmetic per store, ~20
+                // instructions each for a lone wave that issues one instruction per ~6.5 cycles).
+                const bool interior = mw + pass * 32 + 32 <= pc.M;                   // wave-uniform
+                const size_t co0 = cbase + (size_t)mp * pc.ldc + n, rstep = (size_t)4 * pc.ldc;
+                if (out_f32) {
+                    float* cp = reinterpret_cast<float*>(pc.C) + co0;
+                    if (interior) {
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int m = mp + it * 4;
-                    if (m < pc.M) {
-                        const size_t co = cbase + (size_t)m * pc.ldc + n;
-                        if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(pc.C) + co) = x[it];
-                        else st4<bf16>(reinterpret_cast<bf16*>(pc.C) + co, x[it]);
+                        for (int it = 0; it < NIT; ++it) *reinterpret_cast<f32x4*>(cp + it * rstep) = x[it];
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) if (mp + it * 4 < pc.M) *reinterpret_cast<f32x4*>(cp + it * rstep) = x[it];
+                    }
+                } else {
+                    bf16* cp = reinterpret_cast<bf16*>(pc.C) + co0;
+                    if (interior) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) st4<bf16>(cp + it * rstep, x[it]);
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) if (mp + it * 4 < pc.M) st4<bf16>(cp + it * rstep, x[it]);
                     }
                 }
             } else {
@@ -1176,9 +1215,10 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
                 PA_TR3(3);
                 epilogue(cun);
 #ifdef PA_GEMM_TRACE3
+                PA_TR3(5);                                     // every store of the tile issued
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-                PA_TR3(4);
+                PA_TR3(4);                                     // ... and retired
                 if (has_next) cmp_enter(cc_u + ustride);
             }
             --pending;
@@ -1323,8 +1363,8 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
                         const size_t ro = (size_t)un.b * p.sR + (size_t)min(mp + it * 8, p.M - 1) * p.ldr + n;
-                        res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(p.R) + ro)
-                                          : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+                        if (out_f32) res[it] = ld4<float>(reinterpret_cast<const float*>(p.R) + ro);
+                        else res[it] = ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
                     }
                 }
             }
@@ -1340,28 +1380,58 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
                     }
                 }
             }
+            // one straight-line loop per optional stage behind its own uniform branch, stores with the output type and the
+            // row-validity test decided once (see gemm3_kernel)
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
+            for (int it = 0; it < NIT; ++it)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float y = x[it][e] * p.alpha + bias[e];
-                    if (p.relu) y = fmaxf(y, 0.f);
-                    if (has_aux) y = gate[it][e] > 0.f ? y * p.aux_scale : 0.f;
-                    if (has_drop) {
-                        const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + mp + it * 8) * p.N + n + e);
-                        y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
-                    }
-                    if (has_res) y += res[it][e];
-                    x[it][e] = y;
-                }
+                for (int e = 0; e < 4; ++e) x[it][e] = x[it][e] * p.alpha + bias[e];
+            if (p.relu) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[it][e] = fmaxf(x[it][e], 0.f);
             }
+            if (has_aux) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int m = mp + it * 8;
-                if (m < p.M) {
-                    const size_t co = cbase + (size_t)m * p.ldc + n;
-                    if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = x[it];
-                    else st4<bf16>(reinterpret_cast<bf16*>(p.C) + co, x[it]);
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[it][e] = gate[it][e] > 0.f ? x[it][e] * p.aux_scale : 0.f;
+            }
+            if (has_drop) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + mp + it * 8) * p.N + n + e);
+                        x[it][e] = drop_keep(p.drop_seed, idx, p.drop_thr) ? x[it][e] * p.drop_scale : 0.f;
+                    }
+            }
+            if (has_res) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[it][e] += res[it][e];
+            }
+            const bool interior = mw + 32 <= p.M;                                  // wave-uniform
+            const size_t co0 = cbase + (size_t)mp * p.ldc + n, rstep = (size_t)8 * p.ldc;
+            if (out_f32) {
+                float* cp = reinterpret_cast<float*>(p.C) + co0;
+                if (interior) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) *reinterpret_cast<f32x4*>(cp + it * rstep) = x[it];
+                } else {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) if (mp + it * 8 < p.M) *reinterpret_cast<f32x4*>(cp + it * rstep) = x[it];
+                }
+            } else {
+                bf16* cp = reinterpret_cast<bf16*>(p.C) + co0;
+                if (interior) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) st4<bf16>(cp + it * rstep, x[it]);
+                } else {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) if (mp + it * 8 < p.M) st4<bf16>(cp + it * rstep, x[it]);
                 }
             }
         } else {

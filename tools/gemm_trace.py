@@ -32,7 +32,7 @@ def run(M, N, K, res=True, drop=0.0):
     spread = t[:, 0].max() - t[:, 0].min()
     span = t[:, 4].max() - t[:, 0].min()
     print(f"M {M:5d} N {N:5d} K {K:5d} res {int(res)} drop {drop}: {e0.elapsed_time(e1) / 20 * 1e3:6.1f} us/launch | blocks {len(t)}  setup {d[0].mean():6.0f}  "
-          f"first tile {d[1].mean():6.0f}  K loop {d[2].mean():7.0f} ({d[2].mean() / (K // 64):5.0f}/tile)  epilogue {d[3].mean():6.0f}  "
+          f"first tile {d[1].mean():6.0f}  K loop {d[2].mean():7.0f} ({d[2].mean() / (K // 64):5.0f}/tile)  epilogue {d[3].mean():6.0f} (stores issued after {(t[:, 5] - t[:, 3]).mean():6.0f})  "
           f"block total {(t[:, 4] - t[:, 0]).mean():7.0f}  first entry -> last exit {span}  entry spread {spread}", flush=True)
 
 
