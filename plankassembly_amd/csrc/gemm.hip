@@ -415,20 +415,37 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                     }
                 }
                 if (!slab) {
+                    // one straight-line loop per optional stage behind its own uniform branch (see gemm3_kernel)
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
+                    for (int it = 0; it < NIT; ++it)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float y = x[it][e] * alpha + bias[e];
-                            if (p.relu) y = fmaxf(y, 0.f);
-                            if (has_aux) y = gate[it][e] > 0.f ? y * p.aux_scale : 0.f;
-                            if (has_drop) {
+                        for (int e = 0; e < 4; ++e) x[it][e] = x[it][e] * alpha + bias[e];
+                    if (p.relu) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[it][e] = fmaxf(x[it][e], 0.f);
+                    }
+                    if (has_aux) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[it][e] = gate[it][e] > 0.f ? x[it][e] * p.aux_scale : 0.f;
+                    }
+                    if (has_drop) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
                                 const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + mp + it * 4) * p.N + n + e);
-                                y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
+                                x[it][e] = drop_keep(p.drop_seed, idx, p.drop_thr) ? x[it][e] * p.drop_scale : 0.f;
                             }
-                            if (has_res) y += res[it][e];
-                            x[it][e] = y;
-                        }
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[it][e] += res[it][e];
                     }
                 }
                 TR(23);
