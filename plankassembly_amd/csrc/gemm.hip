@@ -1278,6 +1278,7 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
     __shared__ __attribute__((aligned(256))) char smem[NSTG * STAGE + 4 * EPI];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    PA_TR3(0);
     const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5;
     constexpr int esz = 2;
@@ -1522,10 +1523,12 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+    PA_TR3(1);
 #pragma unroll 1
     for (int k = 0; k < 3; ++k) if (cd_u < p.units) issue();
     wait_items(pending - 1);
     __builtin_amdgcn_s_barrier();
+    PA_TR3(2);
     int sc = 0;
     u32x4 F0[2], F1[2];
     frag(F0, lds0, 0);
@@ -1552,7 +1555,13 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
         if constexpr (HOT) { ++cc_t; return true; }
         else {
             if (++cc_t >= nt) {
+                PA_TR3(3);
                 epilogue(cun);
+#ifdef PA_GEMM_TRACE3
+                PA_TR3(5);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                PA_TR3(4);
                 cc_u += ustride; cc_t = 0;
                 if (cc_u < p.units) unit_of(cc_u, cun);
             }

@@ -25,7 +25,8 @@ def run(M, N, K, res=True, drop=0.0):
     fn.restype = C.c_int
     assert fn(buf.ctypes.data_as(C.c_void_p), C.c_int32(buf.size)) == 0
     t = buf.reshape(-1, 8).astype(np.int64)
-    nb = min(512, (M + 127) // 128 * ((N + 127) // 128))
+    tb = 64 if os.environ.get("SMALL") == "1" else 128
+    nb = min(512, (M + tb - 1) // tb * ((N + tb - 1) // tb))
     t = t[:nb]
     t = t[t[:, 4] > 0]
     d = [t[:, i + 1] - t[:, i] for i in range(4)]
@@ -36,6 +37,13 @@ def run(M, N, K, res=True, drop=0.0):
           f"block total {(t[:, 4] - t[:, 0]).mean():7.0f}  first entry -> last exit {span}  entry spread {spread}", flush=True)
 
 
+if os.environ.get("SMALL") == "1":
+    for K in (512, 1024, 1536):
+        run(2048, 512, K)
+    run(2048, 1536, 512, res=False)
+    run(2048, 1024, 512, res=False, drop=0.2)
+    run(256, 512, 512)
+    sys.exit(0)
 for K in (512, 1024, 1536):
     run(7940, 512, K)
 run(7940, 512, 512, res=False)
