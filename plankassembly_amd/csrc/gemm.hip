@@ -1727,28 +1727,60 @@ __global__ __launch_bounds__(NT, 1) void gemm3w_kernel(GemmP p) {
                             gate[it] = ld4<T>(reinterpret_cast<const T*>(p.aux) + ao);
                         }
                     }
+                    // one straight-line loop per optional stage behind its own uniform branch; stores with the output type and the
+                    // row test decided once (see gemm3_kernel)
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
+                    for (int it = 0; it < NIT; ++it)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float y = x[it][e] * p.alpha + bias[e];
-                            if (p.relu) y = fmaxf(y, 0.f);
-                            if (has_aux) y = gate[it][e] > 0.f ? y * p.aux_scale : 0.f;
-                            if (has_drop) {
-                                const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + mp + it * 8) * p.N + n + e);
-                                y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
-                            }
-                            if (has_res) y += res[it][e];
-                            x[it][e] = y;
-                        }
+                        for (int e = 0; e < 4; ++e) x[it][e] = x[it][e] * p.alpha + bias[e];
+                    if (p.relu) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[it][e] = fmaxf(x[it][e], 0.f);
                     }
+                    if (has_aux) {
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        const int m = mp + it * 8;
-                        if (m < p.M) {
-                            const size_t co = cbase + (size_t)m * p.ldc + n;
-                            if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = x[it];
-                            else st4<bf16>(reinterpret_cast<bf16*>(p.C) + co, x[it]);
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[it][e] = gate[it][e] > 0.f ? x[it][e] * p.aux_scale : 0.f;
+                    }
+                    if (has_drop) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + mp + it * 8) * p.N + n + e);
+                                x[it][e] = drop_keep(p.drop_seed, idx, p.drop_thr) ? x[it][e] * p.drop_scale : 0.f;
+                            }
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[it][e] += res[it][e];
+                    }
+                    {
+                        const bool interior = mw + 32 <= p.M;                          // wave-uniform
+                        const size_t co0 = cbase + (size_t)mp * p.ldc + n, rstep = (size_t)8 * p.ldc;
+                        if (out_f32) {
+                            float* cp = reinterpret_cast<float*>(p.C) + co0;
+                            if (interior) {
+#pragma unroll
+                                for (int it = 0; it < NIT; ++it) *reinterpret_cast<f32x4*>(cp + it * rstep) = x[it];
+                            } else {
+#pragma unroll
+                                for (int it = 0; it < NIT; ++it) if (mp + it * 8 < p.M) *reinterpret_cast<f32x4*>(cp + it * rstep) = x[it];
+                            }
+                        } else {
+                            bf16* cp = reinterpret_cast<bf16*>(p.C) + co0;
+                            if (interior) {
+#pragma unroll
+                                for (int it = 0; it < NIT; ++it) st4<bf16>(cp + it * rstep, x[it]);
+                            } else {
+#pragma unroll
+                                for (int it = 0; it < NIT; ++it) if (mp + it * 8 < p.M) st4<bf16>(cp + it * rstep, x[it]);
+                            }
                         }
                     }
                 } else {
@@ -2093,9 +2125,13 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     static const int use_small = getenv("PA_GEMM_SMALL") ? atoi(getenv("PA_GEMM_SMALL")) : 1;
     static const int small_max = getenv("PA_GEMM_SMALL_MAX") ? atoi(getenv("PA_GEMM_SMALL_MAX")) : 128;
     const bool go_small = go_v3 && use_small && a->a_kcontig && a->b_kcontig && splitk == 1 && valid_units <= small_max && a->K % 64 == 0;
-    static const int use_wide = getenv("PA_GEMM_WIDE") ? atoi(getenv("PA_GEMM_WIDE")) : 0;
-    const bool go_wide = use_v3 && use_wide && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds && is_aligned<bf16>(a) && a->a_kcontig &&
-                         a->b_kcontig && splitk == 1 && a->K % 64 == 0 && a->N >= 1024 && valid_units > 256;
+    // PA_GEMM_WIDE: 0 never, 1 every eligible launch, 2 (default) when the 128 x 256 tiling is a single round of blocks
+    // (7 940 x 1 024: 248 tiles - measured 15.5 us against 16.8 for the two-blocks-per-CU kernel once the epilogues were
+    // restructured; at N = 1 536 the 378 tiles are a round and a half and the two-blocks-per-CU kernel stays ahead)
+    static const int use_wide = getenv("PA_GEMM_WIDE") ? atoi(getenv("PA_GEMM_WIDE")) : 2;
+    const long long wide_tiles = (long long)((a->M + 127) / 128) * ((a->N + 255) / 256) * a->batch;
+    const bool go_wide = use_v3 && use_wide && (use_wide == 1 || wide_tiles <= cus) && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds &&
+                         is_aligned<bf16>(a) && a->a_kcontig && a->b_kcontig && splitk == 1 && a->K % 64 == 0 && a->N >= 1024 && valid_units > 256;
     if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_wide ? PA_GEMM_KIND_WIDE : (go_small ? PA_GEMM_KIND_SMALL : (go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR))); if (g_rec && g_rec_group) g_rec_group->push_back(-1); }
     // wide-tile ring kernel: large multi-round k-contiguous Linears (N >= 1024): 128 x 256 tiles
     if (go_wide) {
