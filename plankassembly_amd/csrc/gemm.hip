@@ -1138,9 +1138,12 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
     };
     int cd_u, cd_t = 0, cd_end = 0;             // DMA cursor: unit, next tile, end tile
     int cc_u, cc_t = 0, cc_end = 0;             // compute cursor
-    auto dma_enter = [&](int u) {               // position the DMA cursor at the first valid unit >= u
+    // `known`: the unit at `u` was already decoded (the compute cursor's first unit): its integer-division chain is ~1 000
+    // cycles for the lone wave of a SIMD, on the path to the block's first DMA
+    auto dma_enter = [&](int u, const Unit* known = nullptr) {   // position the DMA cursor at the first valid unit >= u
         Unit un;
-        cd_u = seek(u, un, pd, pd_i);
+        if (known) { un = *known; cd_u = u; pd = pc; pd_i = pc_i; }
+        else cd_u = seek(u, un, pd, pd_i);
         if (cd_u < total_units) {
             setup(un);
             cd_t = un.t_begin; cd_end = un.t_end;
@@ -1158,7 +1161,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
     };
     cmp_enter(blockIdx.x);
     if (cc_u >= total_units) return;
-    dma_enter(blockIdx.x);
+    dma_enter(cc_u, &cun);
     // Prefetch of the first unit's residual / gate tiles (bf16, vector path).  Issued BEFORE the first DMA instruction: loads
     // return in order, so the hand-counted `vmcnt` waits of the K loop (which count DMA instructions only) stay exact - these
     // loads are older than every DMA and are retired by the first of those waits, together with the first K tile.
