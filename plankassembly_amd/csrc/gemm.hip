@@ -754,6 +754,8 @@ __device__ __forceinline__ int total_units_of(const GemmGroup& g) { return g.beg
 #ifdef PA_GEMM_TRACE3
 // debug build only (tools/gemm_trace.py): per-block cycle stamps of the ring kernel
 __device__ unsigned long long pa_gemm3_trace[512 * 8];
+__device__ unsigned long long pa_gemm3_items[64];     // block 0: cycle stamp at the start of every K-tile item (bit 63: HOT)
+__device__ int pa_gemm3_nitems;
 #define PA_TR3(i) do { if (threadIdx.x == 0 && blockIdx.x < 512) pa_gemm3_trace[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PA_TR3(i) do { } while (0)
@@ -1200,6 +1202,9 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
     __builtin_amdgcn_s_barrier();
     PA_TR3(2);
     int sc = 0;
+#ifdef PA_GEMM_TRACE3
+    int tr_items = 0;
+#endif
     u32x4 F0[4], F1[4];
     using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
@@ -1213,6 +1218,9 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
         const uint32_t st = lds0 + sc * STAGE;
         // barrier A: every wave has finished the previous item, so its stage may be refilled (HOT: the DMA of the item
         // three ahead is spread over the four k-steps; otherwise it is issued here in one go)
+#ifdef PA_GEMM_TRACE3
+        if (threadIdx.x == 0 && blockIdx.x == 0 && tr_items < 63) pa_gemm3_items[tr_items++] = __builtin_readcyclecounter() | (HOT ? (1ull << 63) : 0ull);
+#endif
         BAR();
         if constexpr (!HOT) { if (cd_u < total_units) issue(); }
         step(F0, F1, st, S1{}, std::true_type{}, QA{});
@@ -1233,6 +1241,9 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
         else {
             if (++cc_t >= cc_end) {
                 PA_TR3(3);
+#ifdef PA_GEMM_TRACE3
+                if (threadIdx.x == 0 && blockIdx.x == 0) { pa_gemm3_items[tr_items] = __builtin_readcyclecounter(); pa_gemm3_nitems = tr_items; }
+#endif
                 epilogue(cun);
 #ifdef PA_GEMM_TRACE3
                 PA_TR3(5);                                     // every store of the tile issued
@@ -2733,5 +2744,11 @@ extern "C" int pa_colsum(const void* X, int32_t dtype, int32_t M, int32_t N, int
 #ifdef PA_GEMM_TRACE3
 extern "C" int pa_gemm3_trace_read(unsigned long long* out, int32_t n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_gemm3_trace), sizeof(unsigned long long) * (size_t)n);
+}
+extern "C" int pa_gemm3_items_read(unsigned long long* out) {      // out[0..63] stamps, returns the item count
+    int n = 0;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_gemm3_items), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(pa_gemm3_nitems), sizeof(int)) != hipSuccess) return -1;
+    return n;
 }
 #endif

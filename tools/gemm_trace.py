@@ -7,6 +7,20 @@ import numpy as np, torch
 from plankassembly_amd import ops, _lib as L
 
 
+def items(K):
+    fn = getattr(L.lib(), 'pa_gemm3_items_read', None)
+    if fn is None:
+        return
+    buf = np.zeros(64, dtype=np.uint64)
+    fn.restype = C.c_int
+    n = fn(buf.ctypes.data_as(C.c_void_p))
+    if n <= 0:
+        return
+    st = [int(x) & ((1 << 63) - 1) for x in buf[:n + 1]]
+    hot = ['H' if int(x) >> 63 else 'c' for x in buf[:n]]
+    print('    block 0 items (H = steady-state item, c = item at a unit boundary): ' + ' '.join(f'{hot[i]}{st[i + 1] - st[i]}' for i in range(n)), flush=True)
+
+
 def run(M, N, K, res=True, drop=0.0):
     x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
@@ -46,6 +60,7 @@ if os.environ.get("SMALL") == "1":
     sys.exit(0)
 for K in (512, 1024, 1536):
     run(7940, 512, K)
+    items(K)
 run(7940, 512, 512, res=False)
 run(7940, 512, 1024, drop=0.2)
 run(7940, 1024, 512, res=False)
