@@ -1012,6 +1012,7 @@ __global__ __launch_bounds__(NTH, 4) void attn_fwd_bf16_kernel(AttnP pin) {
                     }
                 }
             }
+            settle_mfma(sacc);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) mx = max3f(mx, sacc[r], sacc[r + 1]);
             mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl;
@@ -1560,6 +1561,7 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
                 }
             }
         }
+        settle_mfma(sacc[0], sacc[1], sacc[2], sacc[3]);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) mx = max3f(max3f(mx, sacc[kb][0], sacc[kb][1]), sacc[kb][2], sacc[kb][3]);
         mx = quad_max(mx) * sl;

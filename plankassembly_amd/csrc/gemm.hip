@@ -2501,12 +2501,12 @@ namespace {
 constexpr int CS_ROWS = 128;
 // out[n] += sum over this block's rows (f32 atomics: one per column per 128-row block)
 template <typename T, bool VEC>
-__device__ __forceinline__ void colsum_block(const T* X, int M, int N, int ldx, float* out, int bx, int by) {
+__device__ __forceinline__ void colsum_block(const T* X, int M, int N, int ldx, float* out, int bx, int by, int rows_per_block = CS_ROWS) {
     constexpr int EB = ET<T>::EB;
     __shared__ float red[4][64 * EB];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n0 = (bx * 64 + cl) * EB;
-    const int r0 = by * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    const int r0 = by * rows_per_block, r1 = min(M, r0 + rows_per_block);   // (rows_per_block >= M: the only contributor)
     float acc[EB];
 #pragma unroll
     for (int e = 0; e < EB; ++e) acc[e] = 0.f;
@@ -2532,11 +2532,12 @@ __device__ __forceinline__ void colsum_block(const T* X, int M, int N, int ldx, 
     }
 }
 template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, int ldx, float* out) {
-    colsum_block<T, VEC>(X, M, N, ldx, out, blockIdx.x, blockIdx.y);
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, int ldx, float* out, int rows_per_block) {
+    colsum_block<T, VEC>(X, M, N, ldx, out, blockIdx.x, blockIdx.y, rows_per_block);
 }
 // several matrices in one launch: block -> (descriptor, column block, row block)
-struct ColsumTab { pa_colsum_desc d[PA_MAX_COLSUM]; int begin[PA_MAX_COLSUM + 1]; int n; };
+struct ColsumTab { pa_colsum_desc d[PA_MAX_COLSUM]; int begin[PA_MAX_COLSUM + 1]; int n; int ordered; };
+static inline int colsum_row_blocks(int M, bool ordered) { return ordered ? 1 : (M + CS_ROWS - 1) / CS_ROWS; }
 template <typename T>
 __device__ __forceinline__ void colsum_many_block(const ColsumTab& t, int blk) {
     constexpr int EB = ET<T>::EB;
@@ -2545,7 +2546,7 @@ __device__ __forceinline__ void colsum_many_block(const ColsumTab& t, int blk) {
     const pa_colsum_desc d = t.d[di];
     const int nbx = (d.N + 64 * EB - 1) / (64 * EB);
     const int rel = blk - t.begin[di];
-    colsum_block<T, true>(reinterpret_cast<const T*>(d.X), d.M, d.N, d.ldx, d.out, rel % nbx, rel / nbx);
+    colsum_block<T, true>(reinterpret_cast<const T*>(d.X), d.M, d.N, d.ldx, d.out, rel % nbx, rel / nbx, t.ordered ? d.M : CS_ROWS);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_many_kernel(ColsumTab t) { colsum_many_block<T>(t, blockIdx.x); }
@@ -2557,15 +2558,15 @@ __global__ __launch_bounds__(256) void colsum_many_kernel(ColsumTab t) { colsum_
 // blocks there are ~1 000 partial rows per LayerNorm, and 24 blocks walking them 4 at a time were the longest part of the
 // tail.  The chunk sums are combined with one f32 atomic per column.
 constexpr int LN_CHUNKS = 8;
-struct LnTailTab { pa_ln_finish_desc d[PA_MAX_LN_FINISH]; int n; int ncols; int nbx; int nby; };
+struct LnTailTab { pa_ln_finish_desc d[PA_MAX_LN_FINISH]; int n; int ncols; int nbx; int nby; int chunks; };
 __device__ __forceinline__ void ln_finish_block(const LnTailTab& t, int blk) {
     __shared__ float red_ln[256];
-    const int ch = blk % LN_CHUNKS; blk /= LN_CHUNKS;
+    const int ch = blk % t.chunks; blk /= t.chunks;      // (chunks == 1: ordered - this block is the only contributor)
     const int bx = blk % t.nbx, by = (blk / t.nbx) % t.nby, bz = blk / (t.nbx * t.nby);
     const pa_ln_finish_desc d = t.d[bz];
     const int c = bx * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
     float* o = by == 0 ? d.dgamma : (by == 1 ? d.dbeta : d.dzsum);
-    const int per = (d.nparts + LN_CHUNKS - 1) / LN_CHUNKS, i0 = ch * per, i1 = min(d.nparts, i0 + per);
+    const int per = (d.nparts + t.chunks - 1) / t.chunks, i0 = ch * per, i1 = min(d.nparts, i0 + per);
     float sacc = 0.f;
     if (c < t.ncols && o) {
         const float* p = d.partial + (size_t)by * t.ncols + c;
@@ -2591,20 +2592,21 @@ extern "C" int pa_segment_tail(const pa_ln_finish_desc* ln, int32_t n_ln, int32_
     if ((n_ln && !ln) || (n_cs && !cs) || (n_rd && !rd) || n_ln + n_cs + n_rd == 0) return PA_EINVAL;
     if (dtype != PA_BF16 && dtype != PA_F32) return PA_EINVAL;
     const int EB = dtype == PA_BF16 ? 8 : 4;
-    LnTailTab lt; lt.n = n_ln; lt.ncols = d_model; lt.nbx = (d_model + 63) / 64; lt.nby = 2;
+    const bool ordered = pa_ordered_reductions(dtype);
+    LnTailTab lt; lt.n = n_ln; lt.ncols = d_model; lt.nbx = (d_model + 63) / 64; lt.nby = 2; lt.chunks = ordered ? 1 : LN_CHUNKS;
     for (int i = 0; i < n_ln; ++i) {
         if (!ln[i].partial || !ln[i].dgamma || !ln[i].dbeta || ln[i].nparts <= 0 || d_model <= 0) return PA_EINVAL;
         lt.d[i] = ln[i];
         if (ln[i].dzsum) lt.nby = 3;
     }
-    const int n_ln_blocks = n_ln ? lt.nbx * lt.nby * n_ln * LN_CHUNKS : 0;
-    ColsumTab ct; ct.n = n_cs; ct.begin[0] = 0;
+    const int n_ln_blocks = n_ln ? lt.nbx * lt.nby * n_ln * lt.chunks : 0;
+    ColsumTab ct; ct.n = n_cs; ct.begin[0] = 0; ct.ordered = ordered;
     for (int i = 0; i < n_cs; ++i) {
         const pa_colsum_desc& d = cs[i];
         if (!d.X || !d.out || d.M <= 0 || d.N <= 0) return PA_EINVAL;
         if ((reinterpret_cast<uintptr_t>(d.X) & 15) || d.ldx % EB || d.ldx < (d.N + EB - 1) / EB * EB) return PA_EALIGN;
         ct.d[i] = d;
-        ct.begin[i + 1] = ct.begin[i] + ((d.N + 64 * EB - 1) / (64 * EB)) * ((d.M + CS_ROWS - 1) / CS_ROWS);
+        ct.begin[i + 1] = ct.begin[i] + ((d.N + 64 * EB - 1) / (64 * EB)) * colsum_row_blocks(d.M, ordered);
     }
     ReduceTab rt; rt.n = n_rd; rt.begin[0] = 0;
     for (int i = 0; i < n_rd; ++i) {
@@ -2623,14 +2625,15 @@ extern "C" int pa_segment_tail(const pa_ln_finish_desc* ln, int32_t n_ln, int32_
 extern "C" int pa_colsum_many(const pa_colsum_desc* descs, int32_t n_desc, int32_t dtype, void* stream) {
     if (!descs || n_desc <= 0 || n_desc > PA_MAX_COLSUM) return PA_EINVAL;
     const int EB = dtype == PA_BF16 ? 8 : 4;
-    ColsumTab t; t.n = n_desc; t.begin[0] = 0;
+    const bool ordered = pa_ordered_reductions(dtype);
+    ColsumTab t; t.n = n_desc; t.begin[0] = 0; t.ordered = ordered;
     for (int i = 0; i < n_desc; ++i) {
         const pa_colsum_desc& d = descs[i];
         if (!d.X || !d.out || d.M <= 0 || d.N <= 0) return PA_EINVAL;
         // vector path only: 16-byte aligned rows whose allocation covers the last vector
         if ((reinterpret_cast<uintptr_t>(d.X) & 15) || d.ldx % EB || d.ldx < (d.N + EB - 1) / EB * EB) return PA_EALIGN;
         t.d[i] = d;
-        t.begin[i + 1] = t.begin[i] + ((d.N + 64 * EB - 1) / (64 * EB)) * ((d.M + CS_ROWS - 1) / CS_ROWS);
+        t.begin[i + 1] = t.begin[i] + ((d.N + 64 * EB - 1) / (64 * EB)) * colsum_row_blocks(d.M, ordered);
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == PA_BF16) PA_LAUNCH(colsum_many_kernel<bf16>, dim3(t.begin[n_desc]), dim3(256), 0, st, t);
@@ -2726,17 +2729,18 @@ extern "C" int pa_colsum(const void* X, int32_t dtype, int32_t M, int32_t N, int
         hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
-    const int nparts = (M + CS_ROWS - 1) / CS_ROWS;
+    const bool ordered = pa_ordered_reductions(dtype);
+    const int nparts = colsum_row_blocks(M, ordered), rpb = ordered ? M : CS_ROWS;
     const int EB = dtype == PA_BF16 ? 8 : 4;
     // vector path: every 16-byte chunk of a row is fully inside the row allocation (ldx >= round-up of N) and aligned
     const bool vec = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ldx % EB == 0 && ldx >= (N + EB - 1) / EB * EB;
     dim3 grid((N + 64 * EB - 1) / (64 * EB), nparts);
     if (dtype == PA_BF16) {
-        if (vec) PA_LAUNCH((colsum_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)X, M, N, ldx, out);
-        else PA_LAUNCH((colsum_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)X, M, N, ldx, out);
+        if (vec) PA_LAUNCH((colsum_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)X, M, N, ldx, out, rpb);
+        else PA_LAUNCH((colsum_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)X, M, N, ldx, out, rpb);
     } else {
-        if (vec) PA_LAUNCH((colsum_kernel<float, true>), grid, dim3(256), 0, st, (const float*)X, M, N, ldx, out);
-        else PA_LAUNCH((colsum_kernel<float, false>), grid, dim3(256), 0, st, (const float*)X, M, N, ldx, out);
+        if (vec) PA_LAUNCH((colsum_kernel<float, true>), grid, dim3(256), 0, st, (const float*)X, M, N, ldx, out, rpb);
+        else PA_LAUNCH((colsum_kernel<float, false>), grid, dim3(256), 0, st, (const float*)X, M, N, ldx, out, rpb);
     }
     return 0;
 }

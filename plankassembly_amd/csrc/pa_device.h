@@ -17,6 +17,16 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define PA_F32 0
 #define PA_BF16 1
 
+// Ordered (run-to-run bit-identical) gradient reductions.  The f32 path is the parity path: its column sums, LayerNorm
+// gamma/beta finishes and embedding-table segment sums then have ONE contributor per output element (a single block walks
+// all rows in order) instead of several blocks meeting in f32 atomics.  bf16 keeps the faster multi-block form.
+// PA_DETERMINISTIC=0/1 forces either for both dtypes.
+#include <stdlib.h>
+static inline bool pa_ordered_reductions(int dtype) {
+    static const int env = getenv("PA_DETERMINISTIC") ? atoi(getenv("PA_DETERMINISTIC")) : -1;
+    return env < 0 ? dtype == PA_F32 : env != 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // element traits: EB = elements per 16-byte vector; KC = contraction elements one mma16B() covers
 template <typename T> struct ET;
@@ -114,11 +124,15 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t 
 // C and reads A per query tile.  thr32 = p * 2^32, so the drop probability is p to 2^-32 (no quantisation) and the
 // survivors' 1/(1-p) is exact.  Statistics (keep rate, row / column variance, pair correlations, 2 x 2 parity, spectrum
 // of a 256 x 256 block) checked against the binomial expectation; tests/test_kernels_gpu.py checks rate and determinism.
+// Both factors are ODD and have bit 23 SET (values in [2^23, 2^24)): the 48-bit product is then at least 2^46 and its low
+// 32 bits have wrapped at least 2^14 times whatever the two hashes are.  Without the forced top bit a small row hash
+// (A < 52 at p = 0.2: A * C < thr32 for every key) dropped a whole attention row, and A < ~300 kept only 50-70 % of it
+// (ADVICE r2); tests/test_kernels_gpu.py::test_attention_dropout_keep_rate_per_row_and_key checks the smallest hashes.
 __device__ __forceinline__ uint32_t drop_row_hash(uint32_t seed, uint32_t row) {
-    return mix32(row * 0x9e3779b9u + seed) & 0xffffffu;
+    return (mix32(row * 0x9e3779b9u + seed) & 0xffffffu) | 0x800001u;
 }
 __device__ __forceinline__ uint32_t drop_key_hash(uint32_t seed, uint32_t key) {
-    return (mix32(key * 0x85ebca6bu + (seed ^ 0x5bd1e995u)) | 1u) & 0xffffffu;
+    return (mix32(key * 0x85ebca6bu + (seed ^ 0x5bd1e995u)) & 0xffffffu) | 0x800001u;
 }
 __device__ __forceinline__ bool drop_keep2(uint32_t a, uint32_t c, uint32_t thr32) { return __umul24(a, c) >= thr32; }
 
@@ -129,6 +143,15 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
+}
+// hipcc's hazard recogniser does not look inside an asm statement: a v_max3_f32 that reads an MFMA result needs the
+// XDL-write -> VALU-read wait states (8-pass 32x32x16: 12 states) like any other VALU reader, and whether a
+// compiler-visible reader happens to sit in between is scheduling luck.  settle_mfma() is placed between
+// the last MFMA of a score tile and the first max3f on it: the "+v" operands pin the MFMAs before it and every reader
+// after it, the s_nops are the wait states (scalar issue slots of this wave only; the SIMD's other waves keep issuing).
+__device__ __forceinline__ void settle_mfma(f32x16& a) { asm volatile("s_nop 7\n\ts_nop 4" : "+v"(a)); }
+__device__ __forceinline__ void settle_mfma(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+    asm volatile("s_nop 7\n\ts_nop 4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -773,7 +773,7 @@ __device__ __forceinline__ f32x4 seg_sum(const T* dout, const int32_t* order, in
 // ch[k] == 0: one block per SEG_CHUNK consecutive entries of the sorted order, whatever rows they belong to (a table with a
 // handful of rows has segments of thousands of tokens); per overlapped row one atomic per column.
 template <typename T>
-__global__ __launch_bounds__(128) void embed_segment_bwd_kernel(const T* dout, SegTab tb, int d) {
+__global__ __launch_bounds__(128) void embed_segment_bwd_kernel(const T* dout, SegTab tb, int d, int seg_long) {
     int k = 0;
     while (k + 1 < tb.n && (int)blockIdx.x >= tb.begin[k + 1]) ++k;
     const int rel = blockIdx.x - tb.begin[k];
@@ -785,8 +785,8 @@ __global__ __launch_bounds__(128) void embed_segment_bwd_kernel(const T* dout, S
         // over all of them, which then combine with atomics.
         const int r = rel / SEG_SPLIT, j = rel - r * SEG_SPLIT;
         const int b0 = seg[r], b1 = seg[r + 1], len = b1 - b0;
-        if (len <= 0 || (len <= SEG_LONG && j > 0)) return;
-        const bool multi = len > SEG_LONG;
+        if (len <= 0 || (len <= seg_long && j > 0)) return;      // (ordered mode: seg_long = INT_MAX, block 0 sums the whole row)
+        const bool multi = len > seg_long;
         const int per = multi ? (len + SEG_SPLIT - 1) / SEG_SPLIT : len;
         const int lo = b0 + j * per, hi = min(b1, lo + per);
         if (lo >= hi) return;
@@ -818,15 +818,18 @@ extern "C" int pa_embed_segment_bwd(const void* dout, int32_t dtype, float* cons
                                     const int32_t* const* seg, const int32_t* table_rows, int32_t n_tables, int64_t n_rows,
                                     int32_t d, void* stream) {
     if (!dout || !dtables || !order || !seg || !table_rows || n_tables < 1 || n_tables > PA_MAX_SEG_TABLES || (d & 3) || n_rows <= 0) return PA_EINVAL;
+    // ordered (f32 parity path): every table row is summed by ONE block walking its whole segment in order - no atomics
+    const bool ordered = pa_ordered_reductions(dtype);
+    const int seg_long = ordered ? 0x7fffffff : SEG_LONG;
     SegTab tb; tb.n = n_tables; tb.begin[0] = 0;
     for (int k = 0; k < n_tables; ++k) {
         tb.t[k] = dtables[k]; tb.order[k] = order[k]; tb.seg[k] = seg[k]; tb.rows[k] = table_rows[k];
         if (!tb.t[k] || !tb.order[k] || !tb.seg[k] || tb.rows[k] <= 0) return PA_EINVAL;
-        tb.ch[k] = tb.rows[k] > 64 ? 1 : 0;
+        tb.ch[k] = (ordered || tb.rows[k] > 64) ? 1 : 0;
         tb.begin[k + 1] = tb.begin[k] + (tb.ch[k] ? tb.rows[k] * SEG_SPLIT : (int)((n_rows + SEG_CHUNK - 1) / SEG_CHUNK));
     }
-    if (dtype == PA_BF16) PA_LAUNCH(embed_segment_bwd_kernel<bf16>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const bf16*)dout, tb, d);
-    else PA_LAUNCH(embed_segment_bwd_kernel<float>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const float*)dout, tb, d);
+    if (dtype == PA_BF16) PA_LAUNCH(embed_segment_bwd_kernel<bf16>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const bf16*)dout, tb, d, seg_long);
+    else PA_LAUNCH(embed_segment_bwd_kernel<float>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const float*)dout, tb, d, seg_long);
     return 0;
 }
 

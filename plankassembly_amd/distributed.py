@@ -45,6 +45,7 @@ class GradSync:
             raise ValueError("grad_dtype must be 'f32' or 'bf16'")
         self._lp = None               # bf16 staging buffer of the flat gradients (grad_dtype == 'bf16')
         self._works = []
+        self._to_widen = []           # [(target buffer, lo, hi)] bf16 slices in flight that wait() casts back exactly once
         self._pending = None          # (lo, hi) run of contiguous finished-but-unsent slices
         self.launched = []            # [(lo, hi)] of the last backward, for tests / introspection
         self.fired = []               # segment indices in the order the hook saw them (tests)
@@ -58,6 +59,7 @@ class GradSync:
     # the flat-buffer order is the reverse of the backward order, so finished slices extend DOWNWARDS
     def _on_segment(self, seg, lo, hi):
         if seg == 0:
+            self.wait()                     # (a backward that was abandoned half way leaves nothing behind)
             self._works, self.launched, self._pending, self.fired = [], [], None, []
         self.fired.append(seg)
         if self._pending is None:
@@ -93,6 +95,7 @@ class GradSync:
                 self._lp = torch.empty(g.numel(), dtype=torch.bfloat16, device=g.device)
             buf = self._lp[lo:hi]
             self._cast(buf, g[lo:hi])
+            self._to_widen.append((g, lo, hi))      # the buffer this slice came from: it may differ by the time of wait()
         self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.launched.append((lo, hi))
 
@@ -103,15 +106,16 @@ class GradSync:
         L.check(L.lib().pa_cast(L.ptr(dst), L.dt(dst), L.ptr(src), L.dt(src), C.c_int64(src.numel()), L.stream()), "pa_cast")
 
     def wait(self):
+        """Block (stream-level on the GPU) until every collective launched so far has finished; bf16 exchanges are widened
+        back into the buffer they were taken from.  Idempotent: a second call finds nothing to do, so it can neither
+        re-cast stale staging data nor - with gradient accumulation, where the slices come from the fresh micro-batch
+        buffer and not from the accumulated one - write into a different buffer than the one that was reduced."""
         for w in self._works:
             w.wait()                        # stream-level wait on GPU, blocking on gloo
         self._works = []
-        if self.grad_dtype == "bf16" and self._lp is not None and self.launched:
-            g = getattr(self.model, "grad_sync_buffer", None)
-            if g is None:
-                g = self.model.flat_grads
-            for lo, hi in self.launched:    # widen the reduced sums back (after the collectives, before Adam)
-                self._cast(g[lo:hi], self._lp[lo:hi])
+        widen, self._to_widen = self._to_widen, []
+        for g, lo, hi in widen:             # the reduced sums, after the collectives and before Adam
+            self._cast(g[lo:hi], self._lp[lo:hi])
 
     def broadcast_parameters(self, src=0):
         """DDP constructor semantics: every rank starts from rank ``src``'s parameters."""
@@ -123,7 +127,8 @@ class GradSync:
 def allreduce_metric_sums(values, group=None):
     """Sum a small vector of metric accumulators over ranks (reference plankassembly/metric.py:13-16,
     ``dist_reduce_fx='sum'``; trainer_complete.py:87-89 ``sync_dist=True``)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
+        # (world size 1 included: `torchrun --nproc-per-node 1` must exercise the same path as 8 ranks do)
         backend = str(dist.get_backend(group)).lower()
         if values.device.type == "cpu" and "nccl" in backend and "gloo" not in backend:
             # the trainer / bench initialise an RCCL-only group: it has no CPU backend, so the (CPU, float64) metric

@@ -78,3 +78,25 @@ class Criterion:
 
 def build_criterion():
     return Criterion()
+
+
+class PlankScorer:
+    """One sample at a time: match predicted planks against ground-truth planks (row 0 of both is the overall bounding
+    box and takes no part - reference trainer_complete.py:80, evaluate.py:54), feed the running means, hand the three
+    numbers back.  The validation / test hooks of the trainers and the offline re-scoring of evaluate.py all go
+    through here, so a sample is scored the same way wherever it is scored."""
+
+    def __init__(self, threshold: float):
+        self.matcher = build_matcher(threshold)
+        self.criterion = build_criterion()
+
+    def add(self, planks, truth):
+        scores = self.matcher(planks[1:], truth[1:])
+        self.criterion.update(*scores)
+        return {"precision": float(scores[0]), "recall": float(scores[1]), "fmeasure": float(scores[2])}
+
+    def means(self, sync=True):
+        """(precision, recall, fmeasure) averaged over every sample added since the last call; resets."""
+        out = tuple(float(x) for x in self.criterion.compute(sync=sync))
+        self.criterion.reset()
+        return out

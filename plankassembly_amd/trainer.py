@@ -26,7 +26,7 @@ import torch.distributed as dist
 from .config import CfgNode, load_cli_config
 from .data import SynthSpec, synth_sample
 from .datasets import LineDataset, SidefaceDataset, parse_splits_list  # noqa: F401  (parse_splits_list re-exported)
-from .metric import build_criterion, build_matcher
+from .metric import PlankScorer
 from .models import build_model
 
 
@@ -74,8 +74,8 @@ class Trainer(torch.nn.Module):
         cfg = CfgNode(hparams)
         self.cfg = cfg
         self.model = build_model(cfg)
-        self.matcher = build_matcher(cfg.THRESHOLD)
-        self.criterion = build_criterion()
+        self.scorer = PlankScorer(cfg.THRESHOLD)
+        self.matcher, self.criterion = self.scorer.matcher, self.scorer.criterion      # the reference's attribute names
         self.logger = None
         self.global_step = 0
         self._logged = {}
@@ -140,14 +140,14 @@ class Trainer(torch.nn.Module):
     def validation_step(self, batch, batch_idx):
         outputs = self.model(batch)
         for pred, gt in zip(outputs["predicts"], outputs["groundtruths"]):
-            vp = self._valid_pred(pred)
-            prec, rec, f1 = self.matcher(vp[1:], gt[1:])
-            self.criterion.update(prec, rec, f1)
+            self.scorer.add(self._valid_pred(pred), gt)
+
+    def _log_means(self, stage):
+        for key, value in zip(("precision", "recall", "fmeasure"), self.scorer.means()):
+            self.log(f"{stage}/{key}", value)
 
     def validation_epoch_end(self, outputs=None):
-        prec, rec, f1 = self.criterion.compute()
-        self.criterion.reset()
-        self.log("val/precision", prec); self.log("val/recall", rec); self.log("val/fmeasure", f1)
+        self._log_means("val")
 
     def test_step(self, batch, batch_idx):
         outputs = self.model(batch)
@@ -155,19 +155,20 @@ class Trainer(torch.nn.Module):
         os.makedirs(out_dir, exist_ok=True)
         for name, pred, gt, atta in zip(batch["name"], outputs["predicts"], outputs["groundtruths"], outputs["attach"]):
             vp = self._valid_pred(pred)
-            prec, rec, f1 = self.matcher(vp[1:], gt[1:])
-            self.criterion.update(prec, rec, f1)
+            scores = self.scorer.add(vp, gt)
             atta = atta[: vp.numel()].cpu().numpy()
             atta = atta[: len(atta) // 6 * 6].reshape(-1, 6).tolist()
-            with open(os.path.join(out_dir, f"{name}.json"), "w") as f:
-                json.dump({"prediction": vp.cpu().numpy().reshape(-1, 6).tolist(), "attach": atta,
-                           "groundtruth": gt.cpu().numpy().reshape(-1, 6).tolist(), "precision": prec.item(),
-                           "recall": rec.item(), "fmeasure": f1.item()}, f, indent=4, separators=(", ", ": "))
+            self._write_pred_json(out_dir, name, {"prediction": vp.cpu().numpy().reshape(-1, 6).tolist(), "attach": atta,
+                                                  "groundtruth": gt.cpu().numpy().reshape(-1, 6).tolist(), **scores})
+
+    @staticmethod
+    def _write_pred_json(out_dir, name, record):
+        """One `pred_jsons/<name>.json` in the reference's on-disk format (trainer_complete.py:104-118)."""
+        with open(os.path.join(out_dir, f"{name}.json"), "w") as f:
+            json.dump(record, f, indent=4, separators=(", ", ": "))
 
     def test_epoch_end(self, outputs=None):
-        prec, rec, f1 = self.criterion.compute()
-        self.criterion.reset()
-        self.log("test/precision", prec); self.log("test/recall", rec); self.log("test/fmeasure", f1)
+        self._log_means("test")
 
     def configure_optimizers(self):
         from .optim import FusedAdam
@@ -175,16 +176,20 @@ class Trainer(torch.nn.Module):
         return {"optimizer": FusedAdam(self.model, lr=self.cfg.LR, grad_scale=1.0 / world)}
 
     # ------------------------------------------------------------------ checkpoints (Lightning-shaped)
-    def checkpoint(self, epoch, optimizer=None, best_score=None):
-        """The dict pytorch_lightning 1.7's ModelCheckpoint writes for the reference (configs/train_complete.yaml:6-14):
-        `state_dict` with the `model.` prefix, `optimizer_states` in torch.optim.Adam's layout, `hyper_parameters`
-        (save_hyperparameters(hparams), trainer_complete.py:24), epoch / global_step, callbacks, loops - so that a file
-        written here loads in the reference's Lightning CLI and vice versa."""
+    def checkpoint(self, epoch, optimizer=None, best_score=None, steps_this_epoch=0, best_path="", last_path=""):
+        """A pytorch_lightning-1.7-shaped checkpoint dict, the layout ModelCheckpoint writes for the reference
+        (configs/train_complete.yaml:6-14): `state_dict` with the `model.` prefix, `optimizer_states` in
+        torch.optim.Adam's layout, `hyper_parameters` (save_hyperparameters(hparams), trainer_complete.py:24), epoch /
+        global_step, and the loop / callback records of `lightning_state`.  Guaranteed (tested) interop: weights +
+        hyper-parameters + Adam state, both directions, and `fit --ckpt_path` resume inside THIS trainer.  The loop and
+        callback records follow Lightning 1.7's schema from its source but no Lightning process has read them (it is
+        not installable here), so resuming one of these files inside Lightning itself is unverified - INTEGRATION.md."""
+        from . import lightning_state as LS
         ck = {"epoch": epoch, "global_step": self.global_step, "pytorch-lightning_version": "1.7.7",
               "state_dict": {"model." + k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
-              "loops": {"fit_loop": {"state_dict": {}, "epoch_progress": {"current": {"completed": epoch + 1}}}},
-              "callbacks": {"ModelCheckpoint": {"monitor": "val/fmeasure",
-                                                "best_model_score": None if best_score is None else torch.tensor(float(best_score))}},
+              "loops": LS.loops_state(epoch + 1, self.global_step, steps_this_epoch),
+              "callbacks": {LS.checkpoint_callback_key(): LS.checkpoint_callback_state(best_score, best_path, last_path,
+                                                                                       os.path.dirname(last_path))},
               "optimizer_states": [], "lr_schedulers": [],
               "hparams_name": "hparams", "hyper_parameters": {"hparams": self.hparams_dict}}
         if optimizer is not None:
@@ -192,13 +197,26 @@ class Trainer(torch.nn.Module):
                                       else optimizer.state_dict()]
         return ck
 
+    @staticmethod
+    def _read_checkpoint_file(path):
+        """torch.load restricted to tensors / containers / plain scalars (`weights_only=True`).  A file that needs more
+        than that (arbitrary pickled objects - older Lightning files can carry argparse Namespaces or callback objects) is
+        refused unless PLANK_TRUST_CHECKPOINT=1: unpickling runs code from the file, and `--ckpt_path` is user input."""
+        import pickle
+        try:
+            return torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as exc:
+            if os.environ.get("PLANK_TRUST_CHECKPOINT") != "1":
+                raise RuntimeError(f"{path}: not loadable with weights_only=True ({exc}); set PLANK_TRUST_CHECKPOINT=1 to "
+                                   f"unpickle it anyway - only for files you trust") from exc
+            print(f"[plankassembly_amd] WARNING: unpickling {path} without restrictions (PLANK_TRUST_CHECKPOINT=1)")
+            return torch.load(path, map_location="cpu", weights_only=False)
+
     def load_checkpoint(self, path, optimizer=None):
         """Weights always; with ``optimizer`` also the Adam moments / step, epoch and global_step (what Lightning's
         ``fit --ckpt_path`` resumes).  Returns the checkpoint dict."""
-        try:
-            ck = torch.load(path, map_location="cpu", weights_only=True)
-        except Exception:                                           # pickled non-tensor payloads (older files)
-            ck = torch.load(path, map_location="cpu", weights_only=False)
+        from . import lightning_state as LS
+        ck = self._read_checkpoint_file(path)
         sd = ck.get("state_dict", ck)
         sd = {(k[6:] if k.startswith("model.") else k): v for k, v in sd.items()}
         self.model.load_state_dict(sd)
@@ -206,11 +224,10 @@ class Trainer(torch.nn.Module):
             optimizer.load_state_dict(ck["optimizer_states"][0])
         if optimizer is not None:
             self.global_step = int(ck.get("global_step", 0))
-            self.resume_epoch = int(ck.get("epoch", -1)) + 1
-            best = (ck.get("callbacks") or {})
-            for v in best.values():
-                if isinstance(v, dict) and v.get("best_model_score") is not None:
-                    self.resume_best = float(v["best_model_score"])
+            self.resume_epoch = LS.epochs_done_of(ck)
+            for key, state in (ck.get("callbacks") or {}).items():
+                if str(key).startswith("ModelCheckpoint") and isinstance(state, dict) and state.get("best_model_score") is not None:
+                    self.resume_best = float(state["best_model_score"])
         return ck
 
 
@@ -234,15 +251,12 @@ class SidefaceTrainer(Trainer):
         for name, mask, pred, gt in zip(batch["name"], batch["input_mask"], outputs["predicts"], outputs["groundtruths"]):
             gtl = gt.cpu().numpy().reshape(-1, 6).tolist()
             if bool(torch.all(mask[1:])):
-                predl, (prec, rec, f1) = [], (torch.tensor(0.0),) * 3
+                predl, scores = [], {"precision": 0.0, "recall": 0.0, "fmeasure": 0.0}
             else:
                 vp = self._valid_pred(pred)
-                prec, rec, f1 = self.matcher(vp[1:], gt[1:])
-                self.criterion.update(prec, rec, f1)
+                scores = self.scorer.add(vp, gt)
                 predl = vp.cpu().numpy().reshape(-1, 6).tolist()
-            with open(os.path.join(out_dir, f"{name}.json"), "w") as f:
-                json.dump({"prediction": predl, "groundtruth": gtl, "precision": prec.item(), "recall": rec.item(),
-                           "fmeasure": f1.item()}, f, indent=4, separators=(", ", ": "))
+            self._write_pred_json(out_dir, name, {"prediction": predl, "groundtruth": gtl, **scores})
 
 
 # ====================================================================================== loop + CLI
@@ -282,7 +296,8 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
             print({k: round(v, 4) for k, v in module._logged.items()})
         return module
     opt = module.configure_optimizers()["optimizer"]
-    start_epoch, best = 0, -1.0
+    module.optimizer = opt
+    start_epoch, best, best_file = 0, -1.0, ""
     if ckpt_path:                                  # fit --ckpt_path: weights + Adam state + counters, like Lightning
         module.load_checkpoint(ckpt_path, optimizer=opt)
         start_epoch = getattr(module, "resume_epoch", 0)
@@ -300,7 +315,7 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
         module.model.train()
         if hasattr(loader.sampler, "set_epoch"):
             loader.sampler.set_epoch(epoch)
-        t0, n = time.perf_counter(), 0
+        t0, n, steps_here = time.perf_counter(), 0, 0
         from .data import DevicePrefetcher
         for i, batch in enumerate(DevicePrefetcher(module.model, loader)):     # batch i + 1 is prepared while step i runs
             opt.zero_grad()
@@ -308,6 +323,7 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
             loss.backward()
             opt.step()
             module.global_step += 1
+            steps_here += 1
             n += batch["input_value"].shape[0]
             if 0 < max_steps <= module.global_step:
                 break
@@ -319,9 +335,10 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
                   f"{n * world / (time.perf_counter() - t0):.1f} samples/s")
         if (epoch + 1) % every == 0:
             ckdir = os.path.join(module.logger.log_dir, "checkpoints")
+            last = os.path.join(ckdir, "last.ckpt")
             if rank == 0:                                              # save_last: before the metric exchange, so a failure
                 os.makedirs(ckdir, exist_ok=True)                      # in validation cannot lose the epoch's weights
-                torch.save(module.checkpoint(epoch, opt, best if best >= 0 else None), os.path.join(ckdir, "last.ckpt"))
+                torch.save(module.checkpoint(epoch, opt, best if best >= 0 else None, steps_here, best_file, last), last)
             module.model.eval()
             with torch.no_grad():
                 for i, batch in enumerate(module.val_dataloader()):
@@ -329,13 +346,18 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
             module.validation_epoch_end()
             f1 = module._logged.get("val/fmeasure", 0.0)
             if rank == 0:
-                ck = module.checkpoint(epoch, opt, max(best, f1))
-                torch.save(ck, os.path.join(ckdir, "last.ckpt"))
-                if f1 > best:                                      # ModelCheckpoint(monitor=val/fmeasure, mode=max)
+                improved = f1 > best                                   # ModelCheckpoint(monitor=val/fmeasure, mode=max)
+                if improved:
                     best = f1
-                    name = (f"checkpoint_{epoch:03d}-precision={module._logged['val/precision']:.3f}-"
-                            f"recall={module._logged['val/recall']:.3f}-f1={f1:.3f}.ckpt")
-                    torch.save(ck, os.path.join(module.logger.log_dir, "checkpoints", name))
+                    stale, best_file = best_file, os.path.join(ckdir, (
+                        f"checkpoint_{epoch:03d}-precision={module._logged['val/precision']:.3f}-"
+                        f"recall={module._logged['val/recall']:.3f}-f1={f1:.3f}.ckpt"))
+                ck = module.checkpoint(epoch, opt, best, steps_here, best_file, last)
+                torch.save(ck, last)
+                if improved:
+                    torch.save(ck, best_file)
+                    if stale and stale != best_file and os.path.exists(stale):
+                        os.remove(stale)                               # save_top_k: 1
                 print({k: round(v, 4) for k, v in module._logged.items() if k.startswith("val/")})
         if 0 < max_steps <= module.global_step:
             break

@@ -13,6 +13,8 @@ L2 norm, sum and leading slice; for the headline case additionally the greedy to
   fixture_headline.npz  S=1024 (MAX_INPUT_LENGTH 1025), T=128, B=2 train; B=4 greedy decode, 128 steps
   fixture_visible.npz   S=999, B=2 (train_visible.yaml lengths)
   fixture_sideface.npz  S=299, B=16, no `input_type`, two empty rows [END, PAD, ...] (train_sideface.yaml)
+  fixture_t1024.npz     S=1024, T=1024 (MAX_OUTPUT_LENGTH 1024), B=2 train; B=2 greedy decode of ALL 1024 steps (END
+                        logit suppressed) by the reference's own O(T^2) loop - ~35 TFLOP per sequence, minutes
   fixture_live.npz      d=64 fixture config, untrained seeded weights (loss ~ log 514): all gradients
 """
 import os
@@ -34,7 +36,7 @@ import torch
 from plankassembly.models import PlankModel          # the reference (namespace package)
 from plankassembly_amd.data import SynthSpec, spec_for, synth_batch
 from seeded import seeded_state_dict
-from large_cases import CASES, GAINS, SLICE, case_batch, grad_summary, make_empty_rows   # shared with the tests
+from large_cases import CASES, GAINS, SLICE, case_batch, grad_summary, make_empty_rows, suppress_end   # shared with the tests
 
 TOKEN = types.SimpleNamespace(END=512, PAD=513)
 
@@ -43,6 +45,8 @@ def ref_model(c):
     m = PlankModel(c["d"], c["h"], c["ff"], 0.0, "relu", True, c["ne"], c["nd"], 3, 2, 4, 6, c["max_in"], c["max_out"],
                    514, TOKEN)
     sd = seeded_state_dict(((k, v.shape) for k, v in m.state_dict().items()), c["wseed"], c["gains"])
+    if c.get("no_end"):
+        suppress_end(sd)
     m.load_state_dict(sd)
     return m, sd
 

@@ -23,6 +23,16 @@ CASES = {
                      decode_b=4, decode_seed=6),
     "visible": dict(BIG, max_in=1000, max_out=128, B=2, wseed=12, bseed=7, lines=(8, 249), with_type=True),
     "sideface": dict(BIG, max_in=300, max_out=128, B=16, wseed=13, bseed=9, lines=(0, 74), with_type=False, empty_rows=(3, 11)),
+    # BASELINE configs[4] / SURVEY 8d "T = 1024 variant": MAX_OUTPUT_LENGTH 1024.  Train step with T = 1024 (171 rows of
+    # query_pos_embedding, 514 + 1024 labels) and a greedy decode that runs ALL 1024 steps: `no_end` pushes the END logit
+    # down (vocab_head.bias[512] -= 50) so that no row ever samples END and the reference's own loop (models.py:267-307)
+    # cannot stop early.
+    # Its head gains differ from GAINS: with 1 000 pointer candidates the pointer softmax is flat unless the pointer logits
+    # are as peaked as the vocabulary logits; with these the pointer fires 119 times (81 times past step 128, targets up to
+    # step 223+) and the smallest relative top-2 margin of the 2 048 sampled rows is 2.1e-4.
+    "t1024": dict(BIG, max_in=1025, max_out=1024, B=2, wseed=58, bseed=21, lines=(8, 255), planks=(2, 170), with_type=True,
+                  decode_b=2, decode_seed=22, no_end=True,
+                  gains=dict(GAINS, **{"pointer_head.weight": 120.0, "vocab_head.weight": 4.0})),
     "live": dict(d=64, h=4, ff=128, ne=2, nd=2, gains={}, max_in=65, max_out=36, B=4, wseed=3, bseed=2022,
                  lines=(3, 15), planks=(2, 5), with_type=True, all_grads=True),
 }
@@ -74,9 +84,17 @@ def case_shapes(c):
     return [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
 
 
+def suppress_end(sd):
+    """END can never be the argmax: the 1024-step decode fixture must run every step (see CASES['t1024'])."""
+    sd["vocab_head.bias"] = sd["vocab_head.bias"].clone()
+    sd["vocab_head.bias"][512] -= 50.0
+    return sd
+
+
 def case_state_dict(c):
     from seeded import seeded_state_dict
-    return seeded_state_dict(case_shapes(c), c["wseed"], c["gains"])
+    sd = seeded_state_dict(case_shapes(c), c["wseed"], c["gains"])
+    return suppress_end(sd) if c.get("no_end") else sd
 
 
 def case_oracle_cfg(c):

@@ -213,6 +213,64 @@ def test_lightning_checkpoint_loads_weights_optimizer_and_counters():
     assert ref_opt.param_groups[0]["lr"] == 1e-3
 
 
+def test_written_checkpoint_has_lightning_17_loop_and_callback_schema():
+    """the dict `Trainer.checkpoint` writes must carry Lightning 1.7's full loop state (every progress record a
+    total/current pair with its tracker's field set) and the ModelCheckpoint state under Lightning's own `state_key` -
+    the key the golden file (typed from the 1.7 source, tests/golden/make_golden_callers.py) uses."""
+    from plankassembly_amd import lightning_state as LS
+    t, ck = _ckpt_trainer()
+    t.global_step = 37
+    out = t.checkpoint(4, None, 0.25, steps_this_epoch=9, best_path="/x/checkpoints/best.ckpt", last_path="/x/checkpoints/last.ckpt")
+    (golden_key,) = [k for k in ck["callbacks"] if k.startswith("ModelCheckpoint")]
+    assert list(out["callbacks"]) == [golden_key] == [LS.checkpoint_callback_key()]
+    assert set(out["callbacks"][golden_key]) == set(ck["callbacks"][golden_key])
+    cb = out["callbacks"][golden_key]
+    assert float(cb["best_model_score"]) == 0.25 and cb["best_model_path"].endswith("best.ckpt") and cb["dirpath"] == "/x/checkpoints"
+    assert set(out["loops"]) == {"fit_loop", "validate_loop", "test_loop", "predict_loop"}
+    fit = out["loops"]["fit_loop"]
+
+    def fields(rec, names):
+        assert set(rec) >= {"total", "current"}, rec
+        assert set(rec["total"]) == set(names) == set(rec["current"]), rec
+
+    fields(fit["epoch_progress"], ("ready", "completed", "started", "processed"))
+    fields(fit["epoch_loop.batch_progress"], ("ready", "completed", "started", "processed"))
+    assert fit["epoch_loop.batch_progress"]["is_last_batch"] is True
+    fields(fit["epoch_loop.scheduler_progress"], ("ready", "completed"))
+    op = fit["epoch_loop.batch_loop.optimizer_loop.optim_progress"]
+    fields(op["optimizer"]["step"], ("ready", "completed"))
+    fields(op["optimizer"]["zero_grad"], ("ready", "completed", "started"))
+    fields(fit["epoch_loop.val_loop.dataloader_progress"], ("ready", "completed"))
+    fields(fit["epoch_loop.val_loop.epoch_loop.batch_progress"], ("ready", "completed", "started", "processed"))
+    for k in ("state_dict", "epoch_loop.state_dict", "epoch_loop.batch_loop.state_dict", "epoch_loop.batch_loop.optimizer_loop.state_dict",
+              "epoch_loop.batch_loop.manual_loop.state_dict", "epoch_loop.val_loop.state_dict"):
+        assert k in fit, k
+    # counters agree with each other and with the top level: written inside epoch index 4 -> 5 started, 4 completed
+    assert out["epoch"] == 4 == fit["epoch_progress"]["current"]["completed"] and fit["epoch_progress"]["current"]["started"] == 5
+    assert fit["epoch_loop.state_dict"]["_batches_that_stepped"] == 37 == out["global_step"]
+    assert op["optimizer"]["step"]["total"]["completed"] == 37 and op["optimizer"]["step"]["current"]["completed"] == 9
+    assert LS.epochs_done_of(out) == 5 and LS.epochs_done_of(ck) == 2
+    import io
+    buf = io.BytesIO()
+    torch.save(out, buf)                                      # and it is a weights_only-loadable file
+    buf.seek(0)
+    assert torch.load(buf, weights_only=True)["global_step"] == 37
+
+
+def test_load_checkpoint_refuses_arbitrary_pickles(tmp_path, monkeypatch):
+    """a --ckpt_path file that needs full unpickling is refused unless PLANK_TRUST_CHECKPOINT=1."""
+    import argparse
+    t, ck = _ckpt_trainer()
+    bad = dict(ck, hyper_parameters=argparse.Namespace(x=1))
+    path = str(tmp_path / "bad.ckpt")
+    torch.save(bad, path)
+    monkeypatch.delenv("PLANK_TRUST_CHECKPOINT", raising=False)
+    with pytest.raises(RuntimeError, match="PLANK_TRUST_CHECKPOINT"):
+        t.load_checkpoint(path)
+    monkeypatch.setenv("PLANK_TRUST_CHECKPOINT", "1")
+    assert "state_dict" in t.load_checkpoint(path)
+
+
 @pytest.mark.gpu
 def test_resume_from_lightning_checkpoint_continues_the_reference_run():
     """fit --ckpt_path semantics: after loading weights + Adam moments + step, the next FusedAdam step lands on the

@@ -1,0 +1,106 @@
+"""The reference's command line, end to end on the GPU (reference trainer_complete.py:132-133 `LightningCLI(Trainer)`,
+README.md:111-123: `trainer_complete.py fit --config ...`, `fit --ckpt_path`, `test --ckpt_path`, then `evaluate.py`).
+
+A small model (d_model 64, 2+2 layers) trains on the nine info files under tests/golden/infos through the real loop of
+plankassembly_amd.trainer.run: LineDataset -> DataLoader -> DevicePrefetcher -> HIP train step -> FusedAdam, validation
+every epoch (HIP greedy decode -> box filter -> Hungarian matcher -> running means), `last.ckpt` + best-F1 checkpoint,
+resume, test with pred_jsons, offline re-scoring.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_config(tmp_path, max_epochs):
+    names = sorted(f for f in os.listdir(os.path.join(GOLDEN, "infos")) if f.endswith(".json"))
+    split = tmp_path / "all.txt"
+    split.write_text("\n".join(names))
+    with open(os.path.join(REPO, "configs", "train_complete.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    cfg["trainer"].update(max_epochs=max_epochs, check_val_every_n_epoch=1, devices=1)
+    hp = cfg["model"]["hparams"]
+    hp.update(ROOT=os.path.join(GOLDEN, "infos"), DATASETS_TRAIN=str(split), DATASETS_VALID=str(split), DATASETS_TEST=str(split),
+              BATCH_SIZE=4, NUM_WORKERS=0, LR=2e-3)
+    hp["DATA"].update(MAX_INPUT_LENGTH=129, MAX_OUTPUT_LENGTH=60, AUG_RATIO=0.0)
+    hp["MODEL"].update(NUM_MODEL=64, NUM_HEAD=4, NUM_FEEDFORWARD=128, NUM_ENCODER_LAYERS=2, NUM_DECODER_LAYERS=2, DROPOUT=0.0,
+                       COMPUTE_DTYPE="f32")
+    path = tmp_path / "train_small.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    return str(path), len(names)
+
+
+def test_cli_fit_resume_test_evaluate(tmp_path, monkeypatch):
+    from plankassembly_amd import lightning_state as LS
+    from plankassembly_amd.trainer import Trainer, cli
+    import evaluate as EV
+    monkeypatch.chdir(tmp_path)                                   # lightning_logs/version_N lands here
+    config, n_files = _write_config(tmp_path, max_epochs=3)
+    steps_per_epoch = n_files // 4                                # drop_last, as the reference's train loader
+    assert steps_per_epoch == 2
+
+    # ---- fit
+    mod = cli(Trainer, ["fit", "--config", config])
+    losses = [v for _, name, v in mod.logger.history if name == "train/loss"]
+    assert len(losses) == 3 and losses[-1] < losses[0], losses
+    assert mod.global_step == 3 * steps_per_epoch
+    ckdir = os.path.join(mod.logger.log_dir, "checkpoints")
+    last = os.path.join(ckdir, "last.ckpt")
+    best = glob.glob(os.path.join(ckdir, "checkpoint_*-precision=*-recall=*-f1=*.ckpt"))
+    assert os.path.exists(last) and len(best) == 1, os.listdir(ckdir)          # save_last + save_top_k: 1
+    ck = torch.load(last, map_location="cpu", weights_only=True)
+    assert ck["epoch"] == 2 and ck["global_step"] == 6 and ck["pytorch-lightning_version"].startswith("1.7")
+    assert all(k.startswith("model.") for k in ck["state_dict"]) and ck["hyper_parameters"]["hparams"]["BATCH_SIZE"] == 4
+    assert list(ck["callbacks"]) == [LS.checkpoint_callback_key()]
+    assert ck["callbacks"][LS.checkpoint_callback_key()]["best_model_path"] == best[0]
+    st = ck["optimizer_states"][0]
+    assert float(st["state"][0]["step"]) == 6.0 and len(st["state"]) == len(st["param_groups"][0]["params"])
+    vals = [v for _, name, v in mod.logger.history if name == "val/fmeasure"]
+    assert len(vals) == 3 and all(0.0 <= v <= 1.0 for v in vals)
+    p_end = {k: v.detach().cpu().clone() for k, v in mod.model.state_dict().items()}
+    m_end = mod.optimizer._m.detach().cpu().clone()
+
+    # ---- fit --ckpt_path: continues at the stored epoch / global step with the stored Adam moments
+    mod2 = cli(Trainer, ["fit", "--config", config, "--ckpt_path", last, "--trainer.max_epochs", "5"])
+    assert mod2.resume_epoch == 3 and mod2.global_step == 5 * steps_per_epoch and mod2.optimizer._step == 10
+    l2 = [v for _, name, v in mod2.logger.history if name == "train/loss"]
+    assert len(l2) == 2 and l2[-1] < losses[0]                                # epochs 3 and 4 only
+    # the resumed run started from exactly the saved state: re-load the file into a fresh trainer and compare with the
+    # end of the first run
+    probe = Trainer(ck["hyper_parameters"]["hparams"])
+    probe.model.cuda()
+    popt = probe.configure_optimizers()["optimizer"]
+    probe.load_checkpoint(last, optimizer=popt)
+    assert all(torch.equal(v.cpu(), p_end[k]) for k, v in probe.model.state_dict().items())
+    assert torch.equal(popt._m.cpu(), m_end) and popt._step == 6
+    last2 = os.path.join(mod2.logger.log_dir, "checkpoints", "last.ckpt")
+    assert torch.load(last2, map_location="cpu", weights_only=True)["epoch"] == 4
+
+    # ---- test --ckpt_path: pred_jsons in the reference's format, test/* logged
+    mod3 = cli(Trainer, ["test", "--config", config, "--ckpt_path", last2])
+    files = sorted(os.listdir(os.path.join(mod3.logger.log_dir, "pred_jsons")))
+    assert len(files) == n_files
+    per_file = []
+    for fn in files:
+        with open(os.path.join(mod3.logger.log_dir, "pred_jsons", fn)) as f:
+            d = json.load(f)
+        assert sorted(d) == sorted(["prediction", "attach", "groundtruth", "precision", "recall", "fmeasure"])
+        assert all(len(row) == 6 for row in d["prediction"] + d["groundtruth"] + d["attach"])
+        per_file.append(d["fmeasure"])
+    assert abs(np.mean(per_file) - mod3._logged["test/fmeasure"]) < 1e-6
+
+    # ---- evaluate.py on those files: the same scores up to dequantisation (quantised boxes vs the continuous ground truth)
+    p, r, f, metrics = EV.evaluate(GOLDEN, mod3.logger.log_dir, 0.5, 9, verbose=False)
+    assert os.path.exists(os.path.join(mod3.logger.log_dir, "metrics.json")) and len(metrics) <= n_files
+    assert abs(f - mod3._logged["test/fmeasure"]) <= 0.2, (f, mod3._logged)
+    print(f"    CLI: train/loss {losses} -> {l2}; val/fmeasure {vals}; test/fmeasure {mod3._logged['test/fmeasure']:.3f}; "
+          f"evaluate.py f1 {f:.3f}")

@@ -83,6 +83,73 @@ def test_metric_sums_travel_through_the_device_under_an_rccl_only_group(nccl_wor
     assert torch.equal(allreduce_metric_sums(v.clone()), v)
 
 
+def _two_ranks(case, dtype, grad_dtype, tmp_path):
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "rank")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ddp_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), case, dtype, grad_dtype, out], env=env)
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    return [torch.load(f"{out}.{r}", weights_only=True) for r in range(2)]
+
+
+@pytest.mark.parametrize("case,dtype,grad_dtype", [("live", "f32", "f32"), ("sideface", "f32", "f32"), ("live", "bf16", "bf16")])
+def test_two_ranks_on_one_gpu_exchange_the_mean_of_the_real_models_gradients(case, dtype, grad_dtype, tmp_path):
+    """DDP semantics with the REAL model (reference configs/train_complete.yaml:18 `strategy: ddp`):
+    two processes share the GPU (gloo on device tensors - RCCL refuses two ranks per device), rank r gets half of a
+    B = 4 batch.  After the exchange both ranks hold the SUM of the two half-batch gradients a single process computes;
+    FusedAdam's grad_scale = 1/2 turns it into DDP's mean; both ranks end on identical parameters = the single-process
+    Adam step on that mean.  `sideface`: the unused `input_type` table's zero slice travels like any other."""
+    import large_cases as LC
+    from ddp_worker import build, half
+    from plankassembly_amd.optim import FusedAdam
+    r0, r1 = _two_ranks(case, dtype, grad_dtype, tmp_path)
+    c = LC.CASES[case]
+    batch = LC.case_batch(c, batch_size=4)
+    m = build(c, dtype)
+    singles = []
+    for r in range(2):
+        for p in m.parameters():
+            p.grad = None
+        out = m(m.prepare_batch(half(batch, r, 2)))
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        singles.append((float(out["loss"]), m.flat_grads.detach().cpu().clone()))
+    assert abs(r0["loss"] - singles[0][0]) < 1e-5 * max(1.0, abs(singles[0][0])) and abs(r1["loss"] - singles[1][0]) < 1e-5 * max(1.0, abs(singles[1][0]))
+    want = singles[0][1] + singles[1][1]
+    scale = float(want.abs().max())
+    assert torch.equal(r0["p_start"], m.flat_params.detach().cpu()) and torch.equal(r1["p_start"], r0["p_start"])   # broadcast
+    assert torch.equal(r0["grads"], r1["grads"])                            # one all-reduce result, bit-identical on both ranks
+    if grad_dtype == "f32":
+        # (two runs of one backward differ in the last bits - f32 atomics in a few small reductions - hence not torch.equal)
+        assert float((r0["grads"] - want).abs().max()) <= 2e-5 * scale + 1e-9
+    else:
+        assert float((r0["grads"] - want).norm() / want.norm()) < 2e-2      # each rank's slice rounded to bf16 for the wire
+    assert r0["fired"] == list(range(c["ne"] + c["nd"] + 4))
+    cover = sorted(r0["launched"])
+    assert cover[0][0] == 0 and cover[-1][1] == m._numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    assert torch.equal(r0["params"], r1["params"])                          # ranks stay in lock step
+    # the single-process step on the mean gradient
+    with torch.no_grad():
+        m.flat_grads.copy_(r0["grads"].cuda())
+    opt = FusedAdam(m, lr=1e-3, grad_scale=0.5)
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_params.detach().cpu(), r0["params"])
+    if case == "sideface":
+        off = m._offsets["input_embeddings.input_type.weight"]
+        n = m._params["input_embeddings.input_type.weight"].numel()
+        assert not r0["grads"][off:off + n].any()
+    assert r0["sums"].tolist() == [3.0, 4.0, 6.0, 2.0] == r1["sums"].tolist()
+
+
 def test_reserved_cus_knob_keeps_results():
     import ctypes as C
     from plankassembly_amd import _lib as L, ops

@@ -121,7 +121,7 @@ def run_hip_train(m, batch, prepared=True):
     return out, mem, hid, grads
 
 
-@pytest.mark.parametrize("name", ["headline", "visible", "sideface", "live"])
+@pytest.mark.parametrize("name", ["headline", "visible", "sideface", "live", "t1024"])
 def test_f32_train_step_matches_reference_and_oracle(name):
     c = LC.CASES[name]
     g = LC.load_large(name)
@@ -179,7 +179,7 @@ def test_f32_sideface_full_batch_64():
     check_grads("sideface", grads, rgrads, batch_size=64)
 
 
-@pytest.mark.parametrize("name", ["headline", "visible", "sideface", "live"])
+@pytest.mark.parametrize("name", ["headline", "visible", "sideface", "live", "t1024"])
 def test_bf16_train_step_per_tensor(name):
     """The benchmarked bf16 path against the f32 oracle, tensor by tensor: cosine and relative L2 of every gradient
     (weighted summary printed), loss, memory and hiddens."""
@@ -268,3 +268,185 @@ def test_f32_greedy_decode_batch8_vs_oracle_and_bf16_agreement():
     agree = sum(first) / (len(first) * n)
     print(f"    bf16 greedy: exact-prefix agreement {agree:.3f} (rows fully exact: {sum(t == n for t in first)}/{len(first)})")
     assert agree > 0.2 and any(t == n for t in first), (agree, first)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: greedy decode with MAX_OUTPUT_LENGTH 1024 (reference models.py:267-323 loop, :168-186 eval
+# distribution over 514 + t entries, :91-101 pointer mask, :235-256 sampling)
+def pointer_allowed(t, j):
+    """Closed form of the reference's pointer mask entry [t][j] (models.py:91-101; SURVEY 8 a9, pinned by G5)."""
+    if t < 6:
+        return False
+    return (j == t % 6) if j < 6 else (j % 6 == (t % 6 + 3) % 6)
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph", "two_lanes"])
+def test_f32_greedy_decode_1024_steps_token_exact(mode):
+    """All 1024 steps (END suppressed, so the device-side END check is consulted 64 times and never stops the loop) of
+    the f32 path against the tokens of the REFERENCE's own recompute loop: self-attention over up to 1024 cached keys,
+    the pointer softmax over up to 1023 hidden rows, query_pos_embedding rows 0..170.  `two_lanes`: the fixture's two
+    rows tiled to a batch of 32, decoded as two half-batches on two streams inside one captured graph."""
+    c = LC.CASES["t1024"]
+    g = LC.load_large("t1024")
+    sd = LC.case_state_dict(c)
+    db = LC.case_batch(c, decode=True)
+    reps = 16 if mode == "two_lanes" else 1
+    if reps > 1:
+        db = {k: v.repeat(reps, 1) for k, v in db.items()}
+    m = hip_model(c, "f32", sd)
+    s, a = _decode(m, db, use_graph=(mode != "eager"), lanes=(2 if mode == "two_lanes" else 1))
+    assert s.shape == (2 * reps, 1024)
+    want_s, want_a = np.tile(g["d::samples"], (reps, 1)), np.tile(g["d::attach"], (reps, 1))
+    if not np.array_equal(s.numpy(), want_s):
+        r, t = [int(x[0]) for x in np.nonzero(s.numpy() != want_s)]
+        pytest.fail(f"first differing token: row {r} step {t}: got {int(s[r, t])} want {int(want_s[r, t])}; reference "
+                    f"relative top-2 margin there {float(g['d::margins'][r % 2, t]):.3e}")
+    assert np.array_equal(a.numpy(), want_a)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_greedy_decode_full_size_batch_256_by_1024_properties(dtype):
+    """The benchmarked decode (B = 256, S = 1024, 1024 steps, two lanes, graph replay) at FULL size, checked through what
+    must hold for any weights (reference models.py:235-256, 91-101): tokens are vocabulary ids; a pointer at step t points
+    at an earlier step the pointer mask allows and the emitted token is the token of that step; steps < 6 never point;
+    the device-side END bookkeeping equals the first END of each row.  Rows 0-1 (f32) are also decoded by the CPU oracle
+    and must agree token for token."""
+    from oracle import plank_oracle as O
+    from plankassembly_amd.data import spec_for, synth_batch
+    import plankassembly_amd.decode as D
+    c = dict(LC.CASES["t1024"], wseed=77)
+    sd = LC.case_state_dict(dict(c, no_end=False))            # END allowed: the bookkeeping must have something to track
+    db = synth_batch(256, spec_for("decode"), seed=7)
+    db.pop("name")
+    m = hip_model(c, dtype, sd)
+    m.eval(); m._ensure_handle(); m._refresh_shadow()
+    dec = D.GreedyDecoder(m, use_graph=True, strict_graph=True)
+    with torch.no_grad():
+        s, a = dec.run(m.prepare_batch(db), max_len=1024, early_stop=False)
+        first_end = torch.cat([dec._lanes[i].buffers(hi - lo, 1024)[2] for i, (lo, hi) in enumerate(dec._bounds)]).cpu().numpy()
+    s, a = s.cpu().numpy(), a.cpu().numpy()
+    assert s.shape == (256, 1024) == a.shape and len(dec._bounds) == 2
+    assert s.min() >= 0 and s.max() < 514 and a.min() >= -1
+    rows, steps = np.nonzero(a >= 0)
+    assert len(rows) > 1000, "weights chosen so that pointers fire"
+    tgt = a[rows, steps]
+    assert (tgt < steps).all() and (steps >= 6).all()
+    assert all(pointer_allowed(int(t), int(j)) for t, j in zip(steps[:20000], tgt[:20000]))
+    assert (s[rows, steps] == s[rows, tgt]).all()                                   # the copy itself
+    is_end = s == 512
+    want_first = np.where(is_end.any(axis=1), is_end.argmax(axis=1), -1)
+    assert np.array_equal(first_end, want_first), (first_end[:8], want_first[:8])
+    print(f"    [{dtype}] B=256 x 1024: {len(rows)} pointer copies (latest target step {int(tgt.max())}), "
+          f"{len(np.unique(s))} distinct tokens, rows with END {int(is_end.any(axis=1).sum())}")
+    if dtype == "f32":
+        sub = {k: v[:2] for k, v in db.items()}
+        with torch.no_grad():
+            s_ref, a_ref, marg = O.greedy_decode_cached(sd, LC.case_oracle_cfg(c), sub, early_stop=False, return_margins=True)
+        neq = np.nonzero((s[:2] != s_ref.numpy()) | (a[:2] != a_ref.numpy()))
+        if len(neq[0]):
+            r, t = int(neq[0][0]), int(neq[1][0])
+            pytest.fail(f"row {r} step {t}: HIP {s[r, t]}/{a[r, t]} oracle {int(s_ref[r, t])}/{int(a_ref[r, t])}, oracle margin {float(marg[r, t]):.3e}")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The assembled step AT THE BENCHMARK'S OWN DISPATCH: B = 16, S = 1024 (7 200 - 9 700 packed encoder rows), i.e. the
+# ring / wide / pair / small / grouped GEMM kernels, balanced packed attention with 16 elements, plan_group's split-K
+B16 = {"below": 7, "above": 3}       # batch seeds: valid encoder rows below / above the 8 192-row (256-tile) cliff
+
+
+def _b16_case(which):
+    c = dict(LC.CASES["headline"], B=16, bseed=B16[which])
+    batch = LC.case_batch(c)
+    return c, batch, int((~batch["input_mask"]).sum())
+
+
+def test_b16_batches_straddle_the_256_tile_cliff():
+    assert 7000 < _b16_case("below")[2] <= 8192 < _b16_case("above")[2]
+
+
+_b16_cache = {}
+
+
+def _b16_oracle(which):
+    if which not in _b16_cache:
+        from oracle import plank_oracle as O
+        c, batch, _ = _b16_case(which)
+        sd = LC.case_state_dict(c)
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        out = O.train_forward(p, LC.case_oracle_cfg(c), batch, return_all=True)
+        out["loss"].backward()
+        _b16_cache[which] = (c, sd, batch, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()},
+                             {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()})
+    return _b16_cache[which]
+
+
+def _recorded_gemm_kinds(step):
+    """Run `step()` with the library's GEMM recorder on; {kernel family: launches} (bench.py gemm_census naming)."""
+    import ctypes as C
+    from plankassembly_amd import _lib as L
+    lib = L.lib()
+    torch.cuda.synchronize()
+    lib.pa_gemm_record(1)
+    try:
+        res = step()
+        torch.cuda.synchronize()
+    finally:
+        n = lib.pa_gemm_record(0)
+    kinds, groups = (C.c_int32 * n)(), (C.c_int32 * n)()
+    nk = lib.pa_gemm_recorded_kinds(C.cast(kinds, C.c_void_p), n)
+    ng = lib.pa_gemm_recorded_groups(C.cast(groups, C.c_void_p), n)
+    names = {0: "pair", 1: "ring", 2: "wide", 3: "small"}
+    fam = {}
+    for i in range(n):
+        key = "group" if (i < ng and groups[i] >= 0) else names.get(kinds[i] if i < nk else 0, "pair")
+        fam[key] = fam.get(key, 0) + 1
+    return res, fam
+
+
+@pytest.mark.parametrize("which", ["below", "above"])
+def test_f32_b16_step_matches_oracle(which):
+    c, sd, batch, ref, rgrads = _b16_oracle(which)
+    m = hip_model(c, "f32", sd)
+    out, mem, hid, grads = run_hip_train(m, batch)
+    assert abs(out["loss"].item() - float(ref["loss"])) < 1e-4
+    valid = ~batch["input_mask"]
+    assert float((mem - ref["memory"])[valid].abs().max()) < 1e-4
+    assert float((hid - ref["hiddens"]).abs().max()) < 1e-4
+    worst, over = ("", 0.0), []
+    for k, gr in grads.items():
+        r = rgrads[k]
+        err, scale = float((gr - r).abs().max()), float(r.abs().max())
+        if err > 1e-5 + 1e-4 * scale:
+            over.append((k, err, scale))
+        if err / max(scale, 1e-6) > worst[1]:
+            worst = (k, err / max(scale, 1e-6))
+    print(f"[b16 {which}] f32 worst relative gradient error {worst[1]:.2e} ({worst[0]}); beyond 1e-5 + 1e-4*scale: {over}")
+    # long f32 row sums of the REFERENCE computation carry 1.5-2e-5 of their own rounding noise (check_grads): 4x the bound
+    assert all(err <= 4e-5 + 4e-4 * scale for _, err, scale in over) and len(over) <= 12, over
+
+
+@pytest.mark.parametrize("which", ["below", "above"])
+def test_bf16_b16_step_uses_every_gemm_family_and_matches_oracle(which):
+    """The benchmarked dtype at the benchmarked batch: loss, memory, hiddens and every gradient against the f32 oracle,
+    and the kernels the step went through are the ones the benchmark times."""
+    c, sd, batch, ref, rgrads = _b16_oracle(which)
+    m = hip_model(c, "bf16", sd)
+    (out, mem, hid, grads), fam = _recorded_gemm_kinds(lambda: run_hip_train(m, batch))
+    print(f"[b16 {which}] bf16 GEMM launches by family: {fam}")
+    need = {"group", "small", "wide"} | ({"ring"} if which == "below" else {"pair"})
+    assert need <= set(fam), (need, fam)
+    loss_ref = float(ref["loss"])
+    assert abs(out["loss"].item() - loss_ref) < 2e-2 * abs(loss_ref)
+    valid = ~batch["input_mask"]
+    rel = lambda x, y: float((x - y).double().norm() / (y.double().norm() + 1e-30))
+    assert rel(mem[valid], ref["memory"][valid]) < 2e-2 and rel(hid, ref["hiddens"]) < 3e-2
+    tot = sum(float(v.double().norm()) ** 2 for v in rgrads.values()) ** 0.5
+    for k, gr in grads.items():
+        r, a = rgrads[k].double().flatten(), gr.double().flatten()
+        nr = float(r.norm())
+        if nr == 0.0:
+            assert float(a.norm()) == 0.0, k
+            continue
+        cos, rl2 = float(a @ r) / (float(a.norm()) * nr + 1e-300), float((a - r).norm()) / nr
+        big = nr / tot > 1e-3
+        assert cos > (0.99 if big else 0.9) and rl2 < (0.15 if big else 0.5), (k, cos, rl2, nr / tot)

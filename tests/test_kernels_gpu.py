@@ -426,6 +426,45 @@ def test_attention_dropout_forward_backward_against_masked_reference(dtype, B, H
     assert rel_err(dv, vr.grad) < t, ("dv", rel_err(dv, vr.grad))
 
 
+def _mix32(x):
+    x = x.astype(np.uint64)
+    m = np.uint64(0xffffffff)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & m
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & m
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def test_attention_dropout_keep_rate_per_row_and_key():
+    """keep(row, key) = low32(A[row] * C[key]) >= p * 2^32 is only Bernoulli(1 - p) if the product wraps; a
+    24-bit row hash below ~300 (one row in 55 000) used to keep 0-70 % of its keys.  Pick the seed whose raw row hashes
+    contain the smallest value (host-side restatement of pa_device.h's mix32), extract the kernels' mask for that seed
+    and check exactly those rows - and every row and key column - against the binomial expectation."""
+    B, H, Lq, Lk, dh, p = 2, 8, 512, 512, 64, 0.2
+    rows = np.arange(B * H * Lq, dtype=np.uint64)
+    best = None
+    for seed in range(1, 400):
+        raw = _mix32((rows * np.uint64(0x9e3779b9) + np.uint64(seed)) & np.uint64(0xffffffff)) & np.uint64(0xffffff)
+        if best is None or raw.min() < best[1]:
+            best = (seed, int(raw.min()), int(raw.argmin()), np.argsort(raw)[:8])
+    seed, amin, _, smallest = best
+    assert amin < 2000, amin                                   # the case the old hash got wrong is in the sample
+    keep = _extract_keep_mask(B, H, Lq, Lk, dh, p, seed, torch.bfloat16).view(B * H * Lq, Lk).float()
+    sigma = math.sqrt(p * (1 - p) / Lk)
+    per_row = keep.mean(dim=1)
+    assert float(per_row.min()) > 1 - p - 6 * sigma and float(per_row.max()) < 1 - p + 6 * sigma, (per_row.min(), per_row.max())
+    for r in smallest:                                         # rows whose raw 24-bit hash is tiny
+        assert abs(float(per_row[int(r)]) - (1 - p)) < 5 * sigma, (int(r), float(per_row[int(r)]))
+    per_key = keep.view(B * H, Lq, Lk).mean(dim=1)             # each (batch, head)'s key columns over its 512 query rows
+    sk = math.sqrt(p * (1 - p) / Lq)
+    assert float((per_key - (1 - p)).abs().max()) < 6 * sk
+    assert abs(float(per_row.std()) - sigma) < 0.15 * sigma    # rows behave like independent binomials
+    # rows are not copies / complements of each other: correlation of neighbouring rows' decisions is noise
+    a, b = keep[0::2] - (1 - p), keep[1::2] - (1 - p)
+    corr = (a * b).mean(dim=1) / (p * (1 - p))
+    assert float(corr.abs().max()) < 6 / math.sqrt(Lk), float(corr.abs().max())
+
+
 # ------------------------------------------------------------------------------------------ heads / loss
 def test_mixture_nll_vs_oracle(small_fixture):
     from oracle import plank_oracle as O

@@ -19,7 +19,7 @@ def _run_train(c):
     return sd, batch, out, grads
 
 
-@pytest.mark.parametrize("name", ["headline", "visible", "sideface", "live"])
+@pytest.mark.parametrize("name", ["headline", "visible", "sideface", "live", "t1024"])
 def test_oracle_train_matches_reference_at_large_shapes(name):
     c = LC.CASES[name]
     g = LC.load_large(name)
@@ -61,3 +61,19 @@ def test_oracle_greedy_decode_matches_reference_at_headline_shape():
     assert np.array_equal(s.numpy(), g["d::samples"]) and np.array_equal(a.numpy(), g["d::attach"])
     assert s.shape == (c["decode_b"], c["max_out"]) and int((a >= 0).sum()) > 0
     assert float(marg.min()) > 1e-3, "fixture chosen so that no argmax is a near-tie"
+
+
+def test_oracle_greedy_decode_1024_steps_matches_reference():
+    """BASELINE configs[4] length: MAX_OUTPUT_LENGTH 1024, every step run (END suppressed), against the tokens of the
+    reference's own O(T^2) loop (tests/golden/fixture_t1024.npz: 2 x 1024 tokens, 119 pointer copies, 81 of them past
+    step 128)."""
+    c = LC.CASES["t1024"]
+    g = LC.load_large("t1024")
+    torch.set_num_threads(8)
+    sd = LC.case_state_dict(c)
+    db = LC.case_batch(c, decode=True)
+    with torch.no_grad():
+        s, a = O.greedy_decode_cached(sd, LC.case_oracle_cfg(c), db)
+    assert s.shape == (2, 1024) and not bool((s == 512).any())
+    assert np.array_equal(s.numpy(), g["d::samples"]) and np.array_equal(a.numpy(), g["d::attach"])
+    assert int((g["d::attach"][:, 128:] >= 0).sum()) >= 50 and float(g["d::margins"].min()) > 1e-4
