@@ -1,7 +1,7 @@
 """The reference's command line, end to end on the GPU (reference trainer_complete.py:132-133 `LightningCLI(Trainer)`,
 README.md:111-123: `trainer_complete.py fit --config ...`, `fit --ckpt_path`, `test --ckpt_path`, then `evaluate.py`).
 
-A small model (d_model 64, 2+2 layers) trains on the nine info files under tests/golden/infos through the real loop of
+A small model (d_model 64, 2+2 layers) trains on nine synthetic info files (reference schema) through the real loop of
 plankassembly_amd.trainer.run: LineDataset -> DataLoader -> DevicePrefetcher -> HIP train step -> FusedAdam, validation
 every epoch (HIP greedy decode -> box filter -> Hungarian matcher -> running means), `last.ckpt` + best-F1 checkpoint,
 resume, test with pred_jsons, offline re-scoring.
@@ -21,15 +21,47 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _write_infos(root, n=9, seed=11):
+    """`n` info files in the reference's schema (dataset/prepare_info.py:59-70): 3-25 lines in the three
+    views, 2-8 planks (plank 0 = the overall bounding box) with pointer attachments that the reference's pointer mask
+    allows.  (The golden infos hold only three drawings with lines; the f1 cases have none, and a drawing without lines is
+    an error in the reference's LineDataset too.)"""
+    from plankassembly_amd.data import pointer_mask_row
+    rng = np.random.default_rng(seed)
+    os.makedirs(root, exist_ok=True)
+    names = []
+    for i in range(n):
+        grid = np.round(rng.uniform(-1, 1, size=10), 3)
+        nl, npk = int(rng.integers(3, 26)), int(rng.integers(2, 9))
+        a, b = rng.choice(grid, size=(nl, 2)), rng.choice(grid, size=(nl, 2))
+        lines = np.concatenate([np.minimum(a, b), np.maximum(a, b)], axis=1)
+        lo, hi = rng.choice(grid, size=(npk, 3)), rng.choice(grid, size=(npk, 3))
+        coords = np.concatenate([np.minimum(lo, hi), np.maximum(lo, hi) + 0.05], axis=1).round(3)
+        coords[0] = np.concatenate([coords[:, :3].min(0), coords[:, 3:].max(0)])
+        flat, attach = coords.reshape(-1), np.full(npk * 6, -1)
+        for t in range(6, npk * 6):
+            cand = np.nonzero(pointer_mask_row(t, t))[0]
+            cand = cand[np.isclose(flat[cand], flat[t])]
+            if len(cand):
+                attach[t] = int(cand[0])
+        name = f"drawing{i:02d}"
+        with open(os.path.join(root, name + ".json"), "w") as f:
+            json.dump({"name": name, "lines": lines.tolist(), "views": rng.integers(0, 3, nl).tolist(),
+                       "types": rng.integers(0, 2, nl).tolist(), "svgs": [], "coords": coords.tolist(),
+                       "attach": attach.reshape(npk, 6).tolist()}, f)
+        names.append(name + ".json")
+    return names
+
+
 def _write_config(tmp_path, max_epochs):
-    names = sorted(f for f in os.listdir(os.path.join(GOLDEN, "infos")) if f.endswith(".json"))
+    names = _write_infos(str(tmp_path / "data" / "infos"))
     split = tmp_path / "all.txt"
     split.write_text("\n".join(names))
     with open(os.path.join(REPO, "configs", "train_complete.yaml")) as f:
         cfg = yaml.safe_load(f)
     cfg["trainer"].update(max_epochs=max_epochs, check_val_every_n_epoch=1, devices=1)
     hp = cfg["model"]["hparams"]
-    hp.update(ROOT=os.path.join(GOLDEN, "infos"), DATASETS_TRAIN=str(split), DATASETS_VALID=str(split), DATASETS_TEST=str(split),
+    hp.update(ROOT=str(tmp_path / "data" / "infos"), DATASETS_TRAIN=str(split), DATASETS_VALID=str(split), DATASETS_TEST=str(split),
               BATCH_SIZE=4, NUM_WORKERS=0, LR=2e-3)
     hp["DATA"].update(MAX_INPUT_LENGTH=129, MAX_OUTPUT_LENGTH=60, AUG_RATIO=0.0)
     hp["MODEL"].update(NUM_MODEL=64, NUM_HEAD=4, NUM_FEEDFORWARD=128, NUM_ENCODER_LAYERS=2, NUM_DECODER_LAYERS=2, DROPOUT=0.0,
@@ -99,7 +131,7 @@ def test_cli_fit_resume_test_evaluate(tmp_path, monkeypatch):
     assert abs(np.mean(per_file) - mod3._logged["test/fmeasure"]) < 1e-6
 
     # ---- evaluate.py on those files: the same scores up to dequantisation (quantised boxes vs the continuous ground truth)
-    p, r, f, metrics = EV.evaluate(GOLDEN, mod3.logger.log_dir, 0.5, 9, verbose=False)
+    p, r, f, metrics = EV.evaluate(str(tmp_path / "data"), mod3.logger.log_dir, 0.5, 9, verbose=False)
     assert os.path.exists(os.path.join(mod3.logger.log_dir, "metrics.json")) and len(metrics) <= n_files
     assert abs(f - mod3._logged["test/fmeasure"]) <= 0.2, (f, mod3._logged)
     print(f"    CLI: train/loss {losses} -> {l2}; val/fmeasure {vals}; test/fmeasure {mod3._logged['test/fmeasure']:.3f}; "
