@@ -1011,8 +1011,9 @@ __global__ __launch_bounds__(NTH, 4) void attn_fwd_bf16_kernel(AttnP pin) {
                         sacc[4 * g + e] = x;
                     }
                 }
+            } else {
+                settle_mfma(sacc);        // interior tile: no compiler-visible reader of the MFMA result precedes the asm max3f
             }
-            settle_mfma(sacc);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) mx = max3f(mx, sacc[r], sacc[r + 1]);
             mx = fmaxf(mx, __shfl_xor(mx, 32)) * sl;
@@ -1476,12 +1477,20 @@ __device__ unsigned long long pa_attn_trace[8192 * 8];
 #else
 #define PA_TR(i) do { } while (0)
 #endif
-template <bool DROP>
-__global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
+// KS = 2 (in-block key split): the block has 16 waves; waves 8..15 ("key half 1") own the same 128 query rows as waves
+// 0..7 but walk the SECOND half of the element's key tiles, from their own pair of LDS stages; the two partial results
+// (reference point m, row sum l, O^T) are merged through LDS at the end.  A block's serial chain of key steps - what the
+// duration of a launch with few blocks is made of (cross-attention: one 128-row block per (sample, head), up to 16 steps) -
+// is halved at the same number of resident waves.  Only launches without a key-padding mask and without causality
+// (packed / cross attention: the key range is known before the loop).
+template <bool DROP, int KS>
+__global__ __launch_bounds__(NT4 * KS, 4) void attn4_fwd_kernel(AttnP pin) {
     constexpr int DH = 64, NAT = BT<DH>::NAT, BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
     extern __shared__ __attribute__((aligned(256))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kh = KS == 2 ? (wave_all >> 3) : 0;            // key half of this wave
+    const int wave = wave_all & 7, tid = threadIdx.x & (NT4 - 1);     // position inside the half
     PA_TR(0);
     int tile_, h, b, off_ = 0, len_ = -1;
     if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_)) return; }
@@ -1504,11 +1513,15 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
     const int voffK = tile_voff4(p.ldk, tid), voffV = tile_voff4(p.ldv, tid);
     Lds4 lb;
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    lb.init(smem_base, lane);
-    const uint32_t cbase = smem_base + g * 16;            // this lane group's 4 keys of a 16-key block (aux words, natural order)
+    lb.init(smem_base + kh * 2 * BUF, lane);
+    const uint32_t cbase = smem_base + kh * 2 * BUF + g * 16;   // this lane group's 4 keys of a 16-key block (aux words, natural order)
+    // key tiles of this half: [kbase / 64, kbase / 64 + nst_h)
+    const int ksteps = (p.Lk + BSTR - 1) / BSTR;
+    const int s0 = KS == 2 ? (ksteps + 1) / 2 : ksteps;
+    const int kbase = kh * s0 * BSTR, nst_h = KS == 2 ? (kh ? ksteps - s0 : s0) : 0;
     auto issue = [&](int step, int buf, int kfirst_) {
-        char* base = smem + buf * BUF;
-        const int k0 = step * BSTR;
+        char* base = smem + kh * 2 * BUF + buf * BUF;
+        const int k0 = kbase + step * BSTR;
         const bool tile_masked = k0 + BSTR > kfirst_;
         uint8_t mb = 0;
         if (tile_masked && tid < BSTR) {
@@ -1522,11 +1535,13 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
             if (DROP) reinterpret_cast<uint32_t*>(base + AUX + 64)[tid] = drop_key_hash(p.drop_seed, (uint32_t)(k0 + tid));
         }
     };
-    issue(0, 0, 0);
+    if (KS == 1 || nst_h > 0) issue(0, 0, 0);
     int kfirst = p.Lk, klast = p.Lk;
-    if (mp) scan_key_mask4(mp, p.Lk, tid, reinterpret_cast<int*>(smem + 2 * BUF), kfirst, klast);
+    if (KS == 1 && mp) scan_key_mask4(mp, p.Lk, tid, reinterpret_cast<int*>(smem + 2 * BUF), kfirst, klast);
     int nsteps = (klast + BSTR - 1) / BSTR;
     if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+    const int my_steps = KS == 2 ? nst_h : nsteps;          // steps this wave computes; the block loops over the longer half
+    if (KS == 2) nsteps = s0;
 
     f32x4 oacc[4];
 #pragma unroll
@@ -1539,10 +1554,10 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
 
     auto body = [&](int step, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        if (step + 1 < nsteps) issue(step + 1, buf ^ 1, kfirst);
-        if (!wave_on) { tile_barrier(); return; }      // this wave's 16 rows lie past the element's last row: DMA + barriers only
-        const uint8_t* mk = reinterpret_cast<const uint8_t*>(smem + buf * BUF + AUX);
-        const int k0 = step * BSTR;
+        if (step + 1 < my_steps) issue(step + 1, buf ^ 1, kfirst);
+        if (!wave_on || step >= my_steps) { tile_barrier(); return; }      // rows past the element's end / the shorter key half: DMA + barriers only
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(smem + kh * 2 * BUF + buf * BUF + AUX);
+        const int k0 = kbase + step * BSTR;
         f32x4 sacc[4];
         mma_nat4<buf * BUF>(sacc, lb, qreg);
         const bool key_masked = k0 + BSTR > kfirst;
@@ -1560,8 +1575,9 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
                     sacc[kb][e] = x;
                 }
             }
+        } else {
+            settle_mfma(sacc[0], sacc[1], sacc[2], sacc[3]);   // interior tile (see the 32-row-wave kernel)
         }
-        settle_mfma(sacc[0], sacc[1], sacc[2], sacc[3]);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) mx = max3f(max3f(mx, sacc[kb][0], sacc[kb][1]), sacc[kb][2], sacc[kb][3]);
         mx = quad_max(mx) * sl;
@@ -1605,7 +1621,28 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
         if (step + 1 < nsteps) body(step + 1, IC<1>{});
     }
     PA_TR(3);
-    const float l_tot = quad_sum(l_run);
+    float l_tot = quad_sum(l_run);
+    if constexpr (KS == 2) {
+        // merge the two key halves (every stage is free after the loop's last barrier): half 1 publishes (O^T, m, l) of its 16
+        // rows per wave, half 0 rescales both to the common reference point and stores.  [db][lane] f32x4: conflict-free.
+        f32x4* xo = reinterpret_cast<f32x4*>(smem) + wave * 4 * 64;
+        float* xml = reinterpret_cast<float*>(smem + 8 * 4 * 64 * 16) + wave * 2 * 64;
+        if (kh == 1) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) xo[db * 64 + lane] = oacc[db];
+            xml[lane] = m_run; xml[64 + lane] = l_tot;
+        }
+        __syncthreads();
+        if (kh == 1) return;
+        const float m1 = xml[lane], l1 = xml[64 + lane];
+        const float m_new = fmaxf(m_run, m1);
+        const float ms = (m_new == -INFINITY) ? 0.f : m_new;
+        const float a0 = fast_exp2(m_run - ms), a1 = fast_exp2(m1 - ms);
+        l_tot = l_tot * a0 + l1 * a1;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) oacc[db] = oacc[db] * a0 + xo[db * 64 + lane] * a1;
+        m_run = m_new;
+    }
     const float inv = l_tot > 0.f ? (DROP ? p.drop_scale : 1.0f) / l_tot : 0.f;
     bf16* Op = reinterpret_cast<bf16*>(p.o) + (size_t)qoff * p.ldo + h * DH;
     store_rows4(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);
@@ -1618,12 +1655,14 @@ __global__ __launch_bounds__(NT4, 4) void attn4_fwd_kernel(AttnP pin) {
 #endif
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(NT4, 4) void attn4_bwd_dq_kernel(AttnP pin) {
+template <bool DROP, int KS>          // KS = 2: in-block key split, see attn4_fwd_kernel (the partial dQ^T of the two halves are summed)
+__global__ __launch_bounds__(NT4 * KS, 4) void attn4_bwd_dq_kernel(AttnP pin) {
     constexpr int DH = 64, NAT = BT<DH>::NAT, BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
     extern __shared__ __attribute__((aligned(256))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 4;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kh = KS == 2 ? (wave_all >> 3) : 0;
+    const int wave = wave_all & 7, tid = threadIdx.x & (NT4 - 1);
     int tile_, h, b, off_ = 0, len_ = -1;
     if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_)) return; }
     else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
@@ -1656,18 +1695,21 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dq_kernel(AttnP pin) {
             for (int w = 0; w < 4; ++w)
                 dsum += bf16_lo(oreg[s_][w]) * bf16_lo(doreg[s_][w]) + bf16_hi(oreg[s_][w]) * bf16_hi(doreg[s_][w]);
         dsum = quad_sum(dsum);
-        if (g == 0 && qrow < p.Lq) p.delta[srow] = dsum;
+        if (g == 0 && qrow < p.Lq && kh == 0) p.delta[srow] = dsum;
     }
     const float dlt = (qrow < p.Lq) ? dsum * keep_p : 0.f;
     const TileSrc srcK = tile_src(Kp, p.ldk, p.Lk, DH), srcV = tile_src(Vp, p.ldv, p.Lk, DH);
     const int voffK = tile_voff4(p.ldk, tid), voffV = tile_voff4(p.ldv, tid);
     Lds4 lb;
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    lb.init(smem_base, lane);
-    const uint32_t cbase = smem_base + g * 16;
+    lb.init(smem_base + kh * 2 * BUF, lane);
+    const uint32_t cbase = smem_base + kh * 2 * BUF + g * 16;
+    const int ksteps = (p.Lk + BSTR - 1) / BSTR;
+    const int s0 = KS == 2 ? (ksteps + 1) / 2 : ksteps;
+    const int kbase = kh * s0 * BSTR, nst_h = KS == 2 ? (kh ? ksteps - s0 : s0) : 0;
     auto issue = [&](int step, int buf, int kfirst_) {
-        char* base = smem + buf * BUF;
-        const int k0 = step * BSTR;
+        char* base = smem + kh * 2 * BUF + buf * BUF;
+        const int k0 = kbase + step * BSTR;
         const bool tile_masked = k0 + BSTR > kfirst_;
         uint8_t mb = 0;
         if (tile_masked && tid < BSTR) {
@@ -1681,11 +1723,13 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dq_kernel(AttnP pin) {
             if (DROP) reinterpret_cast<uint32_t*>(base + AUX + 64)[tid] = drop_key_hash(p.drop_seed, (uint32_t)(k0 + tid));
         }
     };
-    issue(0, 0, 0);
+    if (KS == 1 || nst_h > 0) issue(0, 0, 0);
     int kfirst = p.Lk, klast = p.Lk;
-    if (mp) scan_key_mask4(mp, p.Lk, tid, reinterpret_cast<int*>(smem + 2 * BUF), kfirst, klast);
+    if (KS == 1 && mp) scan_key_mask4(mp, p.Lk, tid, reinterpret_cast<int*>(smem + 2 * BUF), kfirst, klast);
     int nsteps = (klast + BSTR - 1) / BSTR;
     if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+    const int my_steps = KS == 2 ? nst_h : nsteps;
+    if (KS == 2) nsteps = s0;
 
     f32x4 dqacc[4];
 #pragma unroll
@@ -1697,10 +1741,10 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dq_kernel(AttnP pin) {
 
     auto body = [&](int step, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        if (step + 1 < nsteps) issue(step + 1, buf ^ 1, kfirst);
-        if (!wave_on) { tile_barrier(); return; }      // this wave's 16 rows lie past the element's last row: DMA + barriers only
-        const uint8_t* mk = reinterpret_cast<const uint8_t*>(smem + buf * BUF + AUX);
-        const int k0 = step * BSTR;
+        if (step + 1 < my_steps) issue(step + 1, buf ^ 1, kfirst);
+        if (!wave_on || step >= my_steps) { tile_barrier(); return; }      // rows past the element's end / the shorter key half: DMA + barriers only
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(smem + kh * 2 * BUF + buf * BUF + AUX);
+        const int k0 = kbase + step * BSTR;
         const bool key_masked = k0 + BSTR > kfirst;
         const bool need_mask = key_masked || (p.causal && (k0 + BSTR - 1 > qw0));
         f32x4 sacc[4], dpacc[4];
@@ -1739,6 +1783,17 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dq_kernel(AttnP pin) {
     for (int step = 0; step < nsteps; step += 2) {
         body(step, IC<0>{});
         if (step + 1 < nsteps) body(step + 1, IC<1>{});
+    }
+    if constexpr (KS == 2) {
+        f32x4* xo = reinterpret_cast<f32x4*>(smem) + wave * 4 * 64;
+        if (kh == 1) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) xo[db * 64 + lane] = dqacc[db];
+        }
+        __syncthreads();
+        if (kh == 1) return;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dqacc[db] += xo[db * 64 + lane];
     }
     bf16* dQp = reinterpret_cast<bf16*>(p.dq) + (size_t)qoff * p.lddq + h * DH;
     store_rows4(dQp, p.lddq, qrow, p.Lq, dqacc, p.scale * (DROP ? p.drop_scale : 1.0f), lane);
@@ -1896,13 +1951,29 @@ static bool use_v4(const AttnP& p, int rows_owned) {
     const long long waves32 = (long long)p.B * p.H * ((rows_owned + 31) / 32);
     return p.cu_q != nullptr || p.cu_k != nullptr || waves32 < 4 * 1024;
 }
+// In-block key split of the 16-row-wave forward / dQ kernels (attn4_fwd_kernel): for launches whose duration is one block's
+// serial chain of key steps - few blocks, many keys.  PA_ATTN_KSPLIT: 0 never, 1 (default) cross-attention-like launches (at
+// most one block per CU and at least 4 key tiles), 2 every eligible launch (no key-padding mask, not causal).
+static bool use_ksplit(const AttnP& p, unsigned blocks) {
+    static const int mode = getenv("PA_ATTN_KSPLIT") ? atoi(getenv("PA_ATTN_KSPLIT")) : 1;
+    if (mode == 0 || p.kpm || p.causal || p.Lk < 4 * BSTR) return false;
+    return mode >= 2 || blocks <= 256;
+}
 template <int DH> int run_fwd_bf16(const AttnP& p, hipStream_t st) {
     const int shm = BL<DH>::SHM;
     dim3 grid(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B);
     if constexpr (DH == 64) {
         if (use_v4(p, p.Lq)) {
-            if (p.drop_thr) PA_LAUNCH((attn4_fwd_kernel<true>), grid, dim3(NT4), shm, st, p);
-            else PA_LAUNCH((attn4_fwd_kernel<false>), grid, dim3(NT4), shm, st, p);
+            if (use_ksplit(p, grid.x)) {
+                constexpr int shm2 = 4 * BL<DH>::BUF + 64;                 // two pairs of stages: > 64 KiB, opt in once
+                static const int rc_d = set_lds(attn4_fwd_kernel<true, 2>, shm2), rc_n = set_lds(attn4_fwd_kernel<false, 2>, shm2);
+                if (rc_d || rc_n) return rc_d ? rc_d : rc_n;
+                if (p.drop_thr) PA_LAUNCH((attn4_fwd_kernel<true, 2>), grid, dim3(2 * NT4), shm2, st, p);
+                else PA_LAUNCH((attn4_fwd_kernel<false, 2>), grid, dim3(2 * NT4), shm2, st, p);
+                return 0;
+            }
+            if (p.drop_thr) PA_LAUNCH((attn4_fwd_kernel<true, 1>), grid, dim3(NT4), shm, st, p);
+            else PA_LAUNCH((attn4_fwd_kernel<false, 1>), grid, dim3(NT4), shm, st, p);
             return 0;
         }
     }
@@ -1915,12 +1986,20 @@ template <int DH> int run_bwd_bf16(const AttnP& p, hipStream_t st) {
     const dim3 gq(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B), gk(((p.Lk + BOWN - 1) / BOWN) * p.H * p.B);
     if constexpr (DH == 64) {
         if (use_v4(p, p.Lq > p.Lk ? p.Lq : p.Lk)) {
+            const bool ks = use_ksplit(p, gq.x);
+            constexpr int shm2 = 4 * BL<DH>::BUF + 64;
+            if (ks) {
+                static const int rc_d = set_lds(attn4_bwd_dq_kernel<true, 2>, shm2), rc_n = set_lds(attn4_bwd_dq_kernel<false, 2>, shm2);
+                if (rc_d || rc_n) return rc_d ? rc_d : rc_n;
+            }
             if (p.drop_thr) {
-                PA_LAUNCH((attn4_bwd_dq_kernel<true>), gq, dim3(NT4), shm, st, p);
+                if (ks) PA_LAUNCH((attn4_bwd_dq_kernel<true, 2>), gq, dim3(2 * NT4), shm2, st, p);
+                else PA_LAUNCH((attn4_bwd_dq_kernel<true, 1>), gq, dim3(NT4), shm, st, p);
                 if (p.causal) PA_LAUNCH((attn4_bwd_dkv_kernel<true, true>), gk, dim3(NT4), shm, st, p);
                 else PA_LAUNCH((attn4_bwd_dkv_kernel<true, false>), gk, dim3(NT4), shm, st, p);
             } else {
-                PA_LAUNCH((attn4_bwd_dq_kernel<false>), gq, dim3(NT4), shm, st, p);
+                if (ks) PA_LAUNCH((attn4_bwd_dq_kernel<false, 2>), gq, dim3(2 * NT4), shm2, st, p);
+                else PA_LAUNCH((attn4_bwd_dq_kernel<false, 1>), gq, dim3(NT4), shm, st, p);
                 if (p.causal) PA_LAUNCH((attn4_bwd_dkv_kernel<false, true>), gk, dim3(NT4), shm, st, p);
                 else PA_LAUNCH((attn4_bwd_dkv_kernel<false, false>), gk, dim3(NT4), shm, st, p);
             }

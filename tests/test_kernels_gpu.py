@@ -556,7 +556,7 @@ def test_pack_rows_matches_nonzero():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,dh,Lq,Lk,self_attn", [(3, 4, 16, 70, 70, True), (4, 8, 64, 128, 300, False), (2, 8, 64, 260, 260, True),
-                                                    (14, 8, 64, 450, 450, True)])
+                                                    (14, 8, 64, 450, 450, True), (5, 8, 64, 128, 1021, False), (3, 8, 64, 700, 700, True)])
 def test_attention_varlen_matches_masked_dense(dtype, B, H, dh, Lq, Lk, self_attn):
     """Packed K/V (and Q for self-attention) without any mask == dense attention with a key-padding mask."""
     dm = H * dh
@@ -595,6 +595,34 @@ def test_attention_varlen_matches_masked_dense(dtype, B, H, dh, Lq, Lk, self_att
     assert torch.equal(o2, o) and torch.equal(lse2[rows_ok], lse[rows_ok])
     dq2, dk2, dv2 = ops.attn_varlen_bwd(dop, qp, kp, vp, o, lse, H, cu_q, cu_k, B, Lq, Lk, order=order)
     assert torch.equal(dq2, dq) and torch.equal(dk2, dk) and torch.equal(dv2, dv)
+
+
+def test_attention_key_split_blocks_same_dropout_as_dense():
+    """The in-block key split (16-wave blocks: two key halves merged through LDS; taken by packed launches with at most one
+    block per CU - cross-attention) must make the decisions of the unsplit kernels: with the same seed, packed K/V + split
+    == dense K/V under a key-padding mask (32-row-wave / unsplit kernels), forward and all three gradients, dropout on.
+    Lengths include elements shorter than one key tile (second half empty) and an odd number of tiles."""
+    B, H, dh, Lq, Lk, p, seed = 6, 8, 64, 128, 1021, 0.2, 4711
+    dm = H * dh
+    lens = torch.tensor([1021, 40, 130, 577, 960, 64])
+    kpm = torch.arange(Lk)[None, :] >= lens[:, None]
+    q = rnd(B, Lq, dm, dtype=torch.bfloat16, seed=120).to(DEV)
+    kv = rnd(B, Lk, 2 * dm, dtype=torch.bfloat16, seed=121).to(DEV)
+    dout = rnd(B, Lq, dm, dtype=torch.bfloat16, seed=122).to(DEV)
+    k, v = kv[..., :dm], kv[..., dm:]
+    o_d, lse_d = ops.attn_fwd(q, k, v, H, kpm=kpm.to(DEV), drop_p=p, drop_seed=seed)
+    dq_d, dk_d, dv_d = ops.attn_bwd(dout, q, k, v, o_d, lse_d, H, kpm=kpm.to(DEV), drop_p=p, drop_seed=seed)
+    sel = (~kpm).flatten().nonzero().flatten().to(DEV)
+    cu_k = torch.cat((torch.zeros(1, dtype=torch.long), lens.cumsum(0))).to(torch.int32).to(DEV)
+    kvp = kv.reshape(B * Lk, 2 * dm)[sel]
+    qp, dop = q.reshape(B * Lq, dm), dout.reshape(B * Lq, dm)
+    o, lse = ops.attn_varlen_fwd(qp, kvp[:, :dm], kvp[:, dm:], H, None, cu_k, B, Lq, Lk, drop_p=p, drop_seed=seed)
+    assert rel_err(o, o_d.reshape(B * Lq, dm)) < 1e-2 and float((lse - lse_d).abs().max()) < 1e-3
+    dq, dk, dv = ops.attn_varlen_bwd(dop, qp, kvp[:, :dm], kvp[:, dm:], o, lse, H, None, cu_k, B, Lq, Lk, drop_p=p, drop_seed=seed)
+    assert rel_err(dq, dq_d.reshape(B * Lq, dm)) < 1.5e-2
+    assert rel_err(dk, dk_d.reshape(B * Lk, dm)[sel]) < 1.5e-2 and rel_err(dv, dv_d.reshape(B * Lk, dm)[sel]) < 1.5e-2
+    o0, _ = ops.attn_varlen_fwd(qp, kvp[:, :dm], kvp[:, dm:], H, None, cu_k, B, Lq, Lk)
+    assert rel_err(o, o0) > 0.05                                   # (dropout really was on)
 
 
 def test_gemm_wide_tile_bf16():
