@@ -41,6 +41,7 @@ struct AttnP {
     const int32_t* cu_q; const int32_t* cu_k;     // packed (variable-length) row offsets per batch element, or NULL
     const int32_t* order;                         // batch elements in dispatch order (longest first), or NULL
     int balanced;                                 // self-attention over packed rows with `order`: decode_block_balanced
+    int ks_min;                                   // in-block key split (KS = 2 kernels): elements with fewer key tiles run unsplit
 };
 
 // Variable-length ("unpadded") batches: with cu_q / cu_k given, batch element b owns rows [cu[b], cu[b+1]) of the
@@ -1392,33 +1393,70 @@ template <int OFF> __device__ __forceinline__ void mma_nat4(f32x4 (&acc)[4], con
         }
     }
 }
-// acc[db] (16 d x 16) += TILE^T[d][64 rows] x P  (P = the lane's 16 values p[kb][r] <-> row 16kb + 4g + r)
-template <int OFF> __device__ __forceinline__ void mma_tr4(f32x4 (&acc)[4], const Lds4& lb, const f32x4 (&p)[4]) {
-    u32x4 pb[2];
+// The same product started from a per-lane constant c0 instead of zero (all four values of a lane's 16 x 16 accumulator
+// belong to ONE column = one query row): with the rows pre-multiplied by scale * log2(e) and c0 = -(the row's softmax
+// reference point) the MFMA itself delivers the exponent, and the score loop needs no FMA (one VALU instruction per score
+// less in a VALU-bound loop).  c4 = {c0, c0, c0, c0}.
+template <int OFF> __device__ __forceinline__ void mma_nat4c(f32x4 (&acc)[4], const Lds4& lb, const u32x4 (&regs)[2], const f32x4& c4) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        u32x4 a[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            PA_DS128(a[2 * j], lb.nat[0], OFF + (2 * h2 + j) * 2048);
+            PA_DS128(a[2 * j + 1], lb.nat[1], OFF + (2 * h2 + j) * 2048);
+        }
+        wait_lds(a);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 z = c4;
+            mma16(z, a[2 * j], regs[0]);
+            mma16(z, a[2 * j + 1], regs[1]);
+            acc[2 * h2 + j] = z;
+        }
+    }
+}
+// rows held as bf16 fragments *= f (f32 product, one rounding back to bf16)
+__device__ __forceinline__ void scale_row4(u32x4 (&regs)[2], float f) {
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) regs[s_][w] = pack_bf16(bf16_lo(regs[s_][w]) * f, bf16_hi(regs[s_][w]) * f);
+}
+// acc[db] (16 d x 16) += TILE^T[d][64 rows] x P  (P = the lane's 16 values p[kb][r] <-> row 16kb + 4g + r).
+// Split into the operand reads of one half (d blocks 2*H2, 2*H2 + 1) and its MFMAs so that a caller can request the
+// reads BEFORE the arithmetic that produces P (the forward kernel: the V^T fragments travel while the softmax runs).
+template <int OFF, int H2> __device__ __forceinline__ void tr4_reads(u32x4 (&a)[4], const Lds4& lb) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x2 x0, x1;
+            PA_DSTR(x0, lb.tr[2 * H2 + j], OFF + (32 * kk) * 128);
+            PA_DSTR(x1, lb.tr[2 * H2 + j], OFF + (32 * kk + 16) * 128);
+            a[2 * j + kk][0] = x0[0]; a[2 * j + kk][1] = x0[1]; a[2 * j + kk][2] = x1[0]; a[2 * j + kk][3] = x1[1];
+        }
+}
+__device__ __forceinline__ void pack_p4(u32x4 (&pb)[2], const f32x4 (&p)[4]) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         pb[kk][0] = pack_bf16(p[2 * kk][0], p[2 * kk][1]); pb[kk][1] = pack_bf16(p[2 * kk][2], p[2 * kk][3]);
         pb[kk][2] = pack_bf16(p[2 * kk + 1][0], p[2 * kk + 1][1]); pb[kk][3] = pack_bf16(p[2 * kk + 1][2], p[2 * kk + 1][3]);
     }
+}
+template <int H2> __device__ __forceinline__ void tr4_mmas(f32x4 (&acc)[4], u32x4 (&a)[4], const u32x4 (&pb)[2]) {
+    wait_lds(a);
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-        u32x4 a[4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                u32x2 x0, x1;
-                PA_DSTR(x0, lb.tr[2 * h2 + j], OFF + (32 * kk) * 128);
-                PA_DSTR(x1, lb.tr[2 * h2 + j], OFF + (32 * kk + 16) * 128);
-                a[2 * j + kk][0] = x0[0]; a[2 * j + kk][1] = x0[1]; a[2 * j + kk][2] = x1[0]; a[2 * j + kk][3] = x1[1];
-            }
-        wait_lds(a);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            mma16(acc[2 * h2 + j], a[2 * j], pb[0]);
-            mma16(acc[2 * h2 + j], a[2 * j + 1], pb[1]);
-        }
+    for (int j = 0; j < 2; ++j) {
+        mma16(acc[2 * H2 + j], a[2 * j], pb[0]);
+        mma16(acc[2 * H2 + j], a[2 * j + 1], pb[1]);
     }
+}
+template <int OFF> __device__ __forceinline__ void mma_tr4(f32x4 (&acc)[4], const Lds4& lb, const f32x4 (&p)[4]) {
+    u32x4 pb[2], a[4];
+    pack_p4(pb, p);
+    tr4_reads<OFF, 0>(a, lb); tr4_mmas<0>(acc, a, pb);
+    tr4_reads<OFF, 1>(a, lb); tr4_mmas<1>(acc, a, pb);
 }
 __device__ __forceinline__ void load_row4(u32x4 (&regs)[2], const bf16* base, int ld, int row, int nrows, int lane) {
     const int g = lane >> 4;
@@ -1509,6 +1547,8 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_fwd_kernel(AttnP pin) {
 
     u32x4 qreg[2];
     load_row4(qreg, Qp, p.ldq, qrow, p.Lq, lane);
+    const float sl = p.scale * LOG2E;
+    scale_row4(qreg, sl);                                 // scores come out of the MFMA in log2 units (see mma_nat4c)
     const TileSrc srcK = tile_src(Kp, p.ldk, p.Lk, DH), srcV = tile_src(Vp, p.ldv, p.Lk, DH);
     const int voffK = tile_voff4(p.ldk, tid), voffV = tile_voff4(p.ldv, tid);
     Lds4 lb;
@@ -1517,7 +1557,11 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_fwd_kernel(AttnP pin) {
     const uint32_t cbase = smem_base + kh * 2 * BUF + g * 16;   // this lane group's 4 keys of a 16-key block (aux words, natural order)
     // key tiles of this half: [kbase / 64, kbase / 64 + nst_h)
     const int ksteps = (p.Lk + BSTR - 1) / BSTR;
-    const int s0 = KS == 2 ? (ksteps + 1) / 2 : ksteps;
+    // an element with few key tiles is not split: its second-half waves leave before the first barrier (their wave
+    // slots and registers are free for other blocks at once; s_barrier only counts live waves)
+    const bool split = KS == 2 && ksteps >= pin.ks_min;                    // block-uniform
+    if (KS == 2 && kh == 1 && !split) return;
+    const int s0 = split ? (ksteps + 1) / 2 : ksteps;
     const int kbase = kh * s0 * BSTR, nst_h = KS == 2 ? (kh ? ksteps - s0 : s0) : 0;
     auto issue = [&](int step, int buf, int kfirst_) {
         char* base = smem + kh * 2 * BUF + buf * BUF;
@@ -1547,7 +1591,6 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_fwd_kernel(AttnP pin) {
 #pragma unroll
     for (int db = 0; db < 4; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
-    const float sl = p.scale * LOG2E;
     const uint32_t arow = DROP ? drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow)) : 0u;
     tile_barrier();
     PA_TR(2);
@@ -1558,8 +1601,13 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_fwd_kernel(AttnP pin) {
         if (!wave_on || step >= my_steps) { tile_barrier(); return; }      // rows past the element's end / the shorter key half: DMA + barriers only
         const uint8_t* mk = reinterpret_cast<const uint8_t*>(smem + kh * 2 * BUF + buf * BUF + AUX);
         const int k0 = kbase + step * BSTR;
+        // S^T - m_run: the accumulator starts at -(this row's reference point), so the exponent of every probability is
+        // what the MFMA leaves behind (m_run = running maximum of the log2-domain scores, moved only when a row outgrows
+        // it by 2^RESCALE_THR; -inf until the row has seen an unmasked key)
+        const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
+        const f32x4 c4 = {nm, nm, nm, nm};
         f32x4 sacc[4];
-        mma_nat4<buf * BUF>(sacc, lb, qreg);
+        mma_nat4c<buf * BUF>(sacc, lb, qreg, c4);
         const bool key_masked = k0 + BSTR > kfirst;
         const bool need_mask = key_masked || (p.causal && (k0 + BSTR - 1 > qw0));           // wave-uniform
         float mx = -INFINITY;
@@ -1580,18 +1628,28 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_fwd_kernel(AttnP pin) {
         }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) mx = max3f(max3f(mx, sacc[kb][0], sacc[kb][1]), sacc[kb][2], sacc[kb][3]);
-        mx = quad_max(mx) * sl;
-        if (__any(mx > m_run + RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, mx);
+        // deferred rescale: the reference point moves when some row outgrew it by 2^RESCALE_THR (always on a row's first
+        // keys).  The test needs no cross-lane traffic: the four lanes of a row share m_run, so "some LANE's 16 scores
+        // outgrew it" is the same wave-wide condition; the row maximum itself (two lane exchanges + their LDS round trips
+        // in front of every exponential) is only formed on the steps that do move the reference point.
+        const float thr = (m_run == -INFINITY) ? -INFINITY : RESCALE_THR;
+        if (__any(mx > thr)) {
+            mx = quad_max(mx);                                 // relative to the reference point
+            const float m_new = fmaxf(m_run, mx - nm);
             const float ms = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = fast_exp2(m_run - ms);
+            const float shift = ms + nm;                       // new reference - old reference (>= 0)
             l_run *= alpha;
 #pragma unroll
             for (int db = 0; db < 4; ++db) oacc[db] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) sacc[kb] -= shift;
             m_run = m_new;
         }
-        const float nm = (m_run == -INFINITY) ? 0.f : -m_run;
         float lsum[4] = {0.f, 0.f, 0.f, 0.f};
+        // (Requesting the V^T fragments here, before the exponentials, so that their LDS round trip runs under the softmax
+        // arithmetic, was measured: 33.6 vs 33.4 us on the packed encoder shape, 20.3 vs 20.8 us cross-attention - nothing.
+        // With four waves per SIMD the other waves already cover it; profiles/r03_attention_experiments.txt.)
         u32x4 cq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
         if (DROP) PA_DS128(cq[0], cbase, buf * BUF + AUX + 64);
 #pragma unroll
@@ -1606,14 +1664,19 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_fwd_kernel(AttnP pin) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float pe = fast_exp2(__builtin_fmaf(sacc[kb][e], sl, nm));
+                float pe = fast_exp2(sacc[kb][e]);
                 lsum[e] += pe;
                 if (DROP) pe = drop_keep2(arow, cq[kb & 1][e], p.drop_thr) ? pe : 0.f;
                 sacc[kb][e] = pe;
             }
         }
         l_run += (lsum[0] + lsum[1]) + (lsum[2] + lsum[3]);
-        mma_tr4<buf * BUF + NAT>(oacc, lb, sacc);
+        {
+            u32x4 pb[2], va1[4];
+            pack_p4(pb, sacc);
+            tr4_reads<buf * BUF + NAT, 0>(va1, lb); tr4_mmas<0>(oacc, va1, pb);
+            tr4_reads<buf * BUF + NAT, 1>(va1, lb); tr4_mmas<1>(oacc, va1, pb);
+        }
         tile_barrier();
     };
     for (int step = 0; step < nsteps; step += 2) {
@@ -1622,7 +1685,7 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_fwd_kernel(AttnP pin) {
     }
     PA_TR(3);
     float l_tot = quad_sum(l_run);
-    if constexpr (KS == 2) {
+    if (KS == 2 && split) {
         // merge the two key halves (every stage is free after the loop's last barrier): half 1 publishes (O^T, m, l) of its 16
         // rows per wave, half 0 rescales both to the common reference point and stores.  [db][lane] f32x4: conflict-free.
         f32x4* xo = reinterpret_cast<f32x4*>(smem) + wave * 4 * 64;
@@ -1705,7 +1768,11 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_bwd_dq_kernel(AttnP pin) {
     lb.init(smem_base + kh * 2 * BUF, lane);
     const uint32_t cbase = smem_base + kh * 2 * BUF + g * 16;
     const int ksteps = (p.Lk + BSTR - 1) / BSTR;
-    const int s0 = KS == 2 ? (ksteps + 1) / 2 : ksteps;
+    // an element with few key tiles is not split: its second-half waves leave before the first barrier (their wave
+    // slots and registers are free for other blocks at once; s_barrier only counts live waves)
+    const bool split = KS == 2 && ksteps >= pin.ks_min;                    // block-uniform
+    if (KS == 2 && kh == 1 && !split) return;
+    const int s0 = split ? (ksteps + 1) / 2 : ksteps;
     const int kbase = kh * s0 * BSTR, nst_h = KS == 2 ? (kh ? ksteps - s0 : s0) : 0;
     auto issue = [&](int step, int buf, int kfirst_) {
         char* base = smem + kh * 2 * BUF + buf * BUF;
@@ -1784,7 +1851,7 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_bwd_dq_kernel(AttnP pin) {
         body(step, IC<0>{});
         if (step + 1 < nsteps) body(step + 1, IC<1>{});
     }
-    if constexpr (KS == 2) {
+    if (KS == 2 && split) {
         f32x4* xo = reinterpret_cast<f32x4*>(smem) + wave * 4 * 64;
         if (kh == 1) {
 #pragma unroll
@@ -1927,6 +1994,7 @@ AttnP make_params(const pa_attn_args* a) {
     p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
     p.cu_q = a->cu_q; p.cu_k = a->cu_k; p.order = a->order;
     static const bool bal_env = !(getenv("PA_ATTN_BALANCED") && atoi(getenv("PA_ATTN_BALANCED")) == 0);
+    p.ks_min = 4;
     p.balanced = (bal_env && a->order && a->cu_q && a->cu_k && a->H == 8 && a->B <= 64) ? 1 : 0;
     return p;
 }
@@ -1954,12 +2022,17 @@ static bool use_v4(const AttnP& p, int rows_owned) {
 // In-block key split of the 16-row-wave forward / dQ kernels (attn4_fwd_kernel): for launches whose duration is one block's
 // serial chain of key steps - few blocks, many keys.  PA_ATTN_KSPLIT: 0 never, 1 (default) cross-attention-like launches (at
 // most one block per CU and at least 4 key tiles), 2 every eligible launch (no key-padding mask, not causal).
-static bool use_ksplit(const AttnP& p, unsigned blocks) {
+static bool use_ksplit(AttnP& p, unsigned blocks) {
     static const int mode = getenv("PA_ATTN_KSPLIT") ? atoi(getenv("PA_ATTN_KSPLIT")) : 1;
+    static const int min_few = getenv("PA_ATTN_KSPLIT_MIN") ? atoi(getenv("PA_ATTN_KSPLIT_MIN")) : 4;
+    static const int min_many = getenv("PA_ATTN_KSPLIT_MIN2") ? atoi(getenv("PA_ATTN_KSPLIT_MIN2")) : 10;
     if (mode == 0 || p.kpm || p.causal || p.Lk < 4 * BSTR) return false;
+    // at most one block per CU (cross-attention): every element with >= 4 key tiles; more blocks than CUs (packed
+    // self-attention, mode 2): only the long elements, whose chain of key steps sets the duration of the launch
+    p.ks_min = blocks <= 256 ? min_few : min_many;
     return mode >= 2 || blocks <= 256;
 }
-template <int DH> int run_fwd_bf16(const AttnP& p, hipStream_t st) {
+template <int DH> int run_fwd_bf16(AttnP p, hipStream_t st) {
     const int shm = BL<DH>::SHM;
     dim3 grid(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B);
     if constexpr (DH == 64) {
@@ -1981,7 +2054,7 @@ template <int DH> int run_fwd_bf16(const AttnP& p, hipStream_t st) {
     else PA_LAUNCH((attn_fwd_bf16_kernel<DH, false>), grid, dim3(NTH), shm, st, p);
     return 0;
 }
-template <int DH> int run_bwd_bf16(const AttnP& p, hipStream_t st) {
+template <int DH> int run_bwd_bf16(AttnP p, hipStream_t st) {
     const int shm = BL<DH>::SHM;
     const dim3 gq(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B), gk(((p.Lk + BOWN - 1) / BOWN) * p.H * p.B);
     if constexpr (DH == 64) {
