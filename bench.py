@@ -218,7 +218,7 @@ def pmc_traffic(kernel_key):
     """HBM bytes per launch of one kernel from the committed rocprofv3 PMC passes (profiles/r0N_pmc_traffic.json,
     made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 return json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch"]

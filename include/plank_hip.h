@@ -111,6 +111,23 @@ typedef struct {
 int pa_gemm_ln(const pa_gemm_ln_args* a, void* stream);
 int pa_gemm_ln_max_rows(void);
 
+/* Linear on LayerNorm(Z) without a LayerNorm launch - for the post-norm chains of the greedy-decode step, where a sublayer's
+ * output `x = norm(z)` (torch nn/modules/transformer.py, used by plankassembly/models.py:293-294 once per generated token) feeds the
+ * next Linear and the next residual add and a LayerNorm on B rows is pure launch latency.  With y = (z - mean) rstd gamma + beta:
+ *     y W^T + b  =  rstd (z (W gamma)^T - mean u) + v,     u[n] = sum_k W[n][k] gamma[k],   v[n] = b[n] + sum_k W[n][k] beta[k].
+ * pa_ln_fold_weights prepares Wf = bf16(W gamma) (from the f32 master weight), u (summed over the ROUNDED Wf) and v once per
+ * decode; pa_gemm_norm_a runs C = epi(rstd (A Wf^T - mean u) + v) on the raw rows A = Z (bf16, k-contiguous, K % 64 == 0,
+ * N % 32 == 0; `args->B` = Wf, `args->bias` = v; no residual / gate / dropout / split-K), every block computing the row
+ * statistics of its own 64 rows, and - when `y` is given - writes LayerNorm(Z) [M][K] for the later residual add.
+ * 64 x 64 tiles, at most two per CU (PA_ESHAPE beyond). */
+typedef struct {
+    const float* u; const float* gamma; const float* beta;
+    void* y; int32_t ldy; float eps;
+} pa_gemm_norm_ext;
+int pa_ln_fold_weights(void* Wf, float* u, float* v, const float* W, const float* bias, const float* gamma, const float* beta,
+                       int32_t N, int32_t K, void* stream);
+int pa_gemm_norm_a(const pa_gemm_args* args, const pa_gemm_norm_ext* ext, void* stream);
+
 /* Several weight-gradient GEMMs (dW = dY^T X: bf16 operands, contraction index strided in both, f32 output, no
  * epilogue, batch 1; splitk > 1 only with splitk_defer) in one launch of the ring kernel: its unit stream runs through
  * all members.  PA_EINVAL when a member does not qualify - the caller then launches them one by one with pa_gemm. */

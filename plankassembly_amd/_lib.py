@@ -35,6 +35,11 @@ class GemmArgs(C.Structure):
                 ("splitk", C.c_int32), ("splitk_defer", C.c_int32)]
 
 
+class GemmNormExt(C.Structure):
+    _fields_ = [("u", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("y", C.c_void_p),
+                ("ldy", C.c_int32), ("eps", C.c_float)]
+
+
 class GemmLnArgs(C.Structure):
     _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p),
                 ("Z", C.c_void_p), ("Y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),

@@ -26,6 +26,12 @@ struct DecodeLayout {
     int32_t* cu;                               // copy of the packed-row offsets (NULL: dense memory + kpm)
     int32_t* cu_store;
     std::vector<hipEvent_t> pair_ev;           // pa_decode_step_pair: [2][2 * n_dec] attention-done events (lane A's layout owns them)
+    // LayerNorm folded into the Linear that consumes it (bf16; pa_gemm_norm_a): per decoder layer, for the three Linears whose
+    // input is a sublayer's LayerNorm output - [0] self-attention in_proj (norm3 of the layer before), [1] the cross-attention
+    // query projection (norm1), [2] linear1 (norm2): gamma-scaled weight, u, v (include/plank_hip.h)
+    bool fold = false;
+    void* z2 = nullptr;                        // second pre-norm buffer (z of the cross-attention block)
+    std::vector<void*> fw[3]; std::vector<float*> fu[3], fv[3];
 };
 
 namespace {
@@ -53,19 +59,8 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(T* x, const float* value
 }
 
 // K/V caches are kept per head ([B][H][L][dh], each (b, h) a contiguous stream): reading 128-byte head slices out of
-// [B*L][2d] rows is a 2 KiB-strided access that camps on two L2 channels per XCD.
-template <typename T>
-__global__ __launch_bounds__(256) void dec_append_kv_kernel(T* kc, T* vc, const T* qkv, const int32_t* t_dev, int B, int Tmax, int d, int H) {
-    const int t = *t_dev, dh = d / H;
-    const int vec = d >> 2;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < B * vec; e += gridDim.x * 256) {
-        const int b = e / vec, c = (e % vec) << 2;
-        const int h = c / dh, cc = c % dh;
-        const int64_t dst = (((int64_t)b * H + h) * Tmax + t) * dh + cc;
-        st4<T>(kc + dst, ld4<T>(qkv + (int64_t)b * 3 * d + d + c));
-        st4<T>(vc + dst, ld4<T>(qkv + (int64_t)b * 3 * d + 2 * d + c));
-    }
-}
+// [B*L][2d] rows is a 2 KiB-strided access that camps on two L2 channels per XCD.  The self-attention caches are appended
+// to by dec_attn_kernel itself (`newkv`).
 // [B*S][2d] (k | v) -> K [B][H][S][dh], V [B][H][S][dh]
 template <typename T>
 __global__ __launch_bounds__(256) void dec_split_heads_kernel(T* kc, T* vc, const T* kv, int64_t rows, int S, int d, int H,
@@ -85,10 +80,13 @@ __global__ __launch_bounds__(256) void dec_split_heads_kernel(T* kc, T* vc, cons
 }
 
 // single-query attention; grid (H, B), 4 waves.  Lk = fixed_lk or *t_dev + 1.
+// `newkv` (self-attention): the step's in_proj output [B][3d]; key t = Lk - 1 is not in the cache yet - its K / V head
+// slices are taken from there (per-lane source select, no read-after-write through memory) and appended to the caches by
+// this block for the later steps.  That is the whole of what a separate append launch did (6 launches per step).
 template <typename T, int DH>
-__global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int ldq, const T* kc, const T* vc, int Lmax,
+__global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int ldq, T* kc, T* vc, int Lmax,
                                                        const uint8_t* kpm, int fixed_lk, const int32_t* t_dev,
-                                                       int d, float scale, const int32_t* cu) {
+                                                       int d, float scale, const int32_t* cu, const T* newkv) {
     constexpr int EB = ET<T>::EB;
     constexpr int LPR = DH / EB;             // lanes per key row
     constexpr int KPW = 64 / LPR;            // keys per wave step
@@ -102,6 +100,13 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int l
     const int64_t bh = ((int64_t)b * gridDim.x + h) * Lmax * DH + c * EB;
     const T* kb = kc + bh;
     const T* vb = vc + bh;
+    const T* nk = newkv ? newkv + (int64_t)b * 3 * d + d + h * DH + c * EB : nullptr;        // this lane's chunk of the new K row
+    const T* nv = newkv ? nk + d : nullptr;
+    if (newkv && tid < LPR) {                                                                // append for the steps to come
+        const int64_t dst = ((int64_t)b * gridDim.x + h) * Lmax * DH + (int64_t)(Lk - 1) * DH + c * EB;
+        *reinterpret_cast<u32x4*>(kc + dst) = *reinterpret_cast<const u32x4*>(nk);
+        *reinterpret_cast<u32x4*>(vc + dst) = *reinterpret_cast<const u32x4*>(nv);
+    }
     const uint8_t* mk = kpm ? kpm + (int64_t)b * Lmax : nullptr;
     float qv[EB];
     {
@@ -136,9 +141,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(T* out, const T* q, int l
             // unconditional loads (clamped row; out-of-range keys are discarded through okk): a branch around the loads
             // would put a wait between them
             const int64_t kc_ = (int64_t)min(key, Lk - 1) * ldkv;
+            const bool fresh = newkv && key >= Lk - 1;                 // the row this step produced (clamped keys land here too)
             // (streamed once per step, never re-read by this CU: non-temporal, so the lines do not displace the weights in L2)
-            kraw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + kc_));
-            vraw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + kc_));
+            kraw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fresh ? nk : kb + kc_));
+            vraw[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(fresh ? nv : vb + kc_));
         }
         float s[UN];
 #pragma unroll
@@ -369,6 +375,18 @@ int linear_ln(pa_model* m, const void* A, const void* W, const float* bias, cons
     return pa_layernorm_fwd(y, z, gamma, beta, m->dec->mean, m->dec->rstd, M, c.d_model, eps, c.dtype, st);
 }
 
+// C = epi(LayerNorm(Z) W^T + b) with the LayerNorm folded into the product (pa_gemm_norm_a); Y (optional) receives LayerNorm(Z)
+int linear_norm_a(pa_model* m, const void* Z, const void* Wf, const float* u, const float* v, const float* gamma, const float* beta,
+                  float eps, void* Y, void* Cout, int ldc, int M, int N, int K, int relu, void* st) {
+    pa_gemm_args g; memset(&g, 0, sizeof(g));
+    g.A = Z; g.B = Wf; g.C = Cout; g.bias = v;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = ldc;
+    g.batch = 1; g.a_kcontig = 1; g.b_kcontig = 1; g.in_dtype = PA_BF16; g.out_dtype = PA_BF16;
+    g.alpha = 1.f; g.relu = relu; g.aux_scale = 1.f; g.splitk = 1;
+    pa_gemm_norm_ext x; x.u = u; x.gamma = gamma; x.beta = beta; x.y = Y; x.ldy = K; x.eps = eps;
+    return pa_gemm_norm_a(&g, &x, st);
+}
+
 size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tmax) {
     const pa_model_cfg& c = m->cfg;
     const size_t e = c.dtype == PA_BF16 ? 2 : 4, d = c.d_model, ff = c.d_ff;
@@ -390,20 +408,29 @@ size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tm
     L->first_end = (int32_t*)a.take(B * 4); L->t_dev = (int32_t*)a.take(256);
     L->kpm = (uint8_t*)a.take((size_t)B * S);
     L->cu_store = (int32_t*)a.take((size_t)(B + 1) * 4);
+    L->z2 = a.take(B * d * e);
+    for (int k = 0; k < 3; ++k) { L->fw[k].resize(c.n_dec); L->fu[k].resize(c.n_dec); L->fv[k].resize(c.n_dec); }
+    for (int i = 0; i < c.n_dec; ++i) {
+        const size_t rows[3] = {3 * d, d, ff};
+        for (int k = 0; k < 3; ++k) {
+            L->fw[k][i] = a.take(rows[k] * d * 2);
+            L->fu[k][i] = (float*)a.take(rows[k] * 4); L->fv[k][i] = (float*)a.take(rows[k] * 4);
+        }
+    }
     return a.off;
 }
 
 template <typename T>
-int launch_attn(pa_model* m, T* out, const T* q, int ldq, const T* kc, const T* vc, int Lmax, const uint8_t* kpm,
-                int fixed_lk, const int32_t* t_dev, int B, void* st, const int32_t* cu = nullptr) {
+int launch_attn(pa_model* m, T* out, const T* q, int ldq, T* kc, T* vc, int Lmax, const uint8_t* kpm,
+                int fixed_lk, const int32_t* t_dev, int B, void* st, const int32_t* cu = nullptr, const T* newkv = nullptr) {
     const int d = m->cfg.d_model, H = m->cfg.n_head, dh = d / H;
     const float scale = 1.0f / sqrtf((float)dh);
     dim3 grid(H, B);
     hipStream_t s = (hipStream_t)st;
     switch (dh) {
-        case 16: PA_LAUNCH((dec_attn_kernel<T, 16>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale, cu); break;
-        case 32: PA_LAUNCH((dec_attn_kernel<T, 32>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale, cu); break;
-        case 64: PA_LAUNCH((dec_attn_kernel<T, 64>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale, cu); break;
+        case 16: PA_LAUNCH((dec_attn_kernel<T, 16>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale, cu, newkv); break;
+        case 32: PA_LAUNCH((dec_attn_kernel<T, 32>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale, cu, newkv); break;
+        case 64: PA_LAUNCH((dec_attn_kernel<T, 64>), grid, dim3(256), 0, s, out, q, ldq, kc, vc, Lmax, kpm, fixed_lk, t_dev, d, scale, cu, newkv); break;
         default: return PA_ESHAPE;
     }
     return 0;
@@ -432,12 +459,23 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
         PA_LAUNCH(dec_embed_kernel<T>, dim3(g1), dim3(256), 0, s, (T*)L->x, PF(P_IN_VALUE), PF(P_Q_COORD), PF(P_Q_POS),
                            L->tokens, Tmax, L->t_dev, B, d, c.out_dof);
     }
+    const bool fold = L->fold;
     if (part >= 2 && (part & 1) == 0) {
         // the feed-forward block of the previous layer (everything after its cross-attention)
-        const int pb = m->dec_base(part / 2 - 1);
-        RC(linear_ln(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->y, L->z, L->x, PF(pb + D_N2_W), PF(pb + D_N2_B), c.eps_layer, B, d, st));
-        RC(linear(m, L->x, PL(pb + D_L1_W), PF(pb + D_L1_B), L->ff, ff, B, ff, d, 1, nullptr, -1, st));
-        RC(linear_ln(m, L->ff, PL(pb + D_L2_W), PF(pb + D_L2_B), L->x, L->z, L->x, PF(pb + D_N3_W), PF(pb + D_N3_B), c.eps_layer, B, ff, st));
+        const int j = part / 2 - 1, pb = m->dec_base(j);
+        if (fold) {
+            // z2 = ao Wo^T + b + y1;  ff = relu(norm2(z2) W1^T + b1), y2 -> x;  z3 = ff W2^T + b2 + y2 -> z
+            RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z2, d, B, d, d, 0, L->y, -1, st));
+            RC(linear_norm_a(m, L->z2, L->fw[2][j], L->fu[2][j], L->fv[2][j], PF(pb + D_N2_W), PF(pb + D_N2_B), c.eps_layer, L->x,
+                             L->ff, ff, B, ff, d, 1, st));
+            RC(linear(m, L->ff, PL(pb + D_L2_W), PF(pb + D_L2_B), L->z, d, B, d, ff, 0, L->x, -1, st));
+            if (part == n_parts - 1)          // the last layer's norm3 has no Linear behind it: explicit
+                RC(pa_layernorm_fwd(L->x, L->z, PF(pb + D_N3_W), PF(pb + D_N3_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
+        } else {
+            RC(linear_ln(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->y, L->z, L->x, PF(pb + D_N2_W), PF(pb + D_N2_B), c.eps_layer, B, d, st));
+            RC(linear(m, L->x, PL(pb + D_L1_W), PF(pb + D_L1_B), L->ff, ff, B, ff, d, 1, nullptr, -1, st));
+            RC(linear_ln(m, L->ff, PL(pb + D_L2_W), PF(pb + D_L2_B), L->x, L->z, L->x, PF(pb + D_N3_W), PF(pb + D_N3_B), c.eps_layer, B, ff, st));
+        }
     }
     if (part == n_parts - 1) {
         RC(pa_layernorm_fwd(L->h, L->x, PF(m->dec_norm()), PF(m->dec_norm() + 1), L->mean, L->rstd, B, d, c.eps_final, c.dtype, st));
@@ -453,18 +491,29 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
     const int i = part / 2;
     const int pb = m->dec_base(i);
     if ((part & 1) == 0) {
-        RC(linear(m, x, PL(pb + D_SA_IN_W), PF(pb + D_SA_IN_B), L->qkv, 3 * d, B, 3 * d, d, 0, nullptr, -1, st));
-        PA_LAUNCH(dec_append_kv_kernel<T>, dim3((B * (d / 4) + 255) / 256), dim3(256), 0, s, (T*)L->self_k[i], (T*)L->self_v[i],
-                           (const T*)L->qkv, L->t_dev, B, Tmax, d, c.n_head);
+        if (fold && i > 0) {                   // x = norm3(z) of the layer before, materialised by this launch for the residual add
+            const int pp = m->dec_base(i - 1);
+            RC(linear_norm_a(m, L->z, L->fw[0][i], L->fu[0][i], L->fv[0][i], PF(pp + D_N3_W), PF(pp + D_N3_B), c.eps_layer, L->x,
+                             L->qkv, 3 * d, B, 3 * d, d, 0, st));
+        } else {
+            RC(linear(m, x, PL(pb + D_SA_IN_W), PF(pb + D_SA_IN_B), L->qkv, 3 * d, B, 3 * d, d, 0, nullptr, -1, st));
+        }
+        // (the attention kernel appends this step's K / V rows to the caches itself)
         RC(fence_in());
-        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->qkv, 3 * d, (const T*)L->self_k[i], (const T*)L->self_v[i], Tmax, nullptr, 0,
-                          L->t_dev, B, st));
+        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->qkv, 3 * d, (T*)L->self_k[i], (T*)L->self_v[i], Tmax, nullptr, 0,
+                          L->t_dev, B, st, nullptr, (const T*)L->qkv));
         RC(fence_out());
     } else {
-        RC(linear_ln(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), x, L->z, L->y, PF(pb + D_N1_W), PF(pb + D_N1_B), c.eps_layer, B, d, st));
-        RC(linear(m, L->y, PL(pb + D_CA_IN_W), PF(pb + D_CA_IN_B), L->q, d, B, d, d, 0, nullptr, -1, st));
+        if (fold) {                            // z1 = ao Wo^T + b + x -> z2;  q = norm1(z1) Wq^T + bq, y1 -> y
+            RC(linear(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), L->z2, d, B, d, d, 0, x, -1, st));
+            RC(linear_norm_a(m, L->z2, L->fw[1][i], L->fu[1][i], L->fv[1][i], PF(pb + D_N1_W), PF(pb + D_N1_B), c.eps_layer, L->y,
+                             L->q, d, B, d, d, 0, st));
+        } else {
+            RC(linear_ln(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), x, L->z, L->y, PF(pb + D_N1_W), PF(pb + D_N1_B), c.eps_layer, B, d, st));
+            RC(linear(m, L->y, PL(pb + D_CA_IN_W), PF(pb + D_CA_IN_B), L->q, d, B, d, d, 0, nullptr, -1, st));
+        }
         RC(fence_in());
-        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->q, d, (const T*)L->cross_k[i], (const T*)L->cross_v[i], S, L->cu ? nullptr : L->kpm, S,
+        RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->q, d, (T*)L->cross_k[i], (T*)L->cross_v[i], S, L->cu ? nullptr : L->kpm, S,
                           L->t_dev, B, st, L->cu));
         RC(fence_out());
     }
@@ -518,6 +567,21 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
         else
             PA_LAUNCH(dec_split_heads_kernel<float>, dim3(2048), dim3(256), 0, s, (float*)L->cross_k[i], (float*)L->cross_v[i],
                       (const float*)L->kv_tmp, (int64_t)m->NE, S, d, c.n_head, m->batch.cu_in, m->batch.rowmap);
+    }
+    // LayerNorm folded into its consumer Linear (bf16 decode; PLANK_DECODE_FOLD_LN=0 keeps the separate LayerNorm launches)
+    static const bool fold_env = !(getenv("PLANK_DECODE_FOLD_LN") && atoi(getenv("PLANK_DECODE_FOLD_LN")) == 0);
+    L->fold = fold_env && c.dtype == PA_BF16 && d % 64 == 0 && c.d_ff % 32 == 0 && (size_t)((B + 63) / 64) * ((3 * d + 63) / 64) <= 512;
+    if (L->fold) {
+        for (int i = 0; i < c.n_dec; ++i) {
+            const int pb = m->dec_base(i);
+            auto F = [&](int idx) { return (const float*)m->pf[idx]; };
+            if (i > 0) {
+                const int pp = m->dec_base(i - 1);
+                RC(pa_ln_fold_weights(L->fw[0][i], L->fu[0][i], L->fv[0][i], F(pb + D_SA_IN_W), F(pb + D_SA_IN_B), F(pp + D_N3_W), F(pp + D_N3_B), 3 * d, d, stream));
+            }
+            RC(pa_ln_fold_weights(L->fw[1][i], L->fu[1][i], L->fv[1][i], F(pb + D_CA_IN_W), F(pb + D_CA_IN_B), F(pb + D_N1_W), F(pb + D_N1_B), d, d, stream));
+            RC(pa_ln_fold_weights(L->fw[2][i], L->fu[2][i], L->fv[2][i], F(pb + D_L1_W), F(pb + D_L1_B), F(pb + D_N2_W), F(pb + D_N2_B), c.d_ff, d, stream));
+        }
     }
     L->cu = nullptr;
     if (m->batch.cu_in) {

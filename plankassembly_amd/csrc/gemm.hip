@@ -45,6 +45,10 @@ struct GemmP {
     int vec_ok;                    // epilogue may use 4-element vector accesses on C / R / aux / bias
     int plain_order;               // units enumerate (tile_m, tile_n) row-major instead of the XCD interleave
     int dbg;                       // ablation bits (PA_GEMM_DBG): 1 no MFMA, 2 no ds_read, 4 no loads, 8 no epilogue
+    // "A = LayerNorm(Z)" folded into the product (gemm3s_kernel only, pa_gemm_norm_a): A holds the raw rows Z, B the weight
+    // pre-multiplied by gamma, ln_u[n] = sum_k B[n][k], bias[n] = b[n] + sum_k W[n][k] beta[k]; the kernel computes the row
+    // statistics itself and writes  rstd_m (acc - mean_m u_n) + bias_n.  ln_y: where to materialise LayerNorm(Z) (or null).
+    const float* ln_u; const float* ln_gamma; const float* ln_beta; void* ln_y; int ldy; float ln_eps;
 };
 
 constexpr int BM = 128, BN = 128, NT = 256;
@@ -1348,6 +1352,7 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
     // residual / gate tile of the block's first unit, requested before its first K tile (as in gemm3_kernel)
     u32x2 pre_res[4], pre_aux[4];
     bool pre_live = false;
+    float ln_mean[4] = {0.f, 0.f, 0.f, 0.f}, ln_rstd[4] = {1.f, 1.f, 1.f, 1.f};     // (p.ln_u: statistics of this lane's rows)
     // ---- epilogue: per-wave staging (32 x 32 f32), straight-line fast path ------------------------------------------
     auto epilogue = [&](const Unit& un) {
         char* stage = smem + NSTG * STAGE + wave * EPI;
@@ -1414,10 +1419,18 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
             }
             // one straight-line loop per optional stage behind its own uniform branch, stores with the output type and the
             // row-validity test decided once (see gemm3_kernel)
+            if (p.ln_u) {                                   // A = LayerNorm(Z) folded in: rstd (acc - mean u) + (b + W beta)
+                const f32x4 u4 = *reinterpret_cast<const f32x4*>(p.ln_u + n);
 #pragma unroll
-            for (int it = 0; it < NIT; ++it)
+                for (int it = 0; it < NIT; ++it)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[it][e] = x[it][e] * p.alpha + bias[e];
+                    for (int e = 0; e < 4; ++e) x[it][e] = ln_rstd[it] * (x[it][e] * p.alpha - ln_mean[it] * u4[e]) + bias[e];
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[it][e] = x[it][e] * p.alpha + bias[e];
+            }
             if (p.relu) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
@@ -1521,6 +1534,49 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
                 const int m = min(mp0 + it * 8, p.M - 1);
                 if (p.R) pre_res[it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.R) + (size_t)cun.b * p.sR + (size_t)m * p.ldr + n0);
                 if (p.aux) pre_aux[it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.aux) + (size_t)cun.b * p.sAux + (size_t)m * p.ldaux + n0);
+            }
+        }
+    }
+    if (p.ln_u) {
+        // LayerNorm statistics of this lane's four output rows (the epilogue's rows mp + 8 it): the eight lanes that share a
+        // row (chunk = lane & 7) each sum an eighth of it, three exchanges combine them.  Ordinary loads, all consumed
+        // before the first DMA instruction is issued (the hand-counted vmcnt waits of the K loop stay exact).
+        const int mp0 = cun.tile_m * TB + wm * 32 + (lane >> 3), ch = lane & 7;
+        const bf16* zb = reinterpret_cast<const bf16*>(p.A) + (size_t)cun.b * p.sA;
+        const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const bf16* zr = zb + (size_t)min(mp0 + it * 8, p.M - 1) * p.lda;
+            float s1 = 0.f, s2 = 0.f;
+            for (int k = ch * 8; k < p.K; k += 64) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(zr + k);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float a0 = bf16_lo(v[w]), a1 = bf16_hi(v[w]);
+                    s1 += a0 + a1; s2 += a0 * a0 + a1 * a1;
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            const float mean = s1 * inv_k;
+            ln_mean[it] = mean;
+            ln_rstd[it] = rsqrtf(fmaxf(s2 * inv_k - mean * mean, 0.f) + p.ln_eps);
+        }
+        // y = LayerNorm(z) for the later residual add: the column tiles 0 .. K/64 - 1 each write their 64 columns
+        if (p.ln_y && cun.tile_n * TB < p.K) {
+            const int n0 = cun.tile_n * TB + wn * 32 + ch * 4;
+            if (n0 + 4 <= p.K) {
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(p.ln_gamma + n0), bt = *reinterpret_cast<const f32x4*>(p.ln_beta + n0);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int m = mp0 + it * 8;
+                    if (m < p.M) {
+                        f32x4 z = ld4<bf16>(zb + (size_t)m * p.lda + n0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z[e] = (z[e] - ln_mean[it]) * ln_rstd[it] * gm[e] + bt[e];
+                        st4<bf16>(reinterpret_cast<bf16*>(p.ln_y) + (size_t)m * p.ldy + n0, z);
+                    }
+                }
             }
         }
     }
@@ -2089,6 +2145,7 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     p.drop_scale = 1.0f / (1.0f - a->drop_p);
     p.drop_seed = a->drop_seed;
     p.out_dtype = a->out_dtype;
+    p.ln_u = nullptr; p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_y = nullptr; p.ldy = 0; p.ln_eps = 0.f;
     static const int dbg_bk = getenv("PA_GEMM_BK") ? atoi(getenv("PA_GEMM_BK")) : 64;     // bf16 K tile: 64 or 32
     const bool bk32 = a->in_dtype == PA_BF16 && dbg_bk == 32;
     const int BK = a->in_dtype == PA_BF16 ? (bk32 ? 32 : 64) : 16;
@@ -2203,6 +2260,60 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
 // must be: bf16 operands with the contraction index strided in both (dY^T X), f32 output, no epilogue beyond the
 // split-K slab store (splitk > 1 requires splitk_defer), batch 1, 16-byte aligned.  Anything else: PA_EINVAL and the
 // caller launches the members one by one.
+// ---- Linear on LayerNorm(Z) without a LayerNorm launch (greedy-decode step: B rows, 17 LayerNorm launches per step) ------
+namespace {
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(bf16* Wf, float* u, float* v, const float* W, const float* bias,
+                                                              const float* gamma, const float* beta, int N, int K) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x;
+    float su = 0.f, sv = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float w = W[(size_t)n * K + k];
+        const bf16 wf = (bf16)(w * gamma[k]);
+        Wf[(size_t)n * K + k] = wf;
+        su += (float)wf;                       // the sum of what the MFMA will really multiply by (the rounded values)
+        sv += w * beta[k];
+    }
+    su = wave_sum(su); sv = wave_sum(sv);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = su; red[1][threadIdx.x >> 6] = sv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u[n] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        v[n] = (bias ? bias[n] : 0.f) + (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+}  // namespace
+extern "C" int pa_ln_fold_weights(void* Wf, float* u, float* v, const float* W, const float* bias, const float* gamma,
+                                  const float* beta, int32_t N, int32_t K, void* stream) {
+    if (!Wf || !u || !v || !W || !gamma || !beta || N <= 0 || K <= 0) return PA_EINVAL;
+    PA_LAUNCH(ln_fold_weights_kernel, dim3(N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (bf16*)Wf, u, v, W, bias, gamma, beta, N, K);
+    return 0;
+}
+extern "C" int pa_gemm_norm_a(const pa_gemm_args* a, const pa_gemm_norm_ext* x, void* stream) {
+    if (!a || !x || !a->A || !a->B || !a->C || !a->bias || !x->u || a->M <= 0 || a->N <= 0 || a->K <= 0) return PA_EINVAL;
+    if (a->in_dtype != PA_BF16 || (a->out_dtype != PA_BF16 && a->out_dtype != PA_F32) || !a->a_kcontig || !a->b_kcontig) return PA_EINVAL;
+    if (a->batch != 1 || a->splitk > 1 || a->R || a->aux || a->drop_p != 0.f || a->K % 64 || a->N % 32) return PA_ESHAPE;
+    if (x->y && (!x->gamma || !x->beta || x->ldy < a->K || x->ldy % 4)) return PA_EINVAL;
+    if (x->y && (a->N + 63) / 64 * 64 < a->K) return PA_ESHAPE;      // column tile j materialises columns 64 j .. 64 j + 63 of LayerNorm(Z)
+    if (!is_aligned<bf16>(a)) return PA_EALIGN;
+    const int tiles = ((a->M + 63) / 64) * ((a->N + 63) / 64);
+    const int cus = cus_for_gemm();
+    if (tiles > 2 * cus) return PA_ESHAPE;                 // the row statistics live in registers: one unit per block
+    GemmP p = GemmP();                                     // (value-initialised: every optional pointer null)
+    p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
+    p.batch = 1; p.alpha = a->alpha; p.relu = a->relu; p.aux_scale = 1.f; p.drop_scale = 1.f; p.out_dtype = a->out_dtype;
+    p.splitk = 1; p.tiles_per_slice = a->K / 64;
+    p.tiles_m = (a->M + 63) / 64; p.tiles_n = (a->N + 63) / 64; p.tiles_m_pad = p.tiles_m; p.plain_order = 1; p.units = tiles;
+    const int osz = a->out_dtype == PA_F32 ? 4 : 2;
+    p.vec_ok = ((reinterpret_cast<uintptr_t>(a->C) % (4 * osz)) == 0 && a->ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(a->bias) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(x->u) & 15) == 0) ? 1 : 0;
+    if (!p.vec_ok) return PA_EALIGN;
+    p.ln_u = x->u; p.ln_gamma = x->gamma; p.ln_beta = x->beta; p.ln_y = x->y; p.ldy = x->ldy; p.ln_eps = x->eps;
+    PA_LAUNCH(gemm3s_kernel, dim3(tiles), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), p);
+    return 0;
+}
+
 extern "C" int pa_gemm_group(const pa_gemm_args* args, int32_t n, void* stream) {
     if (!args || n <= 0 || n > PA_MAX_GROUP) return PA_EINVAL;
     static_assert(PA_MAX_GROUP == PA_MAX_GROUP_, "header / kernel table size");

@@ -217,6 +217,32 @@ def gemm_ln(x, w, gamma, beta, eps, *, bias=None, residual=None, drop_p=0.0, dro
     return z, y, mean, rstd
 
 
+def gemm_norm_a(z, w, bias, gamma, beta, eps, *, relu=False, want_y=True, out_dtype=None):
+    """epi(LayerNorm(z) @ w.T + bias) with the LayerNorm folded into the product (pa_ln_fold_weights + pa_gemm_norm_a; the
+    greedy-decode step's form).  z: bf16 [M, K]; w, bias, gamma, beta: f32 master parameters.  Returns (out, y | None)."""
+    M, K = z.shape
+    N = w.shape[0]
+    dev = z.device
+    wf = torch.empty(N, K, dtype=torch.bfloat16, device=dev)
+    u, v = _f32(N, device=dev), _f32(N, device=dev)
+    L.check(L.lib().pa_ln_fold_weights(L.ptr(wf), L.ptr(u), L.ptr(v), L.ptr(w), L.ptr(bias), L.ptr(gamma), L.ptr(beta), N, K,
+                                       L.stream()), "pa_ln_fold_weights")
+    out = torch.empty(M, N, dtype=out_dtype or z.dtype, device=dev)
+    y = torch.empty(M, K, dtype=z.dtype, device=dev) if want_y else None
+    g = L.GemmArgs()
+    g.A, g.B, g.C, g.bias = z.data_ptr(), wf.data_ptr(), out.data_ptr(), v.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = z.stride(0), K, N
+    g.batch, g.a_kcontig, g.b_kcontig = 1, 1, 1
+    g.in_dtype, g.out_dtype = L.dt(z), L.dt(out)
+    g.alpha, g.relu, g.aux_scale, g.splitk = 1.0, int(relu), 1.0, 1
+    x = L.GemmNormExt()
+    x.u, x.gamma, x.beta = u.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    x.y, x.ldy, x.eps = (y.data_ptr() if want_y else None), K, eps
+    L.check(L.lib().pa_gemm_norm_a(C.byref(g), C.byref(x), L.stream()), "pa_gemm_norm_a")
+    return out, y
+
+
 def layernorm_fwd(z, gamma, beta, eps):
     rows, d = z.numel() // z.shape[-1], z.shape[-1]
     y = torch.empty_like(z)

@@ -625,6 +625,30 @@ def test_attention_key_split_blocks_same_dropout_as_dense():
     assert rel_err(o, o0) > 0.05                                   # (dropout really was on)
 
 
+@pytest.mark.parametrize("M,N,K,eps,relu", [(256, 512, 512, 1.0, False), (256, 1536, 512, 1.0, False), (256, 1024, 512, 1.0, True),
+                                              (128, 512, 512, 1e-5, False), (200, 96, 128, 1.0, True)])
+def test_gemm_on_folded_layernorm(M, N, K, eps, relu):
+    """pa_gemm_norm_a: Linear(LayerNorm(z)) with the LayerNorm folded into the product, rstd (z (W gamma)^T - mean u) + v (the
+    greedy-decode step's form; post-norm layers of torch's TransformerDecoderLayer with the reference's eps = 1.0), against
+    torch: LayerNorm in f32 on the bf16 rows, then the Linear; and the materialised LayerNorm(z) itself.  Rows carry a
+    large common offset (mean >> std): the regime where  acc - mean u  cancels most of acc."""
+    z = (rnd(M, K, seed=130) * 1.5 + rnd(M, 1, seed=131) * 6.0).to(torch.bfloat16)
+    w, b = rnd(N, K, seed=132, scale=0.05), rnd(N, seed=133, scale=0.1)
+    gamma, beta = 1.0 + 0.2 * rnd(K, seed=134), 0.1 * rnd(K, seed=135)
+    zf = z.float()
+    y_ref = torch.nn.functional.layer_norm(zf, (K,), gamma, beta, eps)
+    ref = y_ref @ w.t() + b
+    if relu:
+        ref = torch.relu(ref)
+    out, y = ops.gemm_norm_a(z.to(DEV), w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV), eps, relu=relu)
+    assert rel_err(y, y_ref) < 1e-2                          # bf16 rounding of y
+    assert rel_err(out, ref) < 2.5e-2, rel_err(out, ref)
+    # and against what the unfolded pair of launches gives (bf16 LayerNorm output, bf16 weight): same ballpark of error
+    y2, _, _ = ops.layernorm_fwd(z.to(DEV), gamma.to(DEV), beta.to(DEV), eps)
+    out2 = ops.gemm(y2, w.to(torch.bfloat16).to(DEV), bias=b.to(DEV), relu=relu)
+    assert rel_err(out, ref) < 2.0 * rel_err(out2, ref) + 5e-3, (rel_err(out, ref), rel_err(out2, ref))
+
+
 def test_gemm_wide_tile_bf16():
     """Large multi-round Linears: ragged M, N not a multiple of 256, every epilogue.  Runs on the two-blocks-per-CU kernel
     by default and on the 128 x 256 tile kernel under PA_GEMM_WIDE=1 (both were validated with this test)."""
