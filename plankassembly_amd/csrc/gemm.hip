@@ -1537,30 +1537,63 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
             }
         }
     }
+    unit_of(cd_u, dun); setup(dun, 0);
+    int sd = 0, pending = 0;
+    auto issue = [&]() {
+        fetch(sd);
+        sd = (sd + 1) & (NSTG - 1);
+        ++pending;
+        if (++cd_t >= nt) { cd_u += ustride; cd_t = 0; if (cd_u < p.units) { unit_of(cd_u, dun); setup(dun, 0); } }
+    };
+    auto wait_items = [&](int younger) {        // items are 4 DMA instructions each here
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    PA_TR3(1);
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) if (cd_u < p.units) issue();
     if (p.ln_u) {
         // LayerNorm statistics of this lane's four output rows (the epilogue's rows mp + 8 it): the eight lanes that share a
-        // row (chunk = lane & 7) each sum an eighth of it, three exchanges combine them.  Ordinary loads, all consumed
-        // before the first DMA instruction is issued (the hand-counted vmcnt waits of the K loop stay exact).
+        // row (chunk = lane & 7) each sum an eighth of it, three exchanges combine them.  Ordinary loads, issued BEHIND the first
+        // three K tiles' DMA (their round trips overlap); the compiler's wait for them also covers those older DMAs, and the
+        // few y stores that may still be in flight at the first hand-counted vmcnt wait only make it conservative.
         const int mp0 = cun.tile_m * TB + wm * 32 + (lane >> 3), ch = lane & 7;
         const bf16* zb = reinterpret_cast<const bf16*>(p.A) + (size_t)cun.b * p.sA;
         const float inv_k = 1.0f / (float)p.K;
+        // all loads of a 512-column slab are issued before the first is used (unconditional, clamped addresses; surplus
+        // chunks are discarded in the arithmetic): one memory round trip per slab instead of one per chunk
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < p.K; kb += 512) {
+            u32x4 v[4][8];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const bf16* zr = zb + (size_t)min(mp0 + it * 8, p.M - 1) * p.lda;
-            float s1 = 0.f, s2 = 0.f;
-            for (int k = ch * 8; k < p.K; k += 64) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(zr + k);
+            for (int it = 0; it < 4; ++it) {
+                const bf16* zr = zb + (size_t)min(mp0 + it * 8, p.M - 1) * p.lda;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const float a0 = bf16_lo(v[w]), a1 = bf16_hi(v[w]);
-                    s1 += a0 + a1; s2 += a0 * a0 + a1 * a1;
-                }
+                for (int j = 0; j < 8; ++j) v[it][j] = *reinterpret_cast<const u32x4*>(zr + min(kb + ch * 8 + 64 * j, p.K - 8));
             }
 #pragma unroll
-            for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-            const float mean = s1 * inv_k;
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float keep = (kb + ch * 8 + 64 * j < p.K) ? 1.f : 0.f;
+                    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float a0 = bf16_lo(v[it][j][w]), a1 = bf16_hi(v[it][j][w]);
+                        t1 += a0 + a1; t2 += a0 * a0 + a1 * a1;
+                    }
+                    s1[it] += keep * t1; s2[it] += keep * t2;
+                }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            float a1 = s1[it], a2 = s2[it];
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+            const float mean = a1 * inv_k;
             ln_mean[it] = mean;
-            ln_rstd[it] = rsqrtf(fmaxf(s2 * inv_k - mean * mean, 0.f) + p.ln_eps);
+            ln_rstd[it] = rsqrtf(fmaxf(a2 * inv_k - mean * mean, 0.f) + p.ln_eps);
         }
         // y = LayerNorm(z) for the later residual add: the column tiles 0 .. K/64 - 1 each write their 64 columns
         if (p.ln_y && cun.tile_n * TB < p.K) {
@@ -1580,22 +1613,6 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
             }
         }
     }
-    unit_of(cd_u, dun); setup(dun, 0);
-    int sd = 0, pending = 0;
-    auto issue = [&]() {
-        fetch(sd);
-        sd = (sd + 1) & (NSTG - 1);
-        ++pending;
-        if (++cd_t >= nt) { cd_u += ustride; cd_t = 0; if (cd_u < p.units) { unit_of(cd_u, dun); setup(dun, 0); } }
-    };
-    auto wait_items = [&](int younger) {        // items are 4 DMA instructions each here
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    PA_TR3(1);
-#pragma unroll 1
-    for (int k = 0; k < 3; ++k) if (cd_u < p.units) issue();
     wait_items(pending - 1);
     __builtin_amdgcn_s_barrier();
     PA_TR3(2);

@@ -107,7 +107,7 @@ def _split_batch(batch, lo, hi):
 class GreedyDecoder:
     def __init__(self, model, use_graph=None, check_every=16, strict_graph=False, lanes=None):
         """``strict_graph``: a failed hipGraph capture raises instead of falling back to eager launches (benchmarks must
-        not silently measure the slow path; PLANK_DECODE_GRAPH=1 has the same effect).  ``lanes``: 1 or 2 (default 2,
+        not silently measure the slow path; PLANK_DECODE_GRAPH=1 has the same effect).  ``lanes``: 1 or 2 (default 1,
         PLANK_DECODE_LANES overrides); batches of fewer than 32 samples always run as one lane."""
         self.model = model
         self.check_every = check_every
@@ -115,7 +115,9 @@ class GreedyDecoder:
         if use_graph is None:
             use_graph = os.environ.get("PLANK_DECODE_GRAPH", "1") != "0"
         self.use_graph = use_graph
-        self.max_lanes = int(lanes if lanes is not None else os.environ.get("PLANK_DECODE_LANES", "2"))
+        # one lane by default since round 3: with the K/V append folded into the attention kernel the single-stream step
+        # (1.210 ms at B 256) is ahead of the two half-batch lanes (1.239 ms)
+        self.max_lanes = int(lanes if lanes is not None else os.environ.get("PLANK_DECODE_LANES", "1"))
         # PLANK_DECODE_ALTERNATE=1: the lanes' attention launches strictly alternate (pa_decode_step_pair).  OFF: measured
         # 2.15 ms / step against 1.23 - 24 cross-queue event edges per step cost more than the overlap they arrange.
         self.alternate = os.environ.get("PLANK_DECODE_ALTERNATE", "0") == "1"

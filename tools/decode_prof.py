@@ -5,7 +5,7 @@ import torch
 import bench
 from plankassembly_amd.data import spec_for, synth_batch
 from plankassembly_amd.decode import GreedyDecoder
-dm = bench.build("bf16", 1025, 1024, 0.0).eval()
+dm = bench.build(os.environ.get("DTYPE", "bf16"), 1025, 1024, 0.0).eval()
 dm._ensure_handle(); dm._refresh_shadow()
 dec = GreedyDecoder(dm, use_graph=os.environ.get("GRAPH", "1") != "0", strict_graph=True)
 db = synth_batch(256, spec_for("decode"), seed=7, device="cuda"); db.pop("name")
