@@ -69,6 +69,7 @@ typedef struct {
     float drop_p; uint32_t drop_seed;
     int32_t splitk;
     int32_t splitk_defer;   /* 1: only write the f32 slabs to `ws`; the caller reduces them later (pa_splitk_reduce_many) */
+    int64_t sBias;          /* batch stride of `bias` in elements (0: one bias for every batch member) */
 } pa_gemm_args;
 int pa_gemm(const pa_gemm_args* a, void* stream);
 /* Leave `n` of the 256 CUs free in every persistent GEMM launch (0 <= n <= 192; default 0 or PA_RESERVE_CUS): room for the

@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
                 ("batch", C.c_int32), ("a_kcontig", C.c_int32), ("b_kcontig", C.c_int32),
                 ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("alpha", C.c_float), ("relu", C.c_int32),
                 ("aux_scale", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
-                ("splitk", C.c_int32), ("splitk_defer", C.c_int32)]
+                ("splitk", C.c_int32), ("splitk_defer", C.c_int32), ("sBias", C.c_int64)]
 
 
 class GemmNormExt(C.Structure):

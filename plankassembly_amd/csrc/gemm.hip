@@ -35,7 +35,7 @@ struct GemmP {
     const float* bias; const void* R; const void* aux;
     int M, N, K;
     int lda, ldb, ldc, ldr, ldaux;
-    long long sA, sB, sC, sR, sAux;
+    long long sA, sB, sC, sR, sAux, sBias;
     int batch;
     float alpha; int relu; float aux_scale;
     uint32_t drop_thr; float drop_scale; uint32_t drop_seed;
@@ -351,8 +351,9 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
         ubias = f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.bias && p.splitk == 1) {
             const int n = un.tile_n * BN + wn * 64 + (lane & 15) * 4;
-            if (p.vec_ok && n + 3 < p.N) ubias = *reinterpret_cast<const f32x4*>(p.bias + n);
-            else { for (int e = 0; e < 4; ++e) if (n + e < p.N) ubias[e] = p.bias[n + e]; }
+            const float* bp = p.bias + (size_t)un.b * p.sBias;
+            if (p.vec_ok && n + 3 < p.N) ubias = *reinterpret_cast<const f32x4*>(bp + n);
+            else { for (int e = 0; e < 4; ++e) if (n + e < p.N) ubias[e] = bp[n + e]; }
         }
     };
 
@@ -966,8 +967,9 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
         constexpr int NIT = 8;
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
         if (has_bias) {
-            if (fast) bias = *reinterpret_cast<const f32x4*>(pc.bias + n);
-            else { for (int e = 0; e < 4; ++e) if (n + e < pc.N) bias[e] = pc.bias[n + e]; }
+            const float* bp = pc.bias + (size_t)un.b * pc.sBias;
+            if (fast) bias = *reinterpret_cast<const f32x4*>(bp + n);
+            else { for (int e = 0; e < 4; ++e) if (n + e < pc.N) bias[e] = bp[n + e]; }
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {          // pass = tm: output rows mw + 32*pass .. +31
@@ -1368,8 +1370,9 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
         constexpr int NIT = 4;
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
         if (has_bias) {
-            if (fast) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
-            else { for (int e = 0; e < 4; ++e) if (n + e < p.N) bias[e] = p.bias[n + e]; }
+            const float* bp = p.bias + (size_t)un.b * p.sBias;
+            if (fast) bias = *reinterpret_cast<const f32x4*>(bp + n);
+            else { for (int e = 0; e < 4; ++e) if (n + e < p.N) bias[e] = bp[n + e]; }
         }
         {
             const int lrow = lane & 31;                                   // accumulator: row (m) = lane & 31, value r <-> n
@@ -1773,8 +1776,9 @@ __global__ __launch_bounds__(NT, 1) void gemm3w_kernel(GemmP p) {
             const bool fast = p.vec_ok && (nw + 32 <= p.N);
             f32x4 bias = {0.f, 0.f, 0.f, 0.f};
             if (has_bias) {
-                if (fast) bias = *reinterpret_cast<const f32x4*>(p.bias + n);
-                else { for (int e = 0; e < 4; ++e) if (n + e < p.N) bias[e] = p.bias[n + e]; }
+                const float* bp = p.bias + (size_t)un.b * p.sBias;
+                if (fast) bias = *reinterpret_cast<const f32x4*>(bp + n);
+                else { for (int e = 0; e < 4; ++e) if (n + e < p.N) bias[e] = bp[n + e]; }
             }
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm) {
@@ -2155,7 +2159,7 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias; p.R = a->R; p.aux = a->aux;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr; p.ldaux = a->ldaux;
-    p.sA = a->sA; p.sB = a->sB; p.sC = a->sC; p.sR = a->sR; p.sAux = a->sAux;
+    p.sA = a->sA; p.sB = a->sB; p.sC = a->sC; p.sR = a->sR; p.sAux = a->sAux; p.sBias = a->sBias;
     p.batch = a->batch;
     p.alpha = a->alpha; p.relu = a->relu; p.aux_scale = a->aux_scale;
     p.drop_thr = (uint32_t)(a->drop_p * 65536.0f + 0.5f);
@@ -2187,7 +2191,7 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
             return !q || (((reinterpret_cast<uintptr_t>(q) * 1) % (4 * esz) == 0) && (ld % 4 == 0) && (sb % 4 == 0));
         };
         pk.vec_ok = ok(pk.C, pk.ldc, splitk > 1 ? (long long)a->M * a->N : a->sC, osz) && ok(a->R, a->ldr, a->sR, osz) &&
-                    ok(a->aux, a->ldaux, a->sAux, isz) && ok(a->bias, 4, 0, 4);
+                    ok(a->aux, a->ldaux, a->sAux, isz) && ok(a->bias, 4, a->sBias, 4);
     }
     const int cus = cus_for_gemm();                 // 256 minus the CUs left to RCCL's kernels (pa_set_reserved_cus)
     // debug/ablation toggles (environment, read once): PA_GEMM_NOGLDS=1, PA_GEMM_GRID=<blocks> (0 = one block per unit)

@@ -32,6 +32,7 @@ struct EncAct {   // saved activations of one encoder layer
 };
 struct DecAct {
     void *qkv, *o_sa, *z1, *y1, *q_ca, *kv_ca, *o_ca, *z2, *y2, *hff, *z3;
+    int ld_kv = 0;                     // row stride of kv_ca: 2d, or n_dec * 2d when all layers' K|V projections share one matrix
     float *lse_sa, *lse_ca, *m1, *r1, *m2, *r2, *m3, *r3;
 };
 
@@ -63,6 +64,7 @@ struct pa_model {
     pa_colsum_desc cs[PA_MAX_COLSUM]; int ncs = 0; bool defer_ok = false;       // queued bias-gradient column sums of the current segment
     pa_reduce_desc defer[PA_MAX_REDUCE]; int ndefer = 0; size_t slab_used = 0;   // queued split-K reductions of the current segment
     bool dmem_written = false;
+    void* kv_all = nullptr;            // [rows][n_dec * 2d]: cross-attention K|V of every decoder layer (one batched GEMM over the memory)
     void* gKV_all = nullptr; const void* kvT_all = nullptr;   // packed cross-attention K/V path (pa_model_bind_cross_kv_t)
     // Two copies ("parity sets") of every buffer the queued end-of-segment work reads: with the side stream on, that
     // work of segment s runs concurrently with the main stream's segments s+1 (other set) and is joined before s+2.

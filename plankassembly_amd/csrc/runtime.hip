@@ -169,12 +169,15 @@ size_t pa_train_layout(pa_model* m, char* base, int B, int S, int T) {
     for (int i = 0; i < c.n_dec; ++i) {
         DecAct& t = m->da[i];
         t.qkv = a.take(BT * 3 * d * e); t.o_sa = a.take(BT * d * e); t.z1 = a.take(BT * d * e); t.y1 = a.take(BT * d * e);
-        t.q_ca = a.take(BT * d * e); t.kv_ca = a.take(BS * 2 * d * e); t.o_ca = a.take(BT * d * e);
+        t.q_ca = a.take(BT * d * e); t.kv_ca = nullptr; t.o_ca = a.take(BT * d * e);
         t.z2 = a.take(BT * d * e); t.y2 = a.take(BT * d * e); t.hff = a.take(BT * ff * e); t.z3 = a.take(BT * d * e);
         t.lse_sa = (float*)a.take((size_t)B * H * T * 4); t.lse_ca = (float*)a.take((size_t)B * H * T * 4);
         t.m1 = (float*)a.take(BT * 4); t.r1 = (float*)a.take(BT * 4); t.m2 = (float*)a.take(BT * 4);
         t.r2 = (float*)a.take(BT * 4); t.m3 = (float*)a.take(BT * 4); t.r3 = (float*)a.take(BT * 4);
     }
+    // cross-attention K | V of all decoder layers side by side: layer i's slice starts at column i * 2d (row stride n_dec * 2d)
+    m->kv_all = a.take(BS * 2 * d * e * (c.n_dec > 0 ? c.n_dec : 1));
+    for (int i = 0; i < c.n_dec; ++i) { m->da[i].kv_ca = (char*)m->kv_all + (size_t)i * 2 * d * e; m->da[i].ld_kv = c.n_dec * 2 * (int)d; }
     m->hid = a.take(BT * d * e); m->hid_m = (float*)a.take(BT * 4); m->hid_r = (float*)a.take(BT * 4);
     m->ldv = (c.vocab + 63) / 64 * 64;     // logits / d(logits) rows padded to a whole K tile: the pad columns are written as zeros
                                            // (mixture_nll_bwd), so dX = d(logits) x W runs as an aligned GEMM with K = ldv
@@ -258,6 +261,31 @@ int pa_train_forward_impl(pa_model* m, void* st) {
     // ---- decoder (reference models.py:114-138, 204, 209-214) ----
     RC(pa_embed_output_fwd(m->Y[0], c.dtype, PF(P_IN_VALUE), PF(P_Q_COORD), PF(P_Q_POS), m->batch.output_value, T, B, T, d,
                            c.out_dof, st));
+    // Cross-attention K | V projections of ALL decoder layers as one batched GEMM over the memory (they depend on nothing
+    // the decoder computes): the layers' in_proj weights / biases sit at a constant stride in the flat parameter buffers, so
+    // batch member i reads weight rows d..3d of layer i and writes columns i*2d.. of kv_all.  One launch with n_dec x the tiles
+    // instead of n_dec launches in the decoder's latency-bound chain.
+    bool kv_fused = false;
+    if (c.n_dec > 1) {
+        const size_t e = m->esz;
+        const char* w0 = (const char*)PL(m->dec_base(0) + D_CA_IN_W); const char* w1 = (const char*)PL(m->dec_base(1) + D_CA_IN_W);
+        const float* b0 = PF(m->dec_base(0) + D_CA_IN_B); const float* b1 = PF(m->dec_base(1) + D_CA_IN_B);
+        const ptrdiff_t ws = w1 - w0, bs = (const char*)b1 - (const char*)b0;
+        bool uniform = ws > 0 && bs > 0 && ws % (ptrdiff_t)e == 0 && bs % 16 == 0;
+        for (int i = 2; i < c.n_dec && uniform; ++i)
+            uniform = (const char*)PL(m->dec_base(i) + D_CA_IN_W) - w0 == ws * i && (const char*)PF(m->dec_base(i) + D_CA_IN_B) - (const char*)b0 == bs * i;
+        static const bool fuse_env = !(getenv("PLANK_CROSS_KV_FWD") && atoi(getenv("PLANK_CROSS_KV_FWD")) == 0);
+        if (uniform && fuse_env) {
+            pa_gemm_args g; memset(&g, 0, sizeof(g));
+            g.A = memory; g.B = w0 + (size_t)d * d * e; g.C = m->kv_all; g.bias = b0 + d;
+            g.M = BS; g.N = 2 * d; g.K = d; g.lda = d; g.ldb = d; g.ldc = c.n_dec * 2 * d;
+            g.batch = c.n_dec; g.sA = 0; g.sB = ws / (ptrdiff_t)e; g.sC = 2 * d; g.sBias = bs / 4;
+            g.a_kcontig = 1; g.b_kcontig = 1; g.in_dtype = c.dtype; g.out_dtype = c.dtype;
+            g.alpha = 1.f; g.aux_scale = 1.f; g.splitk = 1;
+            RC(pa_gemm(&g, st));
+            kv_fused = true;
+        }
+    }
     for (int i = 0; i < c.n_dec; ++i) {
         const int pb = m->dec_base(i);
         DecAct& t = m->da[i];
@@ -270,8 +298,9 @@ int pa_train_forward_impl(pa_model* m, void* st) {
         RC(k.ln_fwd(t.y1, t.z1, PF(pb + D_N1_W), PF(pb + D_N1_B), t.m1, t.r1, BT, c.eps_layer));
         // cross attention: q from y1 (rows 0..d of in_proj), k/v from memory (rows d..3d)
         RC(k.linear(t.y1, d, PL(pb + D_CA_IN_W), PF(pb + D_CA_IN_B), t.q_ca, d, BT, d, d));
-        RC(k.linear(memory, d, (const char*)PL(pb + D_CA_IN_W) + (size_t)d * d * e, PF(pb + D_CA_IN_B) + d, t.kv_ca, 2 * d, BS, 2 * d, d));
-        RC(k.attn(false, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, 2 * d, t.o_ca, t.lse_ca, in_mask, T, S, 0, p,
+        if (!kv_fused)
+            RC(k.linear(memory, d, (const char*)PL(pb + D_CA_IN_W) + (size_t)d * d * e, PF(pb + D_CA_IN_B) + d, t.kv_ca, t.ld_kv, BS, 2 * d, d));
+        RC(k.attn(false, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, t.ld_kv, t.o_ca, t.lse_ca, in_mask, T, S, 0, p,
                   site_seed(m->seed, sb + 2), nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, cu));
         RC(k.linear(t.o_ca, d, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), t.z2, d, BT, d, d, 0, p, site_seed(m->seed, sb + 3), t.y1, d));
         RC(k.ln_fwd(t.y2, t.z2, PF(pb + D_N2_W), PF(pb + D_N2_B), t.m2, t.r2, BT, c.eps_layer));
@@ -391,7 +420,7 @@ int bwd_dec_layer(pa_model* m, int i, void* st) {
     const bool kv_all = m->kvT_all != nullptr;
     void* gKV = kv_all ? (void*)((char*)m->gKV_all + (size_t)i * 2 * d * e) : m->gKV;
     const int ldg = kv_all ? c.n_dec * 2 * d : 2 * d;
-    RC(k.attn(true, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, 2 * d, t.o_ca, t.lse_ca, in_mask, T, S, 0, p,
+    RC(k.attn(true, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, t.ld_kv, t.o_ca, t.lse_ca, in_mask, T, S, 0, p,
               site_seed(m->seed, sb + 2), m->gD, m->gE, d, gKV, (char*)gKV + d * e, ldg, nullptr, cu));
     float* dWin = G(pb + D_CA_IN_W); float* dbin = G(pb + D_CA_IN_B);
     RC(k.linear_dw(m->gE, d, t.y1, d, dWin, dbin, BT, d, d));

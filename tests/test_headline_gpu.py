@@ -319,6 +319,8 @@ def test_greedy_decode_full_size_batch_256_by_1024_properties(dtype):
     import plankassembly_amd.decode as D
     c = dict(LC.CASES["t1024"], wseed=77)
     sd = LC.case_state_dict(dict(c, no_end=False))            # END allowed: the bookkeeping must have something to track
+    sd["vocab_head.bias"] = sd["vocab_head.bias"].clone()
+    sd["vocab_head.bias"][512] += 13.0                        # ... and likely enough: rows reach END at different steps (46..97 in the oracle)
     db = synth_batch(256, spec_for("decode"), seed=7)
     db.pop("name")
     m = hip_model(c, dtype, sd)
@@ -340,6 +342,7 @@ def test_greedy_decode_full_size_batch_256_by_1024_properties(dtype):
     is_end = s == 512
     want_first = np.where(is_end.any(axis=1), is_end.argmax(axis=1), -1)
     assert np.array_equal(first_end, want_first), (first_end[:8], want_first[:8])
+    assert int(is_end.any(axis=1).sum()) >= 128 and len(np.unique(want_first)) >= 3, "END must occur, at varying steps"
     print(f"    [{dtype}] B=256 x 1024: {len(rows)} pointer copies (latest target step {int(tgt.max())}), "
           f"{len(np.unique(s))} distinct tokens, rows with END {int(is_end.any(axis=1).sum())}")
     if dtype == "f32":
