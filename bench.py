@@ -227,6 +227,33 @@ def pmc_traffic(kernel_key):
     return None
 
 
+def in_step_trace(key):
+    """Average duration (us) and launch count of a GEMM family INSIDE the profiled training step, from the committed
+    rocprofv3 --kernel-trace summary of this same command (profiles/r0N*_train_kernel_trace_summary.txt, newest round first):
+    the independent clock next to bench.py's own HIP-event census.  None for families the kernel name cannot tell apart
+    (the attention kernels serve self-, cross- and causal attention under one name)."""
+    import re
+    pats = {"ring_tt": r"gemm3_kernelILb1ELb1ENS_5GemmPE", "pair_tt": r"gemm_kernelIDF16bLi64ELi2ELb1ELb1", "small_tt": r"gemm3s_kernel",
+            "wide_tt": r"gemm3w_kernel", "group_nn": r"GemmGroup"}
+    if key not in pats:
+        return None
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    try:
+        names = sorted((f for f in os.listdir(here) if re.match(r"r\d+\w*_train_kernel_trace_summary\.txt$", f)), reverse=True)
+    except OSError:
+        return None
+    for name in names:
+        with open(os.path.join(here, name)) as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) >= 4 and re.search(pats[key], parts[0]):
+                    try:
+                        return {"file": "profiles/" + name, "calls": int(parts[1]), "avg_launch_us": float(parts[3])}
+                    except ValueError:
+                        continue
+    return None
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask, clipped by the cgroup CPU quota, capped at 64
     (torch's CPU kernels stop scaling - and oversubscription is catastrophic - well before that)."""
@@ -628,6 +655,10 @@ def main():
                                 "launches_per_step": c["launches"],
                                 "algorithmic_flops_per_launch": c["flops"] / c["launches"],
                                 "avg_launch_us": c["seconds"] / c["launches"] * 1e6}
+            tr = in_step_trace(key)
+            if tr:                                  # the same kernel inside the profiled step (rocprofv3, committed under profiles/)
+                tf = c["flops"] / c["launches"] / (tr["avg_launch_us"] * 1e-6) / 1e12
+                line["roofline"]["in_step_rocprof"] = dict(tr, achieved=tf, frac=tf / PEAK_BF16_TFLOPS)
             line["kernel_census"] = {k: {"launches": round(v["launches"], 2), "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
                                          "ms_per_step": round(v["seconds"] * 1e3, 3),
                                          "tflops": round(v["flops"] / v["seconds"] / 1e12, 1),

@@ -655,8 +655,8 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // Blocks are launched as a 1-D grid and decoded XCD-aware: the hardware places block L on XCD L % 8, and the blocks
 // that stream the same (batch, head) K/V (or Q/dO) panel should share one XCD's L2.  XCD x therefore owns the pairs
 // p = x (mod 8) and walks all their tiles; falls back to the plain order when #pairs is not a multiple of 8.
-__device__ __forceinline__ void decode_block(int ntiles, int H, int Bn, int& tile, int& h, int& b) {
-    const int L = blockIdx.x, npairs = H * Bn;
+__device__ __forceinline__ void decode_block(int ntiles, int H, int Bn, int& tile, int& h, int& b, int L = blockIdx.x) {
+    const int npairs = H * Bn;
     int pair;
     if ((npairs & 7) == 0) {
         const int x = L & 7, j = L >> 3;
@@ -679,8 +679,8 @@ __device__ __forceinline__ int dispatch_batch(const int32_t* order, int b) { ret
 // Blocks past the last valid one exit.  Every wave computes the same mapping from B <= 64 lanes (no LDS, no barrier).
 // `off` / `len`: the element's first row and row count in `cu`, from the lane that loaded them (saves the caller a second,
 // dependent round of loads - ~800 cycles of every block's prologue).
-__device__ __forceinline__ bool decode_block_balanced(const AttnP& pin, const int32_t* cu, int& tile, int& h, int& b, int& off, int& len) {
-    const int L = blockIdx.x, x = L & 7, j = L >> 3;
+__device__ __forceinline__ bool decode_block_balanced(const AttnP& pin, const int32_t* cu, int& tile, int& h, int& b, int& off, int& len, int L = blockIdx.x) {
+    const int x = L & 7, j = L >> 3;
     const int lane = threadIdx.x & 63;
     int o = 0, t = 0, c0 = 0, cl = 0;
     if (lane < pin.B) { o = pin.order[lane]; c0 = cu[o]; cl = cu[o + 1] - c0; t = (cl + BOWN - 1) / BOWN; }
@@ -1719,16 +1719,15 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_fwd_kernel(AttnP pin) {
 }
 
 template <bool DROP, int KS>          // KS = 2: in-block key split, see attn4_fwd_kernel (the partial dQ^T of the two halves are summed)
-__global__ __launch_bounds__(NT4 * KS, 4) void attn4_bwd_dq_kernel(AttnP pin) {
+__device__ __forceinline__ void attn4_dq_body(const AttnP& pin, int bid, char* smem) {
     constexpr int DH = 64, NAT = BT<DH>::NAT, BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
-    extern __shared__ __attribute__((aligned(256))) char smem[];
     const int lane = threadIdx.x & 63, g = lane >> 4;
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kh = KS == 2 ? (wave_all >> 3) : 0;
     const int wave = wave_all & 7, tid = threadIdx.x & (NT4 - 1);
     int tile_, h, b, off_ = 0, len_ = -1;
-    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_)) return; }
-    else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_, bid)) return; }
+    else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b, bid); b = dispatch_batch(pin.order, b); }
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff, off_, len_);
     const int q0 = tile_ * BOWN;
@@ -1866,17 +1865,25 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_bwd_dq_kernel(AttnP pin) {
     store_rows4(dQp, p.lddq, qrow, p.Lq, dqacc, p.scale * (DROP ? p.drop_scale : 1.0f), lane);
 }
 
+template <bool DROP, int KS>
+__global__ __launch_bounds__(NT4 * KS, 4) void attn4_bwd_dq_kernel(AttnP pin) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    attn4_dq_body<DROP, KS>(pin, blockIdx.x, smem);
+}
+
 // CAUSAL is a template parameter here: as a run-time flag the per-score causal select (index, compare, select) was executed
 // on every tile of the non-causal encoder / cross attention, and two copies of the score loop in one kernel spill at 128 VGPRs.
-template <bool DROP, bool CAUSAL>
-__global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
+// SELF_DELTA: the block computes delta[q] = sum_d dO[q][d] O[q][d] of its element's query rows itself (into LDS, Lq <= 128)
+// instead of reading what the dQ kernel published - what lets the dQ and dK/dV blocks of a single-query-tile attention run
+// in ONE launch (attn4_bwd_merged_kernel).
+template <bool DROP, bool CAUSAL, bool SELF_DELTA>
+__device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* smem) {
     constexpr int DH = 64, NAT = BT<DH>::NAT, BUF = BL<DH>::BUF, AUX = BL<DH>::AUX;
-    extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b, off_ = 0, len_ = -1;
-    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_k, tile_, h, b, off_, len_)) return; }
-    else { decode_block((pin.Lk + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
+    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_k, tile_, h, b, off_, len_, bid)) return; }
+    else { decode_block((pin.Lk + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b, bid); b = dispatch_batch(pin.order, b); }
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff, off_, len_);
     const int key0 = tile_ * BOWN;
@@ -1908,11 +1915,15 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     lb.init(smem_base, lane);
     const uint32_t abase = smem_base + g * 16;            // this lane group's 4 query rows of a 16-row block (aux words)
+    float* sdelta = reinterpret_cast<float*>(smem + 2 * BUF + 64);       // [BOWN] (SELF_DELTA; the merged launch allocates it)
     auto issue = [&](int step, int buf) {
         char* base = smem + buf * BUF;
         const int r0 = step * BSTR;
         float lv = INFINITY, dv_ = 0.f;
-        if (tid < BSTR && r0 + tid < p.Lq) { lv = p.lse[srow0 + r0 + tid] * LOG2E; dv_ = p.delta[srow0 + r0 + tid] * keep_p; }
+        if (tid < BSTR && r0 + tid < p.Lq) {
+            lv = p.lse[srow0 + r0 + tid] * LOG2E;
+            dv_ = (SELF_DELTA ? sdelta[r0 + tid] : p.delta[srow0 + r0 + tid]) * keep_p;
+        }
         glds_tile4(base, srcQ, voffQ, r0, wave);
         glds_tile4(base + NAT, srcO, voffO, r0, wave);
         if (tid < BSTR) {
@@ -1922,6 +1933,22 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
             if (DROP) reinterpret_cast<uint32_t*>(aux)[128 + tid] = drop_row_hash(p.drop_seed, (uint32_t)(srow0 + r0 + tid));
         }
     };
+    if constexpr (SELF_DELTA) {
+        const bf16* Op = reinterpret_cast<const bf16*>(p.o) + (size_t)qoff * p.ldo + h * DH;
+        const int ch = tid & 7;                              // eight lanes per row, 8 elements each
+        for (int r = tid >> 3; r < BOWN; r += NT4 / 8) {
+            float a = 0.f;
+            if (r < p.Lq) {
+                const u32x4 o4 = *reinterpret_cast<const u32x4*>(Op + (size_t)r * p.ldo + ch * 8);
+                const u32x4 d4 = *reinterpret_cast<const u32x4*>(dOp + (size_t)r * p.lddo + ch * 8);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) a += bf16_lo(o4[w]) * bf16_lo(d4[w]) + bf16_hi(o4[w]) * bf16_hi(d4[w]);
+            }
+            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
+            if (ch == 0) sdelta[r] = a;
+        }
+        __syncthreads();
+    }
     if (step0 < nsteps) issue(step0, 0);
     tile_barrier();
 
@@ -1978,6 +2005,21 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
     const float ds = DROP ? p.drop_scale : 1.0f;
     store_rows4(dKp, p.lddk, krow, p.Lk, dkacc, kmasked ? 0.f : p.scale * ds, lane, kmasked);
     store_rows4(dVp, p.lddv, krow, p.Lk, dvacc, kmasked ? 0.f : ds, lane, kmasked);
+}
+
+template <bool DROP, bool CAUSAL>
+__global__ __launch_bounds__(NT4, 4) void attn4_bwd_dkv_kernel(AttnP pin) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    attn4_dkv_body<DROP, CAUSAL, false>(pin, blockIdx.x, smem);
+}
+// dQ blocks [0, gq) and dK/dV blocks [gq, ...) of one attention backward in ONE launch, for launches whose queries are a
+// single 128-row tile per (sample, head) - decoder self-attention and cross-attention: a kernel boundary less per layer, and
+// the 128 dQ blocks (half of the CUs) run beside the dK/dV blocks instead of ahead of them.
+template <bool DROP, bool CAUSAL>
+__global__ __launch_bounds__(NT4, 4) void attn4_bwd_merged_kernel(AttnP pin, int gq) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    if ((int)blockIdx.x < gq) attn4_dq_body<DROP, 1>(pin, blockIdx.x, smem);
+    else attn4_dkv_body<DROP, CAUSAL, true>(pin, (int)blockIdx.x - gq, smem);
 }
 
 // =====================================================================================================
@@ -2059,6 +2101,20 @@ template <int DH> int run_bwd_bf16(AttnP p, hipStream_t st) {
     const dim3 gq(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B), gk(((p.Lk + BOWN - 1) / BOWN) * p.H * p.B);
     if constexpr (DH == 64) {
         if (use_v4(p, p.Lq > p.Lk ? p.Lq : p.Lk)) {
+            // single query tile per (sample, head): dQ and dK/dV blocks in one launch (PA_ATTN_BWD_MERGE=0: two launches)
+            static const bool merge_env = !(getenv("PA_ATTN_BWD_MERGE") && atoi(getenv("PA_ATTN_BWD_MERGE")) == 0);
+            if (merge_env && p.Lq <= BOWN && !p.balanced && (gq.x & 7) == 0) {
+                const int shm3 = shm + BOWN * 4 + 64;
+                const dim3 gm(gq.x + gk.x);
+                if (p.drop_thr) {
+                    if (p.causal) PA_LAUNCH((attn4_bwd_merged_kernel<true, true>), gm, dim3(NT4), shm3, st, p, (int)gq.x);
+                    else PA_LAUNCH((attn4_bwd_merged_kernel<true, false>), gm, dim3(NT4), shm3, st, p, (int)gq.x);
+                } else {
+                    if (p.causal) PA_LAUNCH((attn4_bwd_merged_kernel<false, true>), gm, dim3(NT4), shm3, st, p, (int)gq.x);
+                    else PA_LAUNCH((attn4_bwd_merged_kernel<false, false>), gm, dim3(NT4), shm3, st, p, (int)gq.x);
+                }
+                return 0;
+            }
             const bool ks = use_ksplit(p, gq.x);
             constexpr int shm2 = 4 * BL<DH>::BUF + 64;
             if (ks) {
