@@ -67,6 +67,21 @@ def oracle_grads_f64(name, batch_size=None):
     return _f64_cache[key]
 
 
+# Tensors that may take check_grads' float64 clause, per (case, batch size).  The f32 path's reductions are ORDERED since round 3
+# (one contributor per output element: pa_device.h pa_ordered_reductions), so a run is bit-reproducible and this list is a
+# constant of the fixtures - identical in two full GPU runs (gpurun_out/r03b, r03f).  Every entry is a row-sum gradient where
+# the f32 REFERENCE is itself 1.5e-5 .. 6e-4 from the float64 answer, or a linear1 ReLU branch flip (see check_grads).
+PINNED_FALLBACK = {
+    ("headline", None): set(), ("visible", None): set(), ("live", None): set(),
+    ("sideface", None): {"encoder.layers.1.linear1.weight", "decoder.layers.5.linear1.weight", "decoder.layers.5.linear1.bias"},
+    ("t1024", None): {"decoder.layers.0.linear1.weight", "decoder.layers.0.linear1.bias", "decoder.layers.3.linear1.weight",
+                      "decoder.layers.3.linear1.bias"},
+    ("sideface", 64): {"decoder.layers.0.norm1.weight", "decoder.layers.0.norm3.weight", "decoder.layers.1.norm1.weight",
+                       "decoder.layers.1.norm3.weight", "decoder.layers.3.linear1.weight", "decoder.layers.3.linear1.bias",
+                       "decoder.layers.4.linear1.weight", "decoder.layers.4.linear1.bias", "decoder.layers.4.norm1.weight"},
+}
+
+
 def check_grads(name, grads, rgrads, batch_size=None):
     """Every gradient within 1e-5 + 1e-4*scale of the f32 reference computation.  A few reduction-heavy tensors (sums
     over thousands of rows with cancellation: LayerNorm affine / bias gradients, at B = 64 also some weight gradients)
@@ -75,9 +90,9 @@ def check_grads(name, grads, rgrads, batch_size=None):
     float64 evaluation of the same computation, i.e. at least as close to the exact answer as the tolerance asks - or,
     where float32 itself cannot get that close, within 4x the f32 reference's own distance from float64 (seen:
     decoder.layers.5.linear1.weight in the sideface case, HIP and f32 oracle both 5.9e-4 from float64 and 2e-5 from
-    each other: both f32 computations take one ReLU branch and float64 the other).  HIP's f32 gradient sums use
-    atomics, so which tensors land in this list varies from run to run; at most 16 of ~190 may.  linear1 (the
-    ReLU-gated Linear) additionally tolerates a branch flip in at most two hidden units - see below."""
+    each other: both f32 computations take one ReLU branch and float64 the other).  Which tensors may take this clause
+    is PINNED per case (PINNED_FALLBACK: the f32 reductions are ordered, the list is a constant of the fixture); linear1
+    (the ReLU-gated Linear) additionally tolerates a branch flip in at most two hidden units - see below."""
     worst, fallback = ("", 0.0), []
     for k, gr in grads.items():
         r = rgrads[k]
@@ -106,6 +121,9 @@ def check_grads(name, grads, rgrads, batch_size=None):
             assert len(flipped) <= 2 and float(per_unit.max()) <= 1e-2 * scale, (k, flipped, e_hip, scale)
             continue
         assert e_hip <= bound, (k, e_hip, e_ref, scale)
+    allowed = PINNED_FALLBACK.get((name, batch_size))
+    if allowed is not None:
+        assert set(fallback) <= allowed, ("tensors outside the pinned list needed the float64 clause", sorted(set(fallback) - allowed))
     assert len(fallback) <= 16, fallback
     return worst
 
