@@ -1873,7 +1873,7 @@ __global__ __launch_bounds__(NT4 * KS, 4) void attn4_bwd_dq_kernel(AttnP pin) {
 
 // CAUSAL is a template parameter here: as a run-time flag the per-score causal select (index, compare, select) was executed
 // on every tile of the non-causal encoder / cross attention, and two copies of the score loop in one kernel spill at 128 VGPRs.
-// SELF_DELTA: the block computes delta[q] = sum_d dO[q][d] O[q][d] of its element's query rows itself (into LDS, Lq <= 128)
+// SELF_DELTA: the block computes delta[q] = sum_d dO[q][d] O[q][d] of its element's query rows itself (into LDS, Lq <= MERGE_MAX_LQ)
 // instead of reading what the dQ kernel published - what lets the dQ and dK/dV blocks of a single-query-tile attention run
 // in ONE launch (attn4_bwd_merged_kernel).
 template <bool DROP, bool CAUSAL, bool SELF_DELTA>
@@ -1915,7 +1915,7 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     lb.init(smem_base, lane);
     const uint32_t abase = smem_base + g * 16;            // this lane group's 4 query rows of a 16-row block (aux words)
-    float* sdelta = reinterpret_cast<float*>(smem + 2 * BUF + 64);       // [BOWN] (SELF_DELTA; the merged launch allocates it)
+    float* sdelta = reinterpret_cast<float*>(smem + 2 * BUF + 64);       // [Lq] (SELF_DELTA; the merged launch allocates it)
     auto issue = [&](int step, int buf) {
         char* base = smem + buf * BUF;
         const int r0 = step * BSTR;
@@ -1936,16 +1936,26 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
     if constexpr (SELF_DELTA) {
         const bf16* Op = reinterpret_cast<const bf16*>(p.o) + (size_t)qoff * p.ldo + h * DH;
         const int ch = tid & 7;                              // eight lanes per row, 8 elements each
-        for (int r = tid >> 3; r < BOWN; r += NT4 / 8) {
-            float a = 0.f;
-            if (r < p.Lq) {
-                const u32x4 o4 = *reinterpret_cast<const u32x4*>(Op + (size_t)r * p.ldo + ch * 8);
-                const u32x4 d4 = *reinterpret_cast<const u32x4*>(dOp + (size_t)r * p.lddo + ch * 8);
+        // four rows per thread in flight (unconditional clamped loads, surplus rows discarded): the element's Lq rows cost
+        // Lq / 256 memory round trips per block
+        const int r_first = CAUSAL ? step0 * BSTR : 0;       // causal: query rows before this block's keys are never visited
+        for (int r0_ = r_first + (tid >> 3); r0_ < p.Lq; r0_ += 4 * (NT4 / 8)) {
+            u32x4 o4[4], d4[4];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) a += bf16_lo(o4[w]) * bf16_lo(d4[w]) + bf16_hi(o4[w]) * bf16_hi(d4[w]);
+            for (int j = 0; j < 4; ++j) {
+                const int r = min(r0_ + j * (NT4 / 8), p.Lq - 1);
+                o4[j] = *reinterpret_cast<const u32x4*>(Op + (size_t)r * p.ldo + ch * 8);
+                d4[j] = *reinterpret_cast<const u32x4*>(dOp + (size_t)r * p.lddo + ch * 8);
             }
-            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
-            if (ch == 0) sdelta[r] = a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) a += bf16_lo(o4[j][w]) * bf16_lo(d4[j][w]) + bf16_hi(o4[j][w]) * bf16_hi(d4[j][w]);
+                a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
+                const int r = r0_ + j * (NT4 / 8);
+                if (ch == 0 && r < p.Lq) sdelta[r] = a;
+            }
         }
         __syncthreads();
     }
@@ -2103,8 +2113,9 @@ template <int DH> int run_bwd_bf16(AttnP p, hipStream_t st) {
         if (use_v4(p, p.Lq > p.Lk ? p.Lq : p.Lk)) {
             // single query tile per (sample, head): dQ and dK/dV blocks in one launch (PA_ATTN_BWD_MERGE=0: two launches)
             static const bool merge_env = !(getenv("PA_ATTN_BWD_MERGE") && atoi(getenv("PA_ATTN_BWD_MERGE")) == 0);
-            if (merge_env && p.Lq <= BOWN && !p.balanced && (gq.x & 7) == 0) {
-                const int shm3 = shm + BOWN * 4 + 64;
+            static const int merge_max = getenv("PA_ATTN_BWD_MERGE_MAX") ? atoi(getenv("PA_ATTN_BWD_MERGE_MAX")) : 128;
+            if (merge_env && p.Lq <= merge_max && p.Lq <= 2048 && (gq.x & 7) == 0) {
+                const int shm3 = shm + (p.Lq + 15) / 16 * 64 + 64;
                 const dim3 gm(gq.x + gk.x);
                 if (p.drop_thr) {
                     if (p.causal) PA_LAUNCH((attn4_bwd_merged_kernel<true, true>), gm, dim3(NT4), shm3, st, p, (int)gq.x);
