@@ -311,7 +311,9 @@ def attention_census(cfgd, batch, drop_p):
     t = time_kernel(lambda: ops.attn_varlen_fwd(qc, kc, vc, h, None, cu, B, T, S, **kw))
     fam["attn_cross_fwd"] = dict(launches=nd, flops=flc * nd, seconds=t * nd)
     t = time_kernel(lambda: ops.attn_varlen_bwd(doc, qc, kc, vc, oc, lsec, h, None, cu, B, T, S, **kw), iters=10)
-    fam["attn_cross_bwd"] = dict(launches=2 * nd, flops=2.5 * flc * nd, seconds=t * nd)
+    # (T <= 128 queries per (sample, head): dQ and dK/dV blocks run in ONE launch, attn4_bwd_merged_kernel)
+    merged = T <= 128
+    fam["attn_cross_bwd"] = dict(launches=nd if merged else 2 * nd, flops=2.5 * flc * nd, seconds=t * nd)
     qd = rnd(B, T, 3 * d)
     q1, k1, v1 = qd[..., :d], qd[..., d:2 * d], qd[..., 2 * d:]
     dod = rnd(B, T, d)
@@ -320,7 +322,7 @@ def attention_census(cfgd, batch, drop_p):
     t = time_kernel(lambda: ops.attn_fwd(q1, k1, v1, h, causal=True, **kw))
     fam["attn_dec_self_fwd"] = dict(launches=nd, flops=fld * nd, seconds=t * nd)
     t = time_kernel(lambda: ops.attn_bwd(dod, q1, k1, v1, od, lsed, h, causal=True, **kw), iters=10)
-    fam["attn_dec_self_bwd"] = dict(launches=2 * nd, flops=2.5 * fld * nd, seconds=t * nd)
+    fam["attn_dec_self_bwd"] = dict(launches=nd if merged else 2 * nd, flops=2.5 * fld * nd, seconds=t * nd)
     return fam
 
 
@@ -641,12 +643,12 @@ def main():
                      "small_tt": "gemm3s_kernel (bf16, 64x64x64 tiles, 4-stage LDS ring)",
                      "pair_tt": "gemm_kernel<bf16,64,2,true,true,...> (two blocks per CU)",
                      "wide_tt": "gemm3w_kernel<2,4> (bf16, 128x256x64 tiles, one block per CU, 3-stage LDS ring)",
-                     "attn_enc_self_fwd": "attn_fwd_bf16_kernel<64,true> on the packed encoder rows (self-attention forward)",
-                     "attn_enc_self_bwd": "attn_bwd_dq_bf16_kernel + attn_bwd_dkv_bf16_kernel <64,true> on the packed encoder rows",
-                     "attn_cross_fwd": "attn_fwd_bf16_kernel<64,true>, decoder cross-attention forward",
-                     "attn_cross_bwd": "attn_bwd_dq / attn_bwd_dkv_bf16_kernel<64,true>, decoder cross-attention backward",
-                     "attn_dec_self_fwd": "attn_fwd_bf16_kernel<64,true>, decoder causal self-attention forward",
-                     "attn_dec_self_bwd": "attn_bwd_dq / attn_bwd_dkv_bf16_kernel<64,true>, decoder causal self-attention backward"}
+                     "attn_enc_self_fwd": "attn4_fwd_kernel<true,1> on the packed encoder rows (self-attention forward)",
+                     "attn_enc_self_bwd": "attn4_bwd_dq_kernel + attn4_bwd_dkv_kernel on the packed encoder rows",
+                     "attn_cross_fwd": "attn4_fwd_kernel<true,2> (in-block key split), decoder cross-attention forward",
+                     "attn_cross_bwd": "attn4_bwd_merged_kernel (dQ and dK/dV blocks in one launch), decoder cross-attention backward",
+                     "attn_dec_self_fwd": "attn4_fwd_kernel<true,1>, decoder causal self-attention forward",
+                     "attn_dec_self_bwd": "attn4_bwd_merged_kernel (dQ and dK/dV blocks in one launch), decoder causal self-attention backward"}
             ach = c["flops"] / c["seconds"] / 1e12
             line["roofline"] = {"kernel": names.get(key, key) + " - every launch of it in a train step, timed under HIP events at the "
                                           f"step's own arguments, averaged over the {n_pool} batches the timed region cycles through",

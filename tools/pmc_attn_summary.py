@@ -58,7 +58,10 @@ def main():
             print(f"    VALU (non-MFMA) per MFMA     {(va - mf) / mf:16.2f}   (SQ_INSTS_VALU counts the MFMAs too)" if va > mf else
                   f"    VALU per MFMA                {va / mf:16.2f}")
         if mf:
-            print(f"    MFMA-implied TFLOP/s         {mf * 32768 / (us * 1e-6) / 1e12:16.1f}   (32x32x16x2 flop per instruction)")
+            # the 16-row-wave attention kernels (attn4_*) issue v_mfma_f32_16x16x32_bf16: half the flop of a 32x32x16
+            small = "attn4" in k
+            fl = 16384 if small else 32768
+            print(f"    MFMA-implied TFLOP/s         {mf * fl / (us * 1e-6) / 1e12:16.1f}   ({'16x16x32' if small else '32x32x16'}x2 flop per instruction)")
         b = c.get("SQ_VALU_MFMA_BUSY_CYCLES")
         if b:
             print(f"    MFMA pipe utilisation        {b / (1024 * us * 1e-6 * 2.4e9):16.3f}   (busy cycles / (1024 SIMDs x t x 2.4 GHz))")
