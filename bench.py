@@ -415,11 +415,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # PLANK_BENCH_BACKEND=gloo is for TESTS only (tests/test_bench_launch_gpu.py): RCCL refuses two ranks on one device, gloo
+    # carries device tensors through the host, so the N > 1 code path of this file can run on a one-GPU box.
+    backend = os.environ.get("PLANK_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from plankassembly_amd.data import DevicePrefetcher, synth_batch
     from plankassembly_amd.distributed import GradSync
     from plankassembly_amd.optim import FusedAdam
@@ -499,6 +507,14 @@ def main():
 
     def train_step(i):
         return step_on(prepared[i % len(prepared)])
+
+    # Everything below steps the model on rank 0 ONLY (kernel census, padded-encoder variant): the gradient exchange must be
+    # off by then, or rank 0's backward would enqueue collectives the other ranks never join (found by
+    # tests/test_bench_launch_gpu.py: the two-rank run hung here).
+    if sync is not None:
+        fence()
+        sync.detach()
+        sync = None
 
     census = None
     if rank == 0 and not args.no_kernels:

@@ -117,6 +117,13 @@ class GradSync:
         for g, lo, hi in widen:             # the reduced sums, after the collectives and before Adam
             self._cast(g[lo:hi], self._lp[lo:hi])
 
+    def detach(self):
+        """Finish what is in flight and stop exchanging: later backward passes of this model are rank-local (a rank that
+        goes on stepping alone - bench.py's rank-0 kernel census - must not enqueue collectives nobody else joins)."""
+        self.wait()
+        self._pending = None
+        self.model.register_grad_ready_hook(None)
+
     def broadcast_parameters(self, src=0):
         """DDP constructor semantics: every rank starts from rank ``src``'s parameters."""
         dist.broadcast(self.model.flat_params, src=src, group=self.group)

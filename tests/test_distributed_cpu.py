@@ -34,7 +34,8 @@ class FakeModel:
 
     def backward(self):
         for s, (lo, hi) in enumerate(self._slices):
-            self._hook(s, lo, hi)
+            if self._hook is not None:
+                self._hook(s, lo, hi)
 
 
 def _free_port():
@@ -66,6 +67,14 @@ def _worker(rank, world, port, coalesce, out):
         assert torch.allclose(m.flat_grads, torch.full_like(m.flat_grads, float(world)))
         v = allreduce_metric_sums(torch.tensor([1.0 + rank, 2.0, 3.0, 1.0]))
         assert v.tolist() == [3.0, 4.0, 6.0, 2.0]
+        # detach(): rank 0 goes on stepping ALONE (bench.py's rank-0 kernel census) - nothing may be exchanged any more,
+        # or this would wait for a rank 1 that never comes
+        sync.detach()
+        if rank == 0:
+            m.flat_grads = torch.full_like(m.flat_grads, 7.0)
+            m.backward()
+            assert float(m.flat_grads.min()) == 7.0 and float(m.flat_grads.max()) == 7.0
+        dist.barrier()
         if rank == 0:
             out.put(len(sync.launched))
     finally:
