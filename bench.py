@@ -23,6 +23,9 @@ import sys
 import time
 import types
 
+# the host driver of this pool only supports dmabuf IPC: RCCL's peer buffers need this before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 

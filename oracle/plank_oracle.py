@@ -93,8 +93,21 @@ def log_softmax_lastdim(x):
     return z - torch.log(torch.exp(z).sum(dim=-1, keepdim=True))
 
 
-def mha(q_in, kv_in, p, prefix, n_head, add_mask):
-    """torch F.multi_head_attention_forward, batch_first, eval/dropout-free.
+def _drop(drop, site, x):
+    """Dropout with GIVEN decisions: ``drop`` is None (eval / p = 0) or a callable (site, tensor) -> tensor that zeroes the
+    dropped entries and scales the survivors by 1 / (1 - p), i.e. what ``F.dropout(x, p, training=True)`` does for one draw
+    of its mask.  torch draws the masks from its Philox stream, which no other implementation can reproduce; the tests feed
+    the decisions of the implementation under test instead (tests/dropout_masks.py), so that a training step UNDER dropout
+    can be compared tensor by tensor.  Sites (torch nn/modules/transformer.py, TransformerEncoderLayer / DecoderLayer,
+    norm_first=False; nn/functional.py multi_head_attention_forward "attn = dropout(attn, p=dropout_p)"):
+    ``<layer>self_attn`` / ``<layer>multihead_attn`` - attention probabilities [B, H, Lq, Lk];
+    ``<layer>dropout1`` / ``dropout2`` / ``dropout3`` - sublayer outputs before the residual add;
+    ``<layer>dropout`` - the feed-forward hidden activation after the ReLU."""
+    return x if drop is None else drop(site, x)
+
+
+def mha(q_in, kv_in, p, prefix, n_head, add_mask, drop=None):
+    """torch F.multi_head_attention_forward, batch_first; dropout-free unless ``drop`` hands in the decisions (_drop).
 
     ``add_mask`` is an additive float mask broadcastable to [B, H, Lq, Lk]
     (0 = keep, -inf = drop): the merge of attn_mask and key_padding_mask that torch
@@ -115,7 +128,7 @@ def mha(q_in, kv_in, p, prefix, n_head, add_mask):
     s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
     if add_mask is not None:
         s = s + add_mask
-    a = softmax_lastdim(s)
+    a = _drop(drop, prefix[:-1], softmax_lastdim(s))
     o = (a @ v).transpose(1, 2).reshape(B, Lq, d)
     return linear(o, p[prefix + "out_proj.weight"], p[prefix + "out_proj.bias"])
 
@@ -156,38 +169,40 @@ def embed_output(p, cfg: OracleCfg, output):
 
 
 # ----------------------------------------------------------------------------- layers
-def encoder_layer(x, p, pre, cfg, add_mask):
-    """torch TransformerEncoderLayer.forward, norm_first=False branch."""
-    x = layer_norm(x + mha(x, x, p, pre + "self_attn.", cfg.n_head, add_mask),
+def encoder_layer(x, p, pre, cfg, add_mask, drop=None):
+    """torch TransformerEncoderLayer.forward, norm_first=False branch (_sa_block: dropout1(self_attn(x));
+    _ff_block: dropout2(linear2(dropout(activation(linear1(x))))))."""
+    x = layer_norm(x + _drop(drop, pre + "dropout1", mha(x, x, p, pre + "self_attn.", cfg.n_head, add_mask, drop)),
                    p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.eps_layer)
-    h = torch.relu(linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"]))
-    f = linear(h, p[pre + "linear2.weight"], p[pre + "linear2.bias"])
+    h = _drop(drop, pre + "dropout", torch.relu(linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"])))
+    f = _drop(drop, pre + "dropout2", linear(h, p[pre + "linear2.weight"], p[pre + "linear2.bias"]))
     return layer_norm(x + f, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.eps_layer)
 
 
-def encode(p, cfg: OracleCfg, batch):
+def encode(p, cfg: OracleCfg, batch, drop=None):
     """reference models.py:206 / 279."""
     x = embed_input(p, batch)
     add_mask = key_padding_additive(batch["input_mask"])
     for i in range(cfg.n_enc):
-        x = encoder_layer(x, p, f"encoder.layers.{i}.", cfg, add_mask)
+        x = encoder_layer(x, p, f"encoder.layers.{i}.", cfg, add_mask, drop)
     if cfg.has_enc_norm:
         x = layer_norm(x, p["encoder.norm.weight"], p["encoder.norm.bias"], 1e-5)
     return x
 
 
-def decoder_layer(x, memory, p, pre, cfg, self_mask, mem_mask):
-    """torch TransformerDecoderLayer.forward, norm_first=False branch."""
-    x = layer_norm(x + mha(x, x, p, pre + "self_attn.", cfg.n_head, self_mask),
+def decoder_layer(x, memory, p, pre, cfg, self_mask, mem_mask, drop=None):
+    """torch TransformerDecoderLayer.forward, norm_first=False branch (dropout1 / dropout2 / dropout3 on the three sublayer
+    outputs, dropout on the feed-forward hidden activation)."""
+    x = layer_norm(x + _drop(drop, pre + "dropout1", mha(x, x, p, pre + "self_attn.", cfg.n_head, self_mask, drop)),
                    p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.eps_layer)
-    x = layer_norm(x + mha(x, memory, p, pre + "multihead_attn.", cfg.n_head, mem_mask),
+    x = layer_norm(x + _drop(drop, pre + "dropout2", mha(x, memory, p, pre + "multihead_attn.", cfg.n_head, mem_mask, drop)),
                    p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.eps_layer)
-    h = torch.relu(linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"]))
-    f = linear(h, p[pre + "linear2.weight"], p[pre + "linear2.bias"])
+    h = _drop(drop, pre + "dropout", torch.relu(linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"])))
+    f = _drop(drop, pre + "dropout3", linear(h, p[pre + "linear2.weight"], p[pre + "linear2.bias"]))
     return layer_norm(x + f, p[pre + "norm3.weight"], p[pre + "norm3.bias"], cfg.eps_layer)
 
 
-def decode(p, cfg: OracleCfg, tgt, memory, input_mask, tgt_pad_mask=None):
+def decode(p, cfg: OracleCfg, tgt, memory, input_mask, tgt_pad_mask=None, drop=None):
     """reference models.py:212-214 (train) / 293-294 (eval: tgt_pad_mask None)."""
     sz = tgt.shape[1]
     self_mask = causal_additive(sz)[None, None]
@@ -196,7 +211,7 @@ def decode(p, cfg: OracleCfg, tgt, memory, input_mask, tgt_pad_mask=None):
     mem_mask = key_padding_additive(input_mask)
     x = tgt
     for i in range(cfg.n_dec):
-        x = decoder_layer(x, memory, p, f"decoder.layers.{i}.", cfg, self_mask, mem_mask)
+        x = decoder_layer(x, memory, p, f"decoder.layers.{i}.", cfg, self_mask, mem_mask, drop)
     return layer_norm(x, p["decoder.norm.weight"], p["decoder.norm.bias"], 1e-5)
 
 
@@ -250,11 +265,11 @@ def create_dist_eval(p, cfg: OracleCfg, h, eps=1e-6):
 
 
 # ----------------------------------------------------------------------------- train step
-def train_forward(p, cfg: OracleCfg, batch, return_all=False):
-    """reference models.py:190-233 (dropout-free)."""
-    memory = encode(p, cfg, batch)
+def train_forward(p, cfg: OracleCfg, batch, return_all=False, drop=None):
+    """reference models.py:190-233; dropout-free unless ``drop`` hands in the decisions of every site (_drop)."""
+    memory = encode(p, cfg, batch, drop)
     tgt = embed_output(p, cfg, batch["output_value"][:, :-1])
-    hiddens = decode(p, cfg, tgt, memory, batch["input_mask"], batch["output_mask"])
+    hiddens = decode(p, cfg, tgt, memory, batch["input_mask"], batch["output_mask"], drop)
     dists = create_dist_train(p, cfg, hiddens)
     label = batch["output_label"]
     valid = label != cfg.pad

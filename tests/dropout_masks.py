@@ -1,0 +1,97 @@
+"""The HIP library's dropout decisions, restated in numpy (TEST INFRASTRUCTURE).
+
+Dropout in `plankassembly_amd/csrc` is counter-based: every decision is a pure function of (step seed, site, element
+index), so the forward, the backward kernels that regenerate it and - here - a test can all compute the same mask.  This
+module restates those functions (csrc/pa_device.h `mix32`, `drop_keep`, `drop_row_hash`, `drop_key_hash`, `drop_keep2`;
+csrc/model.h `site_seed`; the site numbering of csrc/runtime.hip `forward_enc_layer` / `forward_dec_layer`; the step-seed
+recurrence of models.py `PlankModel.forward`) and hands the masks to the CPU oracle (`oracle.plank_oracle._drop`), so that a
+training step UNDER dropout 0.2 - the benchmarked mode - is compared with the oracle tensor by tensor.
+tests/test_kernels_gpu.py pins every function below against decisions extracted from the kernels themselves."""
+import numpy as np
+import torch
+
+M32 = np.uint64(0xFFFFFFFF)
+
+
+def mix32(x):
+    x = np.asarray(x).astype(np.uint64) & M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7FEB352D)) & M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846CA68B)) & M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def site_seed(base, site):
+    return int(mix32(np.uint64((int(base) + 0x9E3779B9 * (int(site) + 1)) & 0xFFFFFFFF)))
+
+
+def next_step_seed(prev, initial_seed):
+    """models.py PlankModel.forward: the seed the NEXT training forward will hand to pa_model_train_fwd."""
+    return (int(prev) * 1664525 + 1013904223 + int(initial_seed)) & 0xFFFFFFFF
+
+
+def linear_keep(seed, rows, n_cols, p):
+    """Epilogue dropout of a Linear whose output is [n_rows][n_cols] (pa_gemm: idx = row * N + col, 16-bit threshold).
+    ``rows``: the output-row index of every row wanted (packed row numbers for the packed encoder).  bool [len(rows), n_cols]."""
+    thr16 = np.uint64(int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)))
+    rows = np.asarray(rows, dtype=np.uint64)
+    idx = (rows[:, None] * np.uint64(n_cols) + np.arange(n_cols, dtype=np.uint64)[None, :]) & M32
+    h = mix32((idx * np.uint64(0x9E3779B9) + np.uint64(seed)) & M32)
+    return (h >> np.uint64(16)) >= thr16
+
+
+def attn_keep(seed, row_index, n_keys, p):
+    """Attention-probability dropout: keep(row, key) <=> low32(A[row] * C[key]) >= p * 2^32 (pa_device.h drop_keep2).
+    ``row_index``: global query-row numbers ((b * H + h) * Lq + q) of the rows wanted, any shape.  bool [*row_index.shape, n_keys]."""
+    thr32 = np.uint64(int(float(np.float32(p)) * 4294967296.0))
+    r = np.asarray(row_index, dtype=np.uint64)
+    a = (mix32((r * np.uint64(0x9E3779B9) + np.uint64(seed)) & M32) & np.uint64(0xFFFFFF)) | np.uint64(0x800001)
+    k = np.arange(n_keys, dtype=np.uint64)
+    c = (mix32((k * np.uint64(0x85EBCA6B) + np.uint64(seed ^ 0x5BD1E995)) & M32) & np.uint64(0xFFFFFF)) | np.uint64(0x800001)
+    return ((a[..., None] * c) & M32) >= thr32
+
+
+def attn_scale(p):
+    thr32 = int(float(np.float32(p)) * 4294967296.0)
+    return float(np.float32(1.0 / (1.0 - thr32 / 4294967296.0)))
+
+
+class HipDropout:
+    """Callable (site, tensor) -> tensor for `oracle.plank_oracle.train_forward(..., drop=...)`: applies the masks the HIP
+    training step with step seed ``seed`` uses.  ``input_mask`` (bool [B, S], True = PAD) fixes the packed row numbers of the
+    encoder rows when ``packed`` (models.py `unpad`); decoder rows are b * T + t."""
+
+    def __init__(self, seed, p, n_head, input_mask, packed=True):
+        self.seed, self.p, self.H = int(seed), float(p), int(n_head)
+        valid = ~np.asarray(input_mask, dtype=bool)
+        B, S = valid.shape
+        if packed:
+            flat = np.cumsum(valid.reshape(-1)).reshape(B, S) - 1          # packed row of every valid token, batch order
+            self.enc_rows = np.where(valid, flat, 0)
+        else:
+            self.enc_rows = np.arange(B * S).reshape(B, S)
+        self.enc_valid = valid
+        self.sites_seen = []
+
+    def _site(self, name):
+        part = name.split(".")
+        layer, what = int(part[2]), part[3]
+        if part[0] == "encoder":
+            return 8 * layer + {"self_attn": 0, "dropout1": 1, "dropout": 2, "dropout2": 3}[what], True
+        return 1000 + 8 * layer + {"self_attn": 0, "dropout1": 1, "multihead_attn": 2, "dropout2": 3, "dropout": 4, "dropout3": 5}[what], False
+
+    def __call__(self, name, x):
+        site, enc = self._site(name)
+        seed = site_seed(self.seed, site)
+        self.sites_seen.append(name)
+        if name.endswith("attn"):
+            B, H, Lq, Lk = x.shape
+            rows = (np.arange(B)[:, None, None] * H + np.arange(H)[None, :, None]) * Lq + np.arange(Lq)[None, None, :]
+            keep = attn_keep(seed, rows, Lk, self.p)
+            return x * torch.from_numpy(keep).to(x.dtype) * attn_scale(self.p)
+        B, L, N = x.shape
+        rows = self.enc_rows if enc else np.arange(B * L).reshape(B, L)
+        keep = linear_keep(seed, rows.reshape(-1), N, self.p).reshape(B, L, N)
+        if enc:
+            keep = keep | ~self.enc_valid[:, :, None]                      # padded rows never reach the loss
+        return x * torch.from_numpy(keep).to(x.dtype) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(self.p)))

@@ -23,9 +23,9 @@ TOKEN = types.SimpleNamespace(END=512, PAD=513)
 _oracle_cache = {}
 
 
-def hip_model(c, dtype, sd):
+def hip_model(c, dtype, sd, dropout=0.0):
     from plankassembly_amd.models import PlankModel
-    m = PlankModel(c["d"], c["h"], c["ff"], 0.0, "relu", True, c["ne"], c["nd"], 3, 2, 4, 6, c["max_in"], c["max_out"],
+    m = PlankModel(c["d"], c["h"], c["ff"], dropout, "relu", True, c["ne"], c["nd"], 3, 2, 4, 6, c["max_in"], c["max_out"],
                    514, TOKEN, compute_dtype=dtype)
     m.load_state_dict(sd)
     return m.cuda()
@@ -76,13 +76,17 @@ PINNED_FALLBACK = {
     ("sideface", None): {"encoder.layers.1.linear1.weight", "decoder.layers.5.linear1.weight", "decoder.layers.5.linear1.bias"},
     ("t1024", None): {"decoder.layers.0.linear1.weight", "decoder.layers.0.linear1.bias", "decoder.layers.3.linear1.weight",
                       "decoder.layers.3.linear1.bias"},
+    # the same steps under dropout 0.2 with the step seed of test_train_step_under_dropout_... (gpurun_out r03m)
+    ("headline", "dropout"): {"encoder.layers.3.linear1.weight"}, ("live", "dropout"): set(),
+    ("sideface", "dropout"): {"encoder.layers.3.linear1.weight", "decoder.layers.0.linear2.weight", "decoder.layers.1.norm3.weight",
+                              "decoder.layers.3.linear1.weight", "decoder.layers.4.linear1.weight", "decoder.layers.4.linear1.bias"},
     ("sideface", 64): {"decoder.layers.0.norm1.weight", "decoder.layers.0.norm3.weight", "decoder.layers.1.norm1.weight",
                        "decoder.layers.1.norm3.weight", "decoder.layers.3.linear1.weight", "decoder.layers.3.linear1.bias",
                        "decoder.layers.4.linear1.weight", "decoder.layers.4.linear1.bias", "decoder.layers.4.norm1.weight"},
 }
 
 
-def check_grads(name, grads, rgrads, batch_size=None):
+def check_grads(name, grads, rgrads, batch_size=None, f64=None, pin_key=None):
     """Every gradient within 1e-5 + 1e-4*scale of the f32 reference computation.  A few reduction-heavy tensors (sums
     over thousands of rows with cancellation: LayerNorm affine / bias gradients, at B = 64 also some weight gradients)
     sit where the f32 reference's OWN rounding noise exceeds that bound (measured against float64: reference error
@@ -102,7 +106,7 @@ def check_grads(name, grads, rgrads, batch_size=None):
         if err > 1e-5 + 1e-4 * scale:
             fallback.append(k)
     for k in fallback:
-        r64 = oracle_grads_f64(name, batch_size)[k]
+        r64 = (f64() if f64 is not None else oracle_grads_f64(name, batch_size))[k]
         e_hip = float((grads[k].double() - r64).abs().max())
         e_ref = float((rgrads[k].double() - r64).abs().max())
         scale = float(r64.abs().max())
@@ -121,7 +125,7 @@ def check_grads(name, grads, rgrads, batch_size=None):
             assert len(flipped) <= 2 and float(per_unit.max()) <= 1e-2 * scale, (k, flipped, e_hip, scale)
             continue
         assert e_hip <= bound, (k, e_hip, e_ref, scale)
-    allowed = PINNED_FALLBACK.get((name, batch_size))
+    allowed = PINNED_FALLBACK.get(pin_key if pin_key is not None else (name, batch_size))
     if allowed is not None:
         assert set(fallback) <= allowed, ("tensors outside the pinned list needed the float64 clause", sorted(set(fallback) - allowed))
     assert len(fallback) <= 16, fallback
@@ -236,6 +240,67 @@ def test_bf16_train_step_per_tensor(name):
         big = nr / tot > 1e-3
         assert cos > (0.99 if big else 0.9), (k, cos, rl2, nr / tot)
         assert rl2 < (0.15 if big else 0.5), (k, cos, rl2, nr / tot)
+
+
+@pytest.mark.parametrize("name,dtype", [("headline", "f32"), ("headline", "bf16"), ("sideface", "f32"), ("live", "f32")])
+def test_train_step_under_dropout_matches_oracle_given_the_same_decisions(name, dtype):
+    """The benchmarked mode is dropout 0.2.  Every dropout decision of the HIP step is a pure function of (step seed, site,
+    element index); tests/dropout_masks.py restates those functions in numpy (pinned against the kernels at op level in
+    tests/test_kernels_gpu.py) and the oracle applies the resulting masks at torch's dropout sites - so loss, memory,
+    hiddens and EVERY gradient of a step under dropout are compared exactly as in the dropout-free tests."""
+    import dropout_masks as DM
+    from oracle import plank_oracle as O
+    c = LC.CASES[name]
+    sd, batch = LC.case_state_dict(c), LC.case_batch(c)
+    pdrop = 0.2
+    m = hip_model(c, dtype, sd, dropout=pdrop)
+    m._step_seed = 20240917
+    seed = DM.next_step_seed(m._step_seed, torch.initial_seed())
+    out, mem, hid, grads = run_hip_train(m, batch)
+    assert m._step_seed == seed
+    cfg = LC.case_oracle_cfg(c)
+
+    def oracle(dt):
+        drop = DM.HipDropout(seed, pdrop, c["h"], batch["input_mask"].numpy(), packed=m.unpad)
+        p = {k: v.detach().clone().to(dt).requires_grad_(True) for k, v in sd.items()}
+        torch.set_default_dtype(dt)
+        try:
+            r = O.train_forward(p, cfg, batch, return_all=True, drop=drop)
+            r["loss"].backward()
+        finally:
+            torch.set_default_dtype(torch.float32)
+        assert len(set(drop.sites_seen)) == 4 * c["ne"] + 6 * c["nd"]          # every dropout site of torch's layers was fed
+        return r, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
+
+    ref, rgrads = oracle(torch.float32)
+    loss_ref = float(ref["loss"].detach())
+    _, _, plain, _ = oracle_train(name)
+    assert abs(loss_ref - float(plain["loss"])) > 1e-3                         # the masks really change the function
+    valid = ~batch["input_mask"]
+    if dtype == "f32":
+        assert abs(out["loss"].item() - loss_ref) < 1e-4, (out["loss"].item(), loss_ref)
+        assert float((mem - ref["memory"].detach())[valid].abs().max()) < 1e-4
+        assert float((hid - ref["hiddens"].detach()).abs().max()) < 1e-4
+        f64_cache = []
+
+        def f64():                                                             # float64 evaluation under the same masks
+            if not f64_cache:
+                f64_cache.append(oracle(torch.float64)[1])
+            return f64_cache[0]
+        worst = check_grads(name, grads, {k: v.detach() for k, v in rgrads.items()}, f64=f64, pin_key=(name, "dropout"))
+        print(f"[{name}] f32 under dropout: worst relative gradient error {worst[1]:.2e} ({worst[0]})")
+    else:
+        assert abs(out["loss"].item() - loss_ref) < 2e-2 * abs(loss_ref), (out["loss"].item(), loss_ref)
+        tot = sum(float(r.double().norm()) ** 2 for r in rgrads.values()) ** 0.5
+        for k, gr in grads.items():
+            r, a = rgrads[k].double().flatten(), gr.double().flatten()
+            nr = float(r.norm())
+            if nr == 0.0:
+                assert float(a.norm()) == 0.0, k
+                continue
+            cos = float(a @ r) / (float(a.norm()) * nr + 1e-300)
+            big = nr / tot > 1e-3
+            assert cos > (0.99 if big else 0.9), (k, cos, nr / tot)
 
 
 def _decode(m, db, **kw):

@@ -177,6 +177,34 @@ def test_gemm_dropout_statistics():
     assert (other != 0).ne(kept).float().mean().item() > 0.2   # different seed, different mask
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 64), (300, 1024, 128), (9000, 512, 64), (130, 192, 64)])
+def test_gemm_dropout_decisions_equal_the_numpy_restatement(M, N, K):
+    """tests/dropout_masks.py restates the epilogue's decision function; every GEMM kernel family (64 x 64, ring, two blocks
+    per CU, 128 x 256) must drop exactly the entries it predicts - the model-level dropout parity test rests on this."""
+    import dropout_masks as dm
+    for dtype in (torch.float32, torch.bfloat16):
+        a = torch.ones(M, K, dtype=dtype, device=DEV)
+        b = torch.ones(N, K, dtype=dtype, device=DEV)
+        out = ops.gemm(a, b, drop_p=0.2, drop_seed=987654321)
+        want = dm.linear_keep(987654321, np.arange(M), N, 0.2)
+        assert np.array_equal((out != 0).cpu().numpy(), want), (dtype, M, N)
+        assert torch.equal(out[out != 0], torch.full_like(out[out != 0], K * 1.25))
+
+
+def test_layernorm_bwd_dropout_decisions_equal_the_numpy_restatement():
+    import dropout_masks as dm
+    rows, d = 333, 512
+    z = rnd(rows, d, seed=21).to(DEV)
+    gamma = torch.ones(d, device=DEV)
+    _, mean, rstd = ops.layernorm_fwd(z, gamma, torch.zeros(d, device=DEV), 1.0)
+    dy = rnd(rows, d, seed=22).to(DEV)
+    dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    dz, ddrop = ops.layernorm_bwd(dy, z, gamma, mean, rstd, dg, db, drop_p=0.2, drop_seed=4711)
+    want = torch.from_numpy(dm.linear_keep(4711, np.arange(rows), d, 0.2)).to(DEV)
+    assert torch.equal(ddrop != 0, want & (dz != 0))                         # d(sublayer output) = mask o dz / (1 - p)
+    assert rel_err(ddrop[want], dz[want] * 1.25) < 1e-6
+
+
 def test_colsum():
     for dtype in (torch.float32, torch.bfloat16):
         x = rnd(1000, 520, dtype=dtype, seed=13)
@@ -424,6 +452,16 @@ def test_attention_dropout_forward_backward_against_masked_reference(dtype, B, H
     assert rel_err(dq, qr.grad) < t, ("dq", rel_err(dq, qr.grad))
     assert rel_err(dk, kr.grad) < t, ("dk", rel_err(dk, kr.grad))
     assert rel_err(dv, vr.grad) < t, ("dv", rel_err(dv, vr.grad))
+
+
+@pytest.mark.parametrize("dtype,B,H,dh,Lq,Lk", [(torch.bfloat16, 2, 2, 64, 200, 333), (torch.float32, 3, 4, 16, 70, 100)])
+def test_attention_dropout_decisions_equal_the_numpy_restatement(dtype, B, H, dh, Lq, Lk):
+    """keep(row, key) as tests/dropout_masks.py computes it == the decisions extracted from the kernels."""
+    import dropout_masks as dm
+    keep = _extract_keep_mask(B, H, Lq, Lk, dh, 0.2, 31337, dtype)
+    rows = (np.arange(B)[:, None, None] * H + np.arange(H)[None, :, None]) * Lq + np.arange(Lq)[None, None, :]
+    want = dm.attn_keep(31337, rows, Lk, 0.2)
+    assert np.array_equal(keep.numpy(), want)
 
 
 def _mix32(x):

@@ -1,6 +1,7 @@
 """Pin the CPU oracle (oracle/plank_oracle.py) to golden vectors produced by the real
 reference model (tests/golden/make_golden.py).  CPU only."""
 import copy
+import os
 
 import numpy as np
 import torch
@@ -152,3 +153,42 @@ def test_g8_tiny_loss_curve(tiny_fixture):
         O.adam_step(params, grads, m, vv, step=step, lr=1e-4)
         losses.append(float(loss))
     assert np.allclose(losses, g["g8::losses"], atol=2e-5), (losses, g["g8::losses"])
+
+
+class _RuleDrop:
+    """tests/golden/make_golden_dropout.py's rule, replayed by call order: keep(call n, shape) = rand(seed 7000 + n) >= p."""
+
+    def __init__(self, p=0.2):
+        self.p, self.n, self.shapes, self.sites = p, 0, [], []
+
+    def __call__(self, site, x):
+        keep = torch.rand(tuple(x.shape), generator=torch.Generator().manual_seed(7000 + self.n)) >= self.p
+        self.n += 1
+        self.shapes.append(tuple(x.shape))
+        self.sites.append(site)
+        return x * (keep.to(x.dtype) / (1.0 - self.p))
+
+
+def test_g10_train_step_under_dropout_sites_and_order_match_the_reference(small_fixture, ragged_fixture):
+    """fixture_dropout.npz: the REAL reference model in train mode with dropout 0.2, torch's two dropout entry points replaced
+    by a rule of (call order, shape).  The oracle replays the rule through its `drop` hook: same loss and gradients means it
+    applies dropout at the same places, in the same order, to the same tensors as torch's Transformer layers do."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fixture_dropout.npz"))
+    for tag, (sd, batch, _) in (("small", small_fixture), ("ragged", ragged_fixture)):
+        drop = _RuleDrop()
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        out = O.train_forward(p, SMALL, batch, drop=drop)
+        out["loss"].backward()
+        assert drop.n == int(g[f"{tag}::calls"]) == 20
+        shapes = [tuple(int(v) for v in row if v) for row in g[f"{tag}::shapes"]]
+        assert drop.shapes == shapes, (drop.shapes, shapes)              # call by call: the same tensor shapes in the same order
+        assert abs(float(out["loss"]) - float(g[f"{tag}::loss"])) < 2e-6, (tag, float(out["loss"]), float(g[f"{tag}::loss"]))
+        assert abs(out["accuracy"] - float(g[f"{tag}::accuracy"])) < 1e-7
+        for k, v in p.items():
+            ref = torch.from_numpy(g[f"{tag}::grad::" + k])
+            got = v.grad if v.grad is not None else torch.zeros_like(v)
+            err, scale = float((got - ref).abs().max()), float(ref.abs().max())
+            assert err <= 1e-5 + 1e-4 * scale, (tag, k, err, scale)
+        with torch.no_grad():                                            # and the hook left the dropout-free path alone
+            plain = O.train_forward(sd, SMALL, batch)
+        assert abs(float(plain["loss"]) - float(out["loss"])) > 1e-3
