@@ -189,7 +189,7 @@ def gemm_census(model, batch, train_step):
     fam = {}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     reps = 5
-    names = {0: "pair", 1: "ring", 2: "wide", 3: "small"}
+    names = {0: "pair", 1: "ring", 2: "wide", 3: "small", 4: "skinny"}
     i = 0
     while i < n:
         gid = groups[i] if i < ng else -1

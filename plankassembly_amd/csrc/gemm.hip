@@ -1994,6 +1994,134 @@ __global__ __launch_bounds__(NT, 1) void gemm3w_kernel(GemmP p) {
 }
 
 // split-K second pass: sum the slabs and apply the epilogue
+// -------------------------------------------------------------------------------------------------
+// "Skinny" Linear: a few hundred rows (greedy decode: M = batch 256) against a whole weight.  The tiled kernels above give
+// such a launch 8 ... 32 blocks that each walk K in a serial chain of small DMA -> barrier -> MFMA steps; in f32 (the
+// token-exact decode path) that chain is 32 ... 64 steps of 16 columns on 8 blocks: 43 ... 98 us per Linear, 60 % of the f32
+// decode step (profiles/r03_decode_f32_kernel_trace_summary.txt).  Here a block owns a 32 x 32 output tile and K is cut into
+// chunks of 1 KB per operand row (256 f32 / 512 bf16); the first TWO chunks - all of K = 512 in f32, K = 1 024 in bf16 - are
+// requested before anything is waited for (direct-to-LDS DMA, one instruction per operand row and chunk: 64 lanes x 16 B),
+// so a block pays one memory round trip instead of a chain of them.  M 256 x N 512 -> 128 blocks, N 1 536 -> 384.
+// The four waves split each chunk's K range; their partial 32 x 32 accumulators are summed through LDS in a fixed order
+// (deterministic).  LDS rows are padded to 1 040 B: a 16-lane phase of ds_read_b128 then covers all 64 banks.
+// Epilogue = the other kernels' (alpha, bias, ReLU, residual in the output type); no gate / dropout (the dispatcher keeps
+// those on the tiled kernels).
+constexpr int SK_T = 32, SK_ROW = 1024, SK_STRIDE = SK_ROW + 16, SK_STAGE = 2 * SK_T * SK_STRIDE, SK_NSTG = 2;
+constexpr int SK_RED = 33 * 4;                       // row stride of the reduction buffer (f32, padded)
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
+    constexpr int esz = sizeof(T);
+    constexpr int CH = SK_ROW / esz;                 // K elements per chunk
+    __shared__ __attribute__((aligned(256))) char smem[SK_NSTG * SK_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;      // neighbouring blocks share the A rows
+    const int m0 = tm * SK_T, n0 = tn * SK_T;
+    const int nch = p.K / CH;
+    const char* gA = reinterpret_cast<const char*>(p.A) + (size_t)lane * 16;
+    const char* gB = reinterpret_cast<const char*>(p.B) + (size_t)lane * 16;
+    // wave w moves rows 8w .. 8w + 7 of both operands: 16 DMA instructions per chunk and wave
+    auto issue = [&](int c, int stage) {
+        char* base = smem + stage * SK_STAGE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i;
+            const char* sa = gA + ((size_t)min(m0 + r, p.M - 1) * p.lda + (size_t)c * CH) * esz;
+            const char* sb = gB + ((size_t)min(n0 + r, p.N - 1) * p.ldb + (size_t)c * CH) * esz;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                (__attribute__((address_space(3))) void*)(base + r * SK_STRIDE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                (__attribute__((address_space(3))) void*)(base + (SK_T + r) * SK_STRIDE), 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    if (nch > 1) issue(1, 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int half = lane >> 5, row = lane & 31;
+    // this wave's quarter of a chunk, this lane's 16 bytes of every 32-byte (f32: 8 k, bf16: 16 k) group
+    const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    const uint32_t offA = (uint32_t)(row * SK_STRIDE + wave * (SK_ROW / 4) + half * 16);
+    const uint32_t offB = offA + SK_T * SK_STRIDE;
+    for (int c = 0; c < nch; ++c) {
+        const int stage = c & 1;
+        // counted wait + raw barrier (a __syncthreads() would also drain the newer chunk's DMA): chunk c has landed for every wave
+        if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint32_t la = lds0 + stage * SK_STAGE + offA, lb = lds0 + stage * SK_STAGE + offB;
+#define SK_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
+        f32x4 a[8], b[8];
+        SK_RD(a[0], la, 0);   SK_RD(b[0], lb, 0);   SK_RD(a[1], la, 32);  SK_RD(b[1], lb, 32);
+        SK_RD(a[2], la, 64);  SK_RD(b[2], lb, 64);  SK_RD(a[3], la, 96);  SK_RD(b[3], lb, 96);
+        SK_RD(a[4], la, 128); SK_RD(b[4], lb, 128); SK_RD(a[5], la, 160); SK_RD(b[5], lb, 160);
+        SK_RD(a[6], la, 192); SK_RD(b[6], lb, 192); SK_RD(a[7], la, 224); SK_RD(b[7], lb, 224);
+#undef SK_RD
+        // (the operands are tied to the wait, or the MFMAs - plain builtins - could be scheduled above it)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                                               "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (esz == 4) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][t], b[j][t], acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, b[j]), acc, 0, 0, 0);
+            }
+        }
+        if (c + 2 < nch) {                            // the stage is free once every wave has read it (lgkmcnt(0) above)
+            __builtin_amdgcn_s_barrier();
+            issue(c + 2, stage);
+        }
+    }
+    // ---- sum the four K-quarters through LDS (fixed order), then the epilogue: thread -> one row, four columns -------------
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r >> 2) * 8 + half * 4 + (r & 3);
+        red[wave * (SK_T * 33) + rr * 33 + row] = acc[r];
+    }
+    __syncthreads();
+    const int er = tid >> 3, ec = (tid & 7) * 4;
+    const int m = m0 + er, n = n0 + ec;
+    if (m >= p.M || n >= p.N) return;
+    f32x4 x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float* q = red + er * 33 + ec + e;
+        x[e] = ((q[0] + q[SK_T * 33]) + q[2 * SK_T * 33]) + q[3 * SK_T * 33];
+    }
+    const bool out_f32 = p.out_dtype == PA_F32;
+    const bool full = n + 3 < p.N;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (n + e < p.N) {
+            float y = x[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
+            if (p.relu) y = fmaxf(y, 0.f);
+            if (p.R) {
+                const size_t ro = (size_t)m * p.ldr + n + e;
+                y += out_f32 ? reinterpret_cast<const float*>(p.R)[ro] : (float)reinterpret_cast<const bf16*>(p.R)[ro];
+            }
+            x[e] = y;
+        }
+    }
+    const size_t co = (size_t)m * p.ldc + n;
+    if (full && p.vec_ok) {
+        if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = x;
+        else st4<bf16>(reinterpret_cast<bf16*>(p.C) + co, x);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) {
+                if (out_f32) reinterpret_cast<float*>(p.C)[co + e] = x[e];
+                else reinterpret_cast<bf16*>(p.C)[co + e] = (bf16)x[e];
+            }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float* ws) {
     const size_t total = (size_t)p.batch * p.M * p.N;
@@ -2224,6 +2352,24 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     const long long wide_tiles = (long long)((a->M + 127) / 128) * ((a->N + 255) / 256) * a->batch;
     const bool go_wide = use_v3 && use_wide && (use_wide == 1 || wide_tiles <= cus) && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds &&
                          is_aligned<bf16>(a) && a->a_kcontig && a->b_kcontig && splitk == 1 && a->K % 64 == 0 && a->N >= 1024 && valid_units > 256;
+    // skinny kernel (a few hundred rows against a whole weight: the greedy-decode Linears).  PA_GEMM_SKINNY: 0 never, 1 f32 only,
+    // 2 (default) bf16 too.  Measured on MI355X, greedy decode B 256 x 1024 steps: f32 3.65 -> 2.03 ms/step (the f32 Linears were
+    // 43 ... 98 us each on 8 blocks), bf16 1.224 -> 1.112 ms/step (32 blocks of the 64 x 64-tile ring kernel before).
+    static const int use_skinny = getenv("PA_GEMM_SKINNY") ? atoi(getenv("PA_GEMM_SKINNY")) : 2;
+    static const int skinny_rows = getenv("PA_GEMM_SKINNY_ROWS") ? atoi(getenv("PA_GEMM_SKINNY_ROWS")) : 512;
+    const int sk_ch = a->in_dtype == PA_BF16 ? 512 : 256;
+    const bool go_skinny = use_skinny && (a->in_dtype == PA_F32 || use_skinny >= 2) && a->a_kcontig && a->b_kcontig && splitk == 1 &&
+                           a->batch == 1 && a->M <= skinny_rows && a->K % sk_ch == 0 && !a->aux && a->drop_p == 0.f && !dbg_noglds &&
+                           (a->in_dtype == PA_BF16 ? is_aligned<bf16>(a) : is_aligned<float>(a));
+    if (go_skinny) {
+        if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(PA_GEMM_KIND_SKINNY); if (g_rec && g_rec_group) g_rec_group->push_back(-1); }
+        GemmP ps = pk;
+        ps.tiles_m = (a->M + SK_T - 1) / SK_T; ps.tiles_n = (a->N + SK_T - 1) / SK_T;
+        const dim3 gsk(ps.tiles_m * ps.tiles_n);
+        if (a->in_dtype == PA_BF16) PA_LAUNCH(gemm_skinny_kernel<bf16>, gsk, dim3(256), 0, st, ps);
+        else PA_LAUNCH(gemm_skinny_kernel<float>, gsk, dim3(256), 0, st, ps);
+        return 0;
+    }
     if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_wide ? PA_GEMM_KIND_WIDE : (go_small ? PA_GEMM_KIND_SMALL : (go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR))); if (g_rec && g_rec_group) g_rec_group->push_back(-1); }
     // wide-tile ring kernel: large multi-round k-contiguous Linears (N >= 1024): 128 x 256 tiles
     if (go_wide) {

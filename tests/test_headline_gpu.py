@@ -76,17 +76,13 @@ PINNED_FALLBACK = {
     ("sideface", None): {"encoder.layers.1.linear1.weight", "decoder.layers.5.linear1.weight", "decoder.layers.5.linear1.bias"},
     ("t1024", None): {"decoder.layers.0.linear1.weight", "decoder.layers.0.linear1.bias", "decoder.layers.3.linear1.weight",
                       "decoder.layers.3.linear1.bias"},
-    # the same steps under dropout 0.2 with the step seed of test_train_step_under_dropout_... (gpurun_out r03m)
-    ("headline", "dropout"): {"encoder.layers.3.linear1.weight"}, ("live", "dropout"): set(),
-    ("sideface", "dropout"): {"encoder.layers.3.linear1.weight", "decoder.layers.0.linear2.weight", "decoder.layers.1.norm3.weight",
-                              "decoder.layers.3.linear1.weight", "decoder.layers.4.linear1.weight", "decoder.layers.4.linear1.bias"},
     ("sideface", 64): {"decoder.layers.0.norm1.weight", "decoder.layers.0.norm3.weight", "decoder.layers.1.norm1.weight",
                        "decoder.layers.1.norm3.weight", "decoder.layers.3.linear1.weight", "decoder.layers.3.linear1.bias",
                        "decoder.layers.4.linear1.weight", "decoder.layers.4.linear1.bias", "decoder.layers.4.norm1.weight"},
 }
 
 
-def check_grads(name, grads, rgrads, batch_size=None, f64=None, pin_key=None):
+def check_grads(name, grads, rgrads, batch_size=None, f64=None, pin_key=None, flip_mag=1e-2):
     """Every gradient within 1e-5 + 1e-4*scale of the f32 reference computation.  A few reduction-heavy tensors (sums
     over thousands of rows with cancellation: LayerNorm affine / bias gradients, at B = 64 also some weight gradients)
     sit where the f32 reference's OWN rounding noise exceeds that bound (measured against float64: reference error
@@ -122,7 +118,7 @@ def check_grads(name, grads, rgrads, batch_size=None, f64=None, pin_key=None):
             print(f"      ReLU branch flip in hidden unit(s) {flipped}: {per_unit[flipped].tolist()}")
             # (magnitude: ONE (row, unit) entry's whole contribution dY[r, u] * x[r, :] against the largest entry of a sum
             # over all rows - up to ~1 % of it; seen 3.6e-3 at T = 1024, decoder.layers.0 unit 387, identical in every run)
-            assert len(flipped) <= 2 and float(per_unit.max()) <= 1e-2 * scale, (k, flipped, e_hip, scale)
+            assert len(flipped) <= 2 and float(per_unit.max()) <= flip_mag * scale, (k, flipped, e_hip, scale)
             continue
         assert e_hip <= bound, (k, e_hip, e_ref, scale)
     allowed = PINNED_FALLBACK.get(pin_key if pin_key is not None else (name, batch_size))
@@ -253,6 +249,7 @@ def test_train_step_under_dropout_matches_oracle_given_the_same_decisions(name, 
     c = LC.CASES[name]
     sd, batch = LC.case_state_dict(c), LC.case_batch(c)
     pdrop = 0.2
+    torch.manual_seed(1234)                        # the step seed mixes torch.initial_seed() in: same masks whatever ran before
     m = hip_model(c, dtype, sd, dropout=pdrop)
     m._step_seed = 20240917
     seed = DM.next_step_seed(m._step_seed, torch.initial_seed())
@@ -272,23 +269,24 @@ def test_train_step_under_dropout_matches_oracle_given_the_same_decisions(name, 
         assert len(set(drop.sites_seen)) == 4 * c["ne"] + 6 * c["nd"]          # every dropout site of torch's layers was fed
         return r, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
 
-    ref, rgrads = oracle(torch.float32)
+    # f32 path: against the FLOAT64 evaluation under the same masks (the f32 oracle on the host takes ReLU branches of its own
+    # under these masks - seen: 30 tensors 2e-5 .. 8e-5 off while the HIP step is 2e-6 .. 1e-5 from float64 - and would make the
+    # verdict depend on the host's BLAS); bf16 path: against the f32 oracle, per-tensor cosine.
+    ref, rgrads = oracle(torch.float64 if dtype == "f32" else torch.float32)
+    rgrads = {k: v.detach() for k, v in rgrads.items()}
     loss_ref = float(ref["loss"].detach())
     _, _, plain, _ = oracle_train(name)
     assert abs(loss_ref - float(plain["loss"])) > 1e-3                         # the masks really change the function
     valid = ~batch["input_mask"]
     if dtype == "f32":
         assert abs(out["loss"].item() - loss_ref) < 1e-4, (out["loss"].item(), loss_ref)
-        assert float((mem - ref["memory"].detach())[valid].abs().max()) < 1e-4
-        assert float((hid - ref["hiddens"].detach()).abs().max()) < 1e-4
-        f64_cache = []
-
-        def f64():                                                             # float64 evaluation under the same masks
-            if not f64_cache:
-                f64_cache.append(oracle(torch.float64)[1])
-            return f64_cache[0]
-        worst = check_grads(name, grads, {k: v.detach() for k, v in rgrads.items()}, f64=f64, pin_key=(name, "dropout"))
-        print(f"[{name}] f32 under dropout: worst relative gradient error {worst[1]:.2e} ({worst[0]})")
+        assert float((mem.double() - ref["memory"].detach())[valid].abs().max()) < 1e-4
+        assert float((hid.double() - ref["hiddens"].detach()).abs().max()) < 1e-4
+        # every gradient within 1e-5 + 1e-4 * scale of float64; linear1 tensors may carry a ReLU branch flip in at most two hidden
+        # units (one (row, unit) entry's whole contribution: up to a few % of the largest entry when the batch has 256 rows)
+        worst = check_grads(name, grads, {k: v.float() for k, v in rgrads.items()}, f64=lambda: rgrads, pin_key=(name, "dropout"),
+                            flip_mag=5e-2)
+        print(f"[{name}] f32 under dropout vs float64: worst relative gradient error {worst[1]:.2e} ({worst[0]})")
     else:
         assert abs(out["loss"].item() - loss_ref) < 2e-2 * abs(loss_ref), (out["loss"].item(), loss_ref)
         tot = sum(float(r.double().norm()) ** 2 for r in rgrads.values()) ** 0.5
@@ -485,7 +483,7 @@ def _recorded_gemm_kinds(step):
     kinds, groups = (C.c_int32 * n)(), (C.c_int32 * n)()
     nk = lib.pa_gemm_recorded_kinds(C.cast(kinds, C.c_void_p), n)
     ng = lib.pa_gemm_recorded_groups(C.cast(groups, C.c_void_p), n)
-    names = {0: "pair", 1: "ring", 2: "wide", 3: "small"}
+    names = {0: "pair", 1: "ring", 2: "wide", 3: "small", 4: "skinny"}
     fam = {}
     for i in range(n):
         key = "group" if (i < ng and groups[i] >= 0) else names.get(kinds[i] if i < nk else 0, "pair")
