@@ -568,11 +568,13 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
             PA_LAUNCH(dec_split_heads_kernel<float>, dim3(2048), dim3(256), 0, s, (float*)L->cross_k[i], (float*)L->cross_v[i],
                       (const float*)L->kv_tmp, (int64_t)m->NE, S, d, c.n_head, m->batch.cu_in, m->batch.rowmap);
     }
-    // LayerNorm folded into its consumer Linear (bf16 decode)
-    // MEASURED NULL on MI355X (B 256, 1024 steps, one lane): 1.228 ms / step folded against 1.210 with the 17 LayerNorm
-    // launches - what a 256-row LayerNorm launch costs is two dependent memory round trips, and the statistics pass in the
-    // consumer's prologue pays the same ones; off unless PLANK_DECODE_FOLD_LN=1 (like pa_gemm_ln, kept for the record).
-    static const bool fold_env = getenv("PLANK_DECODE_FOLD_LN") && atoi(getenv("PLANK_DECODE_FOLD_LN")) != 0;
+    // LayerNorm folded into its consumer Linear (bf16 decode): 17 LayerNorm launches fewer per step.
+    // On the ring kernel (gemm3s_kernel's prologue statistics pass) this was MEASURED NULL on MI355X (B 256, 1024 steps, one lane:
+    // 1.228 ms / step folded against 1.210 - the statistics pass pays the memory round trips the LayerNorm launch paid).  On
+    // gemm_skinny_kernel the Z tile is resident in LDS and the statistics cost no round trip: 1.072 against 1.089 ms / step.  So: on by
+    // default exactly where pa_gemm_norm_a takes the skinny kernel (d_model 512, at most 512 rows); PLANK_DECODE_FOLD_LN=0 / 1 forces.
+    static const int fold_force = getenv("PLANK_DECODE_FOLD_LN") ? atoi(getenv("PLANK_DECODE_FOLD_LN")) : -1;
+    const bool fold_env = fold_force >= 0 ? fold_force != 0 : (d == 512 && B <= 512);
     L->fold = fold_env && c.dtype == PA_BF16 && d % 64 == 0 && c.d_ff % 32 == 0 && (size_t)((B + 63) / 64) * ((3 * d + 63) / 64) <= 512;
     if (L->fold) {
         for (int i = 0; i < c.n_dec; ++i) {

@@ -2009,7 +2009,11 @@ __global__ __launch_bounds__(NT, 1) void gemm3w_kernel(GemmP p) {
 constexpr int SK_T = 32, SK_ROW = 1024, SK_STRIDE = SK_ROW + 16, SK_STAGE = 2 * SK_T * SK_STRIDE, SK_NSTG = 2;
 constexpr int SK_RED = 33 * 4;                       // row stride of the reduction buffer (f32, padded)
 
-template <typename T>
+// LN = true (bf16, K = one chunk = 512): A = LayerNorm(Z) folded into the product as in gemm3s_kernel's p.ln_u form - the weight is
+// pre-multiplied by gamma, the block takes mean / rstd of its 32 rows from the Z tile that is resident in LDS anyway (no extra
+// memory round trip: the reason the fold did not pay on the ring kernel), the epilogue applies
+// rstd (acc - mean u) + v, and the blocks of column tile 0 materialise LayerNorm(Z) for the later residual add.
+template <typename T, bool LN>
 __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
     constexpr int esz = sizeof(T);
     constexpr int CH = SK_ROW / esz;                 // K elements per chunk
@@ -2019,6 +2023,42 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
     const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;      // neighbouring blocks share the A rows
     const int m0 = tm * SK_T, n0 = tn * SK_T;
     const int nch = p.K / CH;
+    // ---- everything the epilogue needs from memory is requested FIRST (ordinary loads, older than every DMA below, so the
+    // hand-counted vmcnt waits - loads return in order - also cover them): bias / u / residual / gamma / beta of this thread's
+    // one row x four columns.  A load at the end would be a second, fully exposed memory round trip.
+    const int er = tid >> 3, ec = (tid & 7) * 4;
+    const int em = m0 + er, en = n0 + ec;
+    const bool out_f32 = p.out_dtype == PA_F32;
+    const bool in_tile = em < p.M && en < p.N;
+    const bool full = en + 3 < p.N;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, u4 = {0.f, 0.f, 0.f, 0.f}, res4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gam4 = {0.f, 0.f, 0.f, 0.f}, bet4 = {0.f, 0.f, 0.f, 0.f};
+    if (in_tile) {
+        if (full && p.vec_ok) {
+            if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + en);
+            if (LN) u4 = *reinterpret_cast<const f32x4*>(p.ln_u + en);
+            if (p.R) {
+                const size_t ro = (size_t)em * p.ldr + en;
+                res4 = out_f32 ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + ro)
+                               : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (en + e < p.N) {
+                    if (p.bias) bias4[e] = p.bias[en + e];
+                    if (LN) u4[e] = p.ln_u[en + e];
+                    if (p.R) {
+                        const size_t ro = (size_t)em * p.ldr + en + e;
+                        res4[e] = out_f32 ? reinterpret_cast<const float*>(p.R)[ro] : (float)reinterpret_cast<const bf16*>(p.R)[ro];
+                    }
+                }
+        }
+    }
+    // LN: column tile tn materialises columns 32 tn .. 32 tn + 31 of LayerNorm(Z) (N >= K is checked by the host)
+    const bool write_y = LN && p.ln_y != nullptr && n0 < p.K && em < p.M;
+    if (write_y) { gam4 = *reinterpret_cast<const f32x4*>(p.ln_gamma + en); bet4 = *reinterpret_cast<const f32x4*>(p.ln_beta + en); }
+
     const char* gA = reinterpret_cast<const char*>(p.A) + (size_t)lane * 16;
     const char* gB = reinterpret_cast<const char*>(p.B) + (size_t)lane * 16;
     // wave w moves rows 8w .. 8w + 7 of both operands: 16 DMA instructions per chunk and wave
@@ -2045,6 +2085,7 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     const uint32_t offA = (uint32_t)(row * SK_STRIDE + wave * (SK_ROW / 4) + half * 16);
     const uint32_t offB = offA + SK_T * SK_STRIDE;
+    float* stats = reinterpret_cast<float*>(smem + SK_STAGE);          // LN: [32] mean | [32] rstd (stage 1 is unused: one chunk)
     for (int c = 0; c < nch; ++c) {
         const int stage = c & 1;
         // counted wait + raw barrier (a __syncthreads() would also drain the newer chunk's DMA): chunk c has landed for every wave
@@ -2058,6 +2099,34 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
         SK_RD(a[2], la, 64);  SK_RD(b[2], lb, 64);  SK_RD(a[3], la, 96);  SK_RD(b[3], lb, 96);
         SK_RD(a[4], la, 128); SK_RD(b[4], lb, 128); SK_RD(a[5], la, 160); SK_RD(b[5], lb, 160);
         SK_RD(a[6], la, 192); SK_RD(b[6], lb, 192); SK_RD(a[7], la, 224); SK_RD(b[7], lb, 224);
+        if constexpr (LN) {
+            // row statistics from the resident Z tile, all 8 rows of this wave at once: lane -> (row 8w + l / 8, eighth l % 8), 64
+            // elements per lane, two passes over them in registers, three lane exchanges per pass.  Issued between the fragment
+            // reads and their use: the MFMAs below do not wait for it.
+            const int sr = wave * 8 + (lane >> 3), part = lane & 7;
+            const uint32_t lz = lds0 + (uint32_t)(sr * SK_STRIDE + part * 16);
+            u32x4 zz[8];
+            SK_RD(zz[0], lz, 0);   SK_RD(zz[1], lz, 128); SK_RD(zz[2], lz, 256); SK_RD(zz[3], lz, 384);
+            SK_RD(zz[4], lz, 512); SK_RD(zz[5], lz, 640); SK_RD(zz[6], lz, 768); SK_RD(zz[7], lz, 896);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(zz[0]), "+v"(zz[1]), "+v"(zz[2]), "+v"(zz[3]), "+v"(zz[4]), "+v"(zz[5]), "+v"(zz[6]), "+v"(zz[7]));
+            float s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s1 += bf16_lo(zz[j][w]) + bf16_hi(zz[j][w]);
+            s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+            const float mean = s1 * (1.0f / (float)CH);
+            float s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float d0 = bf16_lo(zz[j][w]) - mean, d1 = bf16_hi(zz[j][w]) - mean;
+                    s2 += d0 * d0 + d1 * d1;
+                }
+            s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
+            if (part == 0) { stats[sr] = mean; stats[32 + sr] = rsqrtf(s2 * (1.0f / (float)CH) + p.ln_eps); }
+        }
 #undef SK_RD
         // (the operands are tied to the wait, or the MFMAs - plain builtins - could be scheduled above it)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
@@ -2077,45 +2146,47 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
         }
     }
     // ---- sum the four K-quarters through LDS (fixed order), then the epilogue: thread -> one row, four columns -------------
+    // LN: the reduction buffer lives in the unused second stage (behind the statistics), so the Z tile in stage 0 stays readable
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
+    float* red = reinterpret_cast<float*>(smem + (LN ? SK_STAGE + 1024 : 0));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = (r >> 2) * 8 + half * 4 + (r & 3);
         red[wave * (SK_T * 33) + rr * 33 + row] = acc[r];
     }
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    if constexpr (LN) {
+        ln_mean = stats[er]; ln_rstd = stats[32 + er];
+        if (write_y) {
+            const u32x2 zq = *reinterpret_cast<const u32x2*>(smem + er * SK_STRIDE + (size_t)en * 2);
+            f32x4 y;
+            y[0] = (bf16_lo(zq[0]) - ln_mean) * ln_rstd * gam4[0] + bet4[0]; y[1] = (bf16_hi(zq[0]) - ln_mean) * ln_rstd * gam4[1] + bet4[1];
+            y[2] = (bf16_lo(zq[1]) - ln_mean) * ln_rstd * gam4[2] + bet4[2]; y[3] = (bf16_hi(zq[1]) - ln_mean) * ln_rstd * gam4[3] + bet4[3];
+            st4<bf16>(reinterpret_cast<bf16*>(p.ln_y) + (size_t)em * p.ldy + en, y);
+        }
+    }
     __syncthreads();
-    const int er = tid >> 3, ec = (tid & 7) * 4;
-    const int m = m0 + er, n = n0 + ec;
-    if (m >= p.M || n >= p.N) return;
+    if (!in_tile) return;
     f32x4 x;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float* q = red + er * 33 + ec + e;
         x[e] = ((q[0] + q[SK_T * 33]) + q[2 * SK_T * 33]) + q[3 * SK_T * 33];
     }
-    const bool out_f32 = p.out_dtype == PA_F32;
-    const bool full = n + 3 < p.N;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if (n + e < p.N) {
-            float y = x[e] * p.alpha + (p.bias ? p.bias[n + e] : 0.f);
-            if (p.relu) y = fmaxf(y, 0.f);
-            if (p.R) {
-                const size_t ro = (size_t)m * p.ldr + n + e;
-                y += out_f32 ? reinterpret_cast<const float*>(p.R)[ro] : (float)reinterpret_cast<const bf16*>(p.R)[ro];
-            }
-            x[e] = y;
-        }
+        float y = LN ? ln_rstd * (x[e] * p.alpha - ln_mean * u4[e]) + bias4[e] : x[e] * p.alpha + bias4[e];
+        if (p.relu) y = fmaxf(y, 0.f);
+        x[e] = y + res4[e];
     }
-    const size_t co = (size_t)m * p.ldc + n;
+    const size_t co = (size_t)em * p.ldc + en;
     if (full && p.vec_ok) {
         if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = x;
         else st4<bf16>(reinterpret_cast<bf16*>(p.C) + co, x);
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) {
+            if (en + e < p.N) {
                 if (out_f32) reinterpret_cast<float*>(p.C)[co + e] = x[e];
                 else reinterpret_cast<bf16*>(p.C)[co + e] = (bf16)x[e];
             }
@@ -2366,8 +2437,8 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         GemmP ps = pk;
         ps.tiles_m = (a->M + SK_T - 1) / SK_T; ps.tiles_n = (a->N + SK_T - 1) / SK_T;
         const dim3 gsk(ps.tiles_m * ps.tiles_n);
-        if (a->in_dtype == PA_BF16) PA_LAUNCH(gemm_skinny_kernel<bf16>, gsk, dim3(256), 0, st, ps);
-        else PA_LAUNCH(gemm_skinny_kernel<float>, gsk, dim3(256), 0, st, ps);
+        if (a->in_dtype == PA_BF16) PA_LAUNCH((gemm_skinny_kernel<bf16, false>), gsk, dim3(256), 0, st, ps);
+        else PA_LAUNCH((gemm_skinny_kernel<float, false>), gsk, dim3(256), 0, st, ps);
         return 0;
     }
     if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_wide ? PA_GEMM_KIND_WIDE : (go_small ? PA_GEMM_KIND_SMALL : (go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR))); if (g_rec && g_rec_group) g_rec_group->push_back(-1); }
@@ -2463,6 +2534,25 @@ extern "C" int pa_gemm_norm_a(const pa_gemm_args* a, const pa_gemm_norm_ext* x, 
     if (x->y && (!x->gamma || !x->beta || x->ldy < a->K || x->ldy % 4)) return PA_EINVAL;
     if (x->y && (a->N + 63) / 64 * 64 < a->K) return PA_ESHAPE;      // column tile j materialises columns 64 j .. 64 j + 63 of LayerNorm(Z)
     if (!is_aligned<bf16>(a)) return PA_EALIGN;
+    // <= 512 rows and K = 512: the skinny kernel's form (the Z tile is resident in LDS, the statistics cost no memory round trip)
+    static const int sk_on = getenv("PA_GEMM_SKINNY") ? atoi(getenv("PA_GEMM_SKINNY")) : 2;
+    static const int sk_rows = getenv("PA_GEMM_SKINNY_ROWS") ? atoi(getenv("PA_GEMM_SKINNY_ROWS")) : 512;
+    if (sk_on >= 2 && a->M <= sk_rows && a->K == 512 && (!x->y || (a->N >= a->K && x->ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(x->y) & 15) == 0 &&
+                                                                  (reinterpret_cast<uintptr_t>(x->gamma) & 15) == 0 &&
+                                                                  (reinterpret_cast<uintptr_t>(x->beta) & 15) == 0))) {
+        GemmP p = GemmP();
+        p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias;
+        p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
+        p.batch = 1; p.alpha = a->alpha; p.relu = a->relu; p.aux_scale = 1.f; p.drop_scale = 1.f; p.out_dtype = a->out_dtype;
+        p.splitk = 1;
+        p.tiles_m = (a->M + SK_T - 1) / SK_T; p.tiles_n = (a->N + SK_T - 1) / SK_T;
+        const int osz = a->out_dtype == PA_F32 ? 4 : 2;
+        p.vec_ok = ((reinterpret_cast<uintptr_t>(a->C) % (4 * osz)) == 0 && a->ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(a->bias) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(x->u) & 15) == 0) ? 1 : 0;
+        p.ln_u = x->u; p.ln_gamma = x->gamma; p.ln_beta = x->beta; p.ln_y = x->y; p.ldy = x->ldy; p.ln_eps = x->eps;
+        PA_LAUNCH((gemm_skinny_kernel<bf16, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+        return 0;
+    }
     const int tiles = ((a->M + 63) / 64) * ((a->N + 63) / 64);
     const int cus = cus_for_gemm();
     if (tiles > 2 * cus) return PA_ESHAPE;                 // the row statistics live in registers: one unit per block

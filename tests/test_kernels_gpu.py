@@ -664,7 +664,8 @@ def test_attention_key_split_blocks_same_dropout_as_dense():
 
 
 @pytest.mark.parametrize("M,N,K,eps,relu", [(256, 512, 512, 1.0, False), (256, 1536, 512, 1.0, False), (256, 1024, 512, 1.0, True),
-                                              (128, 512, 512, 1e-5, False), (200, 96, 128, 1.0, True)])
+                                              (128, 512, 512, 1e-5, False), (200, 96, 128, 1.0, True), (77, 512, 512, 1.0, True),
+                                              (600, 512, 512, 1.0, False)])
 def test_gemm_on_folded_layernorm(M, N, K, eps, relu):
     """pa_gemm_norm_a: Linear(LayerNorm(z)) with the LayerNorm folded into the product, rstd (z (W gamma)^T - mean u) + v (the
     greedy-decode step's form; post-norm layers of torch's TransformerDecoderLayer with the reference's eps = 1.0), against
