@@ -274,14 +274,26 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # PLANK_DIST_BACKEND=gloo is for TESTS (tests/test_cli_gpu.py): RCCL refuses two ranks on one device; with gloo the ranks of a
+    # one-GPU box share cuda:0 and the whole DDP path of this loop (DistributedSampler shards, GradSync, metric sums) still runs.
+    backend = os.environ.get("PLANK_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if seed is not None:
         torch.manual_seed(int(seed)); np.random.seed(int(seed))
     module = trainer_cls(hparams)
     module.logger = _Logger()
+    if world > 1:                                  # one lightning_logs/version_N for the whole job: rank 0's choice
+        box = [module.logger.log_dir]
+        dist.broadcast_object_list(box, src=0)
+        module.logger.log_dir = box[0]
     dev = torch.device("cuda", local)
     module.model.to(dev)
     if ckpt_path and subcommand == "test":

@@ -53,8 +53,8 @@ def _write_infos(root, n=9, seed=11):
     return names
 
 
-def _write_config(tmp_path, max_epochs):
-    names = _write_infos(str(tmp_path / "data" / "infos"))
+def _write_config(tmp_path, max_epochs, n=9):
+    names = _write_infos(str(tmp_path / "data" / "infos"), n=n)
     split = tmp_path / "all.txt"
     split.write_text("\n".join(names))
     with open(os.path.join(REPO, "configs", "train_complete.yaml")) as f:
@@ -136,3 +136,63 @@ def test_cli_fit_resume_test_evaluate(tmp_path, monkeypatch):
     assert abs(f - mod3._logged["test/fmeasure"]) <= 0.2, (f, mod3._logged)
     print(f"    CLI: train/loss {losses} -> {l2}; val/fmeasure {vals}; test/fmeasure {mod3._logged['test/fmeasure']:.3f}; "
           f"evaluate.py f1 {f:.3f}")
+
+
+def test_cli_two_ranks_sharing_the_gpu(tmp_path, monkeypatch):
+    """The reference trains with `strategy: ddp` on 4 devices (configs/train_complete.yaml:18-21).  Two ranks of this trainer's
+    command line - launched as torchrun would, sharing the one GPU of the test box through gloo - run `test` and `fit`:
+    * `test`: DistributedSampler shards the 16 drawings, each rank decodes and scores its 8, the metric sums are exchanged:
+      precision / recall / F1 equal the single-process run on the same checkpoint, all 16 pred_jsons land in ONE version dir;
+    * `fit`: both ranks end every epoch with bit-identical parameters (broadcast at start, exchanged gradients, same Adam step),
+      rank 0 alone writes the checkpoints, the validation metrics agree across ranks."""
+    import socket
+    import subprocess
+    import sys
+    from plankassembly_amd.trainer import Trainer, cli
+    monkeypatch.chdir(tmp_path)
+    config, n_files = _write_config(tmp_path, max_epochs=2, n=16)
+    mod = cli(Trainer, ["fit", "--config", config])
+    last = os.path.join(mod.logger.log_dir, "checkpoints", "last.ckpt")
+    single = cli(Trainer, ["test", "--config", config, "--ckpt_path", last])
+
+    def launch(tag, argv):
+        out = tmp_path / tag
+        out.mkdir()
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, PLANK_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(REPO, "tests", "cli_ddp_worker.py"), str(out)] + argv
+        r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-4000:]
+        recs = []
+        for rank in range(2):
+            with open(out / f"rank{rank}.json") as f:
+                recs.append(json.load(f))
+        return recs
+
+    # ---- test on two ranks == test on one
+    r0, r1 = launch("ddp_test", ["test", "--config", config, "--ckpt_path", last])
+    assert r0["log_dir"] == r1["log_dir"]
+    files = sorted(os.listdir(os.path.join(str(tmp_path), r0["log_dir"], "pred_jsons")))
+    assert len(files) == n_files == 16
+    for key in ("test/precision", "test/recall", "test/fmeasure"):
+        assert abs(r0["logged"][key] - single._logged[key]) < 1e-6, (key, r0["logged"], single._logged)
+        assert r0["logged"][key] == r1["logged"][key]
+
+    # ---- fit on two ranks
+    f0, f1 = launch("ddp_fit", ["fit", "--config", config])
+    assert f0["param_sha"] == f1["param_sha"]                                 # DDP: identical replicas after every step
+    assert f0["global_step"] == f1["global_step"] == 2 * (n_files // 2 // 4)   # 8 drawings per rank, batch 4, drop_last
+    l0 = [v for _, name, v in f0["history"] if name == "train/loss"]
+    assert len(l0) == 2 and all(np.isfinite(l0)) and l0[-1] < l0[0]
+    v0 = [v for _, name, v in f0["history"] if name == "val/fmeasure"]
+    v1 = [v for _, name, v in f1["history"] if name == "val/fmeasure"]
+    assert v0 == v1 and len(v0) == 2
+    ckdir = os.path.join(str(tmp_path), f0["log_dir"], "checkpoints")
+    assert f0["log_dir"] == f1["log_dir"] and os.path.exists(os.path.join(ckdir, "last.ckpt"))
+    ck = torch.load(os.path.join(ckdir, "last.ckpt"), map_location="cpu", weights_only=True)
+    assert ck["global_step"] == f0["global_step"] and ck["epoch"] == 1
