@@ -28,9 +28,13 @@ class GradSync:
         back before Adam (the reference's DDP exchanges f32; opt-in because the sum of bf16-rounded gradients differs in the
         last bits).
 
-        ``reserve_cus``: CUs every persistent GEMM launch leaves free while the process group is larger than one rank
-        (pa_set_reserved_cus), so that RCCL's kernels find somewhere to run next to the backward GEMMs.  None reads
-        PA_RESERVE_CUS; unset = 0 (no 8-GPU node was available to tune it: measure 0 / 8 / 16 / 32 on the target box)."""
+        ``reserve_cus``: CUs every persistent GEMM launch leaves free WHILE COLLECTIVES ARE IN FLIGHT (pa_set_reserved_cus from
+        the first slice that is sent until wait() has seen the last one), when the process group is larger than one rank.  The
+        persistent GEMM grids are one block per CU with the whole register file of their SIMDs: a CU that hosts one of RCCL's
+        long-running blocks cannot take a GEMM block, so a 256-block grid beside a collective runs its last blocks as a second
+        round (up to 2x for that launch); with the reservation the grid fits beside RCCL in one round (at most 12.5 % slower, and
+        only inside the exchange window - the forward pass and the backward before the first slice keep all 256 CUs).  None reads
+        PA_RESERVE_CUS, default 32.  UNTUNED: no multi-GPU node was available; measure 0 / 16 / 32 / 48 on the target box."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         import os
@@ -49,12 +53,20 @@ class GradSync:
         self._pending = None          # (lo, hi) run of contiguous finished-but-unsent slices
         self.launched = []            # [(lo, hi)] of the last backward, for tests / introspection
         self.fired = []               # segment indices in the order the hook saw them (tests)
-        if reserve_cus is None and os.environ.get("PA_RESERVE_CUS"):
-            reserve_cus = int(os.environ["PA_RESERVE_CUS"])
-        if reserve_cus is not None and self.world > 1 and model.flat_params.is_cuda:
-            from . import _lib as L
-            L.check(L.lib().pa_set_reserved_cus(int(reserve_cus)), "pa_set_reserved_cus")
+        if reserve_cus is None:
+            reserve_cus = int(os.environ.get("PA_RESERVE_CUS", "32"))
+        self.reserve_cus = int(reserve_cus) if (self.world > 1 and model.flat_params.is_cuda) else 0
+        self._reserved = False
+        self.reserve_log = []         # ('on' | 'off') transitions, for tests
         model.register_grad_ready_hook(self._on_segment)
+
+    def _reserve(self, on):
+        if self.reserve_cus <= 0 or on == self._reserved:
+            return
+        from . import _lib as L
+        L.check(L.lib().pa_set_reserved_cus(self.reserve_cus if on else 0), "pa_set_reserved_cus")
+        self._reserved = on
+        self.reserve_log.append("on" if on else "off")
 
     # the flat-buffer order is the reverse of the backward order, so finished slices extend DOWNWARDS
     def _on_segment(self, seg, lo, hi):
@@ -96,6 +108,7 @@ class GradSync:
             buf = self._lp[lo:hi]
             self._cast(buf, g[lo:hi])
             self._to_widen.append((g, lo, hi))      # the buffer this slice came from: it may differ by the time of wait()
+        self._reserve(True)                 # from here until wait(): the GEMM grids leave room for the collective's blocks
         self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.launched.append((lo, hi))
 
@@ -113,6 +126,7 @@ class GradSync:
         for w in self._works:
             w.wait()                        # stream-level wait on GPU, blocking on gloo
         self._works = []
+        self._reserve(False)
         widen, self._to_widen = self._to_widen, []
         for g, lo, hi in widen:             # the reduced sums, after the collectives and before Adam
             self._cast(g[lo:hi], self._lp[lo:hi])

@@ -36,6 +36,7 @@ def half(batch, r, world):
 
 def main(rank, world, port, case, dtype, grad_dtype, out_path):
     import large_cases as LC
+    from plankassembly_amd import _lib as L
     from plankassembly_amd.distributed import GradSync, allreduce_metric_sums
     from plankassembly_amd.optim import FusedAdam
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -63,7 +64,8 @@ def main(rank, world, port, case, dtype, grad_dtype, out_path):
         torch.cuda.synchronize()
         sums = allreduce_metric_sums(torch.tensor([1.0 + rank, 2.0, 3.0, 1.0], dtype=torch.float64))
         torch.save({"loss": float(out["loss"]), "grads": g, "p_start": p_start, "params": m.flat_params.detach().cpu().clone(),
-                    "launched": list(sync.launched), "fired": list(sync.fired), "sums": sums}, f"{out_path}.{rank}")
+                    "launched": list(sync.launched), "fired": list(sync.fired), "sums": sums,
+                    "reserve_log": list(sync.reserve_log), "reserved_after": int(L.lib().pa_get_reserved_cus())}, f"{out_path}.{rank}")
     finally:
         dist.destroy_process_group()
 

@@ -133,6 +133,9 @@ def test_two_ranks_on_one_gpu_exchange_the_mean_of_the_real_models_gradients(cas
     else:
         assert float((r0["grads"] - want).norm() / want.norm()) < 2e-2      # each rank's slice rounded to bf16 for the wire
     assert r0["fired"] == list(range(c["ne"] + c["nd"] + 4))
+    # the persistent GEMM grids leave CUs to the collective's blocks exactly while slices are in flight: on at the first slice, off
+    # once wait() has seen the last (world size 2: the default reservation applies), nothing reserved afterwards
+    assert r0["reserve_log"] == ["on", "off"] and r0["reserved_after"] == 0, (r0["reserve_log"], r0["reserved_after"])
     cover = sorted(r0["launched"])
     assert cover[0][0] == 0 and cover[-1][1] == m._numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
     assert torch.equal(r0["params"], r1["params"])                          # ranks stay in lock step
