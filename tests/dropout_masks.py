@@ -56,6 +56,28 @@ def attn_scale(p):
     return float(np.float32(1.0 / (1.0 - thr32 / 4294967296.0)))
 
 
+def _mix32_t(x):
+    """mix32 on int64 torch tensors (values < 2^32): multi-threaded, for the B = 16 x 8 heads x 1024 x 1024 attention masks."""
+    m = 0xFFFFFFFF
+    x = x ^ (x >> 16); x = (x * 0x7FEB352D) & m
+    x = x ^ (x >> 15); x = (x * 0x846CA68B) & m
+    return x ^ (x >> 16)
+
+
+def attn_keep_torch(seed, B, H, Lq, Lk, p):
+    """attn_keep for the dense row numbering (b * H + h) * Lq + q, as a bool torch tensor [B, H, Lq, Lk]."""
+    thr32 = int(float(np.float32(p)) * 4294967296.0)
+    r = torch.arange(B * H * Lq, dtype=torch.int64)
+    a = (_mix32_t((r * 0x9E3779B9 + seed) & 0xFFFFFFFF) & 0xFFFFFF) | 0x800001
+    k = torch.arange(Lk, dtype=torch.int64)
+    c = (_mix32_t((k * 0x85EBCA6B + (seed ^ 0x5BD1E995)) & 0xFFFFFFFF) & 0xFFFFFF) | 0x800001
+    out = torch.empty(B * H * Lq, Lk, dtype=torch.bool)
+    step = max(1, (1 << 24) // Lk)                                   # bound the int64 temporaries to 128 MB
+    for i in range(0, B * H * Lq, step):
+        out[i:i + step] = ((a[i:i + step, None] * c[None, :]) & 0xFFFFFFFF) >= thr32
+    return out.view(B, H, Lq, Lk)
+
+
 class HipDropout:
     """Callable (site, tensor) -> tensor for `oracle.plank_oracle.train_forward(..., drop=...)`: applies the masks the HIP
     training step with step seed ``seed`` uses.  ``input_mask`` (bool [B, S], True = PAD) fixes the packed row numbers of the
@@ -86,9 +108,7 @@ class HipDropout:
         self.sites_seen.append(name)
         if name.endswith("attn"):
             B, H, Lq, Lk = x.shape
-            rows = (np.arange(B)[:, None, None] * H + np.arange(H)[None, :, None]) * Lq + np.arange(Lq)[None, None, :]
-            keep = attn_keep(seed, rows, Lk, self.p)
-            return x * torch.from_numpy(keep).to(x.dtype) * attn_scale(self.p)
+            return x * attn_keep_torch(seed, B, H, Lq, Lk, self.p).to(x.dtype) * attn_scale(self.p)
         B, L, N = x.shape
         rows = self.enc_rows if enc else np.arange(B * L).reshape(B, L)
         keep = linear_keep(seed, rows.reshape(-1), N, self.p).reshape(B, L, N)

@@ -448,6 +448,49 @@ def _b16_case(which):
     return c, batch, int((~batch["input_mask"]).sum())
 
 
+@pytest.mark.parametrize("which", ["below", "above"])
+def test_bf16_b16_step_under_dropout_matches_oracle_given_the_same_decisions(which):
+    """EXACTLY the benchmarked step: bf16, batch 16, S = 1024 packed (one batch either side of the 8 192-row dispatch cliff),
+    dropout 0.2 - against the f32 oracle fed the same dropout decisions (tests/dropout_masks.py), tensor by tensor."""
+    import dropout_masks as DM
+    from oracle import plank_oracle as O
+    c, batch, _ = _b16_case(which)
+    sd = LC.case_state_dict(c)
+    torch.manual_seed(1234)
+    m = hip_model(c, "bf16", sd, dropout=0.2)
+    m._step_seed = 77001
+    seed = DM.next_step_seed(m._step_seed, torch.initial_seed())
+    out, mem, hid, grads = run_hip_train(m, batch)
+    assert m._step_seed == seed
+    drop = DM.HipDropout(seed, 0.2, c["h"], batch["input_mask"].numpy(), packed=m.unpad)
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.train_forward(p, LC.case_oracle_cfg(c), batch, return_all=True, drop=drop)
+    ref["loss"].backward()
+    assert len(set(drop.sites_seen)) == 4 * c["ne"] + 6 * c["nd"]
+    loss_ref = float(ref["loss"].detach())
+    assert abs(loss_ref - float(_b16_oracle(which)[3]["loss"])) > 1e-3          # not the dropout-free function
+    assert abs(out["loss"].item() - loss_ref) < 2e-2 * abs(loss_ref), (out["loss"].item(), loss_ref)
+    valid = ~batch["input_mask"]
+    rel = lambda x, y: float((x - y).double().norm() / (y.double().norm() + 1e-30))
+    assert rel(mem[valid], ref["memory"].detach()[valid]) < 2e-2 and rel(hid, ref["hiddens"].detach()) < 3e-2
+    rgrads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
+    tot = sum(float(v.double().norm()) ** 2 for v in rgrads.values()) ** 0.5
+    worst = ("", 1.0)
+    for k, gr in grads.items():
+        r, a = rgrads[k].double().flatten(), gr.double().flatten()
+        nr = float(r.norm())
+        if nr == 0.0:
+            assert float(a.norm()) == 0.0, k
+            continue
+        cos, rl2 = float(a @ r) / (float(a.norm()) * nr + 1e-300), float((a - r).norm()) / nr
+        big = nr / tot > 1e-3
+        if big and cos < worst[1]:
+            worst = (k, cos)
+        assert cos > (0.99 if big else 0.9) and rl2 < (0.15 if big else 0.5), (k, cos, rl2, nr / tot)
+    print(f"[b16 {which}] bf16 under dropout 0.2: loss {out['loss'].item():.5f} vs {loss_ref:.5f}; worst cosine among the large tensors "
+          f"{worst[1]:.5f} ({worst[0]})")
+
+
 def test_b16_batches_straddle_the_256_tile_cliff():
     assert 7000 < _b16_case("below")[2] <= 8192 < _b16_case("above")[2]
 
