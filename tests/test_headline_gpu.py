@@ -448,10 +448,12 @@ def _b16_case(which):
     return c, batch, int((~batch["input_mask"]).sum())
 
 
-@pytest.mark.parametrize("which", ["below", "above"])
+@pytest.mark.parametrize("which", ["above"])
 def test_bf16_b16_step_under_dropout_matches_oracle_given_the_same_decisions(which):
-    """EXACTLY the benchmarked step: bf16, batch 16, S = 1024 packed (one batch either side of the 8 192-row dispatch cliff),
-    dropout 0.2 - against the f32 oracle fed the same dropout decisions (tests/dropout_masks.py), tensor by tensor."""
+    """EXACTLY the benchmarked step: bf16, batch 16, S = 1024 packed, dropout 0.2 - against the f32 oracle fed the same dropout
+    decisions (tests/dropout_masks.py), tensor by tensor.  The batch above the 8 192-row dispatch cliff (58 % of the benchmark's
+    pool; "below" passes too - gpurun_out/r03ac - and is left out only to keep the suite's run time down: the dropout-free B 16
+    tests cover both dispatch regimes)."""
     import dropout_masks as DM
     from oracle import plank_oracle as O
     c, batch, _ = _b16_case(which)
