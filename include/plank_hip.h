@@ -75,7 +75,7 @@ int pa_gemm(const pa_gemm_args* a, void* stream);
 /* Leave `n` of the 256 CUs free in every persistent GEMM launch from now on (0 <= n <= 192; 0 restores the full grid): room for
  * the RCCL kernels that all-reduce finished gradient slices while the backward continues (the data-parallel exchange the
  * reference gets from Lightning's `strategy: ddp`, configs/train_complete.yaml:18).  plankassembly_amd.distributed.GradSync
- * sets it when the first slice of a backward is sent and clears it once the last has been waited for. */
+ * sets it (PA_RESERVE_CUS, default 0) when the first slice of a backward is sent and clears it once the last has been waited for. */
 int pa_set_reserved_cus(int32_t n);
 int pa_get_reserved_cus(void);
 /* Slices pa_gemm really uses for a requested `splitk` (= number of slabs it writes; <= splitk). */

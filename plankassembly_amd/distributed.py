@@ -31,10 +31,11 @@ class GradSync:
         ``reserve_cus``: CUs every persistent GEMM launch leaves free WHILE COLLECTIVES ARE IN FLIGHT (pa_set_reserved_cus from
         the first slice that is sent until wait() has seen the last one), when the process group is larger than one rank.  The
         persistent GEMM grids are one block per CU with the whole register file of their SIMDs: a CU that hosts one of RCCL's
-        long-running blocks cannot take a GEMM block, so a 256-block grid beside a collective runs its last blocks as a second
-        round (up to 2x for that launch); with the reservation the grid fits beside RCCL in one round (at most 12.5 % slower, and
-        only inside the exchange window - the forward pass and the backward before the first slice keep all 256 CUs).  None reads
-        PA_RESERVE_CUS, default 32.  UNTUNED: no multi-GPU node was available; measure 0 / 16 / 32 / 48 on the target box."""
+        long-running blocks cannot take a GEMM block.  Whether leaving room helps depends on the launch: a multi-unit grid (the
+        grouped weight gradients, the two-blocks-per-CU kernel) re-balances over the CUs it is given, but most of the model's
+        Linears are ONE round of ~250 tiles, and a grid of 224 blocks turns those into two rounds whether or not a collective
+        happens to be resident.  None reads PA_RESERVE_CUS; default 0 (off).  UNTUNED: no multi-GPU node was available; measure
+        0 / 16 / 32 on the target box."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         import os
@@ -54,7 +55,7 @@ class GradSync:
         self.launched = []            # [(lo, hi)] of the last backward, for tests / introspection
         self.fired = []               # segment indices in the order the hook saw them (tests)
         if reserve_cus is None:
-            reserve_cus = int(os.environ.get("PA_RESERVE_CUS", "32"))
+            reserve_cus = int(os.environ.get("PA_RESERVE_CUS", "0"))
         self.reserve_cus = int(reserve_cus) if (self.world > 1 and model.flat_params.is_cuda) else 0
         self._reserved = False
         self.reserve_log = []         # ('on' | 'off') transitions, for tests

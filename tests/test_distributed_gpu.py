@@ -92,7 +92,7 @@ def _two_ranks(case, dtype, grad_dtype, tmp_path):
         port = sk.getsockname()[1]
     out = str(tmp_path / "rank")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ddp_worker.py")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PA_RESERVE_CUS="16")
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), case, dtype, grad_dtype, out], env=env)
              for r in range(2)]
     for p in procs:
@@ -133,8 +133,8 @@ def test_two_ranks_on_one_gpu_exchange_the_mean_of_the_real_models_gradients(cas
     else:
         assert float((r0["grads"] - want).norm() / want.norm()) < 2e-2      # each rank's slice rounded to bf16 for the wire
     assert r0["fired"] == list(range(c["ne"] + c["nd"] + 4))
-    # the persistent GEMM grids leave CUs to the collective's blocks exactly while slices are in flight: on at the first slice, off
-    # once wait() has seen the last (world size 2: the default reservation applies), nothing reserved afterwards
+    # PA_RESERVE_CUS=16 (set by this test): the persistent GEMM grids leave CUs to the collective's blocks exactly while slices are in
+    # flight - on at the first slice, off once wait() has seen the last - and nothing stays reserved afterwards
     assert r0["reserve_log"] == ["on", "off"] and r0["reserved_after"] == 0, (r0["reserve_log"], r0["reserved_after"])
     cover = sorted(r0["launched"])
     assert cover[0][0] == 0 and cover[-1][1] == m._numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
