@@ -354,7 +354,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(T* y, const T* z, co
     }
 }
 
-constexpr int LNB_ROWS = 8;    // rows per block in backward: one pair of rows per wave, ~1000 blocks at 7 940 rows (4 per CU in flight)
+#ifndef PA_LNB_ROWS
+#define PA_LNB_ROWS 8
+#endif
+// (A/B builds, round 3, train step: 4 rows 5.17 ms, 8 rows 5.10, 16 rows 5.32 vs 5.26 on a slower box, 32 rows 5.43 vs 5.26)
+constexpr int LNB_ROWS = PA_LNB_ROWS;    // rows per block in backward: one pair of rows per wave, ~1000 blocks at 7 940 rows (4 per CU in flight)
 
 // dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  per-block partial column sums of dy * xhat (dgamma),
 // dy (dbeta) and the (dropped) dz (dzsum) go to partial[block][3][d]; partial_finish_kernel adds them to the outputs.
