@@ -221,7 +221,7 @@ def pmc_traffic(kernel_key):
     """HBM bytes per launch of one kernel from the committed rocprofv3 PMC passes (profiles/r0N_pmc_traffic.json,
     made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 return json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch"]
@@ -403,8 +403,8 @@ def cpu_baseline(cfgd, sample_b=2, budget_s=20.0, fit_style=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS))
     ap.add_argument("--no-decode", action="store_true")
@@ -471,32 +471,52 @@ def main():
         for i in range(n):
             yield pool[i % len(pool)]
 
-    def timed(pool, fresh):
-        """args.warmup untimed + args.steps timed steps.  fresh: every step gets a batch that has not been prepared -
-        pa_pack_rows / pa_group_rows (and the host -> device copies when the pool lives on the host) run inside the timed
-        region, one step ahead on a side stream (DevicePrefetcher), as in trainer.run()."""
-        total = args.warmup + args.steps
-        it = DevicePrefetcher(model, cycle(pool, total)) if fresh else cycle(pool, total)
+    rank_ms = {}
+
+    def timed(pool, fresh, steps=None, warmup=None, tag=None, mdl=None, stepper=None):
+        """`warmup` untimed + `steps` timed steps (default: args.warmup / args.steps).  fresh: every step gets a batch that
+        has not been prepared - pa_pack_rows / pa_group_rows (and the host -> device copies when the pool lives on the host)
+        run inside the timed region, one step ahead on a side stream (DevicePrefetcher), as in trainer.run().  Returns the
+        MAX over ranks of the bracketed wall time; `tag` additionally records every rank's own time (rank_ms)."""
+        steps = args.steps if steps is None else steps
+        warmup = args.warmup if warmup is None else warmup
+        mdl = model if mdl is None else mdl
+        stepper = step_on if stepper is None else stepper
+        total = warmup + steps
+        it = DevicePrefetcher(mdl, cycle(pool, total)) if fresh else cycle(pool, total)
         out = None
-        for _ in range(args.warmup):
-            out = step_on(next(it))
+        for _ in range(warmup):
+            out = stepper(next(it))
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step_on(next(it))
+        for _ in range(steps):
+            out = stepper(next(it))
         fence()
         dt = time.perf_counter() - t0
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         if dist.is_initialized() and world > 1:
+            if tag:
+                every = [torch.zeros_like(tt) for _ in range(world)]
+                dist.all_gather(every, tt)
+                rank_ms[tag] = [float(x.item()) / steps * 1e3 for x in every]
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elif tag:
+            rank_ms[tag] = [dt / steps * 1e3]
         return float(tt.item()), out
 
     log(f"model + batches ready (rank {rank}/{world}, config {args.config})")
-    dt, out = timed(raw, fresh=True)                       # the headline figure: a fresh batch every step
+    dt, out = timed(raw, fresh=True, tag="train")          # the headline figure: a fresh batch every step
     loss = float(out["loss"].detach())
     assert math.isfinite(loss), "training diverged"
     samples_s = args.steps * B * world / dt
     log(f"train: {samples_s:.1f} samples/s, {dt / args.steps * 1e3:.2f} ms/step, loss {loss:.4f} (fresh batch every step)")
+    # A longer region of the same loop (>= 200 steps, ~1 s): `value` is bound to exactly --steps steps by the driver's contract
+    # (20 steps = 0.1 s there), so the run-to-run noise of `value` is read off this figure.
+    long_steps = max(200, args.steps)
+    dt_long, _ = timed(raw, fresh=True, steps=long_steps, warmup=0)
+    steady = dict(value=long_steps * B * world / dt_long, unit="samples/s", steps=long_steps, ms_per_step=dt_long / long_steps * 1e3,
+                  note="the same fresh-batch loop over a longer timed region (barrier + synchronize on both sides, max over ranks)")
+    log(f"       {steady['value']:.1f} samples/s, {steady['ms_per_step']:.3f} ms/step over {long_steps} steps")
     dt_res, _ = timed(prepared, fresh=False)               # round-1 figure: four prepared batches cycled
     resident = dict(value=args.steps * B * world / dt_res, unit="samples/s", ms_per_step=dt_res / args.steps * 1e3,
                     note="the same batches prepared before the timed region and cycled (what round 1 reported)")
@@ -510,6 +530,39 @@ def main():
 
     def train_step(i):
         return step_on(prepared[i % len(prepared)])
+
+    # ------------------------------------------------------------------ the same step on the parity path (exact-f32 MFMA)
+    # north_star's tolerance (1e-4 against the f32 reference) is met by the f32 path only; bf16 is the throughput path
+    # (BASELINE configs[1] names bf16 for the 1-GPU line).  Both figures go into the line; `value` stays the bf16 one.
+    train_f32 = None
+    if args.dtype == "bf16":
+        m32 = build("f32", cfgd["max_in"], cfgd["max_out"], 0.2, cfgd).train()
+        opt32 = FusedAdam(m32, lr=1e-4, grad_scale=1.0 / world)
+        sync32 = None
+        if dist.is_initialized():
+            sync32 = GradSync(m32)
+            sync32.broadcast_parameters(0)
+
+        def step32(batch):
+            opt32.zero_grad()
+            o = m32(batch)
+            o["loss"].backward()
+            opt32.step()
+            return o
+
+        n32 = max(5, min(args.steps, 10))
+        dt32, o32 = timed(raw, fresh=True, steps=n32, warmup=2, tag="train_f32", mdl=m32, stepper=step32)
+        assert math.isfinite(float(o32["loss"].detach())), "f32 training diverged"
+        train_f32 = dict(value=n32 * B * world / dt32, unit="samples/s", steps=n32, warmup=2, ms_per_step=dt32 / n32 * 1e3,
+                         dtype="f32", final_loss=float(o32["loss"].detach()),
+                         note="exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations: the path the 1e-4 parity tests run")
+        log(f"train f32 (parity path): {train_f32['value']:.1f} samples/s, {train_f32['ms_per_step']:.2f} ms/step")
+        if sync32 is not None:
+            fence()
+            sync32.detach()
+        m32.register_grad_ready_hook(None)
+        del m32, opt32, sync32, o32, step32
+        torch.cuda.empty_cache()
 
     # Everything below steps the model on rank 0 ONLY (kernel census, padded-encoder variant): the gradient exchange must be
     # off by then, or rank 0's backward would enqueue collectives the other ranks never join (found by
@@ -631,9 +684,17 @@ def main():
     if dist.is_initialized():
         dist.barrier()
     if rank == 0:
+        if train_f32:
+            parity = {"dtype": "f32", "value": train_f32["value"], "unit": "samples/s", "ms_per_step": train_f32["ms_per_step"]}
+        elif args.dtype == "f32":
+            parity = {"dtype": "f32", "value": samples_s, "unit": "samples/s", "ms_per_step": dt / args.steps * 1e3}
+        else:
+            parity = None
+        prec = (" [value: bf16 MFMA, f32 accumulate / master weights; train.f32: the same step in exact f32 = the parity path]"
+                if args.dtype == "bf16" else " [exact-f32 MFMA: the parity path]")
         line = {
-            "metric": "train samples/sec (fwd+bwd+all-reduce+Adam), d_model=512 seq=1024" if headline else
-                      f"train samples/sec (fwd+bwd+all-reduce+Adam), config {args.config}",
+            "metric": ("train samples/sec (fwd+bwd+all-reduce+Adam), d_model=512 seq=1024" if headline else
+                       f"train samples/sec (fwd+bwd+all-reduce+Adam), config {args.config}") + prec,
             "value": samples_s, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic tokenised-drawing batches (SURVEY 8d), random-init weights; collated "
@@ -642,6 +703,14 @@ def main():
             "config": {"workload": f"{cfgd['name']}, S={S_in} (MAX_INPUT_LENGTH {cfgd['max_in']}), T={T_out}, batch {B}/GPU",
                        "global_batch": B * world, "seq_len": S_in, "parallelism": f"dp{world}"},
             "final_loss": loss,
+            "train": {args.dtype: dict(value=samples_s, unit="samples/s", ms_per_step=dt / args.steps * 1e3, steps=args.steps),
+                      **({"f32": train_f32} if train_f32 else {}),
+                      "parity_meeting": parity},
+            "steady_state": steady,
+            "rccl_ranks": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                           "backend": (dist.get_backend() if dist.is_initialized() else None),
+                           "process_group": bool(dist.is_initialized()),
+                           "ms_per_step_by_rank": {k: {"min": min(v), "max": max(v), "ranks": len(v)} for k, v in rank_ms.items()}},
             "resident_prepared": resident, "fresh_host": fresh_host,
             "encoder_rows": {"padded": B * S_in, "valid_avg": valid_rows,
                              "note": "padded encoder rows are packed away before the first layer (results identical: "
@@ -677,9 +746,11 @@ def main():
                                 "algorithmic_flops_per_launch": c["flops"] / c["launches"],
                                 "avg_launch_us": c["seconds"] / c["launches"] * 1e6}
             tr = in_step_trace(key)
-            if tr:                                  # the same kernel inside the profiled step (rocprofv3, committed under profiles/)
+            if tr:      # the same kernel inside a PROFILED step: an ARCHIVED rocprofv3 summary committed under profiles/, not this run
                 tf = c["flops"] / c["launches"] / (tr["avg_launch_us"] * 1e-6) / 1e12
-                line["roofline"]["in_step_rocprof"] = dict(tr, achieved=tf, frac=tf / PEAK_BF16_TFLOPS)
+                line["roofline"]["in_step_rocprof"] = dict(tr, achieved=tf, frac=tf / PEAK_BF16_TFLOPS, archived=True,
+                                                           note="parsed from the committed profile named in `file` (made by an earlier "
+                                                                "run of this command); every other figure of this line is measured live")
             line["kernel_census"] = {k: {"launches": round(v["launches"], 2), "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
                                          "ms_per_step": round(v["seconds"] * 1e3, 3),
                                          "tflops": round(v["flops"] / v["seconds"] / 1e12, 1),

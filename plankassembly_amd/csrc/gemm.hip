@@ -2202,7 +2202,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
         const int m = (int)(bm % p.M), b = (int)(bm / p.M);
         float v = 0.f;
         for (int s = 0; s < p.splitk; ++s) v += ws[(((size_t)b * p.splitk + s) * p.M + m) * p.N + n];
-        v = v * p.alpha + (p.bias ? p.bias[n] : 0.f);
+        v = v * p.alpha + (p.bias ? p.bias[(size_t)b * p.sBias + n] : 0.f);      // (per-batch bias stride, as in the tile epilogues)
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.aux) {
             float g = ld1(reinterpret_cast<const T*>(p.aux) + (size_t)b * p.sAux + (size_t)m * p.ldaux + n);

@@ -72,7 +72,11 @@ class GradSync:
     # the flat-buffer order is the reverse of the backward order, so finished slices extend DOWNWARDS
     def _on_segment(self, seg, lo, hi):
         if seg == 0:
-            self.wait()                     # (a backward that was abandoned half way leaves nothing behind)
+            # A backward that was abandoned half way leaves nothing behind: its collectives are drained, but its bf16 staging
+            # sums are DROPPED, not widened - this backward has already written segment 0's fresh gradient into the buffer
+            # those stale sums would land in.
+            self._to_widen = []
+            self.wait()
             self._works, self.launched, self._pending, self.fired = [], [], None, []
         self.fired.append(seg)
         if self._pending is None:

@@ -47,14 +47,14 @@ def _eval_loop(batches_seen=0, runs=0):
             "epoch_loop.state_dict": {}, "epoch_loop.batch_progress": _batch_progress(batches_seen, 0, False)}
 
 
-def loops_state(epochs_done, global_step, steps_this_epoch, val_batches_seen=0, val_runs=0):
+def loops_state(epochs_done, global_step, steps_this_epoch, val_batches_seen=0, val_runs=0, epoch_finished=True):
     """`checkpoint["loops"]` at the end of training epoch number `epochs_done` (1-based count of finished epochs), after
     `global_step` optimizer steps in total of which `steps_this_epoch` fell into the last epoch."""
     val = _eval_loop(val_batches_seen, val_runs)
     fit = {
         "state_dict": {},
         "epoch_loop.state_dict": {"_batches_that_stepped": int(global_step)},
-        "epoch_loop.batch_progress": _batch_progress(global_step, steps_this_epoch, True),
+        "epoch_loop.batch_progress": _batch_progress(global_step, steps_this_epoch, epoch_finished),
         "epoch_loop.scheduler_progress": _progress(READY_COMPLETED, 0, 0),
         "epoch_loop.batch_loop.state_dict": {},
         "epoch_loop.batch_loop.optimizer_loop.state_dict": {},
@@ -88,7 +88,11 @@ def epochs_done_of(ck) -> int:
     the epoch the file was written in) + 1, for Lightning's files and ours alike; a dict without it is read through the
     fit loop's `started` counter."""
     if "epoch" in ck:
-        return int(ck["epoch"]) + 1
+        try:            # a file written when max_steps cut an epoch short (is_last_batch False): that epoch runs again
+            cut = ck["loops"]["fit_loop"]["epoch_loop.batch_progress"]["is_last_batch"] is False
+        except (KeyError, TypeError):
+            cut = False
+        return int(ck["epoch"]) + (0 if cut else 1)
     try:
         return int(ck["loops"]["fit_loop"]["epoch_progress"]["current"]["started"])
     except (KeyError, TypeError):

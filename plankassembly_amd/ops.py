@@ -48,6 +48,7 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, residual=None, aux=
     g.sC = O3.stride(0) if batch > 1 else 0
     g.sR = residual.stride(0) if (residual is not None and residual.dim() == 3 and batch > 1) else 0
     g.sAux = aux.stride(0) if (aux is not None and aux.dim() == 3 and batch > 1) else 0
+    g.sBias = bias.stride(0) if (bias is not None and bias.dim() == 2 and batch > 1) else 0     # [batch, N]: one bias per member
     g.batch = batch
     g.a_kcontig, g.b_kcontig = int(a_kcontig), int(b_kcontig)
     g.in_dtype, g.out_dtype = L.dt(a), L.dt(out)

@@ -176,7 +176,8 @@ class Trainer(torch.nn.Module):
         return {"optimizer": FusedAdam(self.model, lr=self.cfg.LR, grad_scale=1.0 / world)}
 
     # ------------------------------------------------------------------ checkpoints (Lightning-shaped)
-    def checkpoint(self, epoch, optimizer=None, best_score=None, steps_this_epoch=0, best_path="", last_path=""):
+    def checkpoint(self, epoch, optimizer=None, best_score=None, steps_this_epoch=0, best_path="", last_path="",
+                   epoch_finished=True):
         """A pytorch_lightning-1.7-shaped checkpoint dict, the layout ModelCheckpoint writes for the reference
         (configs/train_complete.yaml:6-14): `state_dict` with the `model.` prefix, `optimizer_states` in
         torch.optim.Adam's layout, `hyper_parameters` (save_hyperparameters(hparams), trainer_complete.py:24), epoch /
@@ -187,7 +188,7 @@ class Trainer(torch.nn.Module):
         from . import lightning_state as LS
         ck = {"epoch": epoch, "global_step": self.global_step, "pytorch-lightning_version": "1.7.7",
               "state_dict": {"model." + k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
-              "loops": LS.loops_state(epoch + 1, self.global_step, steps_this_epoch),
+              "loops": LS.loops_state(epoch + 1, self.global_step, steps_this_epoch, epoch_finished=epoch_finished),
               "callbacks": {LS.checkpoint_callback_key(): LS.checkpoint_callback_state(best_score, best_path, last_path,
                                                                                        os.path.dirname(last_path))},
               "optimizer_states": [], "lr_schedulers": [],
@@ -228,6 +229,8 @@ class Trainer(torch.nn.Module):
             for key, state in (ck.get("callbacks") or {}).items():
                 if str(key).startswith("ModelCheckpoint") and isinstance(state, dict) and state.get("best_model_score") is not None:
                     self.resume_best = float(state["best_model_score"])
+                    # ModelCheckpoint restores best_model_path too: the file a better epoch must replace (save_top_k: 1)
+                    self.resume_best_path = str(state.get("best_model_path") or "")
         return ck
 
 
@@ -314,6 +317,9 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
         module.load_checkpoint(ckpt_path, optimizer=opt)
         start_epoch = getattr(module, "resume_epoch", 0)
         best = getattr(module, "resume_best", -1.0)
+        best_file = getattr(module, "resume_best_path", "")
+        if best_file and not os.path.exists(best_file):
+            best_file = ""
     sync = None
     if world > 1:
         from .distributed import GradSync
@@ -329,6 +335,7 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
             loader.sampler.set_epoch(epoch)
         t0, n, steps_here = time.perf_counter(), 0, 0
         from .data import DevicePrefetcher
+        n_batches = len(loader) if hasattr(loader, "__len__") else -1
         for i, batch in enumerate(DevicePrefetcher(module.model, loader)):     # batch i + 1 is prepared while step i runs
             opt.zero_grad()
             loss = module.training_step(batch, i)
@@ -345,12 +352,14 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
         if rank == 0:
             print(f"epoch {epoch}: train/loss {float(l):.4f} train/accuracy {float(a):.4f} "
                   f"{n * world / (time.perf_counter() - t0):.1f} samples/s")
+        finished = not (0 <= steps_here < n_batches)       # False: max_steps cut the epoch short - a resume runs it again
         if (epoch + 1) % every == 0:
             ckdir = os.path.join(module.logger.log_dir, "checkpoints")
             last = os.path.join(ckdir, "last.ckpt")
             if rank == 0:                                              # save_last: before the metric exchange, so a failure
                 os.makedirs(ckdir, exist_ok=True)                      # in validation cannot lose the epoch's weights
-                torch.save(module.checkpoint(epoch, opt, best if best >= 0 else None, steps_here, best_file, last), last)
+                torch.save(module.checkpoint(epoch, opt, best if best >= 0 else None, steps_here, best_file, last,
+                                             epoch_finished=finished), last)
             module.model.eval()
             with torch.no_grad():
                 for i, batch in enumerate(module.val_dataloader()):
@@ -364,7 +373,7 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
                     stale, best_file = best_file, os.path.join(ckdir, (
                         f"checkpoint_{epoch:03d}-precision={module._logged['val/precision']:.3f}-"
                         f"recall={module._logged['val/recall']:.3f}-f1={f1:.3f}.ckpt"))
-                ck = module.checkpoint(epoch, opt, best, steps_here, best_file, last)
+                ck = module.checkpoint(epoch, opt, best, steps_here, best_file, last, epoch_finished=finished)
                 torch.save(ck, last)
                 if improved:
                     torch.save(ck, best_file)

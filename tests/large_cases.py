@@ -21,6 +21,9 @@ BIG = dict(d=512, h=8, ff=1024, ne=6, nd=6, gains=GAINS)
 CASES = {
     "headline": dict(BIG, max_in=1025, max_out=128, B=2, wseed=58, bseed=5, lines=(8, 255), with_type=True,
                      decode_b=4, decode_seed=6),
+    # the reference's shipped default, configs/train_complete.yaml:41-42 (MAX_INPUT_LENGTH 1200 -> S = 1199, 300 rows of
+    # input_pos; MAX_OUTPUT_LENGTH 128) = BASELINE configs[1] at model level
+    "complete": dict(BIG, max_in=1200, max_out=128, B=2, wseed=31, bseed=41, lines=(8, 299), with_type=True),
     "visible": dict(BIG, max_in=1000, max_out=128, B=2, wseed=12, bseed=7, lines=(8, 249), with_type=True),
     "sideface": dict(BIG, max_in=300, max_out=128, B=16, wseed=13, bseed=9, lines=(0, 74), with_type=False, empty_rows=(3, 11)),
     # BASELINE configs[4] / SURVEY 8d "T = 1024 variant": MAX_OUTPUT_LENGTH 1024.  Train step with T = 1024 (171 rows of
@@ -35,6 +38,11 @@ CASES = {
                   gains=dict(GAINS, **{"pointer_head.weight": 120.0, "vocab_head.weight": 4.0})),
     "live": dict(d=64, h=4, ff=128, ne=2, nd=2, gains={}, max_in=65, max_out=36, B=4, wseed=3, bseed=2022,
                  lines=(3, 15), planks=(2, 5), with_type=True, all_grads=True),
+    # NORMALIZE_BEFORE: False (reference models.py:60-62: the flag lands in torch's layer_norm_eps slot -> per-layer LayerNorm
+    # eps = 0.0, and no encoder.norm is built; layers stay post-norm).  No shipped config uses it; it is part of build_model's
+    # surface.  Larger LayerNorm inputs than `live` so that eps = 0 vs 1 is far outside the tolerance.
+    "eps0": dict(d=64, h=4, ff=128, ne=2, nd=2, gains={}, max_in=65, max_out=36, B=4, wseed=5, bseed=2023,
+                 lines=(3, 15), planks=(2, 5), with_type=True, all_grads=True, normalize_before=False),
 }
 
 
@@ -79,8 +87,8 @@ def case_shapes(c):
     tests/test_model_surface.py pins to the reference's key names, shapes and order)."""
     import types
     from plankassembly_amd.models import PlankModel
-    m = PlankModel(c["d"], c["h"], c["ff"], 0.0, "relu", True, c["ne"], c["nd"], 3, 2, 4, 6, c["max_in"], c["max_out"],
-                   514, types.SimpleNamespace(END=512, PAD=513))
+    m = PlankModel(c["d"], c["h"], c["ff"], 0.0, "relu", c.get("normalize_before", True), c["ne"], c["nd"], 3, 2, 4, 6,
+                   c["max_in"], c["max_out"], 514, types.SimpleNamespace(END=512, PAD=513))
     return [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
 
 
@@ -100,7 +108,8 @@ def case_state_dict(c):
 def case_oracle_cfg(c):
     from oracle import plank_oracle as O
     return O.OracleCfg(d_model=c["d"], n_head=c["h"], d_ff=c["ff"], n_enc=c["ne"], n_dec=c["nd"],
-                       max_input_length=c["max_in"], max_output_length=c["max_out"])
+                       max_input_length=c["max_in"], max_output_length=c["max_out"],
+                       normalize_before=c.get("normalize_before", True))
 
 
 def load_large(name):

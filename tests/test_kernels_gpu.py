@@ -162,6 +162,20 @@ def test_gemm_batched_pointer_shapes(dtype):
     assert rel_err(out, dptr.float().transpose(1, 2) @ feat.float() / d) < tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("splitk", [1, 4])
+def test_gemm_batched_per_member_bias(dtype, splitk):
+    """pa_gemm_args.sBias: one bias row per batch member (the fused cross-attention K|V projection of all decoder layers),
+    in the tile epilogues AND in the split-K reduce pass (the reduce pass used batch 0's bias for every member)."""
+    Bn, M, N, K = 3, 70, 96, 256
+    a, w = rnd(Bn, M, K, dtype=dtype, seed=21), rnd(Bn, N, K, dtype=dtype, seed=22)
+    bias = rnd(Bn, N, seed=23)
+    ref = torch.einsum("bmk,bnk->bmn", a.float(), w.float()) + bias[:, None, :]
+    out = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), out_dtype=torch.float32, splitk=splitk)
+    assert rel_err(out, ref) < tol(dtype)
+    assert rel_err(out[2], ref[2]) < tol(dtype) and rel_err(out[1], ref[1]) < tol(dtype)
+
+
 def test_gemm_dropout_statistics():
     M, N, K = 512, 512, 64
     a, b = rnd(M, K, seed=11).to(DEV), rnd(N, K, seed=12).to(DEV)

@@ -19,7 +19,35 @@ def _run_train(c):
     return sd, batch, out, grads
 
 
-@pytest.mark.parametrize("name", ["headline", "visible", "sideface", "live", "t1024"])
+@pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "eps0", "t1024"])
+def test_oracle_float64_matches_the_reference_module_in_float64(name):
+    """The GPU gate compares the f32 HIP path with the oracle evaluated in float64 (tests/test_headline_gpu.py oracle_f64).
+    That evaluation is pinned here against the REAL reference module run in float64 (fixture entries g64::*): in double
+    precision the two computations agree to ~1e-12, i.e. the oracle is the reference's function, not merely close to it in f32."""
+    c = LC.CASES[name]
+    g = LC.load_large(name)
+    torch.set_num_threads(8)
+    sd = LC.case_state_dict(c)
+    batch = LC.case_batch(c)
+    p = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    torch.set_default_dtype(torch.float64)
+    try:
+        out = O.train_forward(p, LC.case_oracle_cfg(c), batch)
+        out["loss"].backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert abs(float(out["loss"].detach()) - float(g["g64::loss"])) <= 1e-10 * max(1.0, abs(float(g["g64::loss"])))
+    for k, v in p.items():
+        gr = v.grad if v.grad is not None else torch.zeros_like(v)
+        g2 = gr.reshape(gr.shape[0], -1) if gr.dim() > 1 else gr.reshape(1, -1)
+        scale = float(g["g64::gmax::" + k])
+        err = float(np.abs(g2[:LC.SLICE[0], :LC.SLICE[1]].numpy() - g["g64::gslice::" + k]).max())
+        assert err <= 1e-12 + 1e-8 * scale, (k, err, scale)
+        n_ref = float(g["g64::gnorm::" + k])
+        assert abs(float(gr.norm()) - n_ref) <= 1e-12 + 1e-8 * n_ref, (k, float(gr.norm()), n_ref)
+
+
+@pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "eps0", "t1024"])
 def test_oracle_train_matches_reference_at_large_shapes(name):
     c = LC.CASES[name]
     g = LC.load_large(name)
