@@ -411,6 +411,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--long-steps", type=int, default=200, help="length of the extra steady-state region (noise estimate)")
     args = ap.parse_args()
     cfgd = CONFIGS[args.config]
     headline = args.config == "headline"
@@ -510,9 +511,9 @@ def main():
     assert math.isfinite(loss), "training diverged"
     samples_s = args.steps * B * world / dt
     log(f"train: {samples_s:.1f} samples/s, {dt / args.steps * 1e3:.2f} ms/step, loss {loss:.4f} (fresh batch every step)")
-    # A longer region of the same loop (>= 200 steps, ~1 s): `value` is bound to exactly --steps steps by the driver's contract
+    # A longer region of the same loop (--long-steps, default 200 steps ~ 1 s): `value` is bound to exactly --steps steps by the driver's contract
     # (20 steps = 0.1 s there), so the run-to-run noise of `value` is read off this figure.
-    long_steps = max(200, args.steps)
+    long_steps = max(args.long_steps, args.steps)
     dt_long, _ = timed(raw, fresh=True, steps=long_steps, warmup=0)
     steady = dict(value=long_steps * B * world / dt_long, unit="samples/s", steps=long_steps, ms_per_step=dt_long / long_steps * 1e3,
                   note="the same fresh-batch loop over a longer timed region (barrier + synchronize on both sides, max over ranks)")

@@ -404,6 +404,12 @@ typedef struct {
 #define PA_T_HIDDENS 1
 #define PA_T_VOCAB_LOGITS 2
 #define PA_T_PTR_LOGITS 3
+/* FFN hidden activation relu(linear1(x)) (after its dropout, when training with dropout) of encoder layer l / decoder layer l:
+ * [encoder rows processed (packed: valid rows)][d_ff] resp. [B*T][d_ff], compute dtype.  Its sign pattern (> 0) is the ReLU
+ * branch the backward pass differentiates (torch transformer.py _ff_block, reference models.py:60-61,66-67 activation=relu);
+ * the parity tests evaluate the float64 oracle on exactly these branches. */
+#define PA_T_ENC_FFN(l) (16 + (l))
+#define PA_T_DEC_FFN(l) (80 + (l))
 
 int pa_model_create(const pa_model_cfg* cfg, pa_model** out);
 void pa_model_destroy(pa_model* m);

@@ -169,40 +169,48 @@ def embed_output(p, cfg: OracleCfg, output):
 
 
 # ----------------------------------------------------------------------------- layers
-def encoder_layer(x, p, pre, cfg, add_mask, drop=None):
+def _relu(relu, key, x):
+    """activation=relu of torch's _ff_block.  ``relu`` (optional, tests only): callable (site key, pre-activation) -> activation,
+    so that a test can evaluate the network on GIVEN ReLU branches (tests/test_headline_gpu.py ForcedBranches: the float64
+    oracle on the branches the f32 device run took - a pre-activation within f32 rounding of zero is a coin toss between
+    precisions, and one flipped unit moves every upstream gradient)."""
+    return torch.relu(x) if relu is None else relu(key, x)
+
+
+def encoder_layer(x, p, pre, cfg, add_mask, drop=None, relu=None):
     """torch TransformerEncoderLayer.forward, norm_first=False branch (_sa_block: dropout1(self_attn(x));
     _ff_block: dropout2(linear2(dropout(activation(linear1(x))))))."""
     x = layer_norm(x + _drop(drop, pre + "dropout1", mha(x, x, p, pre + "self_attn.", cfg.n_head, add_mask, drop)),
                    p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.eps_layer)
-    h = _drop(drop, pre + "dropout", torch.relu(linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"])))
+    h = _drop(drop, pre + "dropout", _relu(relu, pre + "linear1", linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"])))
     f = _drop(drop, pre + "dropout2", linear(h, p[pre + "linear2.weight"], p[pre + "linear2.bias"]))
     return layer_norm(x + f, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.eps_layer)
 
 
-def encode(p, cfg: OracleCfg, batch, drop=None):
+def encode(p, cfg: OracleCfg, batch, drop=None, relu=None):
     """reference models.py:206 / 279."""
     x = embed_input(p, batch)
     add_mask = key_padding_additive(batch["input_mask"])
     for i in range(cfg.n_enc):
-        x = encoder_layer(x, p, f"encoder.layers.{i}.", cfg, add_mask, drop)
+        x = encoder_layer(x, p, f"encoder.layers.{i}.", cfg, add_mask, drop, relu)
     if cfg.has_enc_norm:
         x = layer_norm(x, p["encoder.norm.weight"], p["encoder.norm.bias"], 1e-5)
     return x
 
 
-def decoder_layer(x, memory, p, pre, cfg, self_mask, mem_mask, drop=None):
+def decoder_layer(x, memory, p, pre, cfg, self_mask, mem_mask, drop=None, relu=None):
     """torch TransformerDecoderLayer.forward, norm_first=False branch (dropout1 / dropout2 / dropout3 on the three sublayer
     outputs, dropout on the feed-forward hidden activation)."""
     x = layer_norm(x + _drop(drop, pre + "dropout1", mha(x, x, p, pre + "self_attn.", cfg.n_head, self_mask, drop)),
                    p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.eps_layer)
     x = layer_norm(x + _drop(drop, pre + "dropout2", mha(x, memory, p, pre + "multihead_attn.", cfg.n_head, mem_mask, drop)),
                    p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.eps_layer)
-    h = _drop(drop, pre + "dropout", torch.relu(linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"])))
+    h = _drop(drop, pre + "dropout", _relu(relu, pre + "linear1", linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"])))
     f = _drop(drop, pre + "dropout3", linear(h, p[pre + "linear2.weight"], p[pre + "linear2.bias"]))
     return layer_norm(x + f, p[pre + "norm3.weight"], p[pre + "norm3.bias"], cfg.eps_layer)
 
 
-def decode(p, cfg: OracleCfg, tgt, memory, input_mask, tgt_pad_mask=None, drop=None):
+def decode(p, cfg: OracleCfg, tgt, memory, input_mask, tgt_pad_mask=None, drop=None, relu=None):
     """reference models.py:212-214 (train) / 293-294 (eval: tgt_pad_mask None)."""
     sz = tgt.shape[1]
     self_mask = causal_additive(sz)[None, None]
@@ -211,7 +219,7 @@ def decode(p, cfg: OracleCfg, tgt, memory, input_mask, tgt_pad_mask=None, drop=N
     mem_mask = key_padding_additive(input_mask)
     x = tgt
     for i in range(cfg.n_dec):
-        x = decoder_layer(x, memory, p, f"decoder.layers.{i}.", cfg, self_mask, mem_mask, drop)
+        x = decoder_layer(x, memory, p, f"decoder.layers.{i}.", cfg, self_mask, mem_mask, drop, relu)
     return layer_norm(x, p["decoder.norm.weight"], p["decoder.norm.bias"], 1e-5)
 
 
@@ -265,11 +273,11 @@ def create_dist_eval(p, cfg: OracleCfg, h, eps=1e-6):
 
 
 # ----------------------------------------------------------------------------- train step
-def train_forward(p, cfg: OracleCfg, batch, return_all=False, drop=None):
-    """reference models.py:190-233; dropout-free unless ``drop`` hands in the decisions of every site (_drop)."""
-    memory = encode(p, cfg, batch, drop)
+def train_forward(p, cfg: OracleCfg, batch, return_all=False, drop=None, relu=None):
+    """reference models.py:190-233; dropout-free unless ``drop`` hands in the decisions of every site (_drop); ``relu``: _relu."""
+    memory = encode(p, cfg, batch, drop, relu)
     tgt = embed_output(p, cfg, batch["output_value"][:, :-1])
-    hiddens = decode(p, cfg, tgt, memory, batch["input_mask"], batch["output_mask"], drop)
+    hiddens = decode(p, cfg, tgt, memory, batch["input_mask"], batch["output_mask"], drop, relu)
     dists = create_dist_train(p, cfg, hiddens)
     label = batch["output_label"]
     valid = label != cfg.pad

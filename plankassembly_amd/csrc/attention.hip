@@ -740,6 +740,7 @@ __device__ __forceinline__ void glds_nat(char* lds, const bf16* base, int ld, in
 // row offset moves the base instead.)
 struct TileSrc {
     uint64_t base; int ld; int64_t bytes;       // first byte of the sample's rows (head offset included), bytes up to the end of its last row
+    __amdgpu_buffer_rsrc_t rs;                  // ONE descriptor for the whole sample (round 4, see glds_tile)
 };
 __device__ __forceinline__ TileSrc tile_src(const bf16* base, int ld, int nrows, int dh) {
     const uint64_t a = reinterpret_cast<uint64_t>(base);
@@ -749,6 +750,7 @@ __device__ __forceinline__ TileSrc tile_src(const bf16* base, int ld, int nrows,
     t.ld = (int)uni((uint32_t)ld);
     const uint64_t nb = nrows > 0 ? ((uint64_t)(nrows - 1) * ld + dh) * 2 : 0;
     t.bytes = (int64_t)(((uint64_t)uni((uint32_t)(nb >> 32)) << 32) | (uint64_t)uni((uint32_t)nb));
+    t.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(t.base), 0, (int)(t.bytes < 0x7fffffff ? t.bytes : 0x7fffffff), 0x00020000);
     return t;
 }
 template <int DH> __device__ __forceinline__ int tile_voff(int ld, int tid) {
@@ -758,6 +760,11 @@ template <int DH> __device__ __forceinline__ int tile_voff(int ld, int tid) {
     const int ch = ((tid % B::NCHR) ^ (row / RPB)) & (B::NCHR - 1);           // source chunk that belongs at position tid
     return (row * ld + ch * 8) * 2;
 }
+// Round 4: the tile's first row goes into the per-lane offset (one scalar multiply + one vector add per DMA instruction) and the
+// descriptor is the sample's, built once.  Rounds 1-3 rebuilt a descriptor for every DMA instruction - base advanced, size
+// reduced, 64-bit scalar arithmetic, ~18 instructions each - and in kernels that are bound by instruction issue
+// (profiles/r04_attn_issue_bound.txt) those were a fifth of all issue slots.  Rows past the sample's end still read as zeros:
+// the range check compares the per-lane offset with the descriptor's size.
 template <int DH>
 __device__ __forceinline__ void glds_tile(char* lds, const TileSrc& ts, int voff, int row0, int wave) {
     using B = BT<DH>;
@@ -766,12 +773,9 @@ __device__ __forceinline__ void glds_tile(char* lds, const TileSrc& ts, int voff
 #pragma unroll
     for (int i = 0; i < B::NLD; ++i)
         if (B::NCHUNK % NTH == 0 || i * NTH + wave * 64 < B::NCHUNK) {        // (dh = 16: the tile is two waves' worth)
-            const int64_t skip = (int64_t)(row0 + i * RPI) * ts.ld * 2;       // scalar
-            const int64_t left = ts.bytes - skip;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<void*>(ts.base + (uint64_t)skip), 0, (int)(left > 0 ? (left < 0x7fffffff ? left : 0x7fffffff) : 0), 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + (i * NTH + wave * 64) * 16), 16,
-                                                     voff, 0, 0, 0);
+            const int skip = (row0 + i * RPI) * ts.ld * 2;                    // scalar
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ts.rs, (__attribute__((address_space(3))) void*)(lds + (i * NTH + wave * 64) * 16), 16,
+                                                     voff + skip, 0, 0, 0);
         }
 }
 
@@ -1485,11 +1489,8 @@ __device__ __forceinline__ int tile_voff4(int ld, int tid) {
     return (row * ld + ch * 8) * 2;
 }
 __device__ __forceinline__ void glds_tile4(char* lds, const TileSrc& ts, int voff, int row0, int wave) {
-    const int64_t skip = (int64_t)row0 * ts.ld * 2;
-    const int64_t left = ts.bytes - skip;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void*>(ts.base + (uint64_t)skip), 0, (int)(left > 0 ? (left < 0x7fffffff ? left : 0x7fffffff) : 0), 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + wave * 1024), 16, voff, 0, 0, 0);
+    const int skip = row0 * ts.ld * 2;                                        // scalar (see glds_tile)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ts.rs, (__attribute__((address_space(3))) void*)(lds + wave * 1024), 16, voff + skip, 0, 0, 0);
 }
 __device__ __forceinline__ void scan_key_mask4(const uint8_t* mp, int Lk, int tid, int* s_scan, int& kfirst, int& klast) {
     int f = Lk, l = 0;
@@ -2032,6 +2033,8 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_merged_kernel(AttnP pin, int
     else attn4_dkv_body<DROP, CAUSAL, true>(pin, (int)blockIdx.x - gq, smem);
 }
 
+#include "attention5.h"
+
 // =====================================================================================================
 AttnP make_params(const pa_attn_args* a) {
     AttnP p;
@@ -2084,10 +2087,31 @@ static bool use_ksplit(AttnP& p, unsigned blocks) {
     p.ks_min = blocks <= 256 ? min_few : min_many;
     return mode >= 2 || blocks <= 256;
 }
+// v5 forward (attention5.h): PA_ATTN_V5 = 0 never, 1 (default) self-attention-like launches (not causal, at least two 128-row
+// query tiles per element), 2 every non-causal dh = 64 launch.
+static bool use_v5(const AttnP& p) {
+    static const int mode = getenv("PA_ATTN_V5") ? atoi(getenv("PA_ATTN_V5")) : 1;
+    if (mode == 0 || p.causal) return false;
+    return mode >= 2 || p.Lq > BOWN;
+}
 template <int DH> int run_fwd_bf16(AttnP p, hipStream_t st) {
     const int shm = BL<DH>::SHM;
     dim3 grid(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B);
     if constexpr (DH == 64) {
+        if (use_v5(p)) {
+            // PA_ATTN_V5_OCC: 3 (default) three blocks per CU with a 3-stage K/V ring, 2: two blocks per CU, 4 stages
+            static const int occ = getenv("PA_ATTN_V5_OCC") ? atoi(getenv("PA_ATTN_V5_OCC")) : 3;
+            static const int rc4 = set_lds(attn5_fwd_kernel<true, 4, 2>, L5<4>::SHM) | set_lds(attn5_fwd_kernel<false, 4, 2>, L5<4>::SHM);
+            if (rc4) return rc4;
+            if (occ == 2) {
+                if (p.drop_thr) PA_LAUNCH((attn5_fwd_kernel<true, 4, 2>), grid, dim3(NTH), L5<4>::SHM, st, p);
+                else PA_LAUNCH((attn5_fwd_kernel<false, 4, 2>), grid, dim3(NTH), L5<4>::SHM, st, p);
+            } else {
+                if (p.drop_thr) PA_LAUNCH((attn5_fwd_kernel<true, 3, 3>), grid, dim3(NTH), L5<3>::SHM, st, p);
+                else PA_LAUNCH((attn5_fwd_kernel<false, 3, 3>), grid, dim3(NTH), L5<3>::SHM, st, p);
+            }
+            return 0;
+        }
         if (use_v4(p, p.Lq)) {
             if (use_ksplit(p, grid.x)) {
                 constexpr int shm2 = 4 * BL<DH>::BUF + 64;                 // two pairs of stages: > 64 KiB, opt in once

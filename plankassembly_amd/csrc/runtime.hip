@@ -763,6 +763,13 @@ extern "C" int pa_model_tensor(pa_model* m, int32_t which, void** ptr, int64_t* 
         case PA_T_HIDDENS: *ptr = m->hid; *numel = (int64_t)m->B * m->T * d; return 0;
         case PA_T_VOCAB_LOGITS: *ptr = m->vlog; *numel = (int64_t)m->B * m->T * m->ldv; return 0;
         case PA_T_PTR_LOGITS: *ptr = m->plog; *numel = (int64_t)m->B * m->T * m->T; return 0;
-        default: return PA_EINVAL;
+        default: break;
     }
+    if (which >= PA_T_ENC_FFN(0) && which < PA_T_ENC_FFN(m->cfg.n_enc) && (int)m->ea.size() == m->cfg.n_enc) {
+        *ptr = m->ea[which - PA_T_ENC_FFN(0)].hff; *numel = (int64_t)m->NE * m->cfg.d_ff; return *ptr ? 0 : PA_EINVAL;
+    }
+    if (which >= PA_T_DEC_FFN(0) && which < PA_T_DEC_FFN(m->cfg.n_dec) && (int)m->da.size() == m->cfg.n_dec) {
+        *ptr = m->da[which - PA_T_DEC_FFN(0)].hff; *numel = (int64_t)m->B * m->T * m->cfg.d_ff; return *ptr ? 0 : PA_EINVAL;
+    }
+    return PA_EINVAL;
 }

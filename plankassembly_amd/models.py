@@ -706,17 +706,25 @@ class PlankModel(nn.Module):
 
     # ---------------------------------------------------------------------------------- introspection
     def debug_tensor(self, which):
+        """Activations of the last training forward, for the parity tests (pa_model_tensor): 'memory', 'hiddens',
+        'vocab_logits', 'ptr_logits', 'enc_ffn<l>' / 'dec_ffn<l>' (FFN hidden activations [rows, d_ff]; encoder rows are
+        scattered back to [B*S, d_ff] with zeros at PAD when the step ran packed)."""
         names = {"memory": 0, "hiddens": 1, "vocab_logits": 2, "ptr_logits": 3}
+        for l in range(self.num_encoder_layers):
+            names[f"enc_ffn{l}"] = 16 + l
+        for l in range(self.num_decoder_layers):
+            names[f"dec_ffn{l}"] = 80 + l
         p, n = C.c_void_p(), C.c_int64()
         L.check(L.lib().pa_model_tensor(self._handle, names[which], C.byref(p), C.byref(n)), "pa_model_tensor")
         dt = torch.float32 if (which in ("vocab_logits", "ptr_logits") or self.compute_dtype == "f32") else torch.bfloat16
         esz = 4 if dt == torch.float32 else 2
         off = p.value - self._ws.data_ptr()
         t = self._ws[off: off + n.value * esz].view(dt).clone()
-        if which == "memory" and getattr(self, "_last_pack", None) is not None:
-            cu, rowmap, nv, B, S = self._last_pack                    # scatter the packed rows back to [B*S, d] (zeros at PAD)
-            full = torch.zeros(B * S, self.num_model, dtype=dt, device=t.device)
-            full[rowmap[:nv].long()] = t.view(nv, self.num_model)
+        if (which == "memory" or which.startswith("enc_ffn")) and getattr(self, "_last_pack", None) is not None:
+            cu, rowmap, nv, B, S = self._last_pack                    # scatter the packed rows back to [B*S, width] (zeros at PAD)
+            width = self.num_model if which == "memory" else self.num_feedforward
+            full = torch.zeros(B * S, width, dtype=dt, device=t.device)
+            full[rowmap[:nv].long()] = t.view(nv, width)
             return full.view(-1)
         return t
 

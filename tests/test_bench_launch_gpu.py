@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(n, extra_env, steps=4, warmup=2, flags=("--no-cpu", "--no-decode", "--no-kernels")):
+def _launch(n, extra_env, steps=4, warmup=2, flags=("--no-cpu", "--no-decode", "--no-kernels", "--long-steps", "6")):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -47,14 +47,22 @@ def _check_line(line, n, steps, warmup):
 
 
 def test_driver_launch_line_one_rank_rccl():
-    line, _ = _launch(1, {}, flags=("--no-cpu", "--no-decode"))
+    line, _ = _launch(1, {}, flags=("--no-cpu", "--no-decode", "--long-steps", "6"))
     _check_line(line, 1, 4, 2)
     assert line["roofline"]["bound"] == "mfma" and 0.0 < line["roofline"]["frac"] < 1.0
+    # the driver checks that RCCL saw N ranks from these fields; the parity-meeting (f32) training figure rides in the same line
+    assert line["rccl_ranks"]["world_size"] == 1 and line["rccl_ranks"]["backend"] == "nccl" and line["rccl_ranks"]["process_group"]
+    assert line["rccl_ranks"]["ms_per_step_by_rank"]["train"]["ranks"] == 1
+    assert line["train"]["parity_meeting"]["dtype"] == "f32" and 0 < line["train"]["f32"]["value"] < line["train"]["bf16"]["value"]
+    assert line["steady_state"]["steps"] == 6 and "f32" in line["metric"]
 
 
 def test_driver_launch_line_two_ranks_sharing_the_gpu():
-    line, err = _launch(2, {"PLANK_BENCH_BACKEND": "gloo"}, flags=())      # the driver's flags: decode + census legs included
+    line, err = _launch(2, {"PLANK_BENCH_BACKEND": "gloo"}, flags=("--long-steps", "6"))      # the driver's flags: decode + census legs included
     _check_line(line, 2, 4, 2)
+    by_rank = line["rccl_ranks"]["ms_per_step_by_rank"]
+    assert line["rccl_ranks"]["world_size"] == 2 and by_rank["train"]["ranks"] == 2 and by_rank["train_f32"]["ranks"] == 2
+    assert by_rank["train"]["max"] <= line["ms_per_step"] * 1.0001 and by_rank["train"]["min"] <= by_rank["train"]["max"]
     assert line.get("cpu_baseline") is None                      # the CPU leg is rank 0 at N = 1 only
     assert line["decode"]["bf16"]["value"] > 0 and line["decode"]["bf16"]["token_exact"] is None
     assert "rank 0/2" in err                                 # (rank 1 logs nothing: only rank 0 reports)

@@ -36,7 +36,40 @@ def hip_model(c, dtype, sd, dropout=0.0):
     return m.cuda()
 
 
-def oracle_f64(c, sd, batch, drop=None):
+class ForcedBranches:
+    """ReLU hook for the oracle (oracle/plank_oracle.py _relu): evaluate the float64 oracle on the ReLU branches the device
+    run took.  A pre-activation within f32 rounding of zero is +tiny in one precision and -tiny in the other; the loss is
+    continuous there but its gradient is not - one flipped (row, unit) moves that layer's linear1 gradients by a whole entry
+    and EVERY upstream gradient by ~1e-4 of its scale (tools/f32_gate_probe.py: the f32 HIP step and torch's own f32 step sit
+    at the SAME distance, 1.2e-4 .. 4e-3 of scale, from the natural float64 evaluation in 45 .. 112 of 197 tensors of a case).
+    So the branch is taken from the device (sign of its saved FFN activation, pa_model_tensor PA_T_*_FFN) - but ONLY where the
+    float64 pre-activation is within `tau` of zero; everywhere else float64's own branch stands, so a wrong branch on the device
+    at a pre-activation that is not a rounding-level tie still fails the comparison.  `flips` counts the positions that differ."""
+
+    def __init__(self, m, batch, tau=2e-5):
+        B, S = batch["input_value"].shape
+        T = batch["output_value"].shape[1]
+        ff = m.num_feedforward
+        self.tau, self.flips, self.sites = tau, 0, 0
+        self.gate = {}
+        self.valid = (~batch["input_mask"])[:, :, None]       # PAD rows of the encoder never reach the loss (and are not computed on the device)
+        for l in range(m.num_encoder_layers):
+            self.gate[f"encoder.layers.{l}.linear1"] = (m.debug_tensor(f"enc_ffn{l}").view(B, S, ff) > 0).cpu()
+        for l in range(m.num_decoder_layers):
+            self.gate[f"decoder.layers.{l}.linear1"] = (m.debug_tensor(f"dec_ffn{l}").view(B, T, ff) > 0).cpu()
+
+    def __call__(self, key, x):
+        natural = x > 0
+        near = x.detach().abs() <= self.tau
+        if key.startswith("encoder."):
+            near = near & self.valid
+        forced = torch.where(near, self.gate[key], natural)
+        self.flips += int((forced != natural).sum())
+        self.sites += 1
+        return x * forced
+
+
+def oracle_f64(c, sd, batch, drop=None, relu=None):
     """loss / memory / hiddens / every gradient of the CPU oracle evaluated in FLOAT64: for practical purposes the exact
     value of the reference's computation (tests/test_oracle_large.py pins the oracle to the real reference in f32 and in
     float64).  The f32 HIP path is gated against THIS with the plain north-star bound; the f32 torch evaluation of the same
@@ -46,7 +79,7 @@ def oracle_f64(c, sd, batch, drop=None):
     p = {k: v.detach().clone().double().requires_grad_(True) for k, v in sd.items()}
     torch.set_default_dtype(torch.float64)
     try:
-        out = O.train_forward(p, LC.case_oracle_cfg(c), batch, return_all=True, drop=drop)
+        out = O.train_forward(p, LC.case_oracle_cfg(c), batch, return_all=True, drop=drop, relu=relu)
         out["loss"].backward()
     finally:
         torch.set_default_dtype(torch.float32)
@@ -65,49 +98,56 @@ def oracle_train(name, batch_size=None):
     return _oracle_cache[key]
 
 
-def check_grads(name, grads, r64, flip_mag=1e-2):
-    """EVERY gradient within 1e-5 + 1e-4 * scale of the float64 evaluation (scale = the tensor's largest entry).  ONE
-    documented exception: a ReLU branch flip in linear1.  A pre-activation within f32 rounding of zero is +tiny in f32 and
-    -tiny (or 0) in float64, so ONE (row, unit) entry of the gated dY differs by its whole value; that shows up in exactly
-    one hidden unit (= one row of linear1.weight, one entry of linear1.bias) of that layer.  At most two such units per
-    tensor, each at most `flip_mag` of the tensor's scale (one entry's contribution against the largest entry of a sum over
-    all rows), everything else in bound.  Returns the worst (tensor, relative error)."""
+def check_grads(name, grads, r64):
+    """EVERY gradient within 1e-5 + 1e-4 * scale (scale = the tensor's largest entry) of the float64 evaluation on the
+    device's ReLU branches (ForcedBranches).  No other clause.  Returns the worst (tensor, relative error)."""
     worst = ("", 0.0)
     for k, gr in grads.items():
         r = r64[k].double()
-        diff = (gr.double() - r).abs()
-        err, scale = float(diff.max()), float(r.abs().max())
-        bound = 1e-5 + 1e-4 * scale
-        if err <= bound:
-            if err / max(scale, 1e-6) > worst[1]:
-                worst = (k, err / max(scale, 1e-6))
-            continue
-        if k.endswith(("linear1.weight", "linear1.bias")):
-            per_unit = diff.reshape(r.shape[0], -1).amax(dim=1)
-            flipped = torch.nonzero(per_unit > bound).flatten().tolist()
-            print(f"    [{name}] {k}: ReLU branch flip in hidden unit(s) {flipped}: {per_unit[flipped].tolist()} (scale {scale:.3e})")
-            assert len(flipped) <= 2 and float(per_unit.max()) <= flip_mag * scale, (k, flipped, err, scale)
-            continue
-        raise AssertionError((name, k, err, scale, "beyond 1e-5 + 1e-4 * scale of the float64 evaluation"))
+        err, scale = float((gr.double() - r).abs().max()), float(r.abs().max())
+        assert err <= 1e-5 + 1e-4 * scale, (name, k, err, scale, "beyond 1e-5 + 1e-4 * scale of the float64 evaluation")
+        if err / max(scale, 1e-6) > worst[1]:
+            worst = (k, err / max(scale, 1e-6))
     return worst
 
 
-def check_golden_grads(name, g, grads, flip_mag=1e-2):
-    """The same gate against the REAL reference evaluated in float64 (fixture entries g64::*, tests/golden/make_golden_large.py):
-    gradient norm and the leading slice of every parameter."""
+def check_golden_grads(name, g, grads):
+    """The same bound against the REAL reference module evaluated in float64 (fixture entries g64::*,
+    tests/golden/make_golden_large.py): gradient norm and leading slice of every parameter.  Only meaningful when the device run
+    took float64's own ReLU branch everywhere (ForcedBranches.flips == 0); the caller skips it otherwise."""
     got = LC.grad_summary(grads)
     for k in grads:
         scale = float(g["g64::gmax::" + k])
-        bound = 1e-5 + 1e-4 * scale
         diff = np.abs(got["gslice::" + k].astype(np.float64) - g["g64::gslice::" + k])
+        assert diff.max() <= 1e-5 + 1e-4 * scale, (name, k, float(diff.max()), scale)
         n_ref = float(g["g64::gnorm::" + k])
-        n_err = abs(float(got["gnorm::" + k]) - n_ref)
-        if k.endswith(("linear1.weight", "linear1.bias")) and (diff.max() > bound or n_err > 1e-6 + 1e-4 * n_ref):
-            rows = np.nonzero(diff.max(axis=1 if grads[k].dim() > 1 else 0) > bound)[0] if grads[k].dim() > 1 else np.nonzero(diff[0] > bound)[0]
-            assert len(rows) <= 2 and diff.max() <= flip_mag * scale and n_err <= flip_mag * n_ref, (k, rows, diff.max(), scale)   # ReLU flip
-            continue
-        assert diff.max() <= bound, (k, float(diff.max()), scale)
-        assert n_err <= 1e-6 + 1e-4 * n_ref, (k, float(got["gnorm::" + k]), n_ref)
+        assert abs(float(got["gnorm::" + k]) - n_ref) <= 1e-6 + 1e-4 * n_ref, (name, k, float(got["gnorm::" + k]), n_ref)
+
+
+def f32_gate(name, c, sd, batch, m, out, mem, hid, grads, drop=None, g=None):
+    """The whole f32 gate of one step: loss / memory / hiddens within 1e-4 and every gradient within the north-star bound of the
+    float64 oracle on the device's ReLU branches; with fixture `g` also the real reference's own vectors."""
+    fb = ForcedBranches(m, batch)
+    ref, r64 = oracle_f64(c, sd, batch, drop=drop, relu=fb)
+    assert fb.sites == c["ne"] + c["nd"]
+    assert fb.flips <= 256, fb.flips                 # rounding-level ties are rare: a handful among ~10^7 pre-activations
+    assert abs(out["loss"].item() - float(ref["loss"])) < 1e-4, (out["loss"].item(), float(ref["loss"]))
+    valid = ~batch["input_mask"]
+    assert float((mem.double() - ref["memory"])[valid].abs().max()) < 1e-4
+    assert float((hid.double() - ref["hiddens"]).abs().max()) < 1e-4
+    worst = check_grads(name, grads, r64)
+    print(f"[{name}] f32 vs float64: worst relative gradient error {worst[1]:.2e} ({worst[0]}); ReLU ties taken from the device: {fb.flips}")
+    if g is not None:
+        assert abs(out["loss"].item() - float(g["g::loss"])) < 1e-4 and abs(out["loss"].item() - float(g["g64::loss"])) < 1e-4
+        assert abs(out["accuracy"].item() - float(g["g::accuracy"])) < 1e-6
+        rows = torch.arange(0, mem.shape[1], 37)[:24]
+        assert float((mem[:, rows, :LC.SLICE[1]] - torch.from_numpy(g["g::memory_slice"]))[valid[:, rows]].abs().max()) < 1e-4
+        assert float((hid[:, :, :64] - torch.from_numpy(g["g::hiddens_slice"])).abs().max()) < 1e-4
+        if fb.flips == 0:
+            check_golden_grads(name, g, grads)
+        else:
+            print(f"    [{name}] gradient slices of the float64 reference module not compared: {fb.flips} ReLU tie(s) differ from float64's")
+    return fb
 
 
 def run_hip_train(m, batch, prepared=True):
@@ -127,23 +167,10 @@ def run_hip_train(m, batch, prepared=True):
 def test_f32_train_step_matches_reference_and_oracle(name):
     c = LC.CASES[name]
     g = LC.load_large(name)
-    sd, batch, ref, r64 = oracle_train(name)
+    sd, batch = LC.case_state_dict(c), LC.case_batch(c)
     m = hip_model(c, "f32", sd)
     out, mem, hid, grads = run_hip_train(m, batch)
-    # --- against the real reference's golden vectors: forward tensors of its f32 run, gradients of its float64 run
-    assert abs(out["loss"].item() - float(g["g::loss"])) < 1e-4, (out["loss"].item(), float(g["g::loss"]))
-    assert abs(out["loss"].item() - float(g["g64::loss"])) < 1e-4
-    assert abs(out["accuracy"].item() - float(g["g::accuracy"])) < 1e-6
-    valid = ~batch["input_mask"]
-    rows = torch.arange(0, mem.shape[1], 37)[:24]
-    assert float((mem[:, rows, :LC.SLICE[1]] - torch.from_numpy(g["g::memory_slice"]))[valid[:, rows]].abs().max()) < 1e-4
-    assert float((hid[:, :, :64] - torch.from_numpy(g["g::hiddens_slice"])).abs().max()) < 1e-4
-    check_golden_grads(name, g, grads)
-    # --- against the oracle in float64: full tensors
-    assert float((mem.double() - ref["memory"])[valid].abs().max()) < 1e-4
-    assert float((hid.double() - ref["hiddens"]).abs().max()) < 1e-4
-    worst = check_grads(name, grads, r64)
-    print(f"[{name}] f32 vs float64: worst relative gradient error {worst[1]:.2e} ({worst[0]})")
+    f32_gate(name, c, sd, batch, m, out, mem, hid, grads, g=g)
     if name == "sideface":
         gt = grads["input_embeddings.input_type.weight"]
         assert not gt.any()                                  # unused table: zero gradient (no DDP-style error)
@@ -156,26 +183,20 @@ def test_f32_unprepared_batch_same_result(name):
     """forward() also accepts batches that did not go through prepare_batch (packing computed in the step,
     atomic scatter-add embedding gradients): same loss and gradients."""
     c = LC.CASES[name]
-    sd, batch, ref, rgrads = oracle_train(name)
+    sd, batch = LC.case_state_dict(c), LC.case_batch(c)
     m = hip_model(c, "f32", sd)
     out, mem, hid, grads = run_hip_train(m, batch, prepared=False)
-    assert abs(out["loss"].item() - float(ref["loss"])) < 1e-4
-    for k in ("input_embeddings.input_value.weight", "input_embeddings.input_pos.weight", "query_pos_embedding.weight",
-              "encoder.layers.0.self_attn.in_proj_weight"):
-        r = rgrads[k]
-        assert float((grads[k].double() - r).abs().max()) <= 1e-5 + 1e-4 * float(r.abs().max()), k
+    f32_gate(name + "-unprepared", c, sd, batch, m, out, mem, hid, grads)
 
 
 def test_f32_sideface_full_batch_64():
     """train_sideface.yaml's batch (64 samples of S = 299, no input_type, empty rows) against the oracle."""
     c = LC.CASES["sideface"]
-    sd, batch, ref, rgrads = oracle_train("sideface", batch_size=64)
+    sd, batch = LC.case_state_dict(c), LC.case_batch(c, batch_size=64)
     assert bool(batch["input_mask"][3, 1:].all())             # the [END, PAD, ...] rows are in
     m = hip_model(c, "f32", sd)
     out, mem, hid, grads = run_hip_train(m, batch)
-    assert abs(out["loss"].item() - float(ref["loss"])) < 1e-4
-    assert float((hid.double() - ref["hiddens"]).abs().max()) < 1e-4
-    check_grads("sideface-64", grads, rgrads)
+    f32_gate("sideface-64", c, sd, batch, m, out, mem, hid, grads)
 
 
 @pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "t1024"])
@@ -238,21 +259,17 @@ def test_train_step_under_dropout_matches_oracle_given_the_same_decisions(name, 
 
     # both dtypes against the FLOAT64 evaluation of the oracle under the same masks (f32: the north-star bound; bf16: cosine)
     drop = DM.HipDropout(seed, pdrop, c["h"], batch["input_mask"].numpy(), packed=m.unpad)
-    ref, rgrads = oracle_f64(c, sd, batch, drop=drop)
-    assert len(set(drop.sites_seen)) == 4 * c["ne"] + 6 * c["nd"]              # every dropout site of torch's layers was fed
-    loss_ref = float(ref["loss"])
     _, _, plain, _ = oracle_train(name)
-    assert abs(loss_ref - float(plain["loss"])) > 1e-3                         # the masks really change the function
-    valid = ~batch["input_mask"]
     if dtype == "f32":
-        assert abs(out["loss"].item() - loss_ref) < 1e-4, (out["loss"].item(), loss_ref)
-        assert float((mem.double() - ref["memory"])[valid].abs().max()) < 1e-4
-        assert float((hid.double() - ref["hiddens"]).abs().max()) < 1e-4
-        # every gradient within 1e-5 + 1e-4 * scale of float64; linear1 tensors may carry a ReLU branch flip in at most two hidden
-        # units (one (row, unit) entry's whole contribution: up to a few % of the largest entry when the batch has 256 rows)
-        worst = check_grads(name + "-dropout", grads, rgrads, flip_mag=5e-2)
-        print(f"[{name}] f32 under dropout vs float64: worst relative gradient error {worst[1]:.2e} ({worst[0]})")
-    else:
+        f32_gate(name + "-dropout", c, sd, batch, m, out, mem, hid, grads, drop=drop)
+        assert len(set(drop.sites_seen)) == 4 * c["ne"] + 6 * c["nd"]          # every dropout site of torch's layers was fed
+        assert abs(out["loss"].item() - float(plain["loss"])) > 1e-3           # the masks really change the function
+        return
+    ref, rgrads = oracle_f64(c, sd, batch, drop=drop)
+    assert len(set(drop.sites_seen)) == 4 * c["ne"] + 6 * c["nd"]
+    loss_ref = float(ref["loss"])
+    assert abs(loss_ref - float(plain["loss"])) > 1e-3
+    if True:
         assert abs(out["loss"].item() - loss_ref) < 2e-2 * abs(loss_ref), (out["loss"].item(), loss_ref)
         tot = sum(float(r.double().norm()) ** 2 for r in rgrads.values()) ** 0.5
         for k, gr in grads.items():
@@ -505,15 +522,11 @@ def _recorded_gemm_kinds(step):
 
 @pytest.mark.parametrize("which", ["below", "above", "complete"])
 def test_f32_b16_step_matches_oracle(which):
-    c, sd, batch, ref, r64 = _b16_oracle(which)
+    c, batch, _ = _b16_case(which)
+    sd = LC.case_state_dict(c)
     m = hip_model(c, "f32", sd)
     out, mem, hid, grads = run_hip_train(m, batch)
-    assert abs(out["loss"].item() - float(ref["loss"])) < 1e-4
-    valid = ~batch["input_mask"]
-    assert float((mem.double() - ref["memory"])[valid].abs().max()) < 1e-4
-    assert float((hid.double() - ref["hiddens"]).abs().max()) < 1e-4
-    worst = check_grads(f"b16-{which}", grads, r64, flip_mag=5e-2)      # (2 048 decoder rows: one entry of a flip weighs more)
-    print(f"[b16 {which}] f32 vs float64: worst relative gradient error {worst[1]:.2e} ({worst[0]})")
+    f32_gate(f"b16-{which}", c, sd, batch, m, out, mem, hid, grads)
 
 
 @pytest.mark.parametrize("which", ["below", "above", "complete"])
