@@ -349,6 +349,12 @@ int pa_mixture_nll_bwd(void* dvocab, void* dptr, int32_t out_dtype, float* dsw, 
 int pa_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float b1,
                  float b2, float eps, int32_t step, float gscale, void* stream);
 int pa_cast(void* dst, int32_t dst_dtype, const void* src, int32_t src_dtype, int64_t n, void* stream);
+/* One-GPU rehearsal of the data-parallel gradient exchange (the reference's `strategy: ddp`, configs/train_complete.yaml:18-21):
+ * a stand-in for one ring all-reduce.  `blocks` workgroups (<= 256) stay resident for at least `min_us` microseconds and stream
+ * `buf` (16-byte aligned, `bytes` long; contents unchanged) through HBM at least `passes` times.  Launched on a side stream by
+ * plankassembly_amd.distributed.GradSync when PLANK_FAKE_COLLECTIVE is set and the process group has one rank, so that the CU
+ * reservation of the persistent GEMM grids (pa_set_reserved_cus) can be tuned without an 8-GPU node. */
+int pa_fake_collective(void* buf, int64_t bytes, int32_t blocks, int32_t passes, float min_us, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Model-level runtime: one call enqueues the whole training forward of reference

@@ -135,6 +135,7 @@ def lib():
             "pa_mixture_nll_bwd": (I, [P, P, I, P, P, P, P, I, P, P, P, I, I, I, I, F, P]),
             "pa_adam_step": (I, [P, P, P, P, P, I64, F, F, F, F, I, F, P]),
             "pa_cast": (I, [P, I, P, I, I64, P]),
+            "pa_fake_collective": (I, [P, I64, I, I, F, P]),
             "pa_model_create": (I, [P, P]),
             "pa_model_destroy": (None, [P]),
             "pa_model_num_params": (I, [P]),

@@ -442,8 +442,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                         for (int it = 0; it < NIT; ++it)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + mp + it * 4) * p.N + n + e);
-                                x[it][e] = drop_keep(p.drop_seed, idx, p.drop_thr) ? x[it][e] * p.drop_scale : 0.f;
+                                x[it][e] = drop_keep_rc(p.drop_seed, (uint32_t)(un.b * p.M + mp + it * 4), (uint32_t)(n + e), p.drop_thr) ? x[it][e] * p.drop_scale : 0.f;
                             }
                     }
                     if (has_res) {
@@ -513,8 +512,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                         if (p.relu) y = fmaxf(y, 0.f);
                         if (has_aux) y = gate[it][e] > 0.f ? y * p.aux_scale : 0.f;
                         if (has_drop) {
-                            const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + m) * p.N + n + e);
-                            y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
+                            y = drop_keep_rc(p.drop_seed, (uint32_t)(un.b * p.M + m), (uint32_t)(n + e), p.drop_thr) ? y * p.drop_scale : 0.f;
                         }
                         if (has_res) y += res[it][e];
                         x[e] = y;
@@ -1049,8 +1047,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
                         for (int it = 0; it < NIT; ++it)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const uint32_t idx = (uint32_t)(((size_t)un.b * pc.M + mp + it * 4) * pc.N + n + e);
-                                x[it][e] = drop_keep(pc.drop_seed, idx, pc.drop_thr) ? x[it][e] * pc.drop_scale : 0.f;
+                                x[it][e] = drop_keep_rc(pc.drop_seed, (uint32_t)(un.b * pc.M + mp + it * 4), (uint32_t)(n + e), pc.drop_thr) ? x[it][e] * pc.drop_scale : 0.f;
                             }
                     }
                     if (has_res) {
@@ -1101,8 +1098,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
                                 y = g > 0.f ? y * pc.aux_scale : 0.f;
                             }
                             if (has_drop) {
-                                const uint32_t idx = (uint32_t)(((size_t)un.b * pc.M + m) * pc.N + n + e);
-                                y = drop_keep(pc.drop_seed, idx, pc.drop_thr) ? y * pc.drop_scale : 0.f;
+                                y = drop_keep_rc(pc.drop_seed, (uint32_t)(un.b * pc.M + m), (uint32_t)(n + e), pc.drop_thr) ? y * pc.drop_scale : 0.f;
                             }
                             if (has_res) {
                                 const size_t ro = (size_t)un.b * pc.sR + (size_t)m * pc.ldr + n + e;
@@ -1451,8 +1447,7 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
                 for (int it = 0; it < NIT; ++it)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + mp + it * 8) * p.N + n + e);
-                        x[it][e] = drop_keep(p.drop_seed, idx, p.drop_thr) ? x[it][e] * p.drop_scale : 0.f;
+                        x[it][e] = drop_keep_rc(p.drop_seed, (uint32_t)(un.b * p.M + mp + it * 8), (uint32_t)(n + e), p.drop_thr) ? x[it][e] * p.drop_scale : 0.f;
                     }
             }
             if (has_res) {
@@ -1496,8 +1491,7 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
                         y = g > 0.f ? y * p.aux_scale : 0.f;
                     }
                     if (has_drop) {
-                        const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + m) * p.N + n + e);
-                        y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
+                        y = drop_keep_rc(p.drop_seed, (uint32_t)(un.b * p.M + m), (uint32_t)(n + e), p.drop_thr) ? y * p.drop_scale : 0.f;
                     }
                     if (has_res) {
                         const size_t ro = (size_t)un.b * p.sR + (size_t)m * p.ldr + n + e;
@@ -1841,8 +1835,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3w_kernel(GemmP p) {
                         for (int it = 0; it < NIT; ++it)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + mp + it * 8) * p.N + n + e);
-                                x[it][e] = drop_keep(p.drop_seed, idx, p.drop_thr) ? x[it][e] * p.drop_scale : 0.f;
+                                x[it][e] = drop_keep_rc(p.drop_seed, (uint32_t)(un.b * p.M + mp + it * 8), (uint32_t)(n + e), p.drop_thr) ? x[it][e] * p.drop_scale : 0.f;
                             }
                     }
                     if (has_res) {
@@ -1888,8 +1881,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3w_kernel(GemmP p) {
                                 y = g > 0.f ? y * p.aux_scale : 0.f;
                             }
                             if (has_drop) {
-                                const uint32_t idx = (uint32_t)(((size_t)un.b * p.M + m) * p.N + n + e);
-                                y = drop_keep(p.drop_seed, idx, p.drop_thr) ? y * p.drop_scale : 0.f;
+                                y = drop_keep_rc(p.drop_seed, (uint32_t)(un.b * p.M + m), (uint32_t)(n + e), p.drop_thr) ? y * p.drop_scale : 0.f;
                             }
                             if (has_res) {
                                 const size_t ro = (size_t)un.b * p.sR + (size_t)m * p.ldr + n + e;
@@ -2208,7 +2200,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmP p, const float
             float g = ld1(reinterpret_cast<const T*>(p.aux) + (size_t)b * p.sAux + (size_t)m * p.ldaux + n);
             v = g > 0.f ? v * p.aux_scale : 0.f;
         }
-        if (p.drop_thr) v = drop_keep(p.drop_seed, (uint32_t)e, p.drop_thr) ? v * p.drop_scale : 0.f;
+        if (p.drop_thr) v = drop_keep_rc(p.drop_seed, (uint32_t)(b * p.M + m), (uint32_t)n, p.drop_thr) ? v * p.drop_scale : 0.f;
         const size_t co = (size_t)b * p.sC + (size_t)m * p.ldc + n;
         if (p.out_dtype == PA_F32) {
             if (p.R) v += reinterpret_cast<const float*>(p.R)[(size_t)b * p.sR + (size_t)m * p.ldr + n];
@@ -2361,8 +2353,8 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     p.sA = a->sA; p.sB = a->sB; p.sC = a->sC; p.sR = a->sR; p.sAux = a->sAux; p.sBias = a->sBias;
     p.batch = a->batch;
     p.alpha = a->alpha; p.relu = a->relu; p.aux_scale = a->aux_scale;
-    p.drop_thr = (uint32_t)(a->drop_p * 65536.0f + 0.5f);
-    p.drop_scale = 1.0f / (1.0f - a->drop_p);
+    p.drop_thr = (uint32_t)((double)a->drop_p * 4294967296.0);           // keep <=> 32-bit product >= thr (pa_device.h drop_keep_rc)
+    p.drop_scale = (float)(1.0 / (1.0 - (double)p.drop_thr / 4294967296.0));
     p.drop_seed = a->drop_seed;
     p.out_dtype = a->out_dtype;
     p.ln_u = nullptr; p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_y = nullptr; p.ldy = 0; p.ln_eps = 0.f;
@@ -2800,9 +2792,8 @@ __global__ __launch_bounds__(GL_NT, 2) void gemm_ln_kernel(GemmLnP p) {
         for (int e = 0; e < 4; ++e) {
             float y0 = x0[e] * 1.0f + b0[e], y1 = x1[e] * 1.0f + b1[e];
             if (p.drop_thr) {
-                const uint32_t idx = (uint32_t)((size_t)m * GL_N + c0 + e);
-                y0 = drop_keep(p.drop_seed, idx, p.drop_thr) ? y0 * p.drop_scale : 0.f;
-                y1 = drop_keep(p.drop_seed, idx + 256u, p.drop_thr) ? y1 * p.drop_scale : 0.f;
+                y0 = drop_keep_rc(p.drop_seed, (uint32_t)m, (uint32_t)(c0 + e), p.drop_thr) ? y0 * p.drop_scale : 0.f;
+                y1 = drop_keep_rc(p.drop_seed, (uint32_t)m, (uint32_t)(c0 + e + 256), p.drop_thr) ? y1 * p.drop_scale : 0.f;
             }
             if (R) { y0 += r0[i][e]; y1 += r1[i][e]; }
             x0[e] = y0; x1[e] = y1;
@@ -2854,8 +2845,8 @@ extern "C" int pa_gemm_ln(const pa_gemm_ln_args* a, void* stream) {
     p.gamma = a->gamma; p.beta = a->beta; p.mean = a->mean; p.rstd = a->rstd;
     p.M = a->M; p.K = a->K; p.lda = a->lda; p.ldw = a->ldw; p.ldr = a->ldr; p.ldz = a->ldz; p.ldy = a->ldy;
     p.eps = a->eps;
-    p.drop_thr = (uint32_t)(a->drop_p * 65536.0f + 0.5f);           // as pa_gemm
-    p.drop_scale = 1.0f / (1.0f - a->drop_p);
+    p.drop_thr = (uint32_t)((double)a->drop_p * 4294967296.0);           // as pa_gemm
+    p.drop_scale = (float)(1.0 / (1.0 - (double)p.drop_thr / 4294967296.0));
     p.drop_seed = a->drop_seed;
     const int grid = (a->M + GL_BM - 1) / GL_BM;
     PA_LAUNCH(gemm_ln_kernel, dim3(grid), dim3(GL_NT), 0, reinterpret_cast<hipStream_t>(stream), p);

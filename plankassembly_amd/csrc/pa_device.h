@@ -106,17 +106,11 @@ template <> __device__ __forceinline__ void transpose_block<bf16>(const u32x4* i
 }
 
 // ---------------------------------------------------------------------------------------------
-// counter-based dropout RNG: 32-bit avalanche hash of (seed, element index); 16 bits per decision.
+// counter-based dropout RNG: 32-bit avalanche hash (of a row / column / key index mixed with the site seed)
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-// keep-decision for element idx; thr16 = round(p * 65536).  P(keep) = 1 - thr16/65536.
-__device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t thr16) {
-    uint32_t h = mix32(idx * 0x9e3779b9u + seed);
-    return (h >> 16) >= thr16;
-}
-
 // Attention-probability dropout: separable counter-based decisions.  keep(row, key) <=> the low 32 bits of the 24 x 24-bit
 // product A[row] * C[key] are >= thr32, with A = a 24-bit avalanche hash of the global query-row index and C = an odd
 // 24-bit hash of the key index.  One v_mul_u32_u24 + one compare per score in every kernel layout: the forward / dQ
@@ -135,6 +129,15 @@ __device__ __forceinline__ uint32_t drop_key_hash(uint32_t seed, uint32_t key) {
     return (mix32(key * 0x85ebca6bu + (seed ^ 0x5bd1e995u)) & 0xffffffu) | 0x800001u;
 }
 __device__ __forceinline__ bool drop_keep2(uint32_t a, uint32_t c, uint32_t thr32) { return __umul24(a, c) >= thr32; }
+// Dropout on the output of a Linear (GEMM epilogues, the split-K reduce pass, the LayerNorm backward that regenerates the mask):
+// the SAME separable decision, keep(row, col) <=> low32(A[row] * C[col]) >= p * 2^32 with row = the output row (batch folded
+// in: b * M + m) and col = the output column.  Rounds 1-3 hashed the flat element index with mix32 - two 32-bit multiplies,
+// three xor-shifts, an add per ELEMENT plus the index arithmetic, ~14 instructions per element - in epilogues that were as long
+// as the K loop at this model's K = 512 (6.9 non-MFMA VALU per MFMA in the two-blocks-per-CU kernel, profiles/r03_gemm_pmc.txt).
+// Here a thread hashes its few rows and its four columns once per pass and spends multiply + compare + select per element.
+__device__ __forceinline__ bool drop_keep_rc(uint32_t seed, uint32_t row, uint32_t col, uint32_t thr32) {
+    return drop_keep2(drop_row_hash(seed, row), drop_key_hash(seed, col), thr32);
+}
 
 // max(a, b, c) as ONE v_max3_f32.  fmaxf() must quiet signalling NaNs, so hipcc canonicalises every operand that comes out
 // of an MFMA first (v_max_f32 x, x, x): 28 instructions for the row maximum of 16 scores instead of 8.  Scores are never

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(T* dz, T* ddrop, con
                         f32x4 od;
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            od[j] = drop_keep(drop_seed, (uint32_t)(row * d + c + j), drop_thr) ? o[j] * drop_scale : 0.f;
+                            od[j] = drop_keep_rc(drop_seed, (uint32_t)row, (uint32_t)(c + j), drop_thr) ? o[j] * drop_scale : 0.f;
                         st4<T>(ddrop + row * d + c, od);
                         as[i] += od;
                     } else {
@@ -934,9 +934,9 @@ extern "C" int pa_layernorm_bwd_partial(void* dz, void* ddrop, const void* dy, c
                                         int64_t rows, int32_t d, int32_t dtype, float drop_p, uint32_t drop_seed, void* stream) {
     if (!dz || !dy || !z || !gamma || !mean || !rstd || !partial) return PA_EINVAL;
     if (rows <= 0 || (d & 3) || d > 256 * MAXV || drop_p < 0.f || drop_p >= 1.f) return PA_EINVAL;
-    const uint32_t thr = (uint32_t)(drop_p * 65536.0f + 0.5f);
+    const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);        // as pa_gemm: keep <=> 32-bit product >= thr (drop_keep_rc)
     if (thr && !ddrop) return PA_EINVAL;
-    const float scale = 1.0f / (1.0f - drop_p);
+    const float scale = (float)(1.0 / (1.0 - (double)thr / 4294967296.0));
     const int grid = (int)((rows + LNB_ROWS - 1) / LNB_ROWS);
     const size_t shm = (size_t)4 * 3 * d * sizeof(float);
 #define LNB_GO(T_, NV_) PA_LAUNCH((layernorm_bwd_kernel<T_, NV_>), dim3(grid), dim3(256), shm, ST(stream), (T_*)dz, (T_*)ddrop, \
@@ -1036,5 +1036,31 @@ extern "C" int pa_cast(void* dst, int32_t dst_dtype, const void* src, int32_t sr
     else if (dst_dtype == PA_F32 && src_dtype == PA_BF16) PA_LAUNCH((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, ST(stream), (float*)dst, (const bf16*)src, n);
     else if (dst_dtype == PA_F32 && src_dtype == PA_F32) PA_LAUNCH((cast_kernel<float, float>), dim3(grid), dim3(256), 0, ST(stream), (float*)dst, (const float*)src, n);
     else return PA_EINVAL;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stand-in for a ring all-reduce (one-GPU rehearsal of the data-parallel step, plankassembly_amd/distributed.py): `blocks`
+// workgroups hold their CUs for `min_ticks` ticks of the 100 MHz wall clock and meanwhile stream the slice through HBM (read
+// and write back in place, values unchanged) at least `passes` times - what a rank's RCCL kernels do to the chip while the
+// gradient slices of reference configs/train_complete.yaml:18 (`strategy: ddp`) are exchanged: occupy a few CUs for about
+// 2 (n-1)/n * bytes / bus bandwidth and move 2 (n-1)/n * bytes each way through the local memory.
+__global__ __launch_bounds__(256) void fake_collective_kernel(f32x4* buf, long long n4, int passes, long long min_ticks) {
+    const long long t0 = wall_clock64();
+    const long long per = (n4 + gridDim.x - 1) / gridDim.x;
+    const long long lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
+    int pass = 0;
+    do {
+        for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+            f32x4 v = __builtin_nontemporal_load(buf + i);
+            __builtin_nontemporal_store(v, buf + i);
+        }
+        ++pass;
+    } while (pass < passes || wall_clock64() - t0 < min_ticks);
+}
+extern "C" int pa_fake_collective(void* buf, int64_t bytes, int32_t blocks, int32_t passes, float min_us, void* stream) {
+    if (!buf || bytes < 16 || blocks <= 0 || blocks > 256 || passes < 1 || (reinterpret_cast<uintptr_t>(buf) & 15)) return PA_EINVAL;
+    PA_LAUNCH(fake_collective_kernel, dim3(blocks), dim3(256), 0, ST(stream), reinterpret_cast<f32x4*>(buf), (long long)(bytes / 16),
+              passes, (long long)(min_us * 100.0f));
     return 0;
 }

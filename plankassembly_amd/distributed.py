@@ -54,9 +54,20 @@ class GradSync:
         self._pending = None          # (lo, hi) run of contiguous finished-but-unsent slices
         self.launched = []            # [(lo, hi)] of the last backward, for tests / introspection
         self.fired = []               # segment indices in the order the hook saw them (tests)
+        # One-GPU rehearsal (PLANK_FAKE_COLLECTIVE="<blocks>:<GB/s>[:<ranks>]", e.g. "32:200:8"; only with a one-rank group on the
+        # GPU): every slice that would be all-reduced instead launches pa_fake_collective on a side stream - `blocks` CUs held for
+        # 2 (ranks - 1) / ranks * bytes / (GB/s) + 20 us, the slice streamed through HBM twice - so the interplay of the
+        # persistent GEMM grids with a resident collective (and PA_RESERVE_CUS) can be measured without an 8-GPU node.
+        self.fake = None
+        spec = os.environ.get("PLANK_FAKE_COLLECTIVE", "")
+        if spec and spec != "0" and self.world == 1 and model.flat_params.is_cuda:
+            parts = (spec.split(":") + ["", "", ""])[:3] if ":" in spec else ["32", "200", "8"]
+            self.fake = (int(parts[0] or 32), float(parts[1] or 200.0), int(parts[2] or 8))
+            self._fake_stream = torch.cuda.Stream()
+            self.fake_launched = 0
         if reserve_cus is None:
             reserve_cus = int(os.environ.get("PA_RESERVE_CUS", "0"))
-        self.reserve_cus = int(reserve_cus) if (self.world > 1 and model.flat_params.is_cuda) else 0
+        self.reserve_cus = int(reserve_cus) if ((self.world > 1 or self.fake) and model.flat_params.is_cuda) else 0
         self._reserved = False
         self.reserve_log = []         # ('on' | 'off') transitions, for tests
         model.register_grad_ready_hook(self._on_segment)
@@ -114,8 +125,23 @@ class GradSync:
             self._cast(buf, g[lo:hi])
             self._to_widen.append((g, lo, hi))      # the buffer this slice came from: it may differ by the time of wait()
         self._reserve(True)                 # from here until wait(): the GEMM grids leave room for the collective's blocks
-        self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.fake is not None:
+            self._fake_flush(buf)
+        else:
+            self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.launched.append((lo, hi))
+
+    def _fake_flush(self, buf):
+        import ctypes as C
+        from . import _lib as L
+        blocks, gbps, ranks = self.fake
+        nbytes = buf.numel() * buf.element_size() // 16 * 16
+        us = 2.0 * (ranks - 1) / ranks * nbytes / (gbps * 1e3) + 20.0
+        side = self._fake_stream
+        side.wait_stream(torch.cuda.current_stream())          # like ProcessGroupNCCL: after the work already enqueued, on its own stream
+        L.check(L.lib().pa_fake_collective(L.ptr(buf), C.c_int64(nbytes), blocks, 2, C.c_float(us), C.c_void_p(side.cuda_stream)),
+                "pa_fake_collective")
+        self.fake_launched += 1
 
     @staticmethod
     def _cast(dst, src):
@@ -131,6 +157,8 @@ class GradSync:
         for w in self._works:
             w.wait()                        # stream-level wait on GPU, blocking on gloo
         self._works = []
+        if self.fake is not None:
+            torch.cuda.current_stream().wait_stream(self._fake_stream)
         self._reserve(False)
         widen, self._to_widen = self._to_widen, []
         for g, lo, hi in widen:             # the reduced sums, after the collectives and before Adam

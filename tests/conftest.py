@@ -11,8 +11,26 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask clipped by the cgroup CPU quota (the GPU boxes show every core of
+    the host but grant 16: torch's default of one thread per visible core oversubscribes the quota, and the float64 oracle runs
+    of the parity tests then crawl), capped at 32."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    torch.set_num_threads(usable_cores())
 
 
 def _gpu_ready():

@@ -2,7 +2,7 @@
 
 Dropout in `plankassembly_amd/csrc` is counter-based: every decision is a pure function of (step seed, site, element
 index), so the forward, the backward kernels that regenerate it and - here - a test can all compute the same mask.  This
-module restates those functions (csrc/pa_device.h `mix32`, `drop_keep`, `drop_row_hash`, `drop_key_hash`, `drop_keep2`;
+module restates those functions (csrc/pa_device.h `mix32`, `drop_keep_rc`, `drop_row_hash`, `drop_key_hash`, `drop_keep2`;
 csrc/model.h `site_seed`; the site numbering of csrc/runtime.hip `forward_enc_layer` / `forward_dec_layer`; the step-seed
 recurrence of models.py `PlankModel.forward`) and hands the masks to the CPU oracle (`oracle.plank_oracle._drop`), so that a
 training step UNDER dropout 0.2 - the benchmarked mode - is compared with the oracle tensor by tensor.
@@ -31,13 +31,15 @@ def next_step_seed(prev, initial_seed):
 
 
 def linear_keep(seed, rows, n_cols, p):
-    """Epilogue dropout of a Linear whose output is [n_rows][n_cols] (pa_gemm: idx = row * N + col, 16-bit threshold).
+    """Epilogue dropout of a Linear whose output is [n_rows][n_cols] (pa_device.h drop_keep_rc, round 4): the separable
+    decision of the attention dropout, keep(row, col) <=> low32(A[row] * C[col]) >= p * 2^32, with A / C the same 24-bit odd
+    hashes of the output row (batch folded in: b * M + m) and the output column.
     ``rows``: the output-row index of every row wanted (packed row numbers for the packed encoder).  bool [len(rows), n_cols]."""
-    thr16 = np.uint64(int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)))
-    rows = np.asarray(rows, dtype=np.uint64)
-    idx = (rows[:, None] * np.uint64(n_cols) + np.arange(n_cols, dtype=np.uint64)[None, :]) & M32
-    h = mix32((idx * np.uint64(0x9E3779B9) + np.uint64(seed)) & M32)
-    return (h >> np.uint64(16)) >= thr16
+    return attn_keep(seed, np.asarray(rows, dtype=np.uint64), n_cols, p)
+
+
+def linear_scale(p):
+    return attn_scale(p)
 
 
 def attn_keep(seed, row_index, n_keys, p):
@@ -114,4 +116,4 @@ class HipDropout:
         keep = linear_keep(seed, rows.reshape(-1), N, self.p).reshape(B, L, N)
         if enc:
             keep = keep | ~self.enc_valid[:, :, None]                      # padded rows never reach the loss
-        return x * torch.from_numpy(keep).to(x.dtype) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(self.p)))
+        return x * torch.from_numpy(keep).to(x.dtype) * linear_scale(self.p)

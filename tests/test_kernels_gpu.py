@@ -189,6 +189,16 @@ def test_gemm_dropout_statistics():
     assert rel_err(out[kept], full[kept] * 1.25) < 1e-5
     other = ops.gemm(a, b, drop_p=0.2, drop_seed=99)
     assert (other != 0).ne(kept).float().mean().item() > 0.2   # different seed, different mask
+    # the decision is separable (row hash x column hash, pa_device.h drop_keep_rc): no row and no column may be favoured.
+    # 512 Bernoulli(0.8) draws: sigma = 0.0177; every row / column within 5 sigma, their spread as a binomial's
+    k = kept.float()
+    for rate in (k.mean(dim=1), k.mean(dim=0)):
+        assert float((rate - 0.8).abs().max()) < 0.09, float((rate - 0.8).abs().max())
+        assert 0.012 < float(rate.std()) < 0.024, float(rate.std())
+    # neighbouring rows / columns are uncorrelated: the agreement rate of two independent 0.8-masks is 0.68
+    agree_r = (kept[1:] == kept[:-1]).float().mean().item()
+    agree_c = (kept[:, 1:] == kept[:, :-1]).float().mean().item()
+    assert abs(agree_r - 0.68) < 0.01 and abs(agree_c - 0.68) < 0.01, (agree_r, agree_c)
 
 
 @pytest.mark.parametrize("M,N,K", [(512, 512, 64), (300, 1024, 128), (9000, 512, 64), (130, 192, 64)])
