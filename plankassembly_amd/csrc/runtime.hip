@@ -496,6 +496,17 @@ void plan_group(pa_model* m) {
         planned += g.splitk == 0;
     }
     if (!planned) return;
+    if (m->cfg.dtype != PA_BF16) {
+        // f32 (the parity path): pa_gemm_group takes bf16 members only, so flush_segment launches these one by one on the
+        // two-blocks-per-CU kernel - each member then wants the whole chip for itself (512 units), not its share of one grouped
+        // round.  Rounds 1-3 planned them like a grouped launch: the encoder's out_proj gradient ran on 32 of the 512 block
+        // slots, in_proj on 96, and the weight gradients were HALF of the f32 step (30 of 60 ms, 21 TFLOP/s = 0.13 of the f32
+        // MFMA peak; profiles/r04_train_kernel_trace_summary.txt before / after).
+        static const int lone_env = getenv("PA_DW_UNITS") ? atoi(getenv("PA_DW_UNITS")) : 0;
+        const int want = lone_env > 0 ? lone_env : 512;
+        for (int i = 0; i < n; ++i)
+            if (m->dwq[i].splitk == 0) { const int s = want / tiles[i]; sk[i] = s < 1 ? 1 : (s > cap[i] ? cap[i] : s); }
+    } else {
     static const int budget_env = getenv("PA_DW_BUDGET") ? atoi(getenv("PA_DW_BUDGET")) : 0;
     // whole rounds of the 256 CUs: one round for the benchmark model, more when the unsplit tiles already exceed it
     const int budget = budget_env > 0 ? budget_env : (total + 255) / 256 * 256;
@@ -507,6 +518,7 @@ void plan_group(pa_model* m) {
         }
         if (best < 0 || sk[best] >= cap[best] || total + tiles[best] > budget) break;
         ++sk[best]; total += tiles[best];
+    }
     }
     for (int i = 0; i < n; ++i) {
         pa_gemm_args& g = m->dwq[i];

@@ -396,23 +396,28 @@ class PlankModel(nn.Module):
         gr = self._ptr_table(g, 4) if g is not None else None
         L.check(L.lib().pa_model_bind(self._handle, pf, pl, gr), "pa_model_bind")
         self._bound_grads = g
-        if self.compute_dtype == "bf16":
-            self._setup_transposed_shadow()
+        self._setup_transposed_shadow()
 
     def _setup_transposed_shadow(self):
-        """bf16 shadow of W^T for every 2-D Linear weight whose transpose stays 16-byte aligned (all but
-        vocab_head): the backward dX = dY W then runs as a k-contiguous GEMM (csrc/runtime.hip linear_dx)."""
+        """Shadow of W^T (compute dtype) for every 2-D Linear weight whose transpose stays 16-byte aligned: the backward
+        dX = dY W then runs as a k-contiguous GEMM (csrc/runtime.hip linear_dx).  bf16: derived from the bf16 parameter shadow,
+        plus vocab_head^T padded to a whole K tile and the packed cross-attention K|V weights of all decoder layers.  f32
+        (round 4): derived from the parameters themselves - the strided-operand form of the exact-f32 GEMM (register-staged
+        4 x 4 transposes) ran at 0.4 of the f32 MFMA peak and was a quarter of the f32 step."""
         if self._shadowT is not None:
             return
         dev = self._flat.device
-        self._shadowT = torch.zeros(self._numel, dtype=torch.bfloat16, device=dev)
+        bf = self.compute_dtype == "bf16"
+        esz, vec = (2, 8) if bf else (4, 4)
+        src_buf = self._shadow if bf else self._flat
+        self._shadowT = torch.zeros(self._numel, dtype=torch.bfloat16 if bf else torch.float32, device=dev)
         n = len(self._order)
         tab = (C.c_void_p * n)()
         descs, tiles = [], 0
         for i, k in enumerate(self._order):
             s = self._shapes[k]
             is_linear_w = len(s) == 2 and ("proj" in k or "linear" in k or k == "pointer_head.weight")
-            if k == "vocab_head.weight" and s[1] % 8 == 0:
+            if bf and k == "vocab_head.weight" and s[1] % 8 == 0:
                 # [vocab][d] -> W^T [d][ldv] with the vocabulary padded to a whole K tile (pad columns stay zero): the
                 # runtime contracts d(logits) [rows][ldv] with it (csrc/runtime.hip bwd_heads)
                 ldv = (s[0] + 63) // 64 * 64
@@ -422,18 +427,18 @@ class PlankModel(nn.Module):
                 tiles += ((s[0] + 63) // 64) * ((s[1] + 63) // 64)
                 descs.append(d)
                 continue
-            if not is_linear_w or s[0] % 8 or s[1] % 8:
+            if not is_linear_w or s[0] % vec or s[1] % vec:
                 tab[i] = None
                 continue
-            off = self._offsets[k] * 2
+            off = self._offsets[k] * esz
             tab[i] = self._shadowT.data_ptr() + off
-            d = _TrDesc(self._shadow.data_ptr() + off, self._shadowT.data_ptr() + off, s[0], s[1], s[1], s[0], tiles, 0)
+            d = _TrDesc(src_buf.data_ptr() + off, self._shadowT.data_ptr() + off, s[0], s[1], s[1], s[0], tiles, 0)
             tiles += ((s[0] + 63) // 64) * ((s[1] + 63) // 64)
             descs.append(d)
         # cross-attention K/V weights of all decoder layers, transposed and packed: kvT[k][l*2d + n] = W_in_l[d + n][k]
         nd, dm = self.num_decoder_layers, self.num_model
         self._kvT = None
-        if nd > 0 and dm % 8 == 0 and os.environ.get("PLANK_CROSS_KV", "1") != "0":
+        if bf and nd > 0 and dm % 8 == 0 and os.environ.get("PLANK_CROSS_KV", "1") != "0":
             self._kvT = torch.zeros(dm * nd * 2 * dm, dtype=torch.bfloat16, device=dev)
             for li in range(nd):
                 k = f"decoder.layers.{li}.multihead_attn.in_proj_weight"
@@ -453,7 +458,8 @@ class PlankModel(nn.Module):
         if self._tr_descs is None:
             return
         d, n, tiles = self._tr_descs
-        L.check(L.lib().pa_transpose_many(L.ptr(d), n, tiles, L.PA_BF16, L.stream()), "pa_transpose_many")
+        L.check(L.lib().pa_transpose_many(L.ptr(d), n, tiles, L.PA_BF16 if self.compute_dtype == "bf16" else L.PA_F32, L.stream()),
+                "pa_transpose_many")
 
     def _ensure_grads(self):
         if self._gflat is None:
@@ -473,12 +479,11 @@ class PlankModel(nn.Module):
         self._shadow_version = -1
 
     def _refresh_shadow(self):
-        if self.compute_dtype != "bf16":
-            return
         v = self._param_version()
         if v != self._shadow_version:
-            L.check(L.lib().pa_cast(L.ptr(self._shadow), L.PA_BF16, L.ptr(self._flat), L.PA_F32,
-                                    C.c_int64(self._numel), L.stream()), "pa_cast")
+            if self.compute_dtype == "bf16":
+                L.check(L.lib().pa_cast(L.ptr(self._shadow), L.PA_BF16, L.ptr(self._flat), L.PA_F32,
+                                        C.c_int64(self._numel), L.stream()), "pa_cast")
             self._shadow_version = v
             self.refresh_transposed()
 
