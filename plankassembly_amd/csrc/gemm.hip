@@ -2220,6 +2220,14 @@ int launch_t(const GemmP& p, bool aligned, bool glds, dim3 grid, hipStream_t st)
     const bool deep = ALLD && sizeof(T) == 2 && BK_ == 64 && dbg_nst == 3;
     const bool flat = ALLD && sizeof(T) == 2 && BK_ == 64 && dbg_nst == 1;
     if (aligned && glds) {
+        if constexpr (ALLD && sizeof(T) == 4 && BK_ == 16) {
+            // f32, both operands k-contiguous: a 3-stage ring (PA_GEMM_NST=3) was measured and LOSES - 33.9 vs 31.3 ms per f32
+            // train step (round 4): these launches are not waiting for their K tiles.  Opt-in only.
+            if (dbg_nst == 3) {
+                PA_LAUNCH((gemm_kernel<T, BK_, 2, A_KC, B_KC, true, true, false, 3>), grid, dim3(NT), 0, st, p);
+                return 0;
+            }
+        }
         if constexpr (ALLD && sizeof(T) == 2 && BK_ == 64) {
             if (deep) {
                 PA_LAUNCH((gemm_kernel<T, BK_, 1, A_KC, B_KC, true, true, CAN_TR, 3>), grid, dim3(NT), 0, st, p);
@@ -2894,18 +2902,54 @@ template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* X, int M, int N, int ldx, float* out, int rows_per_block) {
     colsum_block<T, VEC>(X, M, N, ldx, out, blockIdx.x, blockIdx.y, rows_per_block);
 }
+// The ordered form (one contributor per output element: the f32 parity path, pa_device.h pa_ordered_reductions): a block owns
+// 4 sixteen-byte column chunks and walks ALL rows on 64 row lanes; the lanes' sums are combined in lane order.  (Rounds 1-3
+// used the 64-chunk x 4-lane block for this too: a 512-column bias gradient was two blocks walking 8 700 rows - 280 us per
+// segment tail, 11 % of the f32 step.  Same result on every run either way; the order of the additions differs from round 3.)
+template <typename T>
+__device__ __forceinline__ void colsum_block_ordered(const T* X, int M, int N, int ldx, float* out, int bx) {
+    constexpr int EB = ET<T>::EB, CCH = 4, RL = 64;
+    __shared__ float red_o[RL][CCH * EB + 1];
+    const int cl = threadIdx.x & (CCH - 1), rl = threadIdx.x / CCH;
+    const int n0 = (bx * CCH + cl) * EB;
+    float acc[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) acc[e] = 0.f;
+    if (n0 < N) {
+#pragma unroll 8
+        for (int r = rl; r < M; r += RL) {
+            const T* p = X + (size_t)r * ldx + n0;
+#pragma unroll
+            for (int e = 0; e < EB; e += 4) { const f32x4 v = ld4<T>(p + e); acc[e] += v[0]; acc[e + 1] += v[1]; acc[e + 2] += v[2]; acc[e + 3] += v[3]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) red_o[rl][cl * EB + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < CCH * EB) {
+        const int n = bx * CCH * EB + threadIdx.x;
+        if (n < N) {
+            float sum = 0.f;
+            for (int i = 0; i < RL; ++i) sum += red_o[i][threadIdx.x];
+            out[n] += sum;                                   // the only contributor (gradients are accumulated into)
+        }
+    }
+}
 // several matrices in one launch: block -> (descriptor, column block, row block)
 struct ColsumTab { pa_colsum_desc d[PA_MAX_COLSUM]; int begin[PA_MAX_COLSUM + 1]; int n; int ordered; };
-static inline int colsum_row_blocks(int M, bool ordered) { return ordered ? 1 : (M + CS_ROWS - 1) / CS_ROWS; }
+static inline int colsum_blocks(int M, int N, int EB, bool ordered) {
+    return ordered ? (N + 4 * EB - 1) / (4 * EB) : ((N + 64 * EB - 1) / (64 * EB)) * ((M + CS_ROWS - 1) / CS_ROWS);
+}
 template <typename T>
 __device__ __forceinline__ void colsum_many_block(const ColsumTab& t, int blk) {
     constexpr int EB = ET<T>::EB;
     int di = 0;
     while (di + 1 < t.n && blk >= t.begin[di + 1]) ++di;
     const pa_colsum_desc d = t.d[di];
-    const int nbx = (d.N + 64 * EB - 1) / (64 * EB);
     const int rel = blk - t.begin[di];
-    colsum_block<T, true>(reinterpret_cast<const T*>(d.X), d.M, d.N, d.ldx, d.out, rel % nbx, rel / nbx, t.ordered ? d.M : CS_ROWS);
+    if (t.ordered) { colsum_block_ordered<T>(reinterpret_cast<const T*>(d.X), d.M, d.N, d.ldx, d.out, rel); return; }
+    const int nbx = (d.N + 64 * EB - 1) / (64 * EB);
+    colsum_block<T, true>(reinterpret_cast<const T*>(d.X), d.M, d.N, d.ldx, d.out, rel % nbx, rel / nbx, CS_ROWS);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_many_kernel(ColsumTab t) { colsum_many_block<T>(t, blockIdx.x); }
@@ -2965,7 +3009,7 @@ extern "C" int pa_segment_tail(const pa_ln_finish_desc* ln, int32_t n_ln, int32_
         if (!d.X || !d.out || d.M <= 0 || d.N <= 0) return PA_EINVAL;
         if ((reinterpret_cast<uintptr_t>(d.X) & 15) || d.ldx % EB || d.ldx < (d.N + EB - 1) / EB * EB) return PA_EALIGN;
         ct.d[i] = d;
-        ct.begin[i + 1] = ct.begin[i] + ((d.N + 64 * EB - 1) / (64 * EB)) * colsum_row_blocks(d.M, ordered);
+        ct.begin[i + 1] = ct.begin[i] + colsum_blocks(d.M, d.N, EB, ordered);
     }
     ReduceTab rt; rt.n = n_rd; rt.begin[0] = 0;
     for (int i = 0; i < n_rd; ++i) {
@@ -2992,7 +3036,7 @@ extern "C" int pa_colsum_many(const pa_colsum_desc* descs, int32_t n_desc, int32
         // vector path only: 16-byte aligned rows whose allocation covers the last vector
         if ((reinterpret_cast<uintptr_t>(d.X) & 15) || d.ldx % EB || d.ldx < (d.N + EB - 1) / EB * EB) return PA_EALIGN;
         t.d[i] = d;
-        t.begin[i + 1] = t.begin[i] + ((d.N + 64 * EB - 1) / (64 * EB)) * colsum_row_blocks(d.M, ordered);
+        t.begin[i + 1] = t.begin[i] + colsum_blocks(d.M, d.N, EB, ordered);
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == PA_BF16) PA_LAUNCH(colsum_many_kernel<bf16>, dim3(t.begin[n_desc]), dim3(256), 0, st, t);
@@ -3089,7 +3133,7 @@ extern "C" int pa_colsum(const void* X, int32_t dtype, int32_t M, int32_t N, int
         if (e != hipSuccess) return (int)e;
     }
     const bool ordered = pa_ordered_reductions(dtype);
-    const int nparts = colsum_row_blocks(M, ordered), rpb = ordered ? M : CS_ROWS;
+    const int nparts = ordered ? 1 : (M + CS_ROWS - 1) / CS_ROWS, rpb = ordered ? M : CS_ROWS;
     const int EB = dtype == PA_BF16 ? 8 : 4;
     // vector path: every 16-byte chunk of a row is fully inside the row allocation (ldx >= round-up of N) and aligned
     const bool vec = (reinterpret_cast<uintptr_t>(X) & 15) == 0 && ldx % EB == 0 && ldx >= (N + EB - 1) / EB * EB;
