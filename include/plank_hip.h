@@ -47,7 +47,9 @@ int pa_version(void);
  *   a_kcontig: 1 -> A stored [M][K] (lda = row stride); 0 -> stored [K][M]
  *   b_kcontig: 1 -> B stored [N][K] (torch Linear weight layout); 0 -> stored [K][N]
  * epilogue order: *alpha, +bias[n], relu, relu-backward gate (aux[m][n] > 0 ? v*aux_scale : 0),
- * dropout(drop_p, drop_seed; element index = (b*M+m)*N+n), +R[m][n].
+ * dropout(drop_p, drop_seed), +R[m][n].  Dropout decisions are counter-based and separable: element (row = b*M+m, col = n) is
+ * kept iff the low 32 bits of A[row] * C[col] are >= drop_p * 2^32, A / C = 24-bit odd hashes of (drop_seed, row) / (drop_seed,
+ * col) (csrc/pa_device.h drop_keep_rc; restated in tests/dropout_masks.py linear_keep); survivors are scaled by 1/(1-p).
  * splitk > 1: contraction split into `splitk` slices, partial products go through `ws`
  * (f32, splitk*batch*M*N elements) and a reduce pass applies the epilogue.
  */
@@ -280,10 +282,10 @@ int pa_segment_tail(const pa_ln_finish_desc* ln, int32_t n_ln, int32_t d_model, 
  *   so Q/K/V may be views into the packed in_proj output);
  *   kpm: uint8 [B][Lk], 1 = masked key (PAD), or NULL;  causal: key j allowed iff j <= i;
  *   lse: f32 [B][H][Lq] log-sum-exp of the scaled, masked scores (saved for backward);
- *   dropout on the attention probabilities (torch MHA `dropout`): counter-based, one hash of
- *   (drop_seed, ((b*H+h)*Lq+i)*ceil(Lk/4) + j/4) decides 4 consecutive keys with 8 bits each, i.e. the
- *   drop probability is quantised to round(256 p)/256 (0.2 -> 51/256) and survivors are scaled by
- *   256/(256 - round(256 p)) so the expectation is exact; backward regenerates the same mask.
+ *   dropout on the attention probabilities (torch MHA `dropout`): counter-based and separable - probability (row, key) with
+ *   row = (b*H+h)*Lq + i is kept iff the low 32 bits of A[row] * C[key] are >= drop_p * 2^32 (csrc/pa_device.h drop_keep2, the
+ *   same function the Linear epilogues use; tests/dropout_masks.py attn_keep); survivors are scaled by 1/(1-p); the backward
+ *   kernels regenerate the same decisions.
  * bwd: dq/dk/dv have the layouts of q/k/v; delta is f32 scratch [B][H][Lq].
  */
 typedef struct {

@@ -19,9 +19,10 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, process_group=None, coalesce_below=2 * 1024 * 1024, grad_dtype=None, reserve_cus=None):
-        """``coalesce_below``: segments smaller than this many elements are merged with the next one
-        (encoder.norm / output-embedding slices are a few KB).
+    def __init__(self, model, process_group=None, coalesce_below=None, grad_dtype=None, reserve_cus=None):
+        """``coalesce_below``: finished segments are merged until a run has at least this many elements, then sent as one
+        all-reduce (encoder.norm / output-embedding slices are a few KB; a layer is 2.1 - 3.2 M elements).  None reads
+        PLANK_SYNC_COALESCE, default 2 M elements (8 MB).
 
         ``grad_dtype``: 'f32' (default; PLANK_GRAD_DTYPE overrides) exchanges the f32 gradients as they are - 130 MB per
         step for the 32.5 M-parameter model; 'bf16' casts each finished slice to bf16, all-reduces 65 MB and widens the sums
@@ -44,6 +45,8 @@ class GradSync:
         self.world = dist.get_world_size(process_group)
         self.slices = model.segment_slices()
         self.nseg = len(self.slices)
+        if coalesce_below is None:
+            coalesce_below = int(float(os.environ.get("PLANK_SYNC_COALESCE", 2 * 1024 * 1024)))
         self.coalesce_below = coalesce_below
         self.grad_dtype = grad_dtype or os.environ.get("PLANK_GRAD_DTYPE", "f32")
         if self.grad_dtype not in ("f32", "bf16"):
