@@ -505,6 +505,13 @@ def main():
             rank_ms[tag] = [dt / steps * 1e3]
         return float(tt.item()), out
 
+    if dist.is_initialized():
+        # Set-up, not warm-up: RCCL builds its communicator state lazily on the first collectives of every size, and the stream
+        # hand-over in front of Adam settles over the first few dozen steps (profiles/r04_gradsync_coalesce_sweep.txt: the first
+        # 100 steps under a process group run 0.2 - 0.4 ms slower than the next 100).  The contract's W warm-up steps follow.
+        for i in range(30):
+            step_on(prepared[i % len(prepared)])
+        fence()
     log(f"model + batches ready (rank {rank}/{world}, config {args.config})")
     dt, out = timed(raw, fresh=True, tag="train")          # the headline figure: a fresh batch every step
     loss = float(out["loss"].detach())
