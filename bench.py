@@ -505,7 +505,7 @@ def main():
             rank_ms[tag] = [dt / steps * 1e3]
         return float(tt.item()), out
 
-    if dist.is_initialized():
+    if dist.is_initialized() and backend == "nccl":
         # Set-up, not warm-up: RCCL builds its communicator state lazily on the first collectives of every size, and the stream
         # hand-over in front of Adam settles over the first few dozen steps (profiles/r04_gradsync_coalesce_sweep.txt: the first
         # 100 steps under a process group run 0.2 - 0.4 ms slower than the next 100).  The contract's W warm-up steps follow.
