@@ -22,6 +22,10 @@
 // slots are spent on everything else.  So this kernel is first of all an instruction diet (no max / FMA / accumulator
 // initialisation per score, dropout compares in SGPR pairs without hazard nops, packed row sums, no register copies at the
 // chunk boundary) and second as many waves per SIMD as its registers allow (OCC = 3 with a 3-stage ring, or 2 with 4 stages).
+// Forward / backward consistency: like attn4_fwd_kernel this kernel scores bf16(q * scale * log2 e) . k, while the
+// backward kernels recompute (q . k) * scale * log2 e from the unscaled rows: the two probabilities differ by one extra bf16 rounding
+// of q (2^-9 relative per element - the size of the input quantisation), pinned by
+// tests/test_kernels_gpu.py::test_attention_backward_probabilities_sum_to_one_per_row.
 // Dropout decisions, lse, masks: identical functions to v3 / v4 (pa_device.h drop_keep2; tests/dropout_masks.py).
 #define PA_SB() __builtin_amdgcn_sched_barrier(0)
 template <int NS> struct L5 {

@@ -367,6 +367,29 @@ def test_attention_fwd_bwd(dtype, B, H, dh, Lq, Lk, use_kpm, causal):
     assert rel_err(dv, vr.grad) < t, ("dv", rel_err(dv, vr.grad))
 
 
+@pytest.mark.parametrize("Lq,Lk", [(64, 300), (64, 1000)])
+def test_attention_backward_probabilities_sum_to_one_per_row(Lq, Lk):
+    """The bf16 forward kernels take their scores from query rows pre-multiplied by scale * log2(e) and RE-ROUNDED to bf16 (the
+    MFMA then delivers the exponent), the backward kernels recompute (q . k) * scale * log2(e) - lse from the unscaled rows, so the
+    forward's and the backward's probabilities are not bit-for-bit the same function.  The difference is one more bf16
+    rounding of q - the size of the input quantisation itself; this pins it: with dO[i] = e_i (64 query rows, dh 64) and no
+    dropout, dV[j][i] = P_bwd[i][j], so the column sums of dV are the ROW sums of the backward's probabilities and must be 1."""
+    B, H, dh = 2, 2, 64
+    q = rnd(B, Lq, H * dh, dtype=torch.bfloat16, seed=31).to(DEV)
+    k = rnd(B, Lk, H * dh, dtype=torch.bfloat16, seed=32, scale=1.5).to(DEV)
+    v = rnd(B, Lk, H * dh, dtype=torch.bfloat16, seed=33).to(DEV)
+    o, lse = ops.attn_fwd(q, k, v, H)
+    do = torch.zeros(B, Lq, H * dh, dtype=torch.bfloat16, device=DEV)
+    idx = torch.arange(Lq, device=DEV)
+    for h in range(H):
+        do[:, idx, h * dh + idx % dh] = 1.0
+    dq, dk, dv = ops.attn_bwd(do, q, k, v, o, lse, H)
+    rows = dv.float().view(B, Lk, H, dh).sum(dim=1)                     # [B, H, 64]: row sums of P_bwd
+    err = float((rows - 1.0).abs().max())
+    print(f"    backward probability row sums: max |sum - 1| = {err:.2e}")
+    assert err < 0.03, err
+
+
 def test_attention_both_wave_shapes_agree():
     """dh = 64 bf16 has two kernel families (32-row waves / 16-row waves, chosen by launch size); both must give the same
     results on the same problem - run in subprocesses because the choice is read once per process (PA_ATTN_V4)."""
