@@ -109,6 +109,25 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
         }
         return 0;
     }
+    // z = R + drop(A W^T + bias), y = LayerNorm(z): the post-norm sublayer tail of a decoder layer.  PLANK_TRAIN_FUSE_LN=<rows>
+    // sends launches of at most that many rows to the one-launch row-block kernel pa_gemm_ln (bit-identical to the two
+    // launches, round 2).  OFF by default: measured in round 4 at the decoder's 2 048 rows (18 sites per step) the step is
+    // 5.29 ms with it against 5.07 ms without - 64 blocks each pulling a whole 512 x K weight through their own CU take ~26 us
+    // where gemm3s + LayerNorm take ~14 (the same per-CU weight streaming that made it lose at 256 and at 7 940 rows).
+    int linear_ln(const void* A, int lda, const void* W, const float* bias, const void* R, void* z, void* y, const float* g,
+                  const float* b, float* mean, float* rstd, int M, int K, float drop_p, uint32_t seed, float eps) const {
+        static const int fuse_max = getenv("PLANK_TRAIN_FUSE_LN") ? atoi(getenv("PLANK_TRAIN_FUSE_LN")) : 0;
+        const int d = m->cfg.d_model;
+        if (dt() == PA_BF16 && d == 512 && M <= fuse_max && M <= pa_gemm_ln_max_rows() && K % 64 == 0) {
+            pa_gemm_ln_args a; memset(&a, 0, sizeof(a));
+            a.A = A; a.W = W; a.bias = bias; a.R = R; a.Z = z; a.Y = y; a.gamma = g; a.beta = b; a.mean = mean; a.rstd = rstd;
+            a.M = M; a.N = d; a.K = K; a.lda = lda; a.ldw = K; a.ldr = d; a.ldz = d; a.ldy = d;
+            a.eps = eps; a.drop_p = drop_p; a.drop_seed = seed;
+            return pa_gemm_ln(&a, st);
+        }
+        RC(linear(A, lda, W, bias, z, d, M, d, K, 0, drop_p, seed, R, d));
+        return ln_fwd(y, z, g, b, mean, rstd, M, eps);
+    }
     int ln_fwd(void* y, const void* z, const float* g, const float* b, float* mean, float* rstd, int64_t rows, float eps) const {
         return pa_layernorm_fwd(y, z, g, b, mean, rstd, rows, m->cfg.d_model, eps, dt(), st);
     }
@@ -294,19 +313,19 @@ int pa_train_forward_impl(pa_model* m, void* st) {
         RC(k.linear(m->Y[i], d, PL(pb + D_SA_IN_W), PF(pb + D_SA_IN_B), t.qkv, 3 * d, BT, 3 * d, d));
         RC(k.attn(false, t.qkv, 3 * d, (char*)t.qkv + d * e, (char*)t.qkv + 2 * d * e, 3 * d, t.o_sa, t.lse_sa,
                   m->batch.output_mask, T, T, 1, p, site_seed(m->seed, sb + 0)));
-        RC(k.linear(t.o_sa, d, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), t.z1, d, BT, d, d, 0, p, site_seed(m->seed, sb + 1), m->Y[i], d));
-        RC(k.ln_fwd(t.y1, t.z1, PF(pb + D_N1_W), PF(pb + D_N1_B), t.m1, t.r1, BT, c.eps_layer));
+        RC(k.linear_ln(t.o_sa, d, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), m->Y[i], t.z1, t.y1, PF(pb + D_N1_W), PF(pb + D_N1_B),
+                       t.m1, t.r1, BT, d, p, site_seed(m->seed, sb + 1), c.eps_layer));
         // cross attention: q from y1 (rows 0..d of in_proj), k/v from memory (rows d..3d)
         RC(k.linear(t.y1, d, PL(pb + D_CA_IN_W), PF(pb + D_CA_IN_B), t.q_ca, d, BT, d, d));
         if (!kv_fused)
             RC(k.linear(memory, d, (const char*)PL(pb + D_CA_IN_W) + (size_t)d * d * e, PF(pb + D_CA_IN_B) + d, t.kv_ca, t.ld_kv, BS, 2 * d, d));
         RC(k.attn(false, t.q_ca, d, t.kv_ca, (char*)t.kv_ca + d * e, t.ld_kv, t.o_ca, t.lse_ca, in_mask, T, S, 0, p,
                   site_seed(m->seed, sb + 2), nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, cu));
-        RC(k.linear(t.o_ca, d, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), t.z2, d, BT, d, d, 0, p, site_seed(m->seed, sb + 3), t.y1, d));
-        RC(k.ln_fwd(t.y2, t.z2, PF(pb + D_N2_W), PF(pb + D_N2_B), t.m2, t.r2, BT, c.eps_layer));
+        RC(k.linear_ln(t.o_ca, d, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), t.y1, t.z2, t.y2, PF(pb + D_N2_W), PF(pb + D_N2_B),
+                       t.m2, t.r2, BT, d, p, site_seed(m->seed, sb + 3), c.eps_layer));
         RC(k.linear(t.y2, d, PL(pb + D_L1_W), PF(pb + D_L1_B), t.hff, ff, BT, ff, d, 1, p, site_seed(m->seed, sb + 4)));
-        RC(k.linear(t.hff, ff, PL(pb + D_L2_W), PF(pb + D_L2_B), t.z3, d, BT, d, ff, 0, p, site_seed(m->seed, sb + 5), t.y2, d));
-        RC(k.ln_fwd(m->Y[i + 1], t.z3, PF(pb + D_N3_W), PF(pb + D_N3_B), t.m3, t.r3, BT, c.eps_layer));
+        RC(k.linear_ln(t.hff, ff, PL(pb + D_L2_W), PF(pb + D_L2_B), t.y2, t.z3, m->Y[i + 1], PF(pb + D_N3_W), PF(pb + D_N3_B),
+                       t.m3, t.r3, BT, ff, p, site_seed(m->seed, sb + 5), c.eps_layer));
     }
     RC(k.ln_fwd(m->hid, m->Y[c.n_dec], PF(m->dec_norm()), PF(m->dec_norm() + 1), m->hid_m, m->hid_r, BT, c.eps_final));
     // ---- heads + mixture NLL (reference models.py:140-166, 219-227) ----
