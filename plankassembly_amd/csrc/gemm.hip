@@ -734,11 +734,17 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
 }
 
 constexpr int PA_MAX_GROUP_ = 8;
-struct GemmGroup { GemmP p[PA_MAX_GROUP_]; int begin[PA_MAX_GROUP_ + 1]; int n; };
+// xcd_chunk > 0: XCD-contiguous unit order.  Blocks are dealt to the 8 XCDs round-robin (block b -> XCD b % 8), so with the
+// plain order the 4 - 8 units that share a dY / X panel (same K slice, same row or column of tiles) land on 4 - 8 different
+// L2s and each of them fetches the panel from HBM.  With xcd_chunk = ceil(units / 8) the launch enumerates 8 * xcd_chunk
+// slots and slot u is unit (u % 8) * xcd_chunk + u / 8 of the table: every XCD walks ONE contiguous eighth of the unit list
+// (whole K slices of a member: each panel is fetched by one L2).  Needs gridDim.x % 8 == 0 (slots of a block stay on its XCD
+// and in ascending unit order).
+struct GemmGroup { GemmP p[PA_MAX_GROUP_]; int begin[PA_MAX_GROUP_ + 1]; int n; int xcd_chunk; };
 __device__ __forceinline__ const GemmP& first_problem(const GemmP& p) { return p; }
 __device__ __forceinline__ const GemmP& first_problem(const GemmGroup& g) { return g.p[0]; }
 __device__ __forceinline__ int total_units_of(const GemmP& p) { return p.units; }
-__device__ __forceinline__ int total_units_of(const GemmGroup& g) { return g.begin[g.n]; }
+__device__ __forceinline__ int total_units_of(const GemmGroup& g) { return g.xcd_chunk > 0 ? 8 * g.xcd_chunk : g.begin[g.n]; }
 
 // -------------------------------------------------------------------------------------------------
 // v3 (bf16, both operands DMA'd): ONE block per CU (4 waves, one per SIMD, up to 512 VGPRs each), a 4-stage LDS
@@ -1130,10 +1136,15 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
         while (u < total_units) {
             int local = u;
             if constexpr (GROUP) {
+                int g = u;
+                if (prm.xcd_chunk > 0) {
+                    g = (u & 7) * prm.xcd_chunk + (u >> 3);
+                    if (g >= prm.begin[prm.n]) { u += ustride; continue; }     // padding slot of the last XCD
+                }
                 bool moved = false;
-                while (u >= prm.begin[pi + 1]) { ++pi; moved = true; }
+                while (g >= prm.begin[pi + 1]) { ++pi; moved = true; }
                 if (moved) px = prm.p[pi];
-                local = u - prm.begin[pi];
+                local = g - prm.begin[pi];
             }
             if (decode_unit<TL>(px, local, un)) break;
             u += ustride;
@@ -2605,7 +2616,14 @@ extern "C" int pa_gemm_group(const pa_gemm_args* args, int32_t n, void* stream) 
     }
     if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec) ++g_rec_ngroups; }
     const int cus = cus_for_gemm();
-    const int grid = valid < cus ? valid : cus;
+    int grid = valid < cus ? valid : cus;
+    static const int xcd_order = [] { const char* e = getenv("PA_DW_XCD"); return e ? atoi(e) : 1; }();
+    g.xcd_chunk = 0;
+    if (xcd_order && valid >= 64) {                 // (a handful of units: nothing to share)
+        g.xcd_chunk = (valid + 7) / 8;
+        grid = (grid + 7) / 8 * 8;                  // slots of a block stay on its XCD
+        if (grid > 8 * g.xcd_chunk) grid = 8 * g.xcd_chunk;
+    }
     PA_LAUNCH((gemm3_kernel<false, false, GemmGroup>), dim3(grid), dim3(NT), 0, reinterpret_cast<hipStream_t>(stream), g);
     return 0;
 }

@@ -85,6 +85,26 @@ def test_gemm_group_weight_gradients():
         assert rel_err(out, ref) < 1e-2, rel_err(out, ref)
 
 
+@pytest.mark.parametrize("shapes", [
+    [(2048, 512, 512, 4), (2048, 1024, 512, 1), (700, 200, 136, 3)],       # 64 + 32 + 12 = 108 units: XCD-contiguous order, 4 padding slots
+    [(2048, 384, 512, 5), (1000, 136, 72, 2)],                              # 60 + 4 units: exactly at the switch
+    [(1000, 256, 256, 3), (300, 136, 72, 2)],                               # 12 + 4 units: plain order
+])
+def test_gemm_group_unit_orders(shapes):
+    """The grouped launch walks its units XCD-contiguously (slot u -> unit (u % 8) * chunk + u / 8) from 64 units on and in the
+    plain order below: one-round launches with padding slots, at the switch, and small ones (the 1 172-unit case above covers
+    several units per block)."""
+    items, refs = [], []
+    for i, (rows, M, N, sk) in enumerate(shapes):
+        dy = rnd(rows, M, dtype=torch.bfloat16, seed=150 + i, scale=0.3)
+        x = rnd(rows, N, dtype=torch.bfloat16, seed=160 + i, scale=0.3)
+        items.append((dy.to(DEV), x.to(DEV), sk))
+        refs.append(dy.float().t() @ x.float())
+    outs = ops.dw_group(items)
+    for out, ref in zip(outs, refs):
+        assert rel_err(out, ref) < 1e-2, rel_err(out, ref)
+
+
 def test_gemm_deferred_splitk_reduce():
     """Weight-gradient path: several split-K GEMMs write only their f32 slabs, one launch reduces all of them.
     (K = 1000 with 5 requested slices is the case where rounding leaves the last slice empty: 16 K tiles -> 4 slices.)"""
