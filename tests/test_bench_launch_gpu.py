@@ -67,6 +67,7 @@ def test_driver_launch_line_two_ranks_sharing_the_gpu():
     assert line["decode"]["bf16"]["value"] > 0 and line["decode"]["bf16"]["token_exact"] is None
     assert "rank 0/2" in err                                 # (rank 1 logs nothing: only rank 0 reports)
     # both ranks draw the same batches and start from broadcast parameters: after the exchange the mean gradient equals each
-    # rank's own, so the two-rank loss trajectory is the one-rank trajectory
-    one, _ = _launch(1, {})
+    # rank's own, so the two-rank loss trajectory is the one-rank trajectory (same backend on both sides: bench.py runs 30
+    # set-up steps in front of the warm-up under RCCL only, which would move the one-rank run 30 optimizer steps ahead)
+    one, _ = _launch(1, {"PLANK_BENCH_BACKEND": "gloo"})
     assert abs(line["final_loss"] - one["final_loss"]) <= 2e-3 * abs(one["final_loss"])
