@@ -410,6 +410,7 @@ def main():
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 training leg (probes only)")
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--long-steps", type=int, default=200, help="length of the extra steady-state region (noise estimate)")
     args = ap.parse_args()
@@ -543,7 +544,7 @@ def main():
     # north_star's tolerance (1e-4 against the f32 reference) is met by the f32 path only; bf16 is the throughput path
     # (BASELINE configs[1] names bf16 for the 1-GPU line).  Both figures go into the line; `value` stays the bf16 one.
     train_f32 = None
-    if args.dtype == "bf16":
+    if args.dtype == "bf16" and not args.no_f32:
         m32 = build("f32", cfgd["max_in"], cfgd["max_out"], 0.2, cfgd).train()
         opt32 = FusedAdam(m32, lr=1e-4, grad_scale=1.0 / world)
         sync32 = None

@@ -27,29 +27,9 @@
 #include <mutex>
 #include <vector>
 #include "../../include/plank_hip.h"
+#include "gemm_common.h"
 
 namespace {
-
-struct GemmP {
-    const void* A; const void* B; void* C;
-    const float* bias; const void* R; const void* aux;
-    int M, N, K;
-    int lda, ldb, ldc, ldr, ldaux;
-    long long sA, sB, sC, sR, sAux, sBias;
-    int batch;
-    float alpha; int relu; float aux_scale;
-    uint32_t drop_thr; float drop_scale; uint32_t drop_seed;
-    int out_dtype;
-    int splitk, tiles_per_slice;   // split-K: C is the f32 slab workspace, plain store
-    int tiles_m, tiles_n, tiles_m_pad, units;   // tiles_m_pad == tiles_m: plain row-major unit order (no XCD interleave)
-    int vec_ok;                    // epilogue may use 4-element vector accesses on C / R / aux / bias
-    int plain_order;               // units enumerate (tile_m, tile_n) row-major instead of the XCD interleave
-    int dbg;                       // ablation bits (PA_GEMM_DBG): 1 no MFMA, 2 no ds_read, 4 no loads, 8 no epilogue
-    // "A = LayerNorm(Z)" folded into the product (gemm3s_kernel only, pa_gemm_norm_a): A holds the raw rows Z, B the weight
-    // pre-multiplied by gamma, ln_u[n] = sum_k B[n][k], bias[n] = b[n] + sum_k W[n][k] beta[k]; the kernel computes the row
-    // statistics itself and writes  rstd_m (acc - mean_m u_n) + bias_n.  ln_y: where to materialise LayerNorm(Z) (or null).
-    const float* ln_u; const float* ln_gamma; const float* ln_beta; void* ln_y; int ldy; float ln_eps;
-};
 
 constexpr int BM = 128, BN = 128, NT = 256;
 __device__ __attribute__((aligned(16))) const uint32_t pa_zero16[4] = {0u, 0u, 0u, 0u};   // source of out-of-range DMA lanes
@@ -89,7 +69,6 @@ template <typename TL> __device__ __forceinline__ int lds_off(int row, int chunk
     return row * TL::RB + (((chunk ^ (row / TL::RPB)) & (TL::NCH - 1)) << 4);
 }
 
-struct Unit { int tile_m, tile_n, b, z, t_begin, t_end; };
 
 template <typename TL>
 __device__ __forceinline__ bool decode_unit(const GemmP& p, int u, Unit& un) {
@@ -1674,12 +1653,6 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
 #undef PA_RD128
 }
 
-// compile-time loop: f(std::integral_constant<int, I>{}) for I in [LO, HI)
-template <int LO, int... I, typename F>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, LO + I>{}), ...); }
-template <int LO, int HI, typename F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl<LO>(f, std::make_integer_sequence<int, (HI > LO ? HI - LO : 0)>{}); }
-
 // -------------------------------------------------------------------------------------------------
 // Wide-tile ring kernel: (64*FM) x (64*FN) x 64 tiles, 2 x 2 waves with FM x FN 32x32 MFMA tiles each, for the large
 // multi-round Linears (N >= 1024).  With FM = 2, FN = 4 (128 x 256) a k-step is 8 MFMAs against 6 fragment reads, so the
@@ -1995,6 +1968,8 @@ __global__ __launch_bounds__(NT, 1) void gemm3w_kernel(GemmP p) {
     }
 #undef PA_RD128O
 }
+
+#include "gemm8.h"
 
 // split-K second pass: sum the slabs and apply the epilogue
 // -------------------------------------------------------------------------------------------------
@@ -2443,6 +2418,27 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     const bool go_skinny = use_skinny && (a->in_dtype == PA_F32 || use_skinny >= 2) && a->a_kcontig && a->b_kcontig && splitk == 1 &&
                            a->batch == 1 && a->M <= skinny_rows && a->K % sk_ch == 0 && !a->aux && a->drop_p == 0.f && !dbg_noglds &&
                            (a->in_dtype == PA_BF16 ? is_aligned<bf16>(a) : is_aligned<float>(a));
+    // eight-wave big-tile kernel (gemm8.h): PA_GEMM_BIG 0 (default) never, 1 plain k-contiguous bf16 Linears of at least
+    // PA_GEMM_BIG_MINM rows - 256 x 256 tiles from N = 1024 on, 256 x 128 tiles below.  Opt-in: level with the kernels below at this
+    // model's shapes, never ahead (profiles/r04_step_floor_probes.txt section 8).
+    static const int use_big = getenv("PA_GEMM_BIG") ? atoi(getenv("PA_GEMM_BIG")) : 0;
+    static const int big_minm = getenv("PA_GEMM_BIG_MINM") ? atoi(getenv("PA_GEMM_BIG_MINM")) : 4096;
+    static const int big_minn = getenv("PA_GEMM_BIG_MINN") ? atoi(getenv("PA_GEMM_BIG_MINN")) : 256;
+    const bool go_big = use_big && !go_skinny && a->in_dtype == PA_BF16 && !dbg_noglds && is_aligned<bf16>(a) && a->a_kcontig && a->b_kcontig &&
+                        splitk == 1 && a->K % 64 == 0 && a->M >= big_minm && a->N >= big_minn;
+    if (go_big) {
+        if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(PA_GEMM_KIND_BIG); if (g_rec && g_rec_group) g_rec_group->push_back(-1); }
+        const bool sq = a->N >= 1024;
+        GemmP pb = pk;
+        pb.tiles_m = (a->M + 255) / 256; pb.tiles_n = (a->N + (sq ? 255 : 127)) / (sq ? 256 : 128);
+        pb.plain_order = pb.tiles_m < 8;
+        pb.tiles_m_pad = pb.plain_order ? pb.tiles_m : (pb.tiles_m + 7) / 8 * 8;
+        pb.units = pb.tiles_m_pad * pb.tiles_n * a->batch;
+        const int gb = pb.units < cus ? pb.units : cus;
+        if (sq) PA_LAUNCH((gemm8_kernel<4, 2, 2, 4, 64, 2>), dim3(gb), dim3(512), 0, st, pb);
+        else PA_LAUNCH((gemm8_kernel<4, 2, 2, 2, 64, 2>), dim3(gb), dim3(512), 0, st, pb);
+        return 0;
+    }
     if (go_skinny) {
         if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(PA_GEMM_KIND_SKINNY); if (g_rec && g_rec_group) g_rec_group->push_back(-1); }
         GemmP ps = pk;

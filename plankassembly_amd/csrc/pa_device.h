@@ -63,7 +63,13 @@ template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
 template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 template <> __device__ __forceinline__ void st4<bf16>(bf16* p, f32x4 v) {
     u32x2 u; u[0] = pack_bf16(v[0], v[1]); u[1] = pack_bf16(v[2], v[3]);
+#ifdef PA_WT_STORES
+    // probe build (-DPA_WT_STORES): write-through stores (relaxed agent-scope atomic store = global_store_dwordx2 ... sc1): the row
+    // leaves for memory while the kernel is still running instead of sitting dirty in L2 until the end-of-kernel write-back
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)u[1] << 32) | u[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     *reinterpret_cast<u32x2*>(p) = u;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -788,6 +788,18 @@ def _gemm_kinds(fn):
     return out, [kinds[i] for i in range(nk)]
 
 
+def test_gemm_eight_wave_big_tiles():
+    """The opt-in eight-wave 256 x 256 / 256 x 128 kernel (PA_GEMM_BIG=1, csrc/gemm8.h) in its own process: every epilogue stage,
+    ragged edge tiles, several units per block, the batched launch; the worker also checks the launches went to that kernel."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gemm_big_worker.py")], cwd=root, capture_output=True, text=True,
+                       env=dict(os.environ, PA_GEMM_BIG="1"), timeout=600)
+    assert r.returncode == 0 and "gemm8 ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(256, 512, 512), (256, 1536, 512), (256, 512, 1024), (256, 514, 512), (250, 1024, 512),
                                    (2, 512, 512), (37, 100, 1536), (512, 96, 2048)])

@@ -21,8 +21,12 @@ def items(K):
     print('    block 0 items (H = steady-state item, c = item at a unit boundary): ' + ' '.join(f'{hot[i]}{st[i + 1] - st[i]}' for i in range(n)), flush=True)
 
 
-def run(M, N, K, res=True, drop=0.0):
+def run(M, N, K, res=True, drop=0.0, alias_a=False):
+    """alias_a: every row of A is the SAME 1 KB row (row stride 0) - the activation operand then lives in L2 like the weight,
+    which separates the HBM latency of the A panel from everything else in the K loop."""
     x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    if alias_a:
+        x = x[:1].expand(M, K)
     w = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
     b = torch.randn(N, device="cuda")
     r = torch.randn(M, N, device="cuda").to(torch.bfloat16) if res else None
@@ -46,7 +50,7 @@ def run(M, N, K, res=True, drop=0.0):
     d = [t[:, i + 1] - t[:, i] for i in range(4)]
     spread = t[:, 0].max() - t[:, 0].min()
     span = t[:, 4].max() - t[:, 0].min()
-    print(f"M {M:5d} N {N:5d} K {K:5d} res {int(res)} drop {drop}: {e0.elapsed_time(e1) / 20 * 1e3:6.1f} us/launch | blocks {len(t)}  setup {d[0].mean():6.0f}  "
+    print(f"M {M:5d} N {N:5d} K {K:5d} res {int(res)} drop {drop}{' A aliased (L2-resident)' if alias_a else ''}: {e0.elapsed_time(e1) / 20 * 1e3:6.1f} us/launch | blocks {len(t)}  setup {d[0].mean():6.0f}  "
           f"first tile {d[1].mean():6.0f}  K loop {d[2].mean():7.0f} ({d[2].mean() / (K // 64):5.0f}/tile)  epilogue {d[3].mean():6.0f} (stores issued after {(t[:, 5] - t[:, 3]).mean():6.0f})  "
           f"block total {(t[:, 4] - t[:, 0]).mean():7.0f}  first entry -> last exit {span}  entry spread {spread}", flush=True)
 
@@ -57,6 +61,13 @@ if os.environ.get("SMALL") == "1":
     run(2048, 1536, 512, res=False)
     run(2048, 1024, 512, res=False, drop=0.2)
     run(256, 512, 512)
+    sys.exit(0)
+if os.environ.get("ALIAS") == "1":
+    for K in (512, 1536):
+        run(7940, 512, K, res=False)
+        items(K)
+        run(7940, 512, K, res=False, alias_a=True)
+        items(K)
     sys.exit(0)
 for K in (512, 1024, 1536):
     run(7940, 512, K)
