@@ -72,6 +72,10 @@ typedef struct {
     int32_t splitk;
     int32_t splitk_defer;   /* 1: only write the f32 slabs to `ws`; the caller reduces them later (pa_splitk_reduce_many) */
     int64_t sBias;          /* batch stride of `bias` in elements (0: one bias for every batch member) */
+    void* C_lp;             /* optional bf16 copy [M][ldc_lp] of an f32 output (out_dtype PA_F32): the next Linear's matrix operand when
+                             * the residual stream is kept in f32 (bf16 greedy decode).  Launches of at most 512 rows that take the
+                             * skinny kernel only (PA_EINVAL otherwise) */
+    int32_t ldc_lp; int32_t pad_lp_;
 } pa_gemm_args;
 int pa_gemm(const pa_gemm_args* a, void* stream);
 /* Leave `n` of the 256 CUs free in every persistent GEMM launch from now on (0 <= n <= 192; 0 restores the full grid): room for
@@ -129,6 +133,10 @@ int pa_gemm_ln_max_rows(void);
 typedef struct {
     const float* u; const float* gamma; const float* beta;
     void* y; int32_t ldy; float eps;
+    /* f32 residual stream (optional; <= 512 rows, K = 512 only - PA_ESHAPE otherwise): `zf` = the f32 rows Z [M][ldzf] of which
+     * `args->A` is the bf16 copy.  The row statistics and the materialised LayerNorm(Z) are then computed from zf, and `y` is
+     * written as f32 when y_f32 != 0. */
+    const float* zf; int32_t ldzf; int32_t y_f32;
 } pa_gemm_norm_ext;
 int pa_ln_fold_weights(void* Wf, float* u, float* v, const float* W, const float* bias, const float* gamma, const float* beta,
                        int32_t N, int32_t K, void* stream);

@@ -32,12 +32,14 @@ class GemmArgs(C.Structure):
                 ("batch", C.c_int32), ("a_kcontig", C.c_int32), ("b_kcontig", C.c_int32),
                 ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("alpha", C.c_float), ("relu", C.c_int32),
                 ("aux_scale", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
-                ("splitk", C.c_int32), ("splitk_defer", C.c_int32), ("sBias", C.c_int64)]
+                ("splitk", C.c_int32), ("splitk_defer", C.c_int32), ("sBias", C.c_int64),
+                ("C_lp", C.c_void_p), ("ldc_lp", C.c_int32), ("pad_lp_", C.c_int32)]
 
 
 class GemmNormExt(C.Structure):
     _fields_ = [("u", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("y", C.c_void_p),
-                ("ldy", C.c_int32), ("eps", C.c_float)]
+                ("ldy", C.c_int32), ("eps", C.c_float),
+                ("zf", C.c_void_p), ("ldzf", C.c_int32), ("y_f32", C.c_int32)]
 
 
 class GemmLnArgs(C.Structure):

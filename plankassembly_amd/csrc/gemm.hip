@@ -2036,6 +2036,22 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
     // LN: column tile tn materialises columns 32 tn .. 32 tn + 31 of LayerNorm(Z) (N >= K is checked by the host)
     const bool write_y = LN && p.ln_y != nullptr && n0 < p.K && em < p.M;
     if (write_y) { gam4 = *reinterpret_cast<const f32x4*>(p.ln_gamma + en); bet4 = *reinterpret_cast<const f32x4*>(p.ln_beta + en); }
+    // f32 residual stream (p.ln_zf): A is only the bf16 copy of the f32 rows Z.  The statistics and LayerNorm(Z) come from the f32
+    // rows, requested here with the other epilogue inputs (older than every DMA): lane -> (row 8w + l / 8, eighth l % 8), elements
+    // 64 j + 8 (l % 8) .. + 7 for j = 0 .. 7 - the elements the bf16 path reads from the resident tile.
+    const bool zf_on = LN && p.ln_zf != nullptr;                        // (kernel-uniform)
+    f32x4 zfr[16], zy4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (LN) {
+        if (zf_on) {
+            const float* zrow = p.ln_zf + (size_t)min(m0 + wave * 8 + (lane >> 3), p.M - 1) * p.ldzf + (lane & 7) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                zfr[2 * j] = *reinterpret_cast<const f32x4*>(zrow + j * 64);
+                zfr[2 * j + 1] = *reinterpret_cast<const f32x4*>(zrow + j * 64 + 4);
+            }
+            if (write_y) zy4 = *reinterpret_cast<const f32x4*>(p.ln_zf + (size_t)em * p.ldzf + en);
+        }
+    }
 
     const char* gA = reinterpret_cast<const char*>(p.A) + (size_t)lane * 16;
     const char* gB = reinterpret_cast<const char*>(p.B) + (size_t)lane * 16;
@@ -2082,26 +2098,36 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
             // elements per lane, two passes over them in registers, three lane exchanges per pass.  Issued between the fragment
             // reads and their use: the MFMAs below do not wait for it.
             const int sr = wave * 8 + (lane >> 3), part = lane & 7;
-            const uint32_t lz = lds0 + (uint32_t)(sr * SK_STRIDE + part * 16);
-            u32x4 zz[8];
-            SK_RD(zz[0], lz, 0);   SK_RD(zz[1], lz, 128); SK_RD(zz[2], lz, 256); SK_RD(zz[3], lz, 384);
-            SK_RD(zz[4], lz, 512); SK_RD(zz[5], lz, 640); SK_RD(zz[6], lz, 768); SK_RD(zz[7], lz, 896);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(zz[0]), "+v"(zz[1]), "+v"(zz[2]), "+v"(zz[3]), "+v"(zz[4]), "+v"(zz[5]), "+v"(zz[6]), "+v"(zz[7]));
-            float s1 = 0.f;
+            float s1 = 0.f, s2 = 0.f, mean;
+            if (zf_on) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < 16; ++j) s1 += (zfr[j][0] + zfr[j][1]) + (zfr[j][2] + zfr[j][3]);
+                s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+                mean = s1 * (1.0f / (float)CH);
 #pragma unroll
-                for (int w = 0; w < 4; ++w) s1 += bf16_lo(zz[j][w]) + bf16_hi(zz[j][w]);
-            s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
-            const float mean = s1 * (1.0f / (float)CH);
-            float s2 = 0.f;
+                for (int j = 0; j < 16; ++j)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+                    for (int w = 0; w < 4; ++w) { const float d0 = zfr[j][w] - mean; s2 += d0 * d0; }
+            } else {
+                const uint32_t lz = lds0 + (uint32_t)(sr * SK_STRIDE + part * 16);
+                u32x4 zz[8];
+                SK_RD(zz[0], lz, 0);   SK_RD(zz[1], lz, 128); SK_RD(zz[2], lz, 256); SK_RD(zz[3], lz, 384);
+                SK_RD(zz[4], lz, 512); SK_RD(zz[5], lz, 640); SK_RD(zz[6], lz, 768); SK_RD(zz[7], lz, 896);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(zz[0]), "+v"(zz[1]), "+v"(zz[2]), "+v"(zz[3]), "+v"(zz[4]), "+v"(zz[5]), "+v"(zz[6]), "+v"(zz[7]));
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const float d0 = bf16_lo(zz[j][w]) - mean, d1 = bf16_hi(zz[j][w]) - mean;
-                    s2 += d0 * d0 + d1 * d1;
-                }
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) s1 += bf16_lo(zz[j][w]) + bf16_hi(zz[j][w]);
+                s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+                mean = s1 * (1.0f / (float)CH);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float d0 = bf16_lo(zz[j][w]) - mean, d1 = bf16_hi(zz[j][w]) - mean;
+                        s2 += d0 * d0 + d1 * d1;
+                    }
+            }
             s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
             if (part == 0) { stats[sr] = mean; stats[32 + sr] = rsqrtf(s2 * (1.0f / (float)CH) + p.ln_eps); }
         }
@@ -2136,11 +2162,17 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
     if constexpr (LN) {
         ln_mean = stats[er]; ln_rstd = stats[32 + er];
         if (write_y) {
-            const u32x2 zq = *reinterpret_cast<const u32x2*>(smem + er * SK_STRIDE + (size_t)en * 2);
+            f32x4 zv;
+            if (zf_on) zv = zy4;
+            else {
+                const u32x2 zq = *reinterpret_cast<const u32x2*>(smem + er * SK_STRIDE + (size_t)en * 2);
+                zv[0] = bf16_lo(zq[0]); zv[1] = bf16_hi(zq[0]); zv[2] = bf16_lo(zq[1]); zv[3] = bf16_hi(zq[1]);
+            }
             f32x4 y;
-            y[0] = (bf16_lo(zq[0]) - ln_mean) * ln_rstd * gam4[0] + bet4[0]; y[1] = (bf16_hi(zq[0]) - ln_mean) * ln_rstd * gam4[1] + bet4[1];
-            y[2] = (bf16_lo(zq[1]) - ln_mean) * ln_rstd * gam4[2] + bet4[2]; y[3] = (bf16_hi(zq[1]) - ln_mean) * ln_rstd * gam4[3] + bet4[3];
-            st4<bf16>(reinterpret_cast<bf16*>(p.ln_y) + (size_t)em * p.ldy + en, y);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (zv[e] - ln_mean) * ln_rstd * gam4[e] + bet4[e];
+            if (p.ln_y_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.ln_y) + (size_t)em * p.ldy + en) = y;
+            else st4<bf16>(reinterpret_cast<bf16*>(p.ln_y) + (size_t)em * p.ldy + en, y);
         }
     }
     __syncthreads();
@@ -2161,12 +2193,14 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
     if (full && p.vec_ok) {
         if (out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = x;
         else st4<bf16>(reinterpret_cast<bf16*>(p.C) + co, x);
+        if (p.c_lp) st4<bf16>(reinterpret_cast<bf16*>(p.c_lp) + (size_t)em * p.ldc_lp + en, x);
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (en + e < p.N) {
                 if (out_f32) reinterpret_cast<float*>(p.C)[co + e] = x[e];
                 else reinterpret_cast<bf16*>(p.C)[co + e] = (bf16)x[e];
+                if (p.c_lp) reinterpret_cast<bf16*>(p.c_lp)[(size_t)em * p.ldc_lp + en + e] = (bf16)x[e];
             }
     }
 }
@@ -2352,6 +2386,8 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     p.drop_seed = a->drop_seed;
     p.out_dtype = a->out_dtype;
     p.ln_u = nullptr; p.ln_gamma = nullptr; p.ln_beta = nullptr; p.ln_y = nullptr; p.ldy = 0; p.ln_eps = 0.f;
+    p.c_lp = a->C_lp; p.ldc_lp = a->ldc_lp; p.ln_zf = nullptr; p.ldzf = 0; p.ln_y_f32 = 0;
+    if (a->C_lp && (a->out_dtype != PA_F32 || a->ldc_lp < a->N || a->ldc_lp % 4 || (reinterpret_cast<uintptr_t>(a->C_lp) & 7))) return PA_EINVAL;
     static const int dbg_bk = getenv("PA_GEMM_BK") ? atoi(getenv("PA_GEMM_BK")) : 64;     // bf16 K tile: 64 or 32
     const bool bk32 = a->in_dtype == PA_BF16 && dbg_bk == 32;
     const int BK = a->in_dtype == PA_BF16 ? (bk32 ? 32 : 64) : 16;
@@ -2439,6 +2475,7 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         else PA_LAUNCH((gemm8_kernel<4, 2, 2, 2, 64, 2>), dim3(gb), dim3(512), 0, st, pb);
         return 0;
     }
+    if (a->C_lp && !go_skinny) return PA_EINVAL;          // the bf16 copy of an f32 output exists in the skinny kernel only
     if (go_skinny) {
         if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(PA_GEMM_KIND_SKINNY); if (g_rec && g_rec_group) g_rec_group->push_back(-1); }
         GemmP ps = pk;
@@ -2541,6 +2578,8 @@ extern "C" int pa_gemm_norm_a(const pa_gemm_args* a, const pa_gemm_norm_ext* x, 
     if (x->y && (!x->gamma || !x->beta || x->ldy < a->K || x->ldy % 4)) return PA_EINVAL;
     if (x->y && (a->N + 63) / 64 * 64 < a->K) return PA_ESHAPE;      // column tile j materialises columns 64 j .. 64 j + 63 of LayerNorm(Z)
     if (!is_aligned<bf16>(a)) return PA_EALIGN;
+    if (x->zf && (x->ldzf < a->K || x->ldzf % 4 || (reinterpret_cast<uintptr_t>(x->zf) & 15))) return PA_EINVAL;
+    if (x->y && x->y_f32 && (reinterpret_cast<uintptr_t>(x->y) & 15)) return PA_EALIGN;
     // <= 512 rows and K = 512: the skinny kernel's form (the Z tile is resident in LDS, the statistics cost no memory round trip)
     static const int sk_on = getenv("PA_GEMM_SKINNY") ? atoi(getenv("PA_GEMM_SKINNY")) : 2;
     static const int sk_rows = getenv("PA_GEMM_SKINNY_ROWS") ? atoi(getenv("PA_GEMM_SKINNY_ROWS")) : 512;
@@ -2557,9 +2596,11 @@ extern "C" int pa_gemm_norm_a(const pa_gemm_args* a, const pa_gemm_norm_ext* x, 
         p.vec_ok = ((reinterpret_cast<uintptr_t>(a->C) % (4 * osz)) == 0 && a->ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(a->bias) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(x->u) & 15) == 0) ? 1 : 0;
         p.ln_u = x->u; p.ln_gamma = x->gamma; p.ln_beta = x->beta; p.ln_y = x->y; p.ldy = x->ldy; p.ln_eps = x->eps;
+        p.ln_zf = x->zf; p.ldzf = x->ldzf; p.ln_y_f32 = x->y_f32;
         PA_LAUNCH((gemm_skinny_kernel<bf16, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
         return 0;
     }
+    if (x->zf || x->y_f32) return PA_ESHAPE;               // the f32-residual form exists in the skinny kernel only
     const int tiles = ((a->M + 63) / 64) * ((a->N + 63) / 64);
     const int cus = cus_for_gemm();
     if (tiles > 2 * cus) return PA_ESHAPE;                 // the row statistics live in registers: one unit per block

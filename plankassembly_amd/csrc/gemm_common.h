@@ -27,6 +27,11 @@ struct GemmP {
     // pre-multiplied by gamma, ln_u[n] = sum_k B[n][k], bias[n] = b[n] + sum_k W[n][k] beta[k]; the kernel computes the row
     // statistics itself and writes  rstd_m (acc - mean_m u_n) + bias_n.  ln_y: where to materialise LayerNorm(Z) (or null).
     const float* ln_u; const float* ln_gamma; const float* ln_beta; void* ln_y; int ldy; float ln_eps;
+    // f32 residual stream beside bf16 matrix operands (gemm_skinny_kernel only; the bf16 greedy-decode step): c_lp = bf16 copy of
+    // an f32 output (the next Linear's MFMA operand); ln_zf = the f32 rows Z behind the bf16 operand A = bf16(Z): the row
+    // statistics and the materialised LayerNorm(Z) come from them, ln_y_f32: ln_y is f32
+    void* c_lp; int ldc_lp;
+    const float* ln_zf; int ldzf; int ln_y_f32;
 };
 
 struct Unit { int tile_m, tile_n, b, z, t_begin, t_end; };

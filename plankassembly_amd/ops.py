@@ -19,7 +19,7 @@ def _f32(*shape, device):
 
 
 def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, residual=None, aux=None, aux_scale=1.0,
-         relu=False, alpha=1.0, drop_p=0.0, drop_seed=0, out_dtype=None, splitk=1, out=None, defer=False):
+         relu=False, alpha=1.0, drop_p=0.0, drop_seed=0, out_dtype=None, splitk=1, out=None, defer=False, out_lp=None):
     """C[b] = epi(alpha * A[b] @ B[b]).  a: [batch?, M, K] (or [K, M] if not a_kcontig);
     b: [batch?, N, K] if b_kcontig (Linear weight layout) else [K, N]."""
     batched = a.dim() == 3
@@ -54,6 +54,8 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, bias=None, residual=None, aux=
     g.in_dtype, g.out_dtype = L.dt(a), L.dt(out)
     g.alpha, g.relu, g.aux_scale = alpha, int(relu), aux_scale
     g.drop_p, g.drop_seed = drop_p, drop_seed
+    if out_lp is not None:                    # bf16 copy of an f32 output (skinny kernel: the f32-residual decode step's form)
+        g.C_lp, g.ldc_lp = out_lp.data_ptr(), out_lp.stride(-2)
     splitk = int(L.lib().pa_gemm_effective_splitk(K, L.dt(a), splitk))       # slabs actually written
     g.splitk = splitk
     ws = None
@@ -218,9 +220,10 @@ def gemm_ln(x, w, gamma, beta, eps, *, bias=None, residual=None, drop_p=0.0, dro
     return z, y, mean, rstd
 
 
-def gemm_norm_a(z, w, bias, gamma, beta, eps, *, relu=False, want_y=True, out_dtype=None):
+def gemm_norm_a(z, w, bias, gamma, beta, eps, *, relu=False, want_y=True, out_dtype=None, zf=None):
     """epi(LayerNorm(z) @ w.T + bias) with the LayerNorm folded into the product (pa_ln_fold_weights + pa_gemm_norm_a; the
-    greedy-decode step's form).  z: bf16 [M, K]; w, bias, gamma, beta: f32 master parameters.  Returns (out, y | None)."""
+    greedy-decode step's form).  z: bf16 [M, K]; w, bias, gamma, beta: f32 master parameters.  Returns (out, y | None).
+    zf: the f32 rows of which z is the bf16 copy - statistics and y (then f32) come from them (f32 residual stream)."""
     M, K = z.shape
     N = w.shape[0]
     dev = z.device
@@ -229,7 +232,7 @@ def gemm_norm_a(z, w, bias, gamma, beta, eps, *, relu=False, want_y=True, out_dt
     L.check(L.lib().pa_ln_fold_weights(L.ptr(wf), L.ptr(u), L.ptr(v), L.ptr(w), L.ptr(bias), L.ptr(gamma), L.ptr(beta), N, K,
                                        L.stream()), "pa_ln_fold_weights")
     out = torch.empty(M, N, dtype=out_dtype or z.dtype, device=dev)
-    y = torch.empty(M, K, dtype=z.dtype, device=dev) if want_y else None
+    y = torch.empty(M, K, dtype=(torch.float32 if zf is not None else z.dtype), device=dev) if want_y else None
     g = L.GemmArgs()
     g.A, g.B, g.C, g.bias = z.data_ptr(), wf.data_ptr(), out.data_ptr(), v.data_ptr()
     g.M, g.N, g.K = M, N, K
@@ -240,6 +243,8 @@ def gemm_norm_a(z, w, bias, gamma, beta, eps, *, relu=False, want_y=True, out_dt
     x = L.GemmNormExt()
     x.u, x.gamma, x.beta = u.data_ptr(), gamma.data_ptr(), beta.data_ptr()
     x.y, x.ldy, x.eps = (y.data_ptr() if want_y else None), K, eps
+    if zf is not None:
+        x.zf, x.ldzf, x.y_f32 = zf.data_ptr(), zf.stride(0), 1
     L.check(L.lib().pa_gemm_norm_a(C.byref(g), C.byref(x), L.stream()), "pa_gemm_norm_a")
     return out, y
 

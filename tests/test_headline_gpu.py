@@ -333,16 +333,17 @@ def test_f32_greedy_decode_batch8_vs_oracle_and_bf16_agreement():
         if t < n:
             print(f"    bf16 row {i}: first mismatch at step {t}: got {int(sb[i, t])}/{int(ab[i, t])} want "
                   f"{int(s_ref[i, t])}/{int(a_ref[i, t])}, oracle relative top-2 margin {float(marg[i, t]):.3e}")
-            assert float(marg[i, t]) < 0.25, "bf16 flipped an argmax that was not close"
+            assert float(marg[i, t]) < 0.05, "bf16 flipped an argmax that was not close"
     agree = sum(first) / (len(first) * n)
     print(f"    bf16 greedy: exact-prefix agreement {agree:.3f} (rows fully exact: {sum(t == n for t in first)}/{len(first)})")
-    # What bf16 can be asked for here: rounding the 512 hidden features (or the head weights) to 8 mantissa bits moves a logit
-    # that is a sum of 512 products of size ~2 by ~2^-9 / sqrt(3) * sqrt(512) * 2 = 0.05, i.e. argmax decisions whose top-2
-    # margin is below ~0.1 are coin tosses and every row of this fixture has some within its first 100 steps (margins printed
-    # above).  The bf16 path is therefore NOT the parity-meeting decode (the f32 path above is); it must only never flip a
-    # decision that is not close, and agree on a visible share of the prefixes.  Which rows survive to the end changes with
-    # any re-ordering of bf16 arithmetic upstream (round 4's encoder attention kernel moved it from 3 rows to 0 or 2).
-    assert agree > 0.15, (agree, first)
+    # The bf16 step keeps its residual stream, LayerNorm statistics and vocabulary head in f32 (csrc/decode.hip `f32res`; weights,
+    # matrix operands, Q / K / V and the caches are bf16): measured on MI355X 6 of these 8 rows exact to the end, the two flips at
+    # oracle margins 1.6e-2 / 1.8e-2 (round 3, everything bf16: 0-3 rows, flips at margins up to 8e-2).  What is left is the rounding
+    # of the matrix operands themselves: tests/bf16_decode_sim.py re-runs the oracle with bf16 roundings inserted where a device
+    # path has them and gets, on 32 rows, 0.40 agreement with everything bf16 and 0.63-0.70 with the f32 residual stream, flips up
+    # to a margin of 3.5e-2 (profiles/r04_bf16_decode_rounding_sim.txt) - so the bf16 path is still NOT the parity-meeting decode
+    # (the f32 path above is); it must never flip a decision that is not close and agree on most of the prefixes.
+    assert agree > 0.5, (agree, first)
 
 
 # ------------------------------------------------------------------------------------------------------------------

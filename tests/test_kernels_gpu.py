@@ -788,6 +788,36 @@ def _gemm_kinds(fn):
     return out, [kinds[i] for i in range(nk)]
 
 
+@pytest.mark.parametrize("M", [256, 250, 37])
+def test_gemm_skinny_f32_residual_stream_forms(M):
+    """The two Linear forms of the bf16 decode step's f32 residual stream (csrc/decode.hip f32res): (a) Z (f32) = A W^T + b + R (f32)
+    with a bf16 copy of Z for the next product; (b) LayerNorm(Zf) W^T + b folded, the product on the bf16 copy, the statistics
+    and the materialised LayerNorm(Zf) (f32) from the f32 rows."""
+    K, N = 512, 1536
+    a, w = rnd(M, K, dtype=torch.bfloat16, seed=71, scale=0.5), rnd(512, K, dtype=torch.bfloat16, seed=72, scale=0.1)
+    bias, res = rnd(512, seed=73), rnd(M, 512, seed=74, scale=3.0)
+    out = torch.empty(M, 512, dtype=torch.float32, device=DEV)
+    lp = torch.full((M, 512), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), residual=res.to(DEV), out=out, out_lp=lp)
+    ref = a.float() @ w.float().t() + bias + res
+    assert rel_err(out, ref) < 1e-5                                        # bf16 operands are exact inputs; f32 accumulate + f32 residual
+    assert torch.equal(lp.cpu(), out.cpu().to(torch.bfloat16))
+    # (b) rows with a large common offset: statistics from the bf16 copy would be visibly off, from the f32 rows they are not
+    zf = rnd(M, K, seed=75, scale=2.0) + 40.0
+    wn, bn = rnd(N, K, seed=76, scale=0.05), rnd(N, seed=77)
+    gamma, beta = 1.0 + 0.1 * rnd(K, seed=78), 0.1 * rnd(K, seed=79)
+    o2, y = ops.gemm_norm_a(zf.to(torch.bfloat16).to(DEV), wn.to(DEV), bn.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, zf=zf.to(DEV))
+    yref = torch.nn.functional.layer_norm(zf, (K,), gamma, beta, 1e-5)
+    assert y.dtype == torch.float32 and float((y.cpu() - yref).abs().max()) < 2e-4      # 40 +- 2 rows: f32 statistics
+    oref = yref @ wn.t() + bn
+    # the product sees bf16(zf): |z| ~ 40 rounds by up to 0.125 against a row spread of 2 - the operand's rounding, not the statistics'
+    assert rel_err(o2, oref) < 0.2 and o2.dtype == torch.bfloat16
+    zc = rnd(M, K, seed=80, scale=2.0)                                     # centred rows: the usual bf16 tolerance
+    o3, y3 = ops.gemm_norm_a(zc.to(torch.bfloat16).to(DEV), wn.to(DEV), bn.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, zf=zc.to(DEV))
+    y3ref = torch.nn.functional.layer_norm(zc, (K,), gamma, beta, 1e-5)
+    assert float((y3.cpu() - y3ref).abs().max()) < 1e-4 and rel_err(o3, y3ref @ wn.t() + bn) < 2.5e-2
+
+
 def test_gemm_eight_wave_big_tiles():
     """The opt-in eight-wave 256 x 256 / 256 x 128 kernel (PA_GEMM_BIG=1, csrc/gemm8.h) in its own process: every epilogue stage,
     ragged edge tiles, several units per block, the batched launch; the worker also checks the launches went to that kernel."""
