@@ -258,10 +258,33 @@ __global__ __launch_bounds__(1024) void group_rows_kernel(GroupTab tab) {
     __syncthreads();
     const int chunk = ((n + 15) / 16 + 63) / 64 * 64;
     const int lo = wave * chunk, hi = min(n, lo + chunk);
-    for (int i0 = lo; i0 < hi; i0 += 64) {
+    // The ids of this lane's tokens are fetched ONCE, all loads in flight together (idx[rowmap[i]] is two dependent round trips;
+    // the two passes below then run from registers).  Up to GR_NIT batches per wave (16 * 64 * GR_NIT = 24 576 tokens per table:
+    // B * S of every shipped config); longer tables re-fetch.  (The launch's ~100 us in the step's kernel trace did not move: it
+    // runs on the prefetch stream beside the step's one-block-per-CU grids and mostly waits for a CU.)
+    constexpr int GR_NIT = 24;
+    int idr[GR_NIT];
+#pragma unroll
+    for (int it = 0; it < GR_NIT; ++it) {
+        const int i = lo + it * 64 + lane;
+        int row;
+        idr[it] = (i < hi) ? group_id(g, i, row) : -1;
+    }
+    auto id_of = [&](int it, int i, int& row) -> int {
+        if (it < GR_NIT) {                      // (row is pure arithmetic on i; only the id needs memory)
+            if (g.kind == 0) row = i;
+            else { const int b = i / (g.T - 1); row = b * g.T + (i - b * (g.T - 1)) + 1; }
+            int v = -1;
+#pragma unroll
+            for (int k = 0; k < GR_NIT; ++k) v = (k == it) ? idr[k] : v;
+            return v;
+        }
+        return i < hi ? group_id(g, i, row) : -1;
+    };
+    for (int i0 = lo, it = 0; i0 < hi; i0 += 64, ++it) {
         const int i = i0 + lane;
         int row;
-        const int id = i < hi ? group_id(g, i, row) : -1;
+        const int id = id_of(it, i, row);
         if (id >= 0 && id < R) atomicAdd(&hist[wave * R + id], 1);
     }
     __syncthreads();
@@ -291,11 +314,11 @@ __global__ __launch_bounds__(1024) void group_rows_kernel(GroupTab tab) {
     if (threadIdx.x == 0) seg[R] = carry;
     __syncthreads();
     for (int r = threadIdx.x; r <= R; r += 1024) g.seg[r] = seg[r];
-    for (int i0 = lo; i0 < hi; i0 += 64) {
+    for (int i0 = lo, it = 0; i0 < hi; i0 += 64, ++it) {
         const int i = i0 + lane;
         int row = 0;
-        int id = i < hi ? group_id(g, i, row) : -1;
-        if (id >= R) id = -1;
+        int id = id_of(it, i, row);
+        if (i >= hi || id >= R) id = -1;
         unsigned long long todo = __ballot(id >= 0);
         while (todo) {
             const int first = __ffsll((long long)todo) - 1;
