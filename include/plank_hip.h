@@ -340,6 +340,16 @@ int pa_attn_bwd(const pa_attn_args* a, void* stream);
  * (dh += ds * w fused into the caller's GEMM epilogue is not possible, so dh_out is written
  * and dw/db accumulated).  `partial`: scratch of pa_layernorm_bwd_nparts(rows) x 2 x d floats.
  */
+/* ACTIVATION: gelu (reference models.py:60-61,66-67 -> torch F.gelu, exact erf form).  The GEMM epilogues are ReLU-only; in GELU
+ * mode the FFN's first Linear writes its pre-activation and these two element-wise launches do the rest:
+ *   pa_gelu_fwd: out[r][c] = keep(seed, r, c) ? gelu(pre[r][c]) / (1 - p) : 0        (may run in place)
+ *   pa_gelu_bwd: dpre[r][c] = dh[r][c] * gelu'(pre[r][c]) * (keep(seed, r, c) ? 1 / (1 - p) : 0)   (dpre may alias dh)
+ * keep = pa_gemm's Linear-output dropout decision for (row r, column c) (csrc/pa_device.h drop_keep_rc), so a step under dropout takes
+ * the same decisions as the fused ReLU epilogue would.  rows x cols elements, row stride ld, cols % 4 == 0, 8 / 16-byte aligned rows. */
+int pa_gelu_fwd(void* out, const void* pre, int64_t rows, int32_t cols, int32_t ld, int32_t dtype, float drop_p, uint32_t drop_seed,
+                void* stream);
+int pa_gelu_bwd(void* dpre, const void* dh, const void* pre, int64_t rows, int32_t cols, int32_t ld, int32_t dtype, float drop_p,
+                uint32_t drop_seed, void* stream);
 int pa_switch_fwd(float* s, const void* h, int32_t dtype, const float* w, const float* b, int64_t rows,
                   int32_t d, void* stream);
 int pa_switch_bwd(void* dh, int32_t accumulate, float* dw, float* db, const float* ds, const void* h,
@@ -398,6 +408,8 @@ typedef struct {
     float dropout;
     int32_t pad, end;
     int32_t dtype;
+    int32_t activation;            /* FFN activation: 1 ReLU (every shipped config), 2 GELU (torch's exact erf form); the reference hands
+                                    * cfg.MODEL.ACTIVATION to nn.TransformerEncoderLayer / DecoderLayer (models.py:60-61,66-67).  0 = 1. */
 } pa_model_cfg;
 typedef struct {
     const int64_t* input_idx[5];   /* input_value, input_pos, input_coord, input_view, input_type (NULL ok) : [B][S] */

@@ -53,6 +53,7 @@ class OracleCfg:
     normalize_before: bool = True
     pad: int = 513
     end: int = 512
+    activation: str = "relu"                 # cfg.MODEL.ACTIVATION, handed to torch's Transformer layers (models.py:60-61,66-67)
 
     @property
     def eps_layer(self) -> float:           # the positional-argument slip
@@ -169,11 +170,14 @@ def embed_output(p, cfg: OracleCfg, output):
 
 
 # ----------------------------------------------------------------------------- layers
-def _relu(relu, key, x):
-    """activation=relu of torch's _ff_block.  ``relu`` (optional, tests only): callable (site key, pre-activation) -> activation,
-    so that a test can evaluate the network on GIVEN ReLU branches (tests/test_headline_gpu.py ForcedBranches: the float64
-    oracle on the branches the f32 device run took - a pre-activation within f32 rounding of zero is a coin toss between
-    precisions, and one flipped unit moves every upstream gradient)."""
+def _act(cfg, relu, key, x):
+    """The `activation` of torch's _ff_block (nn/modules/transformer.py: relu, or gelu = F.gelu in its exact erf form).  ``relu``
+    (optional, tests only, ReLU models): callable (site key, pre-activation) -> activation, so that a test can evaluate the
+    network on GIVEN ReLU branches (tests/test_headline_gpu.py ForcedBranches: the float64 oracle on the branches the f32 device
+    run took - a pre-activation within f32 rounding of zero is a coin toss between precisions, and one flipped unit moves every
+    upstream gradient)."""
+    if cfg.activation == "gelu":
+        return torch.nn.functional.gelu(x)
     return torch.relu(x) if relu is None else relu(key, x)
 
 
@@ -182,7 +186,7 @@ def encoder_layer(x, p, pre, cfg, add_mask, drop=None, relu=None):
     _ff_block: dropout2(linear2(dropout(activation(linear1(x))))))."""
     x = layer_norm(x + _drop(drop, pre + "dropout1", mha(x, x, p, pre + "self_attn.", cfg.n_head, add_mask, drop)),
                    p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.eps_layer)
-    h = _drop(drop, pre + "dropout", _relu(relu, pre + "linear1", linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"])))
+    h = _drop(drop, pre + "dropout", _act(cfg, relu, pre + "linear1", linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"])))
     f = _drop(drop, pre + "dropout2", linear(h, p[pre + "linear2.weight"], p[pre + "linear2.bias"]))
     return layer_norm(x + f, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.eps_layer)
 
@@ -205,7 +209,7 @@ def decoder_layer(x, memory, p, pre, cfg, self_mask, mem_mask, drop=None, relu=N
                    p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.eps_layer)
     x = layer_norm(x + _drop(drop, pre + "dropout2", mha(x, memory, p, pre + "multihead_attn.", cfg.n_head, mem_mask, drop)),
                    p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.eps_layer)
-    h = _drop(drop, pre + "dropout", _relu(relu, pre + "linear1", linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"])))
+    h = _drop(drop, pre + "dropout", _act(cfg, relu, pre + "linear1", linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"])))
     f = _drop(drop, pre + "dropout3", linear(h, p[pre + "linear2.weight"], p[pre + "linear2.bias"]))
     return layer_norm(x + f, p[pre + "norm3.weight"], p[pre + "norm3.bias"], cfg.eps_layer)
 
@@ -274,7 +278,7 @@ def create_dist_eval(p, cfg: OracleCfg, h, eps=1e-6):
 
 # ----------------------------------------------------------------------------- train step
 def train_forward(p, cfg: OracleCfg, batch, return_all=False, drop=None, relu=None):
-    """reference models.py:190-233; dropout-free unless ``drop`` hands in the decisions of every site (_drop); ``relu``: _relu."""
+    """reference models.py:190-233; dropout-free unless ``drop`` hands in the decisions of every site (_drop); ``relu``: _act."""
     memory = encode(p, cfg, batch, drop, relu)
     tgt = embed_output(p, cfg, batch["output_value"][:, :-1])
     hiddens = decode(p, cfg, tgt, memory, batch["input_mask"], batch["output_mask"], drop, relu)
@@ -383,7 +387,7 @@ def greedy_decode_cached(p, cfg: OracleCfg, batch, max_steps=None, early_stop=Tr
             o = (softmax_lastdim(s) @ cv).reshape(B, d)
             o = linear(o, p[pre + "multihead_attn.out_proj.weight"], p[pre + "multihead_attn.out_proj.bias"])
             x = layer_norm(x + o, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.eps_layer)
-            h = torch.relu(linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"]))
+            h = _act(cfg, None, pre + "linear1", linear(x, p[pre + "linear1.weight"], p[pre + "linear1.bias"]))
             f = linear(h, p[pre + "linear2.weight"], p[pre + "linear2.bias"])
             x = layer_norm(x + f, p[pre + "norm3.weight"], p[pre + "norm3.bias"], cfg.eps_layer)
         x = layer_norm(x, p["decoder.norm.weight"], p["decoder.norm.bias"], 1e-5)

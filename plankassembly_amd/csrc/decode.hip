@@ -490,6 +490,10 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
     auto PF = [&](int i) { return (const float*)m->pf[i]; };
     auto PL = [&](int i) { return (const void*)m->pl[i]; };
     void* x = L->x;
+    // FFN activation: ReLU rides in the first Linear's epilogue (relu flag); ACTIVATION gelu is a launch of its own behind it
+    const bool gelu = c.activation == 2;
+    const int act = gelu ? 0 : 1;
+    auto gelu_ff = [&]() -> int { return gelu ? pa_gelu_fwd(L->ff, L->ff, B, ff, ff, c.dtype, 0.f, 0, st) : 0; };
     const int n_parts = 2 * c.n_dec + 1;
     if (part < 0 || part >= n_parts) return PA_EINVAL;
     auto fence_in = [&]() -> int { if (wait_ev) { hipError_t e = hipStreamWaitEvent(s, wait_ev, 0); if (e != hipSuccess) return (int)e; } return 0; };
@@ -511,7 +515,8 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
             const int j = part / 2 - 1, pb = m->dec_base(j);
             RC(linear_res32(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), yf, z2f, L->z2b, B, d, d, st));
             RC(linear_norm_a32(m, L->z2b, z2f, L->fw[2][j], L->fu[2][j], L->fv[2][j], PF(pb + D_N2_W), PF(pb + D_N2_B), c.eps_layer, xf,
-                               L->ff, ff, B, ff, d, 1, st));
+                               L->ff, ff, B, ff, d, act, st));
+            RC(gelu_ff());
             RC(linear_res32(m, L->ff, PL(pb + D_L2_W), PF(pb + D_L2_B), xf, zf, L->zb, B, d, ff, st));
             if (part == n_parts - 1)
                 RC(pa_layernorm_fwd(xf, zf, PF(pb + D_N3_W), PF(pb + D_N3_B), L->mean, L->rstd, B, d, c.eps_layer, PA_F32, st));
@@ -566,13 +571,15 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
             // z2 = ao Wo^T + b + y1;  ff = relu(norm2(z2) W1^T + b1), y2 -> x;  z3 = ff W2^T + b2 + y2 -> z
             RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z2, d, B, d, d, 0, L->y, -1, st));
             RC(linear_norm_a(m, L->z2, L->fw[2][j], L->fu[2][j], L->fv[2][j], PF(pb + D_N2_W), PF(pb + D_N2_B), c.eps_layer, L->x,
-                             L->ff, ff, B, ff, d, 1, st));
+                             L->ff, ff, B, ff, d, act, st));
+            RC(gelu_ff());
             RC(linear(m, L->ff, PL(pb + D_L2_W), PF(pb + D_L2_B), L->z, d, B, d, ff, 0, L->x, -1, st));
             if (part == n_parts - 1)          // the last layer's norm3 has no Linear behind it: explicit
                 RC(pa_layernorm_fwd(L->x, L->z, PF(pb + D_N3_W), PF(pb + D_N3_B), L->mean, L->rstd, B, d, c.eps_layer, c.dtype, st));
         } else {
             RC(linear_ln(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->y, L->z, L->x, PF(pb + D_N2_W), PF(pb + D_N2_B), c.eps_layer, B, d, st));
-            RC(linear(m, L->x, PL(pb + D_L1_W), PF(pb + D_L1_B), L->ff, ff, B, ff, d, 1, nullptr, -1, st));
+            RC(linear(m, L->x, PL(pb + D_L1_W), PF(pb + D_L1_B), L->ff, ff, B, ff, d, act, nullptr, -1, st));
+            RC(gelu_ff());
             RC(linear_ln(m, L->ff, PL(pb + D_L2_W), PF(pb + D_L2_B), L->x, L->z, L->x, PF(pb + D_N3_W), PF(pb + D_N3_B), c.eps_layer, B, ff, st));
         }
     }

@@ -57,6 +57,7 @@ struct pa_model {
     float* stats = nullptr;
     // backward temporaries
     void *gA, *gB, *gC, *gD, *gE, *gF, *gQ3, *gKV, *dmem, *dvlog, *dplog; float *dsw, *delta, *partial, *splitws;
+    void* gPre = nullptr;                        // ACTIVATION gelu: the FFN pre-activation, recomputed by the backward pass (rows x d_ff)
     size_t splitws_floats = 0;
     void* gBs[3] = {nullptr, nullptr, nullptr}; void* gCs[3] = {nullptr, nullptr, nullptr};   // per-site LN-backward outputs (ffn, cross, self)
     float* lnp[3] = {nullptr, nullptr, nullptr}; pa_ln_finish_desc lnq[PA_MAX_LN_FINISH]; int nlnq = 0;   // queued LayerNorm-backward finishes

@@ -996,6 +996,58 @@ extern "C" int pa_layernorm_bwd(void* dz, void* ddrop, const void* dy, const voi
     return pa_layernorm_finish_many(&fd, 1, d, stream);
 }
 
+// ---- ACTIVATION: gelu (element-wise; include/plank_hip.h pa_gelu_fwd / pa_gelu_bwd) -----------------------------------------
+namespace {
+__device__ __forceinline__ float gelu_f(float y) { return 0.5f * y * (1.0f + erff(y * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {       // Phi(x) + x phi(x)
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void gelu_kernel(T* out, const T* dh, const T* pre, int64_t rows, int cols, int ld, uint32_t thr,
+                                                   float scale, uint32_t seed) {
+    const int vec = cols >> 2;
+    const int64_t total = rows * vec;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / vec;
+        const int c = (int)(e - r * vec) << 2;
+        const f32x4 x = ld4<T>(pre + r * ld + c);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (BWD) g = ld4<T>(dh + r * ld + c);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v = BWD ? g[k] * gelu_grad_f(x[k]) : gelu_f(x[k]);
+            o[k] = (thr == 0u || drop_keep_rc(seed, (uint32_t)r, (uint32_t)(c + k), thr)) ? v * scale : 0.f;
+        }
+        st4<T>(out + r * ld + c, o);
+    }
+}
+template <bool BWD>
+int gelu_launch(void* out, const void* dh, const void* pre, int64_t rows, int32_t cols, int32_t ld, int32_t dtype, float drop_p,
+                uint32_t seed, void* stream) {
+    if (!out || !pre || (BWD && !dh) || rows <= 0 || cols <= 0 || (cols & 3) || ld < cols || (ld & 3)) return PA_EINVAL;
+    if (dtype != PA_BF16 && dtype != PA_F32) return PA_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f) return PA_EINVAL;
+    const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);         // as pa_gemm: keep <=> 32-bit product >= thr
+    const float scale = (float)(1.0 / (1.0 - (double)thr / 4294967296.0));
+    const int64_t total = rows * (cols >> 2);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == PA_BF16)
+        PA_LAUNCH((gelu_kernel<bf16, BWD>), dim3(grid), dim3(256), 0, ST(stream), (bf16*)out, (const bf16*)dh, (const bf16*)pre, rows, cols, ld, thr, scale, seed);
+    else
+        PA_LAUNCH((gelu_kernel<float, BWD>), dim3(grid), dim3(256), 0, ST(stream), (float*)out, (const float*)dh, (const float*)pre, rows, cols, ld, thr, scale, seed);
+    return 0;
+}
+}  // namespace
+extern "C" int pa_gelu_fwd(void* out, const void* pre, int64_t rows, int32_t cols, int32_t ld, int32_t dtype, float drop_p, uint32_t drop_seed,
+                           void* stream) {
+    return gelu_launch<false>(out, nullptr, pre, rows, cols, ld, dtype, drop_p, drop_seed, stream);
+}
+extern "C" int pa_gelu_bwd(void* dpre, const void* dh, const void* pre, int64_t rows, int32_t cols, int32_t ld, int32_t dtype, float drop_p,
+                           uint32_t drop_seed, void* stream) {
+    return gelu_launch<true>(dpre, dh, pre, rows, cols, ld, dtype, drop_p, drop_seed, stream);
+}
+
 extern "C" int pa_switch_fwd(float* s, const void* h, int32_t dtype, const float* w, const float* b, int64_t rows,
                              int32_t d, void* stream) {
     if (!s || !h || !w || !b || rows <= 0 || (d & 3)) return PA_EINVAL;

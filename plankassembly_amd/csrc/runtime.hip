@@ -20,6 +20,17 @@ namespace {
 struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
     pa_model* m; void* st;
     int dt() const { return m->cfg.dtype; }
+    bool gelu() const { return m->cfg.activation == 2; }
+    // hidden = drop(activation(A W1^T + b1)): the FFN's first Linear.  ReLU: one launch (activation and dropout in the GEMM epilogue).
+    // GELU (ACTIVATION: gelu - no shipped config; reference models.py:60-61,66-67): the Linear writes the pre-activation and
+    // pa_gelu_fwd turns it into drop(gelu(.)) in place - the GEMM epilogues stay ReLU-only (erf in every epilogue variant
+    // doubled the library and touched the register budgets of the benchmarked kernels).
+    int ffn1(const void* A, const void* W, const float* bias, void* hidden, int rows, float drop_p, uint32_t seed) const {
+        const int d = m->cfg.d_model, ff = m->cfg.d_ff;
+        if (!gelu()) return linear(A, d, W, bias, hidden, ff, rows, ff, d, 1, drop_p, seed);
+        RC(linear(A, d, W, bias, hidden, ff, rows, ff, d, 0));
+        return pa_gelu_fwd(hidden, hidden, rows, ff, ff, dt(), drop_p, seed, st);
+    }
 
     // C[M,N] = epi(A[M,K] x W^T) with W a torch Linear weight [N][K]
     int linear(const void* A, int lda, const void* W, const float* bias, void* Cout, int ldc, int M, int N, int K,
@@ -209,6 +220,7 @@ size_t pa_train_layout(pa_model* m, char* base, int B, int S, int T) {
     m->gBs[0] = m->gB; m->gCs[0] = m->gC;
     for (int s_ = 1; s_ < 3; ++s_) { m->gBs[s_] = a.take(R * d * e); m->gCs[s_] = a.take(R * d * e); }
     m->gE = a.take(R * d * e); m->gF = a.take(R * ff * e); m->gQ3 = a.take(R * 3 * d * e);
+    m->gPre = c.activation == 2 ? a.take(R * ff * e) : nullptr;
     m->gKV = a.take(BS * 2 * d * e); m->dmem = a.take(BS * d * e);
     m->gKV_all = a.take(BS * 2 * d * e * (c.n_dec > 0 ? c.n_dec : 1));     // d(K|V) of every decoder layer side by side (packed K/V shadow mode)
     {   // parity set 1 (set 0 = the buffers above)
@@ -267,7 +279,7 @@ int pa_train_forward_impl(pa_model* m, void* st) {
                   in_mask, S, S, 0, p, site_seed(m->seed, 8 * i + 0), nullptr, nullptr, 0, nullptr, nullptr, 0, cu, cu));
         RC(k.linear(t.o, d, PL(pb + E_OUT_W), PF(pb + E_OUT_B), t.z1, d, BS, d, d, 0, p, site_seed(m->seed, 8 * i + 1), m->X[i], d));
         RC(k.ln_fwd(t.y1, t.z1, PF(pb + E_N1_W), PF(pb + E_N1_B), t.m1, t.r1, BS, c.eps_layer));
-        RC(k.linear(t.y1, d, PL(pb + E_L1_W), PF(pb + E_L1_B), t.hff, ff, BS, ff, d, 1, p, site_seed(m->seed, 8 * i + 2)));
+        RC(k.ffn1(t.y1, PL(pb + E_L1_W), PF(pb + E_L1_B), t.hff, BS, p, site_seed(m->seed, 8 * i + 2)));
         RC(k.linear(t.hff, ff, PL(pb + E_L2_W), PF(pb + E_L2_B), t.z2, d, BS, d, ff, 0, p, site_seed(m->seed, 8 * i + 3), t.y1, d));
         RC(k.ln_fwd(m->X[i + 1], t.z2, PF(pb + E_N2_W), PF(pb + E_N2_B), t.m2, t.r2, BS, c.eps_layer));
     }
@@ -323,7 +335,7 @@ int pa_train_forward_impl(pa_model* m, void* st) {
                   site_seed(m->seed, sb + 2), nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, cu));
         RC(k.linear_ln(t.o_ca, d, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), t.y1, t.z2, t.y2, PF(pb + D_N2_W), PF(pb + D_N2_B),
                        t.m2, t.r2, BT, d, p, site_seed(m->seed, sb + 3), c.eps_layer));
-        RC(k.linear(t.y2, d, PL(pb + D_L1_W), PF(pb + D_L1_B), t.hff, ff, BT, ff, d, 1, p, site_seed(m->seed, sb + 4)));
+        RC(k.ffn1(t.y2, PL(pb + D_L1_W), PF(pb + D_L1_B), t.hff, BT, p, site_seed(m->seed, sb + 4)));
         RC(k.linear_ln(t.hff, ff, PL(pb + D_L2_W), PF(pb + D_L2_B), t.y2, t.z3, m->Y[i + 1], PF(pb + D_N3_W), PF(pb + D_N3_B),
                        t.m3, t.r3, BT, ff, p, site_seed(m->seed, sb + 5), c.eps_layer));
     }
@@ -400,12 +412,20 @@ int bwd_ffn(pa_model* m, Ctx& k, int rows, const void* z, const float* mean, con
     const int d = c.d_model, ff = c.d_ff;
     const float p = m->p_drop;
     auto G = [&](int i) { return (float*)m->gr[i]; };
-    (void)seed_inner;
     void* ddrop = p > 0.f ? gC : gB;
     RC(k.ln_bwd(gB, p > 0.f ? gC : nullptr, m->gA, z, (const float*)m->pf[nw], mean, rstd, G(nw), G(nw + 1),
                 G(w2 + 1), rows, p, seed_out));
     RC(k.linear_dw(ddrop, d, hff, ff, G(w2), nullptr, rows, d, ff));
-    RC(k.linear_dx(ddrop, d, m->pl[w2], ff, m->gF, ff, rows, d, ff, nullptr, 0, hff, ff, 1.0f / (1.0f - p), m->plT[w2], d));
+    if (c.activation == 2) {
+        // GELU: d pre = (dY W2) * gelu'(pre) * keep / (1 - p).  The forward keeps only drop(gelu(pre)) (linear2's operand), so the
+        // pre-activation y W1^T + b1 is recomputed here (one more Linear per FFN in this mode; ReLU reads its gate off the saved hidden
+        // rows), and pa_gelu_bwd re-applies the FFN1 dropout decisions - a pure function of (site seed, row, column).
+        RC(k.linear(yin, d, m->pl[w1], (const float*)m->pf[w1 + 1], m->gPre, ff, rows, ff, d, 0));
+        RC(k.linear_dx(ddrop, d, m->pl[w2], ff, m->gF, ff, rows, d, ff, nullptr, 0, nullptr, 0, 1.f, m->plT[w2], d));
+        RC(pa_gelu_bwd(m->gF, m->gF, m->gPre, rows, ff, ff, c.dtype, p, seed_inner, k.st));
+    } else {
+        RC(k.linear_dx(ddrop, d, m->pl[w2], ff, m->gF, ff, rows, d, ff, nullptr, 0, hff, ff, 1.0f / (1.0f - p), m->plT[w2], d));
+    }
     RC(k.linear_dw(m->gF, ff, yin, d, G(w1), G(w1 + 1), rows, ff, d));
     RC(k.linear_dx(m->gF, ff, m->pl[w1], d, m->gA, d, rows, ff, d, gB, d, nullptr, 0, 1.f, m->plT[w1], ff));
     return 0;
@@ -679,6 +699,7 @@ extern "C" int pa_model_create(const pa_model_cfg* cfg, pa_model** out) {
     if (cfg->d_model % 8 || cfg->d_ff % 8) return PA_ESHAPE;
     if (cfg->dtype != PA_F32 && cfg->dtype != PA_BF16) return PA_EINVAL;
     if (cfg->dropout < 0.f || cfg->dropout >= 1.f) return PA_EINVAL;
+    if (cfg->activation < 0 || cfg->activation > 2) return PA_EINVAL;
     pa_model* m = new (std::nothrow) pa_model();
     if (!m) return PA_EINVAL;
     m->cfg = *cfg;

@@ -38,7 +38,8 @@ class _ModelCfg(C.Structure):
     _fields_ = [("d_model", C.c_int32), ("n_head", C.c_int32), ("d_ff", C.c_int32), ("n_enc", C.c_int32),
                 ("n_dec", C.c_int32), ("vocab", C.c_int32), ("out_dof", C.c_int32), ("in_table_rows", C.c_int32 * 5),
                 ("eps_layer", C.c_float), ("eps_final", C.c_float), ("has_enc_norm", C.c_int32),
-                ("dropout", C.c_float), ("pad", C.c_int32), ("end", C.c_int32), ("dtype", C.c_int32)]
+                ("dropout", C.c_float), ("pad", C.c_int32), ("end", C.c_int32), ("dtype", C.c_int32),
+                ("activation", C.c_int32)]
 
 
 class _TrDesc(C.Structure):
@@ -131,8 +132,10 @@ class PlankModel(nn.Module):
                  num_input_dof=4, num_output_dof=6, max_input_length=400, max_output_length=128, vocab_size=514,
                  token=None, compute_dtype=None):
         super().__init__()
-        if activation != "relu":
-            raise ValueError("only ACTIVATION: relu is implemented (all reference configs use it)")
+        # the reference hands the string to torch's Transformer layers (models.py:60-61,66-67), which take "relu" or "gelu"
+        if activation not in ("relu", "gelu"):
+            raise ValueError(f"ACTIVATION must be 'relu' or 'gelu' (torch's _get_activation_fn), got {activation!r}")
+        self.activation = activation
         # run the encoder on the valid (non-PAD) rows only; PLANK_UNPAD=0 keeps the dense layout
         self.unpad = os.environ.get("PLANK_UNPAD", "1") != "0"
         compute_dtype = compute_dtype or os.environ.get("PLANK_COMPUTE_DTYPE", "f32")
@@ -345,6 +348,9 @@ class PlankModel(nn.Module):
     def _pa_dtype(self):
         return L.PA_BF16 if self.compute_dtype == "bf16" else L.PA_F32
 
+    def _pa_activation(self):
+        return {"relu": 1, "gelu": 2}[self.activation]
+
     def _ensure_handle(self):
         self._require_gpu()
         if self._handle is not None:
@@ -353,7 +359,7 @@ class PlankModel(nn.Module):
         cfg = _ModelCfg(self.num_model, self.num_head, self.num_feedforward, self.num_encoder_layers,
                         self.num_decoder_layers, self.vocab_size, self.num_output_dof, rows, self.eps_layer, 1e-5,
                         int(self.has_enc_norm), self.dropout, int(self.token.PAD), int(self.token.END),
-                        self._pa_dtype())
+                        self._pa_dtype(), self._pa_activation())
         h = C.c_void_p()
         L.check(L.lib().pa_model_create(C.byref(cfg), C.byref(h)), "pa_model_create")
         self._handle = h
@@ -367,7 +373,8 @@ class PlankModel(nn.Module):
         rows = (C.c_int32 * 5)(*[self._shapes[f"input_embeddings.{k}.weight"][0] for k in INPUT_KEYS])
         cfg = _ModelCfg(self.num_model, self.num_head, self.num_feedforward, self.num_encoder_layers,
                         self.num_decoder_layers, self.vocab_size, self.num_output_dof, rows, self.eps_layer, 1e-5,
-                        int(self.has_enc_norm), self.dropout, int(self.token.PAD), int(self.token.END), self._pa_dtype())
+                        int(self.has_enc_norm), self.dropout, int(self.token.PAD), int(self.token.END), self._pa_dtype(),
+                        self._pa_activation())
         h = C.c_void_p()
         L.check(L.lib().pa_model_create(C.byref(cfg), C.byref(h)), "pa_model_create")
         pf = self._ptr_table(self._flat, 4)

@@ -16,6 +16,7 @@ L2 norm, sum and leading slice; for the headline case additionally the greedy to
   fixture_t1024.npz     S=1024, T=1024 (MAX_OUTPUT_LENGTH 1024), B=2 train; B=2 greedy decode of ALL 1024 steps (END
                         logit suppressed) by the reference's own O(T^2) loop - ~35 TFLOP per sequence, minutes
   fixture_live.npz      d=64 fixture config, untrained seeded weights (loss ~ log 514): all gradients
+  fixture_eps0.npz      NORMALIZE_BEFORE False;   fixture_gelu.npz  ACTIVATION gelu (train step, all gradients, greedy decode)
 """
 import os
 import sys
@@ -42,7 +43,7 @@ TOKEN = types.SimpleNamespace(END=512, PAD=513)
 
 
 def ref_model(c):
-    m = PlankModel(c["d"], c["h"], c["ff"], 0.0, "relu", c.get("normalize_before", True), c["ne"], c["nd"], 3, 2, 4, 6,
+    m = PlankModel(c["d"], c["h"], c["ff"], 0.0, c.get("activation", "relu"), c.get("normalize_before", True), c["ne"], c["nd"], 3, 2, 4, 6,
                    c["max_in"], c["max_out"], 514, TOKEN)
     sd = seeded_state_dict(((k, v.shape) for k, v in m.state_dict().items()), c["wseed"], c["gains"])
     if c.get("no_end"):
@@ -129,7 +130,7 @@ def main():
             with torch.no_grad():
                 ev = m(db)                                     # the reference's own O(T^2) eval loop
             cfg = O.OracleCfg(d_model=c["d"], n_head=c["h"], d_ff=c["ff"], n_enc=c["ne"], n_dec=c["nd"],
-                              max_input_length=c["max_in"], max_output_length=c["max_out"])
+                              max_input_length=c["max_in"], max_output_length=c["max_out"], activation=c.get("activation", "relu"))
             with torch.no_grad():
                 s2, a2, marg = O.greedy_decode_cached(sd, cfg, db, early_stop=True, return_margins=True)
             assert torch.equal(ev["samples"], s2) and torch.equal(ev["attach"], a2), "oracle decode != reference decode"

@@ -43,6 +43,10 @@ CASES = {
     # surface.  Larger LayerNorm inputs than `live` so that eps = 0 vs 1 is far outside the tolerance.
     "eps0": dict(d=64, h=4, ff=128, ne=2, nd=2, gains={}, max_in=65, max_out=36, B=4, wseed=5, bseed=2023,
                  lines=(3, 15), planks=(2, 5), with_type=True, all_grads=True, normalize_before=False),
+    # ACTIVATION: gelu (reference models.py:60-61,66-67 hand cfg.MODEL.ACTIVATION to torch's Transformer layers; no shipped config
+    # uses it): train step with every gradient + a greedy decode, GELU in torch's exact erf form
+    "gelu": dict(d=64, h=4, ff=128, ne=2, nd=2, gains=GAINS, max_in=65, max_out=36, B=4, wseed=7, bseed=2024,
+                 lines=(3, 15), planks=(2, 5), with_type=True, all_grads=True, activation="gelu", decode_b=4, decode_seed=8),
 }
 
 
@@ -87,7 +91,7 @@ def case_shapes(c):
     tests/test_model_surface.py pins to the reference's key names, shapes and order)."""
     import types
     from plankassembly_amd.models import PlankModel
-    m = PlankModel(c["d"], c["h"], c["ff"], 0.0, "relu", c.get("normalize_before", True), c["ne"], c["nd"], 3, 2, 4, 6,
+    m = PlankModel(c["d"], c["h"], c["ff"], 0.0, c.get("activation", "relu"), c.get("normalize_before", True), c["ne"], c["nd"], 3, 2, 4, 6,
                    c["max_in"], c["max_out"], 514, types.SimpleNamespace(END=512, PAD=513))
     return [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
 
@@ -109,7 +113,7 @@ def case_oracle_cfg(c):
     from oracle import plank_oracle as O
     return O.OracleCfg(d_model=c["d"], n_head=c["h"], d_ff=c["ff"], n_enc=c["ne"], n_dec=c["nd"],
                        max_input_length=c["max_in"], max_output_length=c["max_out"],
-                       normalize_before=c.get("normalize_before", True))
+                       normalize_before=c.get("normalize_before", True), activation=c.get("activation", "relu"))
 
 
 def load_large(name):

@@ -25,13 +25,10 @@ TOKEN = types.SimpleNamespace(END=512, PAD=513)
 _oracle_cache = {}
 
 
-_oracle_cache = {}
-
-
 def hip_model(c, dtype, sd, dropout=0.0):
     from plankassembly_amd.models import PlankModel
-    m = PlankModel(c["d"], c["h"], c["ff"], dropout, "relu", c.get("normalize_before", True), c["ne"], c["nd"], 3, 2, 4, 6,
-                   c["max_in"], c["max_out"], 514, TOKEN, compute_dtype=dtype)
+    m = PlankModel(c["d"], c["h"], c["ff"], dropout, c.get("activation", "relu"), c.get("normalize_before", True), c["ne"], c["nd"],
+                   3, 2, 4, 6, c["max_in"], c["max_out"], 514, TOKEN, compute_dtype=dtype)
     m.load_state_dict(sd)
     return m.cuda()
 
@@ -129,8 +126,9 @@ def check_golden_grads(name, g, grads):
 def f32_gate(name, c, sd, batch, m, out, mem, hid, grads, drop=None, g=None, keep=None):
     """The whole f32 gate of one step: loss / memory / hiddens within 1e-4 and every gradient within the north-star bound of the
     float64 oracle on the device's ReLU branches; with fixture `g` also the real reference's own vectors."""
-    fb = ForcedBranches(m, batch)
-    ref, r64 = oracle_f64(c, sd, batch, drop=drop, relu=fb)
+    gelu = c.get("activation", "relu") == "gelu"           # smooth activation: no branches to take from the device
+    fb = ForcedBranches(m, batch) if not gelu else types.SimpleNamespace(sites=c["ne"] + c["nd"], flips=0)
+    ref, r64 = oracle_f64(c, sd, batch, drop=drop, relu=None if gelu else fb)
     if keep is not None:
         keep[0][keep[1]] = (c, sd, batch, ref, r64)
     assert fb.sites == c["ne"] + c["nd"]
@@ -167,7 +165,7 @@ def run_hip_train(m, batch, prepared=True):
     return out, mem, hid, grads
 
 
-@pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "eps0", "t1024"])
+@pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "eps0", "gelu", "t1024"])
 def test_f32_train_step_matches_reference_and_oracle(name):
     c = LC.CASES[name]
     g = LC.load_large(name)
@@ -203,7 +201,7 @@ def test_f32_sideface_full_batch_64():
     f32_gate("sideface-64", c, sd, batch, m, out, mem, hid, grads)
 
 
-@pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "t1024"])
+@pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "gelu", "t1024"])
 def test_bf16_train_step_per_tensor(name):
     """The benchmarked bf16 path against the f32 oracle, tensor by tensor: cosine and relative L2 of every gradient
     (weighted summary printed), loss, memory and hiddens."""
@@ -242,7 +240,8 @@ def test_bf16_train_step_per_tensor(name):
         assert rl2 < (0.15 if big else 0.5), (k, cos, rl2, nr / tot)
 
 
-@pytest.mark.parametrize("name,dtype", [("headline", "f32"), ("headline", "bf16"), ("sideface", "f32"), ("live", "f32")])
+@pytest.mark.parametrize("name,dtype", [("headline", "f32"), ("headline", "bf16"), ("sideface", "f32"), ("live", "f32"), ("gelu", "f32"),
+                                        ("gelu", "bf16")])
 def test_train_step_under_dropout_matches_oracle_given_the_same_decisions(name, dtype):
     """The benchmarked mode is dropout 0.2.  Every dropout decision of the HIP step is a pure function of (step seed, site,
     element index); tests/dropout_masks.py restates those functions in numpy (pinned against the kernels at op level in
@@ -308,6 +307,20 @@ def test_f32_greedy_decode_token_exact_at_headline_shape(graph):
     s, a = _decode(m, db, use_graph=graph)
     assert np.array_equal(s.numpy(), g["d::samples"]), "greedy tokens differ from the reference's"
     assert np.array_equal(a.numpy(), g["d::attach"])
+
+
+def test_gelu_greedy_decode_matches_the_reference_tokens():
+    """ACTIVATION: gelu through the decode step (the FFN's activation in the step's Linears): f32 tokens / attach equal the real
+    reference's own eval loop (fixture_gelu.npz d::*), eagerly and under graph replay; the bf16 step runs and agrees on a prefix."""
+    c = LC.CASES["gelu"]
+    g = LC.load_large("gelu")
+    sd, db = LC.case_state_dict(c), LC.case_batch(c, decode=True)
+    for graph in (False, True):
+        s, a = _decode(hip_model(c, "f32", sd), db, use_graph=graph)
+        assert np.array_equal(s.numpy(), g["d::samples"]) and np.array_equal(a.numpy(), g["d::attach"])
+    sb, ab = _decode(hip_model(c, "bf16", sd), db)
+    n = min(sb.shape[1], g["d::samples"].shape[1])
+    assert np.array_equal(sb.numpy()[:, :4], g["d::samples"][:, :4])
 
 
 def test_f32_greedy_decode_batch8_vs_oracle_and_bf16_agreement():

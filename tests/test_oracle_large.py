@@ -19,7 +19,7 @@ def _run_train(c):
     return sd, batch, out, grads
 
 
-@pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "eps0", "t1024"])
+@pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "eps0", "gelu", "t1024"])
 def test_oracle_float64_matches_the_reference_module_in_float64(name):
     """The GPU gate compares the f32 HIP path with the oracle evaluated in float64 (tests/test_headline_gpu.py oracle_f64).
     That evaluation is pinned here against the REAL reference module run in float64 (fixture entries g64::*): in double
@@ -47,7 +47,7 @@ def test_oracle_float64_matches_the_reference_module_in_float64(name):
         assert abs(float(gr.norm()) - n_ref) <= 1e-12 + 1e-8 * n_ref, (k, float(gr.norm()), n_ref)
 
 
-@pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "eps0", "t1024"])
+@pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "eps0", "gelu", "t1024"])
 def test_oracle_train_matches_reference_at_large_shapes(name):
     c = LC.CASES[name]
     g = LC.load_large(name)
