@@ -1159,6 +1159,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
     // Prefetch of the first unit's residual / gate tiles (bf16, vector path).  Issued BEFORE the first DMA instruction: loads
     // return in order, so the hand-counted `vmcnt` waits of the K loop (which count DMA instructions only) stay exact - these
     // loads are older than every DMA and are retired by the first of those waits, together with the first K tile.
+#ifndef PA_RING_NO_PRE
     if constexpr (!GROUP) {
         const int nw0 = cun.tile_n * BN + wn * 64;
         if (pc.splitk <= 1 && pc.vec_ok && nw0 + 64 <= pc.N && pc.out_dtype != PA_F32 && (pc.R != nullptr || pc.aux != nullptr)) {
@@ -1174,6 +1175,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
                 }
         }
     }
+#endif
     int pending = 0;                            // items issued and not yet finished by the MFMAs
     auto issue = [&]() {
         DMA(fetch(sd));
