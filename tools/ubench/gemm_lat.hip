@@ -1,6 +1,6 @@
 // Back-to-back launch latency of pa_gemm for small shapes (no instrumentation).  Build:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I../../plankassembly_amd/csrc gemm_lat.hip -o gemm_lat
-// Usage: gemm_lat M N K [a_kc b_kc splitk]
+// Usage: gemm_lat M N K [a_kc b_kc splitk res]      (res 1: bf16 residual added in the epilogue)
 #include "../../plankassembly_amd/csrc/gemm.hip"
 #include <stdio.h>
 #include <string.h>
@@ -9,6 +9,7 @@
 int main(int argc, char** argv) {
     int M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]);
     int akc = argc > 4 ? atoi(argv[4]) : 1, bkc = argc > 5 ? atoi(argv[5]) : 1, sk = argc > 6 ? atoi(argv[6]) : 1;
+    const int res = argc > 7 ? atoi(argv[7]) : 0;
     void *A, *B, *C, *ws; float* bias;
     (void)hipMalloc(&A, (size_t)M * K * 2); (void)hipMalloc(&B, (size_t)N * K * 2); (void)hipMalloc(&C, (size_t)M * N * 4);
     (void)hipMalloc(&bias, N * 4); (void)hipMalloc(&ws, (size_t)sk * M * N * 4);
@@ -16,6 +17,8 @@ int main(int argc, char** argv) {
     pa_gemm_args g; memset((void*)&g, 0, sizeof(g));
     g.A = A; g.B = B; g.C = C; g.bias = sk > 1 ? nullptr : bias; g.ws = ws; g.M = M; g.N = N; g.K = K;
     g.lda = akc ? K : M; g.ldb = bkc ? K : N; g.ldc = N; g.batch = 1;
+    void* Rb = nullptr;
+    if (res && sk == 1) { (void)hipMalloc(&Rb, (size_t)M * N * 2); (void)hipMemset(Rb, 0, (size_t)M * N * 2); g.R = Rb; g.ldr = N; }
     g.a_kcontig = akc; g.b_kcontig = bkc; g.in_dtype = PA_BF16; g.out_dtype = sk > 1 ? PA_F32 : PA_BF16; g.alpha = 1.f; g.aux_scale = 1.f; g.splitk = sk;
     // correctness spot check on small problems (random data, CPU reference)
     if ((long long)M * N * K <= (1LL << 28) && akc && bkc && sk == 1) {
@@ -42,7 +45,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 50; ++i) rc |= pa_gemm(&g, 0);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        if (rep == 2) printf("%5d %5d %5d kc%d%d sk%d  rc %d  %.2f us/launch  %.0f TF\n", M, N, K, akc, bkc, sk, rc, ms * 1e3 / 50, 2.0 * M * N * K / (ms * 1e-3 / 50) / 1e12);
+        if (rep == 2) printf("%5d %5d %5d kc%d%d sk%d res%d  rc %d  %.2f us/launch  %.0f TF\n", M, N, K, akc, bkc, sk, res, rc, ms * 1e3 / 50, 2.0 * M * N * K / (ms * 1e-3 / 50) / 1e12);
     }
     return 0;
 }
