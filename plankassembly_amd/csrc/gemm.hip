@@ -929,7 +929,12 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
 
     // Residual / gate tiles of the block's FIRST unit, requested before its first K tile (see the prefetch below): in a
     // single-round launch - most launches of the training step - every block would otherwise start these loads only after
-    // its K loop, with nothing left to hide their latency behind (measured: 5.9 k of a 15.5 k-cycle epilogue at K = 512).
+    // its K loop, with nothing left to hide their latency behind (measured in round 2: 5.9 k of a 15.5 k-cycle epilogue at K = 512).
+    // OFF since round 4 (-DPA_RING_PREFETCH_RES restores it): the 64 registers held across the K loop pushed the kernel to 256
+    // VGPRs + 203 AGPRs used as spill space - every item outside the hot loop carried 60-130 v_accvgpr copies (+600 cycles per
+    // item, the "last four items of a unit" of profiles/r02_gemm_block_timeline.txt).  Without it: 208 VGPRs + 128 AGPRs, and
+    // 12.15 / 15.66 / 19.12 us against 12.51 / 16.10 / 19.95 us per launch WITH a residual (7 940 x 512, K 512 / 1 024 / 1 536),
+    // 10.83 against 11.28 us without; train step -0.02 ms (three interleaved A/B runs).
     u32x2 pre_res[2][8], pre_aux[2][8];
     bool pre_live = false;
     // ---- epilogue ------------------------------------------------------------------------------------------------
@@ -1159,7 +1164,7 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
     // Prefetch of the first unit's residual / gate tiles (bf16, vector path).  Issued BEFORE the first DMA instruction: loads
     // return in order, so the hand-counted `vmcnt` waits of the K loop (which count DMA instructions only) stay exact - these
     // loads are older than every DMA and are retired by the first of those waits, together with the first K tile.
-#ifndef PA_RING_NO_PRE
+#ifdef PA_RING_PREFETCH_RES
     if constexpr (!GROUP) {
         const int nw0 = cun.tile_n * BN + wn * 64;
         if (pc.splitk <= 1 && pc.vec_ok && nw0 + 64 <= pc.N && pc.out_dtype != PA_F32 && (pc.R != nullptr || pc.aux != nullptr)) {
