@@ -760,6 +760,12 @@ def main():
                 line["roofline"]["in_step_rocprof"] = dict(tr, achieved=tf, frac=tf / PEAK_BF16_TFLOPS, archived=True,
                                                            note="parsed from the committed profile named in `file` (made by an earlier "
                                                                 "run of this command); every other figure of this line is measured live")
+            # context, ARCHIVED (measured once in round 4, not by this run): what the vendor's GEMM reaches at these shapes
+            line["roofline"]["vendor_same_shapes"] = {
+                "archived": True, "file": "profiles/r04_vendor_calibration.txt",
+                "note": "torch.matmul (hipBLASLt) at the step's Linear shapes: best case 8704x1536x512 in 22.4 us = 0.24 of the bf16 MFMA peak "
+                        "(pa_gemm 28.6 us), elsewhere level or behind pa_gemm; 4-14 GFLOP per launch set these fractions "
+                        "(profiles/r04_step_floor_probes.txt)"}
             line["kernel_census"] = {k: {"launches": round(v["launches"], 2), "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
                                          "ms_per_step": round(v["seconds"] * 1e3, 3),
                                          "tflops": round(v["flops"] / v["seconds"] / 1e12, 1),
