@@ -141,6 +141,11 @@ typedef struct {
 int pa_ln_fold_weights(void* Wf, float* u, float* v, const float* W, const float* bias, const float* gamma, const float* beta,
                        int32_t N, int32_t K, void* stream);
 int pa_gemm_norm_a(const pa_gemm_args* args, const pa_gemm_norm_ext* ext, void* stream);
+/* The same fold in exact f32 (the f32 greedy-decode step, round 4): pa_ln_fold_weights_f32 writes Wf = W gamma as f32; pa_gemm_norm_a
+ * with in_dtype = out_dtype = PA_F32 takes f32 rows A (ext->zf = the same rows: the statistics source), Wf, u, v and writes f32.
+ * At most 512 rows, K = 512 (PA_ESHAPE otherwise). */
+int pa_ln_fold_weights_f32(float* Wf, float* u, float* v, const float* W, const float* bias, const float* gamma, const float* beta,
+                           int32_t N, int32_t K, void* stream);
 
 /* Several weight-gradient GEMMs (dW = dY^T X: bf16 operands, contraction index strided in both, f32 output, no
  * epilogue, batch 1; splitk > 1 only with splitk_defer) in one launch of the ring kernel: its unit stream runs through

@@ -395,10 +395,11 @@ int linear_norm_a(pa_model* m, const void* Z, const void* Wf, const float* u, co
     pa_gemm_args g; memset(&g, 0, sizeof(g));
     g.A = Z; g.B = Wf; g.C = Cout; g.bias = v;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = ldc;
-    g.batch = 1; g.a_kcontig = 1; g.b_kcontig = 1; g.in_dtype = PA_BF16; g.out_dtype = PA_BF16;
+    g.batch = 1; g.a_kcontig = 1; g.b_kcontig = 1; g.in_dtype = m->cfg.dtype; g.out_dtype = m->cfg.dtype;
     g.alpha = 1.f; g.relu = relu; g.aux_scale = 1.f; g.splitk = 1;
     pa_gemm_norm_ext x; memset(&x, 0, sizeof(x));
     x.u = u; x.gamma = gamma; x.beta = beta; x.y = Y; x.ldy = K; x.eps = eps;
+    if (m->cfg.dtype == PA_F32) { x.zf = (const float*)Z; x.ldzf = K; x.y_f32 = 1; }     // exact-f32 fold: statistics from the rows themselves
     return pa_gemm_norm_a(&g, &x, st);
 }
 
@@ -453,7 +454,7 @@ size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tm
     for (int i = 0; i < c.n_dec; ++i) {
         const size_t rows[3] = {3 * d, d, ff};
         for (int k = 0; k < 3; ++k) {
-            L->fw[k][i] = a.take(rows[k] * d * 2);
+            L->fw[k][i] = a.take(rows[k] * d * e);          // folded weight in the step's dtype (bf16, or f32 for the exact-f32 step)
             L->fu[k][i] = (float*)a.take(rows[k] * 4); L->fv[k][i] = (float*)a.take(rows[k] * 4);
         }
     }
@@ -682,21 +683,31 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
     static const int fold_force = getenv("PLANK_DECODE_FOLD_LN") ? atoi(getenv("PLANK_DECODE_FOLD_LN")) : -1;
     const bool fold_env = fold_force >= 0 ? fold_force != 0 : (d == 512 && B <= 512);
     L->fold = fold_env && c.dtype == PA_BF16 && d % 64 == 0 && c.d_ff % 32 == 0 && (size_t)((B + 63) / 64) * ((3 * d + 63) / 64) <= 512;
+    // The exact-f32 step folds too since round 4 (pa_ln_fold_weights_f32 + the f32 skinny kernel with the statistics taken from
+    // the rows themselves): 17 LayerNorm launches fewer per step - measured +0.5 % only (B 256: 1.995 vs 2.005 ms / step; the folded
+    // Linears re-read their rows for the statistics), token-exact against the reference in every decode test.  d_model 512, <= 512 rows.
+    // PLANK_DECODE_FOLD_LN=0 disables it as it does for bf16.
+    if (c.dtype == PA_F32) L->fold = fold_env && d == 512 && B <= 512 && c.d_ff % 32 == 0;
+    const bool fold32 = L->fold && c.dtype == PA_F32;
     // f32 residual stream inside the bf16 step (see DecodeLayout::f32res): on wherever every Linear of the step takes the skinny
     // kernel (d_model 512, at most 512 rows).  tests/bf16_decode_sim.py / profiles/r04_bf16_decode_rounding_sim.txt: exact-prefix
     // agreement with the f32 tokens 0.40 -> 0.63-0.70 on 32 rows x 128 steps.  PLANK_DECODE_F32_RESID=0 restores the all-bf16 step.
     static const int f32res_env = getenv("PLANK_DECODE_F32_RESID") ? atoi(getenv("PLANK_DECODE_F32_RESID")) : 1;
-    L->f32res = L->fold && f32res_env != 0 && d == 512 && B <= 512 && c.d_ff % 512 == 0;
+    L->f32res = L->fold && c.dtype == PA_BF16 && f32res_env != 0 && d == 512 && B <= 512 && c.d_ff % 512 == 0;
     if (L->fold) {
         for (int i = 0; i < c.n_dec; ++i) {
             const int pb = m->dec_base(i);
             auto F = [&](int idx) { return (const float*)m->pf[idx]; };
+            auto foldw = [&](void* wf, float* u, float* v, const float* W, const float* bias, const float* g_, const float* b_, int N) -> int {
+                return fold32 ? pa_ln_fold_weights_f32((float*)wf, u, v, W, bias, g_, b_, N, d, stream)
+                              : pa_ln_fold_weights(wf, u, v, W, bias, g_, b_, N, d, stream);
+            };
             if (i > 0) {
                 const int pp = m->dec_base(i - 1);
-                RC(pa_ln_fold_weights(L->fw[0][i], L->fu[0][i], L->fv[0][i], F(pb + D_SA_IN_W), F(pb + D_SA_IN_B), F(pp + D_N3_W), F(pp + D_N3_B), 3 * d, d, stream));
+                RC(foldw(L->fw[0][i], L->fu[0][i], L->fv[0][i], F(pb + D_SA_IN_W), F(pb + D_SA_IN_B), F(pp + D_N3_W), F(pp + D_N3_B), 3 * d));
             }
-            RC(pa_ln_fold_weights(L->fw[1][i], L->fu[1][i], L->fv[1][i], F(pb + D_CA_IN_W), F(pb + D_CA_IN_B), F(pb + D_N1_W), F(pb + D_N1_B), d, d, stream));
-            RC(pa_ln_fold_weights(L->fw[2][i], L->fu[2][i], L->fv[2][i], F(pb + D_L1_W), F(pb + D_L1_B), F(pb + D_N2_W), F(pb + D_N2_B), c.d_ff, d, stream));
+            RC(foldw(L->fw[1][i], L->fu[1][i], L->fv[1][i], F(pb + D_CA_IN_W), F(pb + D_CA_IN_B), F(pb + D_N1_W), F(pb + D_N1_B), d));
+            RC(foldw(L->fw[2][i], L->fu[2][i], L->fv[2][i], F(pb + D_L1_W), F(pb + D_L1_B), F(pb + D_N2_W), F(pb + D_N2_B), c.d_ff));
         }
     }
     L->cu = nullptr;

@@ -2002,7 +2002,7 @@ template <typename T, bool LN>
 __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
     constexpr int esz = sizeof(T);
     constexpr int CH = SK_ROW / esz;                 // K elements per chunk
-    __shared__ __attribute__((aligned(256))) char smem[SK_NSTG * SK_STAGE];
+    __shared__ __attribute__((aligned(256))) char smem[SK_NSTG * SK_STAGE + 256];       // + [32] mean | [32] rstd behind the stages
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;      // neighbouring blocks share the A rows
@@ -2086,7 +2086,7 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     const uint32_t offA = (uint32_t)(row * SK_STRIDE + wave * (SK_ROW / 4) + half * 16);
     const uint32_t offB = offA + SK_T * SK_STRIDE;
-    float* stats = reinterpret_cast<float*>(smem + SK_STAGE);          // LN: [32] mean | [32] rstd (stage 1 is unused: one chunk)
+    float* stats = reinterpret_cast<float*>(smem + SK_NSTG * SK_STAGE);   // LN: [32] mean | [32] rstd
     for (int c = 0; c < nch; ++c) {
         const int stage = c & 1;
         // counted wait + raw barrier (a __syncthreads() would also drain the newer chunk's DMA): chunk c has landed for every wave
@@ -2100,22 +2100,23 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
         SK_RD(a[2], la, 64);  SK_RD(b[2], lb, 64);  SK_RD(a[3], la, 96);  SK_RD(b[3], lb, 96);
         SK_RD(a[4], la, 128); SK_RD(b[4], lb, 128); SK_RD(a[5], la, 160); SK_RD(b[5], lb, 160);
         SK_RD(a[6], la, 192); SK_RD(b[6], lb, 192); SK_RD(a[7], la, 224); SK_RD(b[7], lb, 224);
-        if constexpr (LN) {
+        if (LN && c == 0) {
+            // (f32 operands - two K chunks - take their statistics from the f32 rows in global memory: pa_gemm_norm_a requires zf)
             // row statistics from the resident Z tile, all 8 rows of this wave at once: lane -> (row 8w + l / 8, eighth l % 8), 64
             // elements per lane, two passes over them in registers, three lane exchanges per pass.  Issued between the fragment
             // reads and their use: the MFMAs below do not wait for it.
             const int sr = wave * 8 + (lane >> 3), part = lane & 7;
-            float s1 = 0.f, s2 = 0.f, mean;
+            float s1 = 0.f, s2 = 0.f, mean = 0.f;
             if (zf_on) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) s1 += (zfr[j][0] + zfr[j][1]) + (zfr[j][2] + zfr[j][3]);
                 s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
-                mean = s1 * (1.0f / (float)CH);
+                mean = s1 * (1.0f / (float)p.K);
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
 #pragma unroll
                     for (int w = 0; w < 4; ++w) { const float d0 = zfr[j][w] - mean; s2 += d0 * d0; }
-            } else {
+            } else if constexpr (sizeof(T) == 2) {
                 const uint32_t lz = lds0 + (uint32_t)(sr * SK_STRIDE + part * 16);
                 u32x4 zz[8];
                 SK_RD(zz[0], lz, 0);   SK_RD(zz[1], lz, 128); SK_RD(zz[2], lz, 256); SK_RD(zz[3], lz, 384);
@@ -2126,7 +2127,7 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
 #pragma unroll
                     for (int w = 0; w < 4; ++w) s1 += bf16_lo(zz[j][w]) + bf16_hi(zz[j][w]);
                 s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
-                mean = s1 * (1.0f / (float)CH);
+                mean = s1 * (1.0f / (float)p.K);
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -2136,7 +2137,7 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
                     }
             }
             s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 4);
-            if (part == 0) { stats[sr] = mean; stats[32 + sr] = rsqrtf(s2 * (1.0f / (float)CH) + p.ln_eps); }
+            if (part == 0) { stats[sr] = mean; stats[32 + sr] = rsqrtf(s2 * (1.0f / (float)p.K) + p.ln_eps); }
         }
 #undef SK_RD
         // (the operands are tied to the wait, or the MFMAs - plain builtins - could be scheduled above it)
@@ -2159,7 +2160,7 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
     // ---- sum the four K-quarters through LDS (fixed order), then the epilogue: thread -> one row, four columns -------------
     // LN: the reduction buffer lives in the unused second stage (behind the statistics), so the Z tile in stage 0 stays readable
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem + (LN ? SK_STAGE + 1024 : 0));
+    float* red = reinterpret_cast<float*>(smem + ((LN && sizeof(T) == 2) ? SK_STAGE : 0));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rr = (r >> 2) * 8 + half * 4 + (r & 3);
@@ -2171,7 +2172,7 @@ __global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(GemmP p) {
         if (write_y) {
             f32x4 zv;
             if (zf_on) zv = zy4;
-            else {
+            else if constexpr (sizeof(T) == 2) {
                 const u32x2 zq = *reinterpret_cast<const u32x2*>(smem + er * SK_STRIDE + (size_t)en * 2);
                 zv[0] = bf16_lo(zq[0]); zv[1] = bf16_hi(zq[0]); zv[2] = bf16_lo(zq[1]); zv[3] = bf16_hi(zq[1]);
             }
@@ -2551,14 +2552,15 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
 // caller launches the members one by one.
 // ---- Linear on LayerNorm(Z) without a LayerNorm launch (greedy-decode step: B rows, 17 LayerNorm launches per step) ------
 namespace {
-__global__ __launch_bounds__(256) void ln_fold_weights_kernel(bf16* Wf, float* u, float* v, const float* W, const float* bias,
+template <typename TW>
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(TW* Wf, float* u, float* v, const float* W, const float* bias,
                                                               const float* gamma, const float* beta, int N, int K) {
     __shared__ float red[2][4];
     const int n = blockIdx.x;
     float su = 0.f, sv = 0.f;
     for (int k = threadIdx.x; k < K; k += 256) {
         const float w = W[(size_t)n * K + k];
-        const bf16 wf = (bf16)(w * gamma[k]);
+        const TW wf = (TW)(w * gamma[k]);
         Wf[(size_t)n * K + k] = wf;
         su += (float)wf;                       // the sum of what the MFMA will really multiply by (the rounded values)
         sv += w * beta[k];
@@ -2575,12 +2577,40 @@ __global__ __launch_bounds__(256) void ln_fold_weights_kernel(bf16* Wf, float* u
 extern "C" int pa_ln_fold_weights(void* Wf, float* u, float* v, const float* W, const float* bias, const float* gamma,
                                   const float* beta, int32_t N, int32_t K, void* stream) {
     if (!Wf || !u || !v || !W || !gamma || !beta || N <= 0 || K <= 0) return PA_EINVAL;
-    PA_LAUNCH(ln_fold_weights_kernel, dim3(N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (bf16*)Wf, u, v, W, bias, gamma, beta, N, K);
+    PA_LAUNCH(ln_fold_weights_kernel<bf16>, dim3(N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (bf16*)Wf, u, v, W, bias, gamma, beta, N, K);
+    return 0;
+}
+extern "C" int pa_ln_fold_weights_f32(float* Wf, float* u, float* v, const float* W, const float* bias, const float* gamma,
+                                      const float* beta, int32_t N, int32_t K, void* stream) {
+    if (!Wf || !u || !v || !W || !gamma || !beta || N <= 0 || K <= 0) return PA_EINVAL;
+    PA_LAUNCH(ln_fold_weights_kernel<float>, dim3(N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Wf, u, v, W, bias, gamma, beta, N, K);
     return 0;
 }
 extern "C" int pa_gemm_norm_a(const pa_gemm_args* a, const pa_gemm_norm_ext* x, void* stream) {
     if (!a || !x || !a->A || !a->B || !a->C || !a->bias || !x->u || a->M <= 0 || a->N <= 0 || a->K <= 0) return PA_EINVAL;
-    if (a->in_dtype != PA_BF16 || (a->out_dtype != PA_BF16 && a->out_dtype != PA_F32) || !a->a_kcontig || !a->b_kcontig) return PA_EINVAL;
+    if ((a->in_dtype != PA_BF16 && a->in_dtype != PA_F32) || (a->out_dtype != PA_BF16 && a->out_dtype != PA_F32) || !a->a_kcontig || !a->b_kcontig) return PA_EINVAL;
+    if (a->in_dtype == PA_F32) {
+        // exact-f32 form (the f32 greedy-decode step): f32 rows, f32 folded weight (pa_ln_fold_weights_f32), f32 output; the statistics
+        // come from the rows themselves (ext->zf, normally == args->A).  Skinny kernel only: <= 512 rows, K = 512.
+        static const int sk_rows32 = getenv("PA_GEMM_SKINNY_ROWS") ? atoi(getenv("PA_GEMM_SKINNY_ROWS")) : 512;
+        if (a->batch != 1 || a->splitk > 1 || a->R || a->aux || a->drop_p != 0.f || a->N % 32) return PA_ESHAPE;
+        if (!x->zf || a->K != 512 || a->M > sk_rows32 || a->out_dtype != PA_F32 || (x->y && (!x->y_f32 || a->N < a->K))) return PA_ESHAPE;
+        if (x->y && (!x->gamma || !x->beta || x->ldy < a->K || x->ldy % 4 || (reinterpret_cast<uintptr_t>(x->y) & 15))) return PA_EINVAL;
+        if (!is_aligned<float>(a) || x->ldzf < a->K || x->ldzf % 4 || (reinterpret_cast<uintptr_t>(x->zf) & 15)) return PA_EALIGN;
+        GemmP p = GemmP();
+        p.A = a->A; p.B = a->B; p.C = a->C; p.bias = a->bias;
+        p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
+        p.batch = 1; p.alpha = a->alpha; p.relu = a->relu; p.aux_scale = 1.f; p.drop_scale = 1.f; p.out_dtype = PA_F32; p.splitk = 1;
+        p.tiles_m = (a->M + SK_T - 1) / SK_T; p.tiles_n = (a->N + SK_T - 1) / SK_T;
+        p.vec_ok = ((reinterpret_cast<uintptr_t>(a->C) & 15) == 0 && a->ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(a->bias) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(x->u) & 15) == 0 && (!x->y || ((reinterpret_cast<uintptr_t>(x->gamma) & 15) == 0 &&
+                                                                          (reinterpret_cast<uintptr_t>(x->beta) & 15) == 0))) ? 1 : 0;
+        if (!p.vec_ok) return PA_EALIGN;
+        p.ln_u = x->u; p.ln_gamma = x->gamma; p.ln_beta = x->beta; p.ln_y = x->y; p.ldy = x->ldy; p.ln_eps = x->eps;
+        p.ln_zf = x->zf; p.ldzf = x->ldzf; p.ln_y_f32 = 1;
+        PA_LAUNCH((gemm_skinny_kernel<float, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+        return 0;
+    }
     if (a->batch != 1 || a->splitk > 1 || a->R || a->aux || a->drop_p != 0.f || a->K % 64 || a->N % 32) return PA_ESHAPE;
     if (x->y && (!x->gamma || !x->beta || x->ldy < a->K || x->ldy % 4)) return PA_EINVAL;
     if (x->y && (a->N + 63) / 64 * 64 < a->K) return PA_ESHAPE;      // column tile j materialises columns 64 j .. 64 j + 63 of LayerNorm(Z)
