@@ -762,10 +762,10 @@ def main():
                                                                 "run of this command); every other figure of this line is measured live")
             # context, ARCHIVED (measured once in round 4, not by this run): what the vendor's GEMM reaches at these shapes
             line["roofline"]["vendor_same_shapes"] = {
-                "archived": True, "file": "profiles/r04_vendor_calibration.txt",
-                "note": "torch.matmul (hipBLASLt) at the step's Linear shapes: best case 8704x1536x512 in 22.4 us = 0.24 of the bf16 MFMA peak "
-                        "(pa_gemm 28.6 us), elsewhere level or behind pa_gemm; 4-14 GFLOP per launch set these fractions "
-                        "(profiles/r04_step_floor_probes.txt)"}
+                "archived": True, "file": "profiles/r04_step_floor_probes.txt",
+                "note": "kernel durations under rocprofv3, torch.matmul (hipBLASLt) vs pa_gemm at 8704 rows: 8704x1536x512 22.0 vs 28.8 us "
+                        "(0.25 of the bf16 MFMA peak), x1024x512 17.3 vs 23.8, x512x1024 16.2 vs 20.7, x512x512 13.2 vs 14.4; weight "
+                        "gradients 54-58 vs 39; 2048-row Linears 7.2-12.5 vs 7.0-17.6 (section 12 of the file: tile-count quantisation)"}
             line["kernel_census"] = {k: {"launches": round(v["launches"], 2), "avg_launch_us": round(v["seconds"] / v["launches"] * 1e6, 2),
                                          "ms_per_step": round(v["seconds"] * 1e3, 3),
                                          "tflops": round(v["flops"] / v["seconds"] / 1e12, 1),

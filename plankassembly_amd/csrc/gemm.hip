@@ -2458,9 +2458,14 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     // 43 ... 98 us each on 8 blocks), bf16 1.224 -> 1.112 ms/step (32 blocks of the 64 x 64-tile ring kernel before).
     static const int use_skinny = getenv("PA_GEMM_SKINNY") ? atoi(getenv("PA_GEMM_SKINNY")) : 2;
     static const int skinny_rows = getenv("PA_GEMM_SKINNY_ROWS") ? atoi(getenv("PA_GEMM_SKINNY_ROWS")) : 512;
+    // f32 has no 64 x 64-tile kernel: a 2048-row f32 Linear (the decoder side of the f32 train step) is 64 blocks of the 128 x 128
+    // pair kernel on 256 CUs.  The K-resident 32 x 32 kernel puts it on 1024 blocks: f32 train step 31.29 -> 29.84 ms (MI355X,
+    // batch 16); at 8704 rows it loses (30.2 ms with the limit at 16384).  PA_GEMM_SKINNY_ROWS_F32 overrides.
+    static const int skinny_rows32 = getenv("PA_GEMM_SKINNY_ROWS_F32") ? atoi(getenv("PA_GEMM_SKINNY_ROWS_F32"))
+                                     : getenv("PA_GEMM_SKINNY_ROWS") ? atoi(getenv("PA_GEMM_SKINNY_ROWS")) : 2048;
     const int sk_ch = a->in_dtype == PA_BF16 ? 512 : 256;
     const bool go_skinny = use_skinny && (a->in_dtype == PA_F32 || use_skinny >= 2) && a->a_kcontig && a->b_kcontig && splitk == 1 &&
-                           a->batch == 1 && a->M <= skinny_rows && a->K % sk_ch == 0 && !a->aux && a->drop_p == 0.f && !dbg_noglds &&
+                           a->batch == 1 && a->M <= (a->in_dtype == PA_F32 ? skinny_rows32 : skinny_rows) && a->K % sk_ch == 0 && !a->aux && a->drop_p == 0.f && !dbg_noglds &&
                            (a->in_dtype == PA_BF16 ? is_aligned<bf16>(a) : is_aligned<float>(a));
     // eight-wave big-tile kernel (gemm8.h): PA_GEMM_BIG 0 (default) never, 1 plain k-contiguous bf16 Linears of at least
     // PA_GEMM_BIG_MINM rows - 256 x 256 tiles from N = 1024 on, 256 x 128 tiles below.  Opt-in: level with the kernels below at this

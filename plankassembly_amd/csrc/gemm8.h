@@ -10,8 +10,13 @@
 //   <WM 4, WN 2, FM 2, FN 4>  256 x 256 tile, wave tile 64 x 128: 8 MFMAs per 6 fragment reads, 64 KB per K tile for 4x the flops of
 //                             a 128 x 128 tile (32 KB).  K loop 2 853 cycles per item = 0.72 of the MFMA peak inside the loop
 //   <WM 4, WN 2, FM 2, FN 2>  256 x 128 tile, wave tile 64 x 64 (N = d_model: 256-wide tiles would leave 3/4 of the CUs idle)
-//   (<WM 2, WN 4, FM 4, FN 2>, the same 256 x 256 tile with 128 x 64 wave tiles, streams its K tiles three times slower - 6 732 cycles
-//   per item - for a reason not found; not used)
+//   (<WM 2, WN 4, FM 4, FN 2>, the same 256 x 256 tile with 128 x 64 wave tiles, first streamed its K tiles three times slower -
+//   6 732 cycles per item: hipcc had left the epilogue's fragment loops rolled, the accumulators were indexed dynamically and 28
+//   bytes per lane went to scratch.  With the loops as static_for it ties with <4, 2, 2, 4>: 25.7 vs 25.3 us at 8704 x 1536 x 512.)
+//   Four waves stacked along M with whole-width wave tiles (tools/ubench/gemm8_lat.hip cfg 6 / 7: <4, 1, 2, 7> 256 x 224 and
+//   <4, 1, 2, 5> 256 x 160, the tile shapes hipBLASLt picks so that M ~ 8 700 is ONE round of 238 blocks; unit order plain_order 2)
+//   do not pay either: 256 x 160 21.5 us at 8704 x 1024 x 512 (default kernels 22.6, hipBLASLt 17.3), 256 x 224 37 us (84 bytes of
+//   scratch per lane, 14 MFMAs per k-step on one wave per SIMD).  profiles/r04_step_floor_probes.txt section 12.
 // What was learned: a CU's direct-to-LDS DMA is processed at ~36 cycles per 1 KB instruction (27-29 B/clk) whatever the ring depth,
 // so only flops per DMA byte help the loop - and at K = 512 the 256 x 256 tile's epilogue (10.4 k cycles: eight staged 32 x 32 passes
 // per wave) and first-item latency (4.2 k) cost what its K loop (22.8 k) saves.
@@ -135,8 +140,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm8_kernel(GemmP p) {
         const bool out_f32 = p.out_dtype == PA_F32;
         const bool has_bias = p.bias != nullptr, has_aux = p.aux != nullptr, has_res = p.R != nullptr, has_drop = p.drop_thr != 0;
         constexpr int NIT = 4;
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) {
+        // (static_for, not #pragma unroll: with FN = 7 hipcc leaves the loop rolled and the accumulators go to scratch)
+        static_for<0, FN>([&](auto FN_) {
+            constexpr int fn = decltype(FN_)::value;
             const int nw = un.tile_n * TBN + (wn * FN + fn) * 32;
             const int n = nw + chunk * 4;
             const bool fast = p.vec_ok && (nw + 32 <= p.N);
@@ -146,13 +152,13 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm8_kernel(GemmP p) {
                 if (fast) bias = *reinterpret_cast<const f32x4*>(bp + n);
                 else { for (int e = 0; e < 4; ++e) if (n + e < p.N) bias[e] = bp[n + e]; }
             }
-#pragma unroll
-            for (int fm = 0; fm < FM; ++fm) {
+            static_for<0, FM>([&](auto FM_) {
+                constexpr int fm = decltype(FM_)::value;
                 const int mw = un.tile_m * TBM + (wm * FM + fm) * 32;
                 if (mw >= p.M || nw >= p.N) {                          // (wave-uniform) sub-tile entirely outside the matrix
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
-                    continue;
+                    return;
                 }
                 {
                     const int lrow = lane & 31;
@@ -291,13 +297,23 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm8_kernel(GemmP p) {
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[fn][fm][r] = 0.f;
-            }
-        }
+            });
+        });
     };
 
     // ---- item stream: units in XCD-interleaved order over the row tiles; DMA cursor up to NSTG items ahead ------------------
     const int ustride = gridDim.x, nt = p.K / BK;
     auto unit_of = [&](int u, Unit& un) -> bool {
+        if (p.plain_order == 2) {
+            // one-round order: block u sits on XCD u & 7; XCD x takes the x-th eighth of the row-major tile list, so a row panel of A
+            // is fetched by one or two L2s and no row-tile padding pushes the launch past 256 units (units = 8 * per * batch)
+            const int tiles = p.tiles_m * p.tiles_n, per = (tiles + 7) >> 3, per_b = per << 3;
+            un.b = u / per_b; un.z = un.b;
+            const int r = u - un.b * per_b, idx = (r & 7) * per + (r >> 3);
+            un.tile_m = idx / p.tiles_n; un.tile_n = idx - un.tile_m * p.tiles_n;
+            un.t_begin = 0; un.t_end = nt;
+            return idx < tiles;
+        }
         const int per_b = p.tiles_m_pad * p.tiles_n;
         un.b = u / per_b; un.z = un.b;
         const int r = u - un.b * per_b;

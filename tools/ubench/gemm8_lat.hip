@@ -19,6 +19,10 @@ static int launch_cfg(GemmP pb, hipStream_t st) {
     pb.plain_order = pb.tiles_m < 8;
     pb.tiles_m_pad = pb.plain_order ? pb.tiles_m : (pb.tiles_m + 7) / 8 * 8;
     pb.units = pb.tiles_m_pad * pb.tiles_n * pb.batch;
+    // the XCD interleave pads the row tiles to a multiple of 8; when that padding alone pushes a launch past one round of 256
+    // blocks, hand every XCD a contiguous eighth of the tile list instead (gemm8.h, plain_order 2)
+    const int tiles = pb.tiles_m * pb.tiles_n, per = (tiles + 7) / 8;
+    if (!pb.plain_order && pb.units > 256 && 8 * per * pb.batch <= 256) { pb.plain_order = 2; pb.units = 8 * per * pb.batch; }
     const int gb = pb.units < 256 ? pb.units : 256;
     hipLaunchKernelGGL((gemm8_kernel<WM, WN, FM, FN, BK, NSTG>), dim3(gb), dim3(64 * WM * WN), 0, st, pb);
     return (int)hipGetLastError();
@@ -31,6 +35,10 @@ static int launch8(GemmP pb, int bk, hipStream_t st) {
         case 3: return launch_cfg<4, 2, 2, 4, 64, 2>(pb, st);      // E: 256 x 256, wave 64 x 128
         case 4: return launch_cfg<4, 2, 2, 3, 64, 2>(pb, st);      // F: 256 x 192, wave 64 x 96
         case 5: return launch_cfg<2, 4, 3, 2, 64, 2>(pb, st);      // G: 192 x 256, wave 96 x 64
+        // four waves (one per SIMD) stacked along M, whole-width wave tiles: one round of <= 256 tiles at M ~ 8 700
+        case 6: return launch_cfg<4, 1, 2, 7, 64, 2>(pb, st);      // H: 256 x 224, wave 64 x 224 (N = 1536: 34 x 7 = 238 tiles)
+        case 7: return launch_cfg<4, 1, 2, 5, 64, 2>(pb, st);      // I: 256 x 160, wave 64 x 160 (N = 1024: 34 x 7 = 238 tiles)
+        case 8: return launch_cfg<4, 1, 2, 4, 64, 2>(pb, st);      // J: 256 x 128, wave 64 x 128
         default: break;
     }
     const bool sq = pb.N >= 1024;
