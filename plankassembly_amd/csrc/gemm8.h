@@ -35,8 +35,8 @@ __device__ unsigned long long pa_gemm8_trace[512 * 8];
 #else
 #define PA_TR8(i) do { } while (0)
 #endif
-template <int WM, int WN, int FM, int FN, int BK, int NSTG>
-__global__ __launch_bounds__(64 * WM * WN, 1) void gemm8_kernel(GemmP p) {
+template <int WM, int WN, int FM, int FN, int BK, int NSTG, int WPS = 1>     // WPS: waves per SIMD the register budget must allow
+__global__ __launch_bounds__(64 * WM * WN, WPS) void gemm8_kernel(GemmP p) {
     using T = bf16;
     PA_TR8(0);
 #if defined(PA_G8_ABL) && (PA_G8_ABL & 64)             // probe: the launch alone (same registers / LDS, no work)

@@ -12,7 +12,7 @@ namespace {
 #include <vector>
 
 static int g_cfg = -1;      // -1: the product's choice (256 x 256 from N = 1024 on, else 256 x 128); >= 0: probe configurations
-template <int WM, int WN, int FM, int FN, int BK, int NSTG>
+template <int WM, int WN, int FM, int FN, int BK, int NSTG, int WPS = 1, int SLOTS = 256>
 static int launch_cfg(GemmP pb, hipStream_t st) {
     constexpr int TBM = 32 * FM * WM, TBN = 32 * FN * WN;
     pb.tiles_m = (pb.M + TBM - 1) / TBM; pb.tiles_n = (pb.N + TBN - 1) / TBN;
@@ -22,9 +22,9 @@ static int launch_cfg(GemmP pb, hipStream_t st) {
     // the XCD interleave pads the row tiles to a multiple of 8; when that padding alone pushes a launch past one round of 256
     // blocks, hand every XCD a contiguous eighth of the tile list instead (gemm8.h, plain_order 2)
     const int tiles = pb.tiles_m * pb.tiles_n, per = (tiles + 7) / 8;
-    if (!pb.plain_order && pb.units > 256 && 8 * per * pb.batch <= 256) { pb.plain_order = 2; pb.units = 8 * per * pb.batch; }
-    const int gb = pb.units < 256 ? pb.units : 256;
-    hipLaunchKernelGGL((gemm8_kernel<WM, WN, FM, FN, BK, NSTG>), dim3(gb), dim3(64 * WM * WN), 0, st, pb);
+    if (!pb.plain_order && pb.units > SLOTS && 8 * per * pb.batch <= SLOTS) { pb.plain_order = 2; pb.units = 8 * per * pb.batch; }
+    const int gb = pb.units < SLOTS ? pb.units : SLOTS;
+    hipLaunchKernelGGL((gemm8_kernel<WM, WN, FM, FN, BK, NSTG, WPS>), dim3(gb), dim3(64 * WM * WN), 0, st, pb);
     return (int)hipGetLastError();
 }
 static int launch8(GemmP pb, int bk, hipStream_t st) {
@@ -39,6 +39,11 @@ static int launch8(GemmP pb, int bk, hipStream_t st) {
         case 6: return launch_cfg<4, 1, 2, 7, 64, 2>(pb, st);      // H: 256 x 224, wave 64 x 224 (N = 1536: 34 x 7 = 238 tiles)
         case 7: return launch_cfg<4, 1, 2, 5, 64, 2>(pb, st);      // I: 256 x 160, wave 64 x 160 (N = 1024: 34 x 7 = 238 tiles)
         case 8: return launch_cfg<4, 1, 2, 4, 64, 2>(pb, st);      // J: 256 x 128, wave 64 x 128
+        // four waves, TWO blocks per CU (512 slots), taller tiles so that 8 704 rows x N 1024 / 1536 stay within one round
+        case 9: return launch_cfg<2, 2, 3, 2, 32, 2, 2, 512>(pb, st);     // K: 192 x 128, wave 96 x 64, BK 32
+        case 10: return launch_cfg<2, 2, 4, 2, 32, 2, 2, 512>(pb, st);    // L: 256 x 128, wave 128 x 64, BK 32
+        case 11: return launch_cfg<2, 2, 2, 2, 32, 3, 2, 512>(pb, st);    // M: 128 x 128, wave 64 x 64, BK 32 (the pair kernel's shape)
+        case 12: return launch_cfg<2, 2, 2, 2, 64, 2, 2, 512>(pb, st);    // N: 128 x 128, BK 64, 2 stages (64 KB + 16 KB)
         default: break;
     }
     const bool sq = pb.N >= 1024;
