@@ -103,7 +103,10 @@ __device__ __forceinline__ int next_valid_unit(int u, int stride) { return u + s
 //   is multiplied, synchronised with counted s_waitcnt vmcnt + raw s_barrier (a __syncthreads() would drain the DMA
 //   queue).  Used for small problems (one block per CU anyway), where every K tile would otherwise pay a full
 //   memory round trip.
-template <typename T, int BK_, int OCC, bool A_KC, bool B_KC, bool ALIGNED, bool GLDS, bool TRG, int NST>
+// EPRE: the launch has bf16 residual or gate rows and a bf16 output - fetch them under the last K tile (prefetch_epi below).  Its own
+//   instantiation because the 16 extra registers spill a few dwords (the kernel sits at 244 of 256): launches without such rows
+//   keep the unspilled code.
+template <typename T, int BK_, int OCC, bool A_KC, bool B_KC, bool ALIGNED, bool GLDS, bool TRG, int NST, bool EPRE = false>
 __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
     using TL = Tile<T, BK_>;
     constexpr int EB = TL::EB;
@@ -336,6 +339,36 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
         }
     };
 
+    // ---- residual / gate rows of a unit's epilogue, fetched while its LAST K tile is multiplied (two-stage variant, bf16 in and
+    // out, interior column block).  The epilogue's two staging passes each used to wait one memory round trip for eight
+    // 8-byte loads per lane.  The kernel already holds 244 of its 256 registers: only the first pass's rows (16 registers,
+    // bf16 pairs) are fetched under the K tile, the second pass's when the epilogue starts (the fragments are dead by then).  Figures at the launch site (launch_t).
+    u32x2 pepi[8];
+    int pre_kind = 0;                     // 0 nothing prefetched, 1 residual rows, 2 gate rows (residual wins when a launch has both)
+    const char* pre_base = nullptr;
+    uint32_t pre_ld2 = 0;
+    // rows [i0 * 4, i0 * 4 + 32) of this wave's 64 x 64 block: eight 8-byte loads per lane
+    auto load_epi_rows = [&](u32x2 (&dst)[8], const Unit& un, int i0) {
+        const int mw = un.tile_m * BM + wm * 64, n = un.tile_n * BN + wn * 64 + (lane & 15) * 4, rsub = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            dst[i] = *reinterpret_cast<const u32x2*>(pre_base + ((uint32_t)min(mw + (i0 + i) * 4 + rsub, p.M - 1) * pre_ld2 + (uint32_t)n * 2u));
+    };
+    auto prefetch_epi = [&](const Unit& un) {
+        pre_kind = 0;
+        if constexpr (EPRE && sizeof(T) == 2 && TL::RPP * 2 == 64 && ALL_DMA && NST == 2) {
+            if (p.splitk > 1 || p.out_dtype == PA_F32 || (p.R == nullptr && p.aux == nullptr)) return;
+            if (!(p.vec_ok && un.tile_n * BN + wn * 64 + 64 <= p.N)) return;     // (wave-uniform)
+            const bool use_r = p.R != nullptr;
+            pre_kind = use_r ? 1 : 2;
+            pre_base = use_r ? reinterpret_cast<const char*>(p.R) + (size_t)un.b * p.sR * 2
+                             : reinterpret_cast<const char*>(p.aux) + (size_t)un.b * p.sAux * 2;
+            pre_ld2 = (uint32_t)(use_r ? p.ldr : p.ldaux) * 2u;
+            load_epi_rows(pepi, un, 0);           // the first staging pass's rows now; the second pass's at the start of the epilogue
+        }
+    };
+    auto widen2 = [](const u32x2& u) { f32x4 r; r[0] = bf16_lo(u[0]); r[1] = bf16_hi(u[0]); r[2] = bf16_lo(u[1]); r[3] = bf16_hi(u[1]); return r; };
+
     // ---- epilogue of one unit: per-wave LDS staging, batched loads, vector row stores -------------------------
     auto epilogue = [&](const Unit& un, int buf) {
         char* stage = smem + buf * 2 * TL::TILE_BYTES + wave * TL::STAGE_BYTES;
@@ -353,8 +386,11 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
         const f32x4 bias = has_bias ? ubias : f32x4{0.f, 0.f, 0.f, 0.f};   // fetched when the unit started (load_bias)
         const float alpha = slab ? 1.f : p.alpha;
         constexpr int NPASS = 64 / TL::RPP, NIT = TL::RPP / 4;
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
+        u32x2 pepi1[8];
+        if (pre_kind) load_epi_rows(pepi1, un, 8);                        // in flight behind the first pass
+        // (static_for: the prefetched residual / gate registers are indexed by the pass - a rolled loop would put them in scratch)
+        static_for<0, NPASS>([&](auto P_) {
+            constexpr int pass = decltype(P_)::value;
             const int tm = (pass * TL::RPP) / 32;
             const int rsel = (pass * TL::RPP) % 32;
             const int lrow = (lane & 31) - rsel;
@@ -384,18 +420,28 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                 }
                 f32x4 res[NIT], gate[NIT];
                 if (has_res) {
+                    if (pre_kind == 1) {                                  // fetched during the last K tile (prefetch_epi)
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        const size_t ro = (size_t)un.b * p.sR + (size_t)min(mp + it * 4, p.M - 1) * p.ldr + n;
-                        res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(p.R) + ro)
-                                          : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+                        for (int it = 0; it < NIT; ++it) res[it] = widen2(pass == 0 ? pepi[it & 7] : pepi1[it & 7]);
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const size_t ro = (size_t)un.b * p.sR + (size_t)min(mp + it * 4, p.M - 1) * p.ldr + n;
+                            res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(p.R) + ro)
+                                              : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+                        }
                     }
                 }
                 if (has_aux) {
+                    if (pre_kind == 2) {
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        const size_t ao = (size_t)un.b * p.sAux + (size_t)min(mp + it * 4, p.M - 1) * p.ldaux + n;
-                        gate[it] = ld4<T>(reinterpret_cast<const T*>(p.aux) + ao);
+                        for (int it = 0; it < NIT; ++it) gate[it] = widen2(pass == 0 ? pepi[it & 7] : pepi1[it & 7]);
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const size_t ao = (size_t)un.b * p.sAux + (size_t)min(mp + it * 4, p.M - 1) * p.ldaux + n;
+                            gate[it] = ld4<T>(reinterpret_cast<const T*>(p.aux) + ao);
+                        }
                     }
                 }
                 if (!slab) {
@@ -441,7 +487,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                         else st4<bf16>(reinterpret_cast<bf16*>(p.C) + co, x[it]);
                     }
                 }
-                continue;
+                return;
             }
             f32x4 v[NIT], res[NIT], gate[NIT];
             bool rowv[NIT];
@@ -517,7 +563,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                     else { for (int e = 0; e < 4; ++e) if (n + e < p.N) cp[e] = (bf16)x[e]; }
                 }
             }
-        }
+        });
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -623,6 +669,9 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                 else fetch(cur, t + 1, buf ^ 1);
             }
             TR(2);
+#ifndef PA_PAIR_NO_EPI_PREFETCH
+            if (last_k) prefetch_epi(cur);
+#endif
             compute(buf);
             TR(3);
             if (last_k) {
@@ -2263,6 +2312,16 @@ int launch_t(const GemmP& p, bool aligned, bool glds, dim3 grid, hipStream_t st)
             }
             if (flat) {
                 PA_LAUNCH((gemm_kernel<T, BK_, 4, A_KC, B_KC, true, true, CAN_TR, 1>), grid, dim3(NT), 0, st, p);
+                return 0;
+            }
+        }
+        if constexpr (ALLD && sizeof(T) == 2 && BK_ == 64) {
+            // bf16 residual / gate rows, bf16 output: the variant that fetches them under the last K tile.  Back-to-back launches at
+            // 8704 rows, with a residual: 512 x 512 16.4 -> 15.5 us, 512 x 1024 24.4 -> 21.5, 512 x 1536 31.0 -> 27.6, 1024 x 512
+            // 31.1 -> 24.4, 1536 x 512 35.8 -> 28.9; strided weight 512 x 1536 38.2 -> 36.4.  PA_GEMM_EPRE=0 turns it off.
+            static const bool epre_on = !(getenv("PA_GEMM_EPRE") && atoi(getenv("PA_GEMM_EPRE")) == 0);
+            if (epre_on && (p.R || p.aux) && p.splitk == 1 && p.out_dtype != PA_F32 && p.vec_ok) {
+                PA_LAUNCH((gemm_kernel<T, BK_, OCC, A_KC, B_KC, true, true, CAN_TR, 2, true>), grid, dim3(NT), 0, st, p);
                 return 0;
             }
         }
