@@ -246,14 +246,17 @@ def in_step_trace(key):
     except OSError:
         return None
     for name in names:
+        calls, total_us = 0, 0.0          # every instantiation of the family (e.g. the pair kernel with and without the epilogue prefetch)
         with open(os.path.join(here, name)) as f:
             for line in f:
                 parts = line.split()
                 if len(parts) >= 4 and re.search(pats[key], parts[0]):
                     try:
-                        return {"file": "profiles/" + name, "calls": int(parts[1]), "avg_launch_us": float(parts[3])}
+                        calls += int(parts[1]); total_us += int(parts[1]) * float(parts[3])
                     except ValueError:
                         continue
+        if calls:
+            return {"file": "profiles/" + name, "calls": calls, "avg_launch_us": total_us / calls}
     return None
 
 
