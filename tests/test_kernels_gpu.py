@@ -138,6 +138,34 @@ def test_gemm_ring_epilogue_bf16():
     assert rel_err(o1.cpu(), keep * (acc[:200] + bias) / 0.75) < 2.5e-2
 
 
+@pytest.mark.parametrize("bkc", [True, False])
+@pytest.mark.parametrize("M,N", [(8300, 512), (8300, 1024), (8197, 576)])
+def test_gemm_pair_epilogue_prefetch(M, N, bkc):
+    """Two-blocks-per-CU kernel with bf16 residual / gate rows (its EPRE instantiation fetches them under the last K tile, csrc/gemm.hip
+    prefetch_epi): more than 256 tiles so that kernel runs, a ragged last row tile, a ragged last column block (N = 576), k-contiguous
+    and strided weights, R aliasing C.  ELEMENT-wise bound: a residual row landing on the wrong output row must not hide in a norm."""
+    K = 512
+    a = rnd(M, K, dtype=torch.bfloat16, seed=31, scale=0.3)
+    w = rnd(N, K, dtype=torch.bfloat16, seed=32, scale=0.3)
+    bias, res, aux = rnd(N, seed=33), rnd(M, N, dtype=torch.bfloat16, seed=34), rnd(M, N, dtype=torch.bfloat16, seed=35)
+    acc = a.float() @ w.float().t()
+    ad = a.to(DEV)
+    wd = w.to(DEV) if bkc else w.t().contiguous().to(DEV)          # strided form: [K, N] row-major
+
+    def close(out, ref):
+        err = (out.float().cpu() - ref).abs()
+        return bool((err <= 2.0 ** -7 * ref.abs() + 2e-2).all())
+    out = ops.gemm(ad, wd, b_kcontig=bkc, bias=bias.to(DEV), residual=res.to(DEV))
+    assert close(out, acc + bias + res.float())
+    out = ops.gemm(ad, wd, b_kcontig=bkc, aux=aux.to(DEV), aux_scale=1.25)
+    assert close(out, torch.where(aux.float() > 0, acc * 1.25, torch.zeros_like(acc)))
+    out = ops.gemm(ad, wd, b_kcontig=bkc, bias=bias.to(DEV), residual=res.to(DEV), aux=aux.to(DEV), aux_scale=0.5)   # both: the residual is prefetched
+    assert close(out, torch.where(aux.float() > 0, (acc + bias) * 0.5, torch.zeros_like(acc)) + res.float())
+    c = res.to(DEV).clone()
+    ops.gemm(ad, wd, b_kcontig=bkc, residual=c, out=c)
+    assert close(c, acc + res.float())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_gemm_epilogues(dtype):
     M, N, K = 300, 200, 128
