@@ -478,6 +478,9 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                     }
                 }
                 TR(23);
+#ifdef PA_PAIR_ABL_NOSTORE                 // timing ablation (wrong results): the fast path's output stores removed
+                if (p.alpha == 123.f)
+#endif
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int m = mp + it * 4;
