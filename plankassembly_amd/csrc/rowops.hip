@@ -260,8 +260,8 @@ __global__ __launch_bounds__(1024) void group_rows_kernel(GroupTab tab) {
     const int lo = wave * chunk, hi = min(n, lo + chunk);
     // The ids of this lane's tokens are fetched ONCE, all loads in flight together (idx[rowmap[i]] is two dependent round trips;
     // the two passes below then run from registers).  Up to GR_NIT batches per wave (16 * 64 * GR_NIT = 24 576 tokens per table:
-    // B * S of every shipped config); longer tables re-fetch.  (The launch's ~100 us in the step's kernel trace did not move: it
-    // runs on the prefetch stream beside the step's one-block-per-CU grids and mostly waits for a CU.)
+    // B * S of every shipped config); longer tables re-fetch.  (Neutral for the launch's duration - 91.5 us on an idle GPU, most of
+    // it the per-distinct-id loop the second pass used to run; 41.8 us with the per-bit ballots below.)
     constexpr int GR_NIT = 24;
     int idr[GR_NIT];
 #pragma unroll
@@ -314,20 +314,26 @@ __global__ __launch_bounds__(1024) void group_rows_kernel(GroupTab tab) {
     if (threadIdx.x == 0) seg[R] = carry;
     __syncthreads();
     for (int r = threadIdx.x; r <= R; r += 1024) g.seg[r] = seg[r];
+    const int idbits = R > 1 ? 32 - __clz(R - 1) : 0;               // ids are 0 .. R - 1
     for (int i0 = lo, it = 0; i0 < hi; i0 += 64, ++it) {
         const int i = i0 + lane;
         int row = 0;
         int id = id_of(it, i, row);
         if (i >= hi || id >= R) id = -1;
-        unsigned long long todo = __ballot(id >= 0);
-        while (todo) {
-            const int first = __ffsll((long long)todo) - 1;
-            const int lid = __shfl(id, first);
-            const unsigned long long m = __ballot(id == lid);
-            const int cur = hist[wave * R + lid];
-            if (id == lid) g.order[cur + __popcll(m & ((1ull << lane) - 1ull))] = row;
-            if (lane == first) hist[wave * R + lid] = cur + __popcll(m);
-            todo &= ~m;
+        // lanes of the batch that carry MY id, without a loop over the distinct ids (that loop - ~64 dependent rounds of shuffle,
+        // ballot and LDS read per batch for value tokens - was most of this launch's 91 us): one ballot per id bit, each lane
+        // keeps the lanes that agree with it on that bit.  The rank among them in lane order keeps the sort stable.
+        unsigned long long eq = __ballot(id >= 0);
+        for (int b = 0; b < idbits; ++b) {
+            const bool bit = (id >> b) & 1;
+            const unsigned long long bb = __ballot(bit);
+            eq &= bit ? bb : ~bb;
+        }
+        if (id >= 0) {
+            const int cur = hist[wave * R + id];                 // every lane reads the cursor before the leader below moves it
+            const int rank = __popcll(eq & ((1ull << lane) - 1ull));
+            g.order[cur + rank] = row;
+            if (rank == 0) hist[wave * R + id] = cur + __popcll(eq);
         }
     }
 }
