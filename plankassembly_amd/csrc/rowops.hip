@@ -847,6 +847,41 @@ __global__ __launch_bounds__(128) void embed_segment_bwd_kernel(const T* dout, S
         }
     }
 }
+// ordered (f32 parity path): one block per table row and no atomics, as embed_segment_bwd_kernel's ch == 1 branch with
+// seg_long = INT_MAX - but FOUR thread groups walk four consecutive quarters of a long segment (each in order, eight rows in
+// flight) and group 0 adds the four sums in quarter order: still one fixed order of additions per table row, a quarter of the
+// serial chain (the type / position tables put thousands of tokens on one row: 197 us per launch on one group).
+template <typename T>
+__global__ __launch_bounds__(512) void embed_segment_ordered_kernel(const T* dout, SegTab tb, int d) {
+    extern __shared__ __attribute__((aligned(16))) float seg_part[];       // [3][d]
+    int k = 0;
+    while (k + 1 < tb.n && (int)blockIdx.x >= tb.begin[k + 1]) ++k;
+    const int rel = blockIdx.x - tb.begin[k];
+    const int r = rel / SEG_SPLIT;
+    if (rel - r * SEG_SPLIT) return;                              // (the grid keeps embed_segment_bwd_kernel's block table)
+    const int32_t* order = tb.order[k];
+    const int b0 = tb.seg[k][r], b1 = tb.seg[k][r + 1], len = b1 - b0;
+    if (len <= 0) return;
+    const int g = threadIdx.x >> 7, t = threadIdx.x & 127;
+    const bool par = len >= 32;                                   // (block-uniform) short rows: group 0 alone
+    const int per = par ? ((len + 3) / 4 + 7) / 8 * 8 : len;
+    const int lo = b0 + g * per, hi = min(b1, lo + per);
+    for (int c = t << 2; c < d; c += 512) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (lo < hi && (par || g == 0)) acc = seg_sum<T>(dout, order, lo, hi, d, c);
+        if (par) {
+            if (g) *reinterpret_cast<f32x4*>(seg_part + (g - 1) * d + c) = acc;
+            __syncthreads();
+            if (g == 0) acc = ((acc + *reinterpret_cast<const f32x4*>(seg_part + c)) + *reinterpret_cast<const f32x4*>(seg_part + d + c))
+                              + *reinterpret_cast<const f32x4*>(seg_part + 2 * d + c);
+            __syncthreads();
+        }
+        if (g == 0) {
+            float* dst = tb.t[k] + (int64_t)r * d + c;
+            *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + acc;
+        }
+    }
+}
 extern "C" int pa_embed_segment_bwd(const void* dout, int32_t dtype, float* const* dtables, const int32_t* const* order,
                                     const int32_t* const* seg, const int32_t* table_rows, int32_t n_tables, int64_t n_rows,
                                     int32_t d, void* stream) {
@@ -860,6 +895,13 @@ extern "C" int pa_embed_segment_bwd(const void* dout, int32_t dtype, float* cons
         if (!tb.t[k] || !tb.order[k] || !tb.seg[k] || tb.rows[k] <= 0) return PA_EINVAL;
         tb.ch[k] = (ordered || tb.rows[k] > 64) ? 1 : 0;
         tb.begin[k + 1] = tb.begin[k] + (tb.ch[k] ? tb.rows[k] * SEG_SPLIT : (int)((n_rows + SEG_CHUNK - 1) / SEG_CHUNK));
+    }
+    static const bool ord4 = !(getenv("PA_EMBED_ORDERED_GROUPS") && atoi(getenv("PA_EMBED_ORDERED_GROUPS")) == 1);
+    if (ordered && ord4 && d <= 2048) {
+        const size_t shm = (size_t)3 * d * sizeof(float);
+        if (dtype == PA_BF16) PA_LAUNCH(embed_segment_ordered_kernel<bf16>, dim3(tb.begin[n_tables]), dim3(512), shm, ST(stream), (const bf16*)dout, tb, d);
+        else PA_LAUNCH(embed_segment_ordered_kernel<float>, dim3(tb.begin[n_tables]), dim3(512), shm, ST(stream), (const float*)dout, tb, d);
+        return 0;
     }
     if (dtype == PA_BF16) PA_LAUNCH(embed_segment_bwd_kernel<bf16>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const bf16*)dout, tb, d, seg_long);
     else PA_LAUNCH(embed_segment_bwd_kernel<float>, dim3(tb.begin[n_tables]), dim3(128), 0, ST(stream), (const float*)dout, tb, d, seg_long);
