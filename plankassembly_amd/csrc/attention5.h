@@ -173,8 +173,10 @@ __global__ __launch_bounds__(NTH, OCC) void attn5_fwd_kernel(AttnP pin) {
         const uint32_t w1 = pack_bf16(r2, 0.f);
         bias_b = half == 0 ? u32x4{w0, w1, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
     };
-    // per lane: the chunk sum above which the slow path is taken - 0 until the row has a reference point, 2^RESCALE_THR after
-    float slow_thr = 0.f;
+    // per lane: the chunk sum above which the slow path is taken - below zero until the row has a reference point (EVERY chunk
+    // takes the slow path until then: a first chunk whose scaled scores all sit below -126 exponentiates to 0 and a `> 0` test
+    // would never give the row a reference - ADVICE r4), 2^RESCALE_THR after
+    float slow_thr = -1.f;
     const float big = __builtin_amdgcn_exp2f(RESCALE_THR);
     const uint32_t thr_s = p.drop_thr;
 
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(NTH, OCC) void attn5_fwd_kernel(AttnP pin) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = fast_exp2(sacc[r] - ms); csum += sacc[r]; }
             m_run = m_new;
-            slow_thr = (m_new == -INFINITY) ? 0.f : big;
+            slow_thr = (m_new == -INFINITY) ? -1.f : big;
             set_reference(-ms);                                        // chunk c + 1 onwards: its bias k-step is issued below
         }
         l_run += csum;

@@ -682,12 +682,12 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
     // default exactly where pa_gemm_norm_a takes the skinny kernel (d_model 512, at most 512 rows); PLANK_DECODE_FOLD_LN=0 / 1 forces.
     static const int fold_force = getenv("PLANK_DECODE_FOLD_LN") ? atoi(getenv("PLANK_DECODE_FOLD_LN")) : -1;
     const bool fold_env = fold_force >= 0 ? fold_force != 0 : (d == 512 && B <= 512);
-    L->fold = fold_env && c.dtype == PA_BF16 && d % 64 == 0 && c.d_ff % 32 == 0 && (size_t)((B + 63) / 64) * ((3 * d + 63) / 64) <= 512;
+    L->fold = fold_env && c.dtype == PA_BF16 && d % 64 == 0 && c.d_ff % 32 == 0 && c.d_ff >= d && (size_t)((B + 63) / 64) * ((3 * d + 63) / 64) <= 512;
     // The exact-f32 step folds too since round 4 (pa_ln_fold_weights_f32 + the f32 skinny kernel with the statistics taken from
     // the rows themselves): 17 LayerNorm launches fewer per step - measured +0.5 % only (B 256: 1.995 vs 2.005 ms / step; the folded
     // Linears re-read their rows for the statistics), token-exact against the reference in every decode test.  d_model 512, <= 512 rows.
     // PLANK_DECODE_FOLD_LN=0 disables it as it does for bf16.
-    if (c.dtype == PA_F32) L->fold = fold_env && d == 512 && B <= 512 && c.d_ff % 32 == 0;
+    if (c.dtype == PA_F32) L->fold = fold_env && d == 512 && B <= 512 && c.d_ff % 32 == 0 && c.d_ff >= d;   // (N < K: pa_gemm_norm_a's f32 form cannot materialise y - ADVICE r4)
     const bool fold32 = L->fold && c.dtype == PA_F32;
     // f32 residual stream inside the bf16 step (see DecodeLayout::f32res): on wherever every Linear of the step takes the skinny
     // kernel (d_model 512, at most 512 rows).  tests/bf16_decode_sim.py / profiles/r04_bf16_decode_rounding_sim.txt: exact-prefix

@@ -866,17 +866,20 @@ __global__ __launch_bounds__(512) void embed_segment_ordered_kernel(const T* dou
     const bool par = len >= 32;                                   // (block-uniform) short rows: group 0 alone
     const int per = par ? ((len + 3) / 4 + 7) / 8 * 8 : len;
     const int lo = b0 + g * per, hi = min(b1, lo + per);
-    for (int c = t << 2; c < d; c += 512) {
+    // (block-uniform trip count: every thread reaches both barriers of every pass, threads past the row's width idle - ADVICE r4)
+    for (int c0 = 0; c0 < d; c0 += 512) {
+        const int c = c0 + (t << 2);
+        const bool on = c < d;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (lo < hi && (par || g == 0)) acc = seg_sum<T>(dout, order, lo, hi, d, c);
+        if (on && lo < hi && (par || g == 0)) acc = seg_sum<T>(dout, order, lo, hi, d, c);
         if (par) {
-            if (g) *reinterpret_cast<f32x4*>(seg_part + (g - 1) * d + c) = acc;
+            if (on && g) *reinterpret_cast<f32x4*>(seg_part + (g - 1) * d + c) = acc;
             __syncthreads();
-            if (g == 0) acc = ((acc + *reinterpret_cast<const f32x4*>(seg_part + c)) + *reinterpret_cast<const f32x4*>(seg_part + d + c))
+            if (on && g == 0) acc = ((acc + *reinterpret_cast<const f32x4*>(seg_part + c)) + *reinterpret_cast<const f32x4*>(seg_part + d + c))
                               + *reinterpret_cast<const f32x4*>(seg_part + 2 * d + c);
             __syncthreads();
         }
-        if (g == 0) {
+        if (on && g == 0) {
             float* dst = tb.t[k] + (int64_t)r * d + c;
             *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + acc;
         }

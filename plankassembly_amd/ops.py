@@ -290,23 +290,33 @@ def _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H, cu_q=N
     return a
 
 
-def attn_fwd(q, k, v, H, kpm=None, causal=False, scale=None, drop_p=0.0, drop_seed=0):
+def mask_order(kpm):
+    """Dispatch order for a padded batch with a key-padding mask: int32 [B], batch elements by descending number of unmasked
+    keys (what pa_pack_rows leaves behind `cu` for packed batches).  A block's duration is proportional to its element's key
+    count (tiles past the last unmasked key are skipped) and the hardware hands out blocks in index order as slots free up, so
+    longest-first is list scheduling's LPT rule: the launch no longer ends with a long element that started late.  Computed
+    once per batch (the mask is the same for every layer, forward and backward); results do not depend on it."""
+    return torch.argsort((kpm == 0).sum(dim=1), descending=True, stable=True).to(torch.int32)
+
+
+def attn_fwd(q, k, v, H, kpm=None, causal=False, scale=None, drop_p=0.0, drop_seed=0, order=None):
     """q: [B, Lq, H*dh] (may be a strided view of a packed projection), k/v: [B, Lk, H*dh];
-    kpm: uint8/bool [B, Lk] (1 = PAD).  Returns (o [B, Lq, H*dh], lse [B, H, Lq])."""
+    kpm: uint8/bool [B, Lk] (1 = PAD); order: optional int32 [B] dispatch order (mask_order).
+    Returns (o [B, Lq, H*dh], lse [B, H, Lq])."""
     B, Lq, dm = q.shape
     o = torch.empty(B, Lq, dm, dtype=q.dtype, device=q.device)
     lse = _f32(B, H, Lq, device=q.device)
     if kpm is not None:
         kpm = kpm.to(torch.uint8).contiguous()
-    a = _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H)
+    a = _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H, order=order)
     L.check(L.lib().pa_attn_fwd(C.byref(a), L.stream()), "pa_attn_fwd")
     return o, lse
 
 
-def attn_bwd(dout, q, k, v, o, lse, H, kpm=None, causal=False, scale=None, drop_p=0.0, drop_seed=0):
+def attn_bwd(dout, q, k, v, o, lse, H, kpm=None, causal=False, scale=None, drop_p=0.0, drop_seed=0, order=None):
     if kpm is not None:
         kpm = kpm.to(torch.uint8).contiguous()
-    a = _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H)
+    a = _attn_args(q, k, v, o, lse, kpm, causal, scale, drop_p, drop_seed, H, order=order)
     dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
     dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
     dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)

@@ -330,6 +330,8 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
     max_steps = int(tkw.get("max_steps", -1))
     loader = module.train_dataloader()
     for epoch in range(start_epoch, max_epochs):
+        if 0 < max_steps <= module.global_step:            # a resumed run whose epoch was cut by max_steps: nothing left to do
+            break
         module.model.train()
         if hasattr(loader.sampler, "set_epoch"):
             loader.sampler.set_epoch(epoch)
@@ -377,8 +379,13 @@ def run(trainer_cls, subcommand, config, ckpt_path=None, overrides=None):
                 torch.save(ck, last)
                 if improved:
                     torch.save(ck, best_file)
-                    if stale and stale != best_file and os.path.exists(stale):
-                        os.remove(stale)                               # save_top_k: 1
+                    # save_top_k: 1 - but only among THIS run's checkpoints.  A best file inherited from the checkpoint being
+                    # resumed lives in an earlier run's version_N/checkpoints (often it IS --ckpt_path): Lightning 1.7 restores
+                    # best_model_path only for a matching dirpath and never deletes another run's file; neither do we.
+                    if (stale and stale != best_file and os.path.exists(stale)
+                            and os.path.abspath(os.path.dirname(stale)) == os.path.abspath(ckdir)
+                            and not (ckpt_path and os.path.abspath(stale) == os.path.abspath(ckpt_path))):
+                        os.remove(stale)
                 print({k: round(v, 4) for k, v in module._logged.items() if k.startswith("val/")})
         if 0 < max_steps <= module.global_step:
             break

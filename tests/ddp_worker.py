@@ -40,8 +40,15 @@ def main(rank, world, port, case, dtype, grad_dtype, out_path):
     from plankassembly_amd.distributed import GradSync, allreduce_metric_sums
     from plankassembly_amd.optim import FusedAdam
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # PLANK_DDP_BACKEND=nccl (tests/test_distributed_gpu.py::test_rccl_two_devices_*, boxes with >= 2 GPUs): one device per
+    # rank and the exchange over RCCL - the transport the product uses; default: both ranks on cuda:0 over gloo
+    backend = os.environ.get("PLANK_DDP_BACKEND", "gloo")
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         c = LC.CASES[case]
         m = build(c, dtype)
@@ -65,7 +72,8 @@ def main(rank, world, port, case, dtype, grad_dtype, out_path):
         sums = allreduce_metric_sums(torch.tensor([1.0 + rank, 2.0, 3.0, 1.0], dtype=torch.float64))
         torch.save({"loss": float(out["loss"]), "grads": g, "p_start": p_start, "params": m.flat_params.detach().cpu().clone(),
                     "launched": list(sync.launched), "fired": list(sync.fired), "sums": sums,
-                    "reserve_log": list(sync.reserve_log), "reserved_after": int(L.lib().pa_get_reserved_cus())}, f"{out_path}.{rank}")
+                    "reserve_log": list(sync.reserve_log), "reserved_after": int(L.lib().pa_get_reserved_cus()),
+                    "backend": dist.get_backend(), "device": torch.cuda.current_device()}, f"{out_path}.{rank}")
     finally:
         dist.destroy_process_group()
 

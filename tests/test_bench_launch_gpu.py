@@ -71,3 +71,12 @@ def test_driver_launch_line_two_ranks_sharing_the_gpu():
     # set-up steps in front of the warm-up under RCCL only, which would move the one-rank run 30 optimizer steps ahead)
     one, _ = _launch(1, {"PLANK_BENCH_BACKEND": "gloo"})
     assert abs(line["final_loss"] - one["final_loss"]) <= 2e-3 * abs(one["final_loss"])
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two devices: RCCL refuses two ranks on one")
+def test_driver_launch_line_two_ranks_over_rccl():
+    """the driver's N = 2 line over the product transport (backend nccl = RCCL, one device per rank)."""
+    line, _ = _launch(2, {}, flags=("--no-cpu", "--no-decode", "--no-kernels", "--long-steps", "6"))
+    _check_line(line, 2, 4, 2)
+    assert line["rccl_ranks"]["world_size"] == 2 and line["rccl_ranks"]["backend"] == "nccl" and line["rccl_ranks"]["process_group"]
+    assert line["rccl_ranks"]["ms_per_step_by_rank"]["train"]["ranks"] == 2

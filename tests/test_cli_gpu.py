@@ -116,6 +116,12 @@ def test_cli_fit_resume_test_evaluate(tmp_path, monkeypatch):
     assert torch.equal(popt._m.cpu(), m_end) and popt._step == 6
     last2 = os.path.join(mod2.logger.log_dir, "checkpoints", "last.ckpt")
     assert torch.load(last2, map_location="cpu", weights_only=True)["epoch"] == 4
+    # the resumed run inherits best_model_path from the checkpoint, but save_top_k only prunes its OWN directory -
+    # the first run's best file and the file passed as --ckpt_path are still there
+    assert os.path.exists(best[0]) and os.path.exists(last), os.listdir(ckdir)
+    # a run that already reached max_steps takes no further optimizer step when resumed
+    mod2b = cli(Trainer, ["fit", "--config", config, "--ckpt_path", last, "--trainer.max_epochs", "5", "--trainer.max_steps", "6"])
+    assert mod2b.global_step == 6 and mod2b.optimizer._step == 6
 
     # ---- test --ckpt_path: pred_jsons in the reference's format, test/* logged
     mod3 = cli(Trainer, ["test", "--config", config, "--ckpt_path", last2])

@@ -83,7 +83,7 @@ def test_metric_sums_travel_through_the_device_under_an_rccl_only_group(nccl_wor
     assert torch.equal(allreduce_metric_sums(v.clone()), v)
 
 
-def _two_ranks(case, dtype, grad_dtype, tmp_path):
+def _two_ranks(case, dtype, grad_dtype, tmp_path, backend="gloo"):
     import socket
     import subprocess
     import sys
@@ -92,7 +92,7 @@ def _two_ranks(case, dtype, grad_dtype, tmp_path):
         port = sk.getsockname()[1]
     out = str(tmp_path / "rank")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ddp_worker.py")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PA_RESERVE_CUS="16")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PA_RESERVE_CUS="16", PLANK_DDP_BACKEND=backend)
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), case, dtype, grad_dtype, out], env=env)
              for r in range(2)]
     for p in procs:
@@ -102,6 +102,20 @@ def _two_ranks(case, dtype, grad_dtype, tmp_path):
 
 @pytest.mark.parametrize("case,dtype,grad_dtype", [("live", "f32", "f32"), ("sideface", "f32", "f32"), ("live", "bf16", "bf16")])
 def test_two_ranks_on_one_gpu_exchange_the_mean_of_the_real_models_gradients(case, dtype, grad_dtype, tmp_path):
+    _check_two_ranks(case, dtype, grad_dtype, tmp_path, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="first contact with real RCCL needs two devices (the 1-GPU lease skips it)")
+@pytest.mark.parametrize("case,dtype,grad_dtype", [("live", "f32", "f32"), ("live", "bf16", "bf16")])
+def test_rccl_two_devices_exchange_the_mean_of_the_real_models_gradients(case, dtype, grad_dtype, tmp_path):
+    """the same check over backend="nccl" (= RCCL over xGMI) with one device per rank - reference
+    configs/train_complete.yaml:18-21 (`strategy: ddp`, `devices: 4`).  Skipped on a one-GPU box; on the first multi-GPU box it
+    turns RCCL's first run with more than one rank into a measurement instead of a debugging session."""
+    r0 = _check_two_ranks(case, dtype, grad_dtype, tmp_path, "nccl")
+    assert r0["backend"] == "nccl" and r0["device"] == 0
+
+
+def _check_two_ranks(case, dtype, grad_dtype, tmp_path, backend):
     """DDP semantics with the REAL model (reference configs/train_complete.yaml:18 `strategy: ddp`):
     two processes share the GPU (gloo on device tensors - RCCL refuses two ranks per device), rank r gets half of a
     B = 4 batch.  After the exchange both ranks hold the SUM of the two half-batch gradients a single process computes;
@@ -110,7 +124,8 @@ def test_two_ranks_on_one_gpu_exchange_the_mean_of_the_real_models_gradients(cas
     import large_cases as LC
     from ddp_worker import build, half
     from plankassembly_amd.optim import FusedAdam
-    r0, r1 = _two_ranks(case, dtype, grad_dtype, tmp_path)
+    r0, r1 = _two_ranks(case, dtype, grad_dtype, tmp_path, backend)
+    assert r0["backend"] == backend and r1["device"] == (1 if backend == "nccl" else 0)
     c = LC.CASES[case]
     batch = LC.case_batch(c, batch_size=4)
     m = build(c, dtype)
@@ -151,6 +166,7 @@ def test_two_ranks_on_one_gpu_exchange_the_mean_of_the_real_models_gradients(cas
         n = m._params["input_embeddings.input_type.weight"].numel()
         assert not r0["grads"][off:off + n].any()
     assert r0["sums"].tolist() == [3.0, 4.0, 6.0, 2.0] == r1["sums"].tolist()
+    return r0
 
 
 def test_reserved_cus_knob_keeps_results():
