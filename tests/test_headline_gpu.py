@@ -115,7 +115,8 @@ def check_grads(name, grads, r64):
 
 
 GOLDEN_COMPARED = {}          # case -> ReLU ties of the device run whose golden gradient slices were compared (module state)
-TIE_SLACK = 4.0               # per tie, in units of the 1e-4 * scale bound (see check_golden_grads)
+TIE_SLACK = 0.5               # per tie, in units of the plain bound (see check_golden_grads); measured on MI355X: every case
+                              # is inside the PLAIN bound once the tied units are excluded (worst 0.74 x, headline, one tie)
 
 
 def check_golden_grads(name, g, grads, flipped=()):
