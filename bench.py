@@ -546,9 +546,16 @@ def main():
     # ------------------------------------------------------------------ the same step on the parity path (exact-f32 MFMA)
     # north_star's tolerance (1e-4 against the f32 reference) is met by the f32 path only; bf16 is the throughput path
     # (BASELINE configs[1] names bf16 for the 1-GPU line).  Both figures go into the line; `value` stays the bf16 one.
-    train_f32 = None
-    if args.dtype == "bf16" and not args.no_f32:
-        m32 = build("f32", cfgd["max_in"], cfgd["max_out"], 0.2, cfgd).train()
+    train_f32, train_x3 = None, None
+    PARITY_NOTES = {
+        "f32": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations: the checker path of the 1e-4 parity tests",
+        "x3": "f32 activations / parameters / LayerNorm / softmax / loss; every GEMM on the bf16 matrix pipe as hi*hi + hi*lo + lo*hi of "
+              "the operands' bf16 hi / lo parts, f32 accumulation (pa_gemm_split_config); attention products in exact f32; passes the "
+              "f32 gate of tests/test_headline_gpu.py unchanged (test_x3_*)",
+    }
+
+    def parity_leg(name):
+        m32 = build(name, cfgd["max_in"], cfgd["max_out"], 0.2, cfgd).train()
         opt32 = FusedAdam(m32, lr=1e-4, grad_scale=1.0 / world)
         sync32 = None
         if dist.is_initialized():
@@ -563,18 +570,22 @@ def main():
             return o
 
         n32 = max(5, min(args.steps, 10))
-        dt32, o32 = timed(raw, fresh=True, steps=n32, warmup=2, tag="train_f32", mdl=m32, stepper=step32)
-        assert math.isfinite(float(o32["loss"].detach())), "f32 training diverged"
-        train_f32 = dict(value=n32 * B * world / dt32, unit="samples/s", steps=n32, warmup=2, ms_per_step=dt32 / n32 * 1e3,
-                         dtype="f32", final_loss=float(o32["loss"].detach()),
-                         note="exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations: the path the 1e-4 parity tests run")
-        log(f"train f32 (parity path): {train_f32['value']:.1f} samples/s, {train_f32['ms_per_step']:.2f} ms/step")
+        dt32, o32 = timed(raw, fresh=True, steps=n32, warmup=2, tag="train_" + name, mdl=m32, stepper=step32)
+        assert math.isfinite(float(o32["loss"].detach())), name + " training diverged"
+        res = dict(value=n32 * B * world / dt32, unit="samples/s", steps=n32, warmup=2, ms_per_step=dt32 / n32 * 1e3,
+                   dtype=name, final_loss=float(o32["loss"].detach()), note=PARITY_NOTES[name])
+        log(f"train {name} (parity path): {res['value']:.1f} samples/s, {res['ms_per_step']:.2f} ms/step")
         if sync32 is not None:
             fence()
             sync32.detach()
         m32.register_grad_ready_hook(None)
         del m32, opt32, sync32, o32, step32
         torch.cuda.empty_cache()
+        return res
+
+    if args.dtype == "bf16" and not args.no_f32:
+        train_f32 = parity_leg("f32")
+        train_x3 = parity_leg("x3")
 
     # Everything below steps the model on rank 0 ONLY (kernel census, padded-encoder variant): the gradient exchange must be
     # off by then, or rank 0's backward would enqueue collectives the other ranks never join (found by
@@ -696,13 +707,17 @@ def main():
     if dist.is_initialized():
         dist.barrier()
     if rank == 0:
-        if train_f32:
+        if train_x3 and train_f32:
+            # the fastest path that passes the 1e-4 / 1e-5 + 1e-4 * scale gates (tests/test_headline_gpu.py: test_f32_* and test_x3_*)
+            best = max((train_x3, train_f32), key=lambda t: t["value"])
+            parity = {"dtype": best["dtype"], "value": best["value"], "unit": "samples/s", "ms_per_step": best["ms_per_step"]}
+        elif train_f32:
             parity = {"dtype": "f32", "value": train_f32["value"], "unit": "samples/s", "ms_per_step": train_f32["ms_per_step"]}
         elif args.dtype == "f32":
             parity = {"dtype": "f32", "value": samples_s, "unit": "samples/s", "ms_per_step": dt / args.steps * 1e3}
         else:
             parity = None
-        prec = (" [value: bf16 MFMA, f32 accumulate / master weights; train.f32: the same step in exact f32 = the parity path]"
+        prec = (" [value: bf16 MFMA, f32 accumulate / master weights; train.f32 / train.x3: the same step in exact f32 / f32 with bf16x3 products = the parity paths]"
                 if args.dtype == "bf16" else " [exact-f32 MFMA: the parity path]")
         line = {
             "metric": ("train samples/sec (fwd+bwd+all-reduce+Adam), d_model=512 seq=1024" if headline else
@@ -716,7 +731,7 @@ def main():
                        "global_batch": B * world, "seq_len": S_in, "parallelism": f"dp{world}"},
             "final_loss": loss,
             "train": {args.dtype: dict(value=samples_s, unit="samples/s", ms_per_step=dt / args.steps * 1e3, steps=args.steps),
-                      **({"f32": train_f32} if train_f32 else {}),
+                      **({"f32": train_f32} if train_f32 else {}), **({"x3": train_x3} if train_x3 else {}),
                       "parity_meeting": parity},
             "steady_state": steady,
             "rccl_ranks": {"world_size": dist.get_world_size() if dist.is_initialized() else 1,

@@ -86,6 +86,17 @@ int pa_set_reserved_cus(int32_t n);
 int pa_get_reserved_cus(void);
 /* Slices pa_gemm really uses for a requested `splitk` (= number of slabs it writes; <= splitk). */
 int pa_gemm_effective_splitk(int32_t K, int32_t in_dtype, int32_t splitk);
+/* bf16x3 ("split") mode: while `on`, every pa_gemm call with in_dtype PA_F32 - the Linears of torch's Transformer layers and of
+ * the heads, reference plankassembly/models.py:60-69,85-88 (nn.TransformerEncoder/DecoderLayer's linear1/2, in_proj, out_proj;
+ * vocab / pointer / switch heads) and every gradient product of their backward - runs on the bf16 matrix pipe as
+ * hi*hi + hi*lo + lo*hi of the operands' bf16 hi / lo parts with f32 accumulation (~2^-17 relative per product; operands, outputs,
+ * epilogues and the split-K slabs stay f32).  `ws` / `bytes`: caller-owned, 256-byte aligned scratch for the split operands of ONE
+ * GEMM at a time (launches are stream-ordered): 6 bytes per operand element, e.g. 256 MB for the 16 x 1024-row headline step.
+ * A GEMM whose shape the bf16 fast paths do not take (contraction length not a multiple of 64 between two k-contiguous
+ * operands, rows / leading dimensions not multiples of 8 / 4, scratch too small) silently runs exact f32 instead; pa_gemm_split_stats
+ * counts both.  The setting is process-global; plankassembly_amd.models.PlankModel(compute_dtype="x3") brackets its own calls. */
+int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes);
+int pa_gemm_split_stats(int64_t* out2, int32_t reset);        /* out2[0] GEMMs run as bf16x3, out2[1] asked but run exact */
 /* Measurement hook (bench.py's roofline census; no reference counterpart): pa_gemm_record(1) starts appending every
  * pa_gemm() argument block to a host-side list; pa_gemm_record(0) returns the count so far; pa_gemm_recorded() copies
  * up to `cap` recorded blocks out and stops recording.  Replaying the blocks re-launches the same GEMMs. */

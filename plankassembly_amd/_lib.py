@@ -106,6 +106,8 @@ def lib():
             "pa_set_reserved_cus": (I, [I]),
             "pa_get_reserved_cus": (I, []),
             "pa_gemm_effective_splitk": (I, [I, I, I]),
+            "pa_gemm_split_config": (I, [I, P, I64]),
+            "pa_gemm_split_stats": (I, [P, I]),
             "pa_gemm_group": (I, [P, I, P]),
             "pa_segment_tail": (I, [P, I, I, P, I, I, P, I, P]),
             "pa_gemm_record": (I, [I]),

@@ -2436,8 +2436,157 @@ extern "C" int pa_set_reserved_cus(int32_t n) {
 }
 extern "C" int pa_get_reserved_cus(void) { return 256 - cus_for_gemm(); }
 
+// -------------------------------------------------------------------------------------------------
+// bf16x3 ("split") products: an f32-accurate GEMM on the bf16 matrix pipe.  Every f32 operand is cut into
+// hi = bf16(x) and lo = bf16(x - hi) (16 mantissa bits together) and the product runs as hi*hi + hi*lo + lo*hi with f32
+// accumulation - the lo*lo term, 2^-16 of the result, is dropped: ~2^-17 relative per product against 2^-9 for plain bf16 and 2^-24
+// for f32, inside north_star's 1e-4 (tools/x3_sim.py: the whole train step evaluated this way sits at <= 0.2 x the f32 gate).
+// Realised WITHOUT a new GEMM kernel: the three products are ONE bf16 GEMM over a three times longer contraction index,
+//     A' = [A_hi | A_hi | A_lo]   B' = [B_hi | B_lo | B_hi]      (k-contiguous operand: the three parts side by side in a row;
+//                                                                  operand with a strided contraction index: stacked as rows)
+// built by one split_kernel launch per GEMM into a caller-owned scratch buffer (pa_gemm_split_config), so every bf16 kernel family
+// (ring / pair / small / wide / skinny, split-K, every epilogue) serves the mode unchanged at 3/16 of the exact-f32 MFMA time.
+// Exact f32 (v_mfma_f32_32x32x2_f32) stays the checker and the fallback for shapes the bf16 fast paths do not take.
+namespace {
+struct SplitJob { const float* src; bf16* dst; int rows, cols, ld, mode; long long sstride, dstride; int batch, pad_; };
+struct SplitTab { SplitJob j[3]; int begin[4]; int n; };
+// mode 0: [rows][cols] -> [rows][3 cols] as (hi, hi, lo);  1: as (hi, lo, hi);  2: -> [3 rows][cols] stacked (hi, hi, lo);
+// 3: stacked (hi, lo, hi);  4: hi only [rows][cols] (the ReLU-backward gate: only its sign is read)
+__global__ __launch_bounds__(256) void split_kernel(SplitTab tb) {
+    int k = 0;
+    while (k + 1 < tb.n && (int)blockIdx.x >= tb.begin[k + 1]) ++k;
+    const SplitJob& J = tb.j[k];
+    const int nb = tb.begin[k + 1] - tb.begin[k], bid = blockIdx.x - tb.begin[k];
+    const int c4 = J.cols >> 2;
+    const long long per = (long long)J.rows * c4, total = per * J.batch;
+    for (long long e = (long long)bid * 256 + threadIdx.x; e < total; e += (long long)nb * 256) {
+        const int b = (int)(e / per);
+        const long long r_ = e - (long long)b * per;
+        const int r = (int)(r_ / c4), c = (int)(r_ - (long long)r * c4) << 2;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(J.src + (size_t)b * J.sstride + (size_t)r * J.ld + c);
+        u32x2 hi, lo;
+        hi[0] = pack_bf16(x[0], x[1]); hi[1] = pack_bf16(x[2], x[3]);
+        lo[0] = pack_bf16(x[0] - bf16_lo(hi[0]), x[1] - bf16_hi(hi[0]));
+        lo[1] = pack_bf16(x[2] - bf16_lo(hi[1]), x[3] - bf16_hi(hi[1]));
+        bf16* d = J.dst + (size_t)b * J.dstride;
+        if (J.mode == 4) { *reinterpret_cast<u32x2*>(d + (size_t)r * J.cols + c) = hi; continue; }
+        const bool a_pat = (J.mode & 1) == 0;                 // (hi, hi, lo) or (hi, lo, hi)
+        if (J.mode < 2) {
+            bf16* row = d + (size_t)r * 3 * J.cols + c;
+            *reinterpret_cast<u32x2*>(row) = hi;
+            *reinterpret_cast<u32x2*>(row + J.cols) = a_pat ? hi : lo;
+            *reinterpret_cast<u32x2*>(row + 2 * J.cols) = a_pat ? lo : hi;
+        } else {
+            const size_t plane = (size_t)J.rows * J.cols;
+            bf16* q = d + (size_t)r * J.cols + c;
+            *reinterpret_cast<u32x2*>(q) = hi;
+            *reinterpret_cast<u32x2*>(q + plane) = a_pat ? hi : lo;
+            *reinterpret_cast<u32x2*>(q + 2 * plane) = a_pat ? lo : hi;
+        }
+    }
+}
+struct SplitState { std::atomic<int> on{0}; char* ws = nullptr; long long bytes = 0; std::atomic<long long> taken{0}, declined{0}; };
+SplitState g_split;
+inline int eff_split(int nt, int sk) { if (sk > nt) sk = nt; if (sk < 1) sk = 1; const int per = (nt + sk - 1) / sk; return (nt + per - 1) / per; }
+}  // namespace
+extern "C" int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes) {
+    if (on && (!ws || bytes <= 0 || (reinterpret_cast<uintptr_t>(ws) & 255))) return PA_EINVAL;
+    g_split.ws = static_cast<char*>(ws); g_split.bytes = bytes;
+    g_split.on.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+// [0] GEMMs that ran as bf16x3 since the last reset, [1] f32 GEMMs that asked for it and ran exact (shape / alignment / scratch)
+extern "C" int pa_gemm_split_stats(int64_t* out2, int32_t reset) {
+    if (out2) { out2[0] = g_split.taken.load(); out2[1] = g_split.declined.load(); }
+    if (reset) { g_split.taken.store(0); g_split.declined.store(0); }
+    return 0;
+}
+// returns 1 when the GEMM was enqueued as bf16x3, 0 when the caller must run it exact, < 0 on error
+static int gemm_split3(const pa_gemm_args* a, void* stream) {
+    const bool akc = a->a_kcontig != 0, bkc = a->b_kcontig != 0;
+    const int M = a->M, N = a->N, K = a->K, nb = a->batch;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    // source rows / cols of each operand as stored
+    const int ar = akc ? M : K, ac = akc ? K : M, br = bkc ? N : K, bc = bkc ? K : N;
+    if ((ac & 7) || (bc & 7) || (a->lda & 3) || (a->ldb & 3) || (a->sA & 3) || (a->sB & 3) || !al16(a->A) || !al16(a->B)) return 0;
+    if (akc && bkc && (K & 63)) return 0;                 // the bf16 fast paths want whole K tiles per part
+    if (a->C_lp) return 0;
+    if (a->aux && ((N & 7) || (a->ldaux & 3) || (a->sAux & 3) || !al16(a->aux))) return 0;
+    const bool a_shared = nb > 1 && a->sA == 0, b_shared = nb > 1 && a->sB == 0;
+    const long long a_el = (long long)ar * ac * 3, b_el = (long long)br * bc * 3, x_el = a->aux ? (long long)M * N : 0;
+    auto up = [](long long v) { return (v + 255) / 256 * 256; };
+    const long long a_bytes = up(a_el * 2 * (a_shared ? 1 : nb)), b_bytes = up(b_el * 2 * (b_shared ? 1 : nb)), x_bytes = up(x_el * 2 * nb);
+    if (a_bytes + b_bytes + x_bytes > g_split.bytes) return 0;
+    // split-K: the caller sized its slabs with the f32 tiling (pa_gemm_effective_splitk(K, PA_F32, .)); ask the bf16 tiling for
+    // exactly as many non-empty slices, or decline
+    int sk_req = a->splitk > 1 ? a->splitk : 1, zero_from = 0, zero_to = 0;
+    if (sk_req > 1) {
+        const int want = eff_split((K + 15) / 16, sk_req), nt3 = (3 * K + 63) / 64;
+        int found = 0, best = 1;
+        for (int s_ = 1; s_ <= nt3 && s_ <= want + 8; ++s_) {
+            const int e_ = eff_split(nt3, s_);
+            if (e_ == want) { found = s_; break; }
+            if (e_ < want && e_ >= eff_split(nt3, best)) best = s_;
+        }
+        if (want <= 1) sk_req = 1;
+        else if (found) sk_req = found;
+        else {
+            // no request yields exactly `want` slices of whole bf16 K tiles: write fewer and (for a deferred reduction, whose
+            // descriptor already says `want`) hand the reducer zeros for the rest
+            sk_req = best;
+            if (a->splitk_defer) { zero_from = eff_split(nt3, best); zero_to = want; }
+            if (!a->ws) return 0;
+        }
+    }
+    bf16* A3 = reinterpret_cast<bf16*>(g_split.ws);
+    bf16* B3 = reinterpret_cast<bf16*>(g_split.ws + a_bytes);
+    bf16* X1 = reinterpret_cast<bf16*>(g_split.ws + a_bytes + b_bytes);
+    SplitTab tb; tb.n = 0; tb.begin[0] = 0;
+    auto add = [&](const void* src, bf16* dst, int rows, int cols, int ld, int mode, long long ss, long long ds, int batch) {
+        SplitJob& j = tb.j[tb.n];
+        j.src = static_cast<const float*>(src); j.dst = dst; j.rows = rows; j.cols = cols; j.ld = ld; j.mode = mode;
+        j.sstride = ss; j.dstride = ds; j.batch = batch; j.pad_ = 0;
+        long long blocks = ((long long)rows * (cols >> 2) * batch + 1023) / 1024;       // four vectors per thread
+        if (blocks < 1) blocks = 1;
+        if (blocks > 2048) blocks = 2048;
+        tb.begin[tb.n + 1] = tb.begin[tb.n] + (int)blocks;
+        ++tb.n;
+    };
+    add(a->A, A3, ar, ac, a->lda, akc ? 0 : 2, a->sA, a_el, a_shared ? 1 : nb);
+    add(a->B, B3, br, bc, a->ldb, bkc ? 1 : 3, a->sB, b_el, b_shared ? 1 : nb);
+    if (a->aux) add(a->aux, X1, M, N, a->ldaux, 4, a->sAux, x_el, nb);
+    PA_LAUNCH(split_kernel, dim3(tb.begin[tb.n]), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tb);
+    pa_gemm_args b = *a;
+    b.in_dtype = PA_BF16;
+    b.A = A3; b.B = B3; b.K = 3 * K;
+    b.lda = akc ? 3 * K : M; b.ldb = bkc ? 3 * K : N;
+    b.sA = a_shared ? 0 : a_el; b.sB = b_shared ? 0 : b_el;
+    if (a->aux) { b.aux = X1; b.ldaux = N; b.sAux = x_el; }
+    b.splitk = sk_req;
+    g_split.on.store(0, std::memory_order_relaxed);            // (the inner call is a plain bf16 GEMM)
+    const int rc = pa_gemm(&b, stream);
+    g_split.on.store(1, std::memory_order_relaxed);
+    if (rc) return rc;
+    if (zero_to > zero_from) {
+        const size_t slab = (size_t)M * N * sizeof(float);
+        if (hipMemsetAsync(static_cast<char*>(a->ws) + (size_t)zero_from * slab, 0, (size_t)(zero_to - zero_from) * slab,
+                           reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return PA_EINVAL;
+    }
+    return 1;
+}
+
 extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return PA_EINVAL;
+    if (a->in_dtype == PA_F32 && g_split.on.load(std::memory_order_relaxed)) {
+        if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return PA_EINVAL;
+        const int r3 = gemm_split3(a, stream);
+        if (r3 < 0) return r3;
+        if (r3 == 1) { g_split.taken.fetch_add(1); return 0; }
+        g_split.declined.fetch_add(1);
+        static const bool dbg_split = getenv("PA_SPLIT_DEBUG") && atoi(getenv("PA_SPLIT_DEBUG"));
+        if (dbg_split) fprintf(stderr, "[pa_gemm x3 declined] M %d N %d K %d batch %d akc %d bkc %d lda %d ldb %d sA %lld sB %lld splitk %d aux %d ldaux %d\n",
+                               a->M, a->N, a->K, a->batch, a->a_kcontig, a->b_kcontig, a->lda, a->ldb, (long long)a->sA, (long long)a->sB, a->splitk, a->aux ? 1 : 0, a->ldaux);
+    }
     if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec) g_rec->push_back(*a); }
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return PA_EINVAL;
     if (a->in_dtype != PA_F32 && a->in_dtype != PA_BF16) return PA_EINVAL;

@@ -125,7 +125,11 @@ class _TrainStepFn(torch.autograd.Function):
 
 class PlankModel(nn.Module):
     """See module docstring.  Constructor signature = reference models.py:13-29 plus
-    ``compute_dtype`` ('f32' parity path / 'bf16' throughput path)."""
+    ``compute_dtype`` ('f32' parity path / 'bf16' throughput path / 'x3': the f32 path with every matrix product of the
+    training step on the bf16 matrix pipe as a three-term hi / lo split - f32-accurate to ~2^-17 per product, see
+    include/plank_hip.h pa_gemm_split_config; parameters, activations, LayerNorm, softmax statistics, the loss and the
+    greedy decode are exactly the f32 path's)."""
+    _x3_scratch = {}            # device index -> uint8 scratch shared by every 'x3' model of the process
 
     def __init__(self, num_model=512, num_head=8, num_feedforward=1024, dropout=0.1, activation="relu",
                  normalize_before=True, num_encoder_layers=6, num_decoder_layers=6, num_view=3, num_type=2,
@@ -139,9 +143,11 @@ class PlankModel(nn.Module):
         # run the encoder on the valid (non-PAD) rows only; PLANK_UNPAD=0 keeps the dense layout
         self.unpad = os.environ.get("PLANK_UNPAD", "1") != "0"
         compute_dtype = compute_dtype or os.environ.get("PLANK_COMPUTE_DTYPE", "f32")
-        if compute_dtype not in ("f32", "bf16"):
-            raise ValueError("compute_dtype must be 'f32' or 'bf16'")
-        self.compute_dtype = compute_dtype
+        if compute_dtype not in ("f32", "bf16", "x3"):
+            raise ValueError("compute_dtype must be 'f32', 'bf16' or 'x3'")
+        self.compute_mode = compute_dtype                      # what the caller asked for
+        self.split3 = compute_dtype == "x3"
+        self.compute_dtype = "f32" if self.split3 else compute_dtype     # storage / kernel dtype: 'x3' is f32 with split products
         self.num_model, self.num_head, self.num_feedforward = num_model, num_head, num_feedforward
         self.dropout = float(dropout)
         # the reference passes normalize_before in torch's layer_norm_eps slot (models.py:60-61,66-67)
@@ -347,6 +353,22 @@ class PlankModel(nn.Module):
 
     def _pa_dtype(self):
         return L.PA_BF16 if self.compute_dtype == "bf16" else L.PA_F32
+
+    def _split(self, on):
+        """'x3': bracket this model's library calls with the process-global bf16x3 GEMM mode (no-op for the other dtypes)."""
+        if not self.split3:
+            return
+        if not on:
+            L.check(L.lib().pa_gemm_split_config(0, None, 0), "pa_gemm_split_config")
+            return
+        dev = self._flat.device.index or 0
+        ws = PlankModel._x3_scratch.get(dev)
+        if ws is None:
+            mb = int(os.environ.get("PLANK_X3_SCRATCH_MB", "384"))
+            ws = torch.empty(mb * (1 << 20) + 256, dtype=torch.uint8, device=self._flat.device)
+            PlankModel._x3_scratch[dev] = ws
+        base = (ws.data_ptr() + 255) // 256 * 256
+        L.check(L.lib().pa_gemm_split_config(1, C.c_void_p(base), C.c_int64(ws.numel() - (base - ws.data_ptr()))), "pa_gemm_split_config")
 
     def _pa_activation(self):
         return {"relu": 1, "gelu": 2}[self.activation]
@@ -639,10 +661,14 @@ class PlankModel(nn.Module):
         base = (ws.data_ptr() + 255) // 256 * 256
         stats = torch.empty(4, dtype=torch.float32, device=self._flat.device)
         self._step_seed = (self._step_seed * 1664525 + 1013904223 + int(torch.initial_seed())) & 0xFFFFFFFF
-        L.check(L.lib().pa_model_train_fwd(self._handle, C.byref(b), C.c_void_p(base),
-                                           C.c_int64(ws.numel() - (base - ws.data_ptr())),
-                                           C.c_uint32(self._step_seed), 1 if self.training else 0,
-                                           L.ptr(stats), L.stream()), "pa_model_train_fwd")
+        self._split(True)
+        try:
+            L.check(L.lib().pa_model_train_fwd(self._handle, C.byref(b), C.c_void_p(base),
+                                               C.c_int64(ws.numel() - (base - ws.data_ptr())),
+                                               C.c_uint32(self._step_seed), 1 if self.training else 0,
+                                               L.ptr(stats), L.stream()), "pa_model_train_fwd")
+        finally:
+            self._split(False)
         self._live = (b, keep, stats)
         if self._hook_leaf is None or self._hook_leaf.device != stats.device:
             self._hook_leaf = torch.zeros((), device=stats.device, requires_grad=True)
@@ -675,8 +701,12 @@ class PlankModel(nn.Module):
         # with the library's side stream the gradients of segment s are final once segment s + lag is enqueued
         lag = int(L.lib().pa_model_grad_lag(self._handle))
         for s in range(nseg):
-            L.check(L.lib().pa_model_train_bwd(self._handle, s, s + 1, C.c_float(1.0), L.stream()),
-                    "pa_model_train_bwd")
+            self._split(True)
+            try:
+                L.check(L.lib().pa_model_train_bwd(self._handle, s, s + 1, C.c_float(1.0), L.stream()),
+                        "pa_model_train_bwd")
+            finally:
+                self._split(False)
             if hook is not None and s - lag >= 0:
                 hook(s - lag, *slices[s - lag])
         if hook is not None:
@@ -742,7 +772,7 @@ class PlankModel(nn.Module):
 
 
 def build_model(cfg):
-    """reference models.py:333-343.  Optional ``cfg.MODEL.COMPUTE_DTYPE`` ('f32' | 'bf16')."""
+    """reference models.py:333-343.  Optional ``cfg.MODEL.COMPUTE_DTYPE`` ('f32' | 'bf16' | 'x3')."""
     model_cfg = cfg.MODEL
     dtype = getattr(model_cfg, "COMPUTE_DTYPE", None) if not isinstance(model_cfg, dict) else model_cfg.get("COMPUTE_DTYPE")
     return PlankModel(

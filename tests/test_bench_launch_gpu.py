@@ -53,7 +53,9 @@ def test_driver_launch_line_one_rank_rccl():
     # the driver checks that RCCL saw N ranks from these fields; the parity-meeting (f32) training figure rides in the same line
     assert line["rccl_ranks"]["world_size"] == 1 and line["rccl_ranks"]["backend"] == "nccl" and line["rccl_ranks"]["process_group"]
     assert line["rccl_ranks"]["ms_per_step_by_rank"]["train"]["ranks"] == 1
-    assert line["train"]["parity_meeting"]["dtype"] == "f32" and 0 < line["train"]["f32"]["value"] < line["train"]["bf16"]["value"]
+    assert line["train"]["parity_meeting"]["dtype"] in ("f32", "x3") and 0 < line["train"]["f32"]["value"] < line["train"]["bf16"]["value"]
+    assert 0 < line["train"]["x3"]["value"] < line["train"]["bf16"]["value"]
+    assert line["train"]["parity_meeting"]["value"] == max(line["train"]["f32"]["value"], line["train"]["x3"]["value"])
     assert line["steady_state"]["steps"] == 6 and "f32" in line["metric"]
 
 

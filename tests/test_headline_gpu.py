@@ -640,3 +640,59 @@ def test_bf16_b16_step_uses_every_gemm_family_and_matches_oracle(which):
         cos, rl2 = float(a @ r) / (float(a.norm()) * nr + 1e-300), float((a - r).norm()) / nr
         big = nr / tot > 1e-3
         assert cos > (0.997 if big else 0.9) and rl2 < (0.08 if big else 0.5), (k, cos, rl2, nr / tot)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# compute_dtype "x3": the f32 path with every matrix product on the bf16 matrix pipe as hi*hi + hi*lo + lo*hi (include/plank_hip.h
+# pa_gemm_split_config).  It must pass the f32 gate UNCHANGED - same bounds, same tie window - and the counters
+# must show that the products really ran split (a silent fall-back to exact f32 would pass the gate for the wrong reason).
+def _split_stats(reset=False):
+    import ctypes as C
+    from plankassembly_amd import _lib as L
+    out = (C.c_int64 * 2)()
+    L.check(L.lib().pa_gemm_split_stats(out, 1 if reset else 0), "pa_gemm_split_stats")
+    return int(out[0]), int(out[1])
+
+
+@pytest.mark.parametrize("name", ["headline", "complete", "visible", "sideface", "live", "eps0", "gelu", "t1024"])
+def test_x3_train_step_passes_the_f32_gate_unchanged(name):
+    c = LC.CASES[name]
+    g = LC.load_large(name)
+    sd, batch = LC.case_state_dict(c), LC.case_batch(c)
+    m = hip_model(c, "x3", sd)
+    assert m.compute_mode == "x3" and m.compute_dtype == "f32"
+    _split_stats(reset=True)
+    out, mem, hid, grads = run_hip_train(m, batch)
+    taken, declined = _split_stats()
+    print(f"[{name}-x3] GEMMs run as bf16x3: {taken}; run exact (shape / alignment): {declined}")
+    nlin = 4 * c["ne"] + 6 * c["nd"]                   # forward Linears of the layers alone; each has a dX and a dW product too
+    assert taken >= 5 * nlin // 2 and declined <= taken // 8, (taken, declined)
+    f32_gate(name + "-x3", c, sd, batch, m, out, mem, hid, grads, g=g)
+
+
+@pytest.mark.parametrize("which", ["above"])
+def test_x3_b16_step_matches_oracle(which):
+    """Batch 16, S = 1024 packed (the benchmarked dispatch: > 8 192 encoder rows)."""
+    c, batch, _ = _b16_case(which)
+    sd = LC.case_state_dict(c)
+    m = hip_model(c, "x3", sd)
+    _split_stats(reset=True)
+    out, mem, hid, grads = run_hip_train(m, batch)
+    taken, declined = _split_stats()
+    assert taken >= 150 and declined <= taken // 8, (taken, declined)
+    f32_gate(f"b16-{which}-x3", c, sd, batch, m, out, mem, hid, grads)
+
+
+def test_x3_train_step_under_dropout_matches_oracle_given_the_same_decisions():
+    import dropout_masks as DM
+    c = LC.CASES["headline"]
+    sd, batch = LC.case_state_dict(c), LC.case_batch(c)
+    torch.manual_seed(1234)
+    m = hip_model(c, "x3", sd, dropout=0.2)
+    m._step_seed = 20240917
+    seed = DM.next_step_seed(m._step_seed, torch.initial_seed())
+    out, mem, hid, grads = run_hip_train(m, batch)
+    assert m._step_seed == seed
+    drop = DM.HipDropout(seed, 0.2, c["h"], batch["input_mask"].numpy(), packed=m.unpad)
+    f32_gate("headline-x3-dropout", c, sd, batch, m, out, mem, hid, grads, drop=drop)
+    assert len(set(drop.sites_seen)) == 4 * c["ne"] + 6 * c["nd"]
