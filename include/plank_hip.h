@@ -338,6 +338,13 @@ typedef struct {
 } pa_attn_args;
 int pa_attn_fwd(const pa_attn_args* a, void* stream);
 int pa_attn_bwd(const pa_attn_args* a, void* stream);
+/* bf16x3 ("split") attention, the companion of pa_gemm_split_config: while `on`, f32 launches with dh = 64 compute every matrix
+ * product of torch's F.multi_head_attention_forward (reference plankassembly/models.py:60-69: S = Q K^T, O = P V) and of its
+ * backward as hi*hi + hi*lo + lo*hi of the operands' bf16 hi / lo parts with f32 accumulation (csrc/attention_x3.h); inputs,
+ * outputs, softmax statistics, masks, lse / delta and dropout decisions are the exact-f32 kernels'.  Other head sizes run exact.
+ * pa_attn_split_taken: launches (forward or backward) that ran split since the last reset. */
+int pa_attn_split_config(int32_t on);
+int64_t pa_attn_split_taken(int32_t reset);
 
 /* ------------------------------------------------------------------------------------------
  * Output heads + mixture NLL (training): reference models.py:140-166,186 (_create_dist training

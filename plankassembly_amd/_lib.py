@@ -133,6 +133,8 @@ def lib():
             "pa_layernorm_finish_many": (I, [P, I, I, P]),
             "pa_attn_fwd": (I, [P, P]),
             "pa_attn_bwd": (I, [P, P]),
+            "pa_attn_split_config": (I, [I]),
+            "pa_attn_split_taken": (I64, [I]),
             "pa_gelu_fwd": (I, [P, P, I64, I, I, I, F, C.c_uint32, P]),
             "pa_gelu_bwd": (I, [P, P, P, I64, I, I, I, F, C.c_uint32, P]),
             "pa_switch_fwd": (I, [P, P, I, P, P, I64, I, P]),

@@ -15,6 +15,7 @@
 // [row][dh] image and/or a transposed [dh][row] image (4 x EB register blocks transposed in
 // flight).  LDS images are XOR-swizzled in 16-byte chunks.  Scores never touch HBM.
 // Softmax runs in the log2 domain (exp2), f32 statistics.
+#include <atomic>
 #include "pa_device.h"
 #include "../../include/plank_hip.h"
 
@@ -2034,6 +2035,7 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_merged_kernel(AttnP pin, int
 }
 
 #include "attention5.h"
+#include "attention_x3.h"
 
 // =====================================================================================================
 AttnP make_params(const pa_attn_args* a) {
@@ -2187,8 +2189,21 @@ template <int DH> int run_bwd_bf16(AttnP p, hipStream_t st) {
     return 0;
 }
 
+// bf16x3 attention (attention_x3.h) for f32 launches with dh = 64 while pa_attn_split_config(1) is in force
+std::atomic<int> g_attn_x3{0};
+std::atomic<long long> g_attn_x3_taken{0};
 template <typename T, int DH> int run_fwd(const AttnP& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) return run_fwd_bf16<DH>(p, st);
+    if constexpr (sizeof(T) == 4 && DH == 64) {
+        if (g_attn_x3.load(std::memory_order_relaxed)) {
+            const int shm = 2 * X3L<DH>::BUF_QK;
+            static const int rc_ = set_lds(attnx_fwd_kernel<DH>, shm);
+            if (rc_) return rc_;
+            PA_LAUNCH((attnx_fwd_kernel<DH>), dim3((p.Lq + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
+            g_attn_x3_taken.fetch_add(1);
+            return 0;
+        }
+    }
     const int shm = 2 * Smem<T, DH>::BUF_FWD;
     int rc = set_lds(attn_fwd_kernel<T, DH>, shm);
     if (rc) return rc;
@@ -2200,6 +2215,17 @@ template <typename T, int DH> int run_bwd(const AttnP& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) return run_bwd_bf16<DH>(p, st);
     const int64_t total = (int64_t)p.B * p.H * p.Lq;
     PA_LAUNCH((attn_delta_kernel<T, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    if constexpr (sizeof(T) == 4 && DH == 64) {
+        if (g_attn_x3.load(std::memory_order_relaxed)) {
+            const int shk = 2 * X3L<DH>::BUF_DKV, shq = 2 * X3L<DH>::BUF_QK;
+            static const int rc_ = set_lds(attnx_bwd_dkv_kernel<DH>, shk) | set_lds(attnx_bwd_dq_kernel<DH>, shq);
+            if (rc_) return rc_;
+            PA_LAUNCH((attnx_bwd_dkv_kernel<DH>), dim3((p.Lk + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shk, st, p);
+            PA_LAUNCH((attnx_bwd_dq_kernel<DH>), dim3((p.Lq + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shq, st, p);
+            g_attn_x3_taken.fetch_add(1);
+            return 0;
+        }
+    }
     int shm = 2 * Smem<T, DH>::BUF_DKV;
     int rc = set_lds(attn_bwd_dkv_kernel<T, DH>, shm);
     if (rc) return rc;
@@ -2237,6 +2263,13 @@ int check_args(const pa_attn_args* a, bool bwd) {
 }
 
 }  // namespace
+
+extern "C" int pa_attn_split_config(int32_t on) { g_attn_x3.store(on ? 1 : 0, std::memory_order_relaxed); return 0; }
+extern "C" int64_t pa_attn_split_taken(int32_t reset) {
+    const long long v = g_attn_x3_taken.load();
+    if (reset) g_attn_x3_taken.store(0);
+    return v;
+}
 
 extern "C" int pa_attn_fwd(const pa_attn_args* a, void* stream) {
     int rc = check_args(a, false);

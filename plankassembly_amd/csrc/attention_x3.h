@@ -1,0 +1,452 @@
+// Included by attention.hip (inside its anonymous namespace, after mma_nat / mma_tr_nat and the first-generation f32 kernels).
+//
+// bf16x3 ("split") attention for the f32 parity path: reference plankassembly/models.py:60-69 (torch
+// F.multi_head_attention_forward inside nn.TransformerEncoder/DecoderLayer) with f32 inputs, outputs, softmax statistics and
+// dropout exactly as attn_fwd_kernel<float> / attn_bwd_dq_kernel<float> / attn_bwd_dkv_kernel<float> above - the same masks, the
+// same deferred-rescale online softmax, the same lse / delta, the same dropout decisions - but every matrix product
+// (S = Q K^T, O = P V, dP = dO V^T, dQ = dS K, dK = dS^T Q, dV = P^T dO) runs on the bf16 matrix pipe as
+// hi*hi + hi*lo + lo*hi of the operands' bf16 hi / lo parts with f32 accumulation (2^-17 relative per product, see gemm.hip
+// "bf16x3"): 12 v_mfma_f32_32x32x16_bf16 (384 cycles) per 32 x 32 x 64 product instead of 32 v_mfma_f32_32x32x2_f32 (2048).
+//
+// Structure = the first-generation kernels (128 owned rows per block, 64 streamed rows per step, global -> registers -> LDS,
+// double buffered, one barrier per step) with two changes that the split makes possible:
+//   * a streamed f32 tile is cut into hi / lo when it is written to LDS and kept as TWO natural [64][dh] bf16 images in the bf16
+//     kernels' swizzle, so mma_nat<bf16> (A operand = rows) and mma_tr_nat (A operand = columns, ds_read_b64_tr_b16) serve both
+//     uses of a tile: no transposed image, half the LDS of the f32 kernels' natural + transposed pair (64 KB per block for all
+//     three kernels -> two blocks per CU; the f32 backward kernels need 98 / 132 KB and run one block per CU);
+//   * a lane's own row operand (Q, dO, K, V rows in registers) is cut once per block.
+template <int DH> struct X3L {
+    static constexpr int NAT = BT<DH>::NAT;                  // one 64-row bf16 image
+    static constexpr int TILE = 2 * NAT;                     // [hi image | lo image]
+    static constexpr int BUF_QK = 2 * TILE + 64;             // two tiles + 64 mask bytes (forward, dQ)
+    static constexpr int BUF_DKV = 2 * TILE + 2 * 64 * 4;    // two tiles + lse, delta of the 64 streamed queries
+};
+
+// four rows x one 16-byte f32 chunk (load_sub<float, DH>) -> hi / lo halves of a bf16 chunk in the two images of `tile`
+template <int DH>
+__device__ __forceinline__ void x3_store(const u32x4* regs, char* tile, int sb) {
+    using A = AT<float, DH>;
+    using B = BT<DH>;
+    const int cb = sb % A::NCHR, rb = sb / A::NCHR;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = rb * 4 + i;
+        const float x0 = __uint_as_float(regs[i][0]), x1 = __uint_as_float(regs[i][1]);
+        const float x2 = __uint_as_float(regs[i][2]), x3 = __uint_as_float(regs[i][3]);
+        u32x2 hi, lo;
+        hi[0] = pack_bf16(x0, x1); hi[1] = pack_bf16(x2, x3);
+        lo[0] = pack_bf16(x0 - bf16_lo(hi[0]), x1 - bf16_hi(hi[0]));
+        lo[1] = pack_bf16(x2 - bf16_lo(hi[1]), x3 - bf16_hi(hi[1]));
+        const int off = swz_off<B::RBN>(row, cb >> 1) + (cb & 1) * 8;
+        *reinterpret_cast<u32x2*>(tile + off) = hi;
+        *reinterpret_cast<u32x2*>(tile + B::NAT + off) = lo;
+    }
+}
+// this lane's row operand, cut into hi / lo: NS = dh / 16 fragments of 8 bf16 each (elements 16 s + 8 half .. + 7)
+template <int DH>
+__device__ __forceinline__ void x3_row_regs(u32x4* hi, u32x4* lo, const float* base, int ld, int row, int nrows, int lane) {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < BT<DH>::NS; ++s) {
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (row < nrows) {
+            const float* src = base + (size_t)row * ld + 16 * s + 8 * half;
+            v0 = *reinterpret_cast<const f32x4*>(src); v1 = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+        hi[s][0] = pack_bf16(v0[0], v0[1]); hi[s][1] = pack_bf16(v0[2], v0[3]);
+        hi[s][2] = pack_bf16(v1[0], v1[1]); hi[s][3] = pack_bf16(v1[2], v1[3]);
+        lo[s][0] = pack_bf16(v0[0] - bf16_lo(hi[s][0]), v0[1] - bf16_hi(hi[s][0]));
+        lo[s][1] = pack_bf16(v0[2] - bf16_lo(hi[s][1]), v0[3] - bf16_hi(hi[s][1]));
+        lo[s][2] = pack_bf16(v1[0] - bf16_lo(hi[s][2]), v1[1] - bf16_hi(hi[s][2]));
+        lo[s][3] = pack_bf16(v1[2] - bf16_lo(hi[s][3]), v1[3] - bf16_hi(hi[s][3]));
+    }
+}
+// acc (32 x 32) += TILE[row0 + (lane & 31)][:] x regs, three terms
+template <int DH>
+__device__ __forceinline__ void x3_mma_nat(f32x16& acc, const char* tile, int row0, const u32x4* rh, const u32x4* rl, int lane) {
+    mma_nat<bf16, DH>(acc, tile, row0, rh, lane);
+    mma_nat<bf16, DH>(acc, tile + BT<DH>::NAT, row0, rh, lane);
+    mma_nat<bf16, DH>(acc, tile, row0, rl, lane);
+}
+// what bf16 rounding left of a 32 x 32 accumulator tile: pv - float(bf16(pv)), pairwise as mma_tr_nat packs it
+__device__ __forceinline__ f32x16 x3_lo_part(const f32x16& pv) {
+    f32x16 r;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const uint32_t u = pack_bf16(pv[2 * w], pv[2 * w + 1]);
+        r[2 * w] = pv[2 * w] - bf16_lo(u); r[2 * w + 1] = pv[2 * w + 1] - bf16_hi(u);
+    }
+    return r;
+}
+// acc[dt] (32 d x 32) += TILE^T[d][32 rows at row0] x pv, three terms (mma_tr_nat rounds its pv argument to bf16 itself)
+template <int DH>
+__device__ __forceinline__ void x3_mma_tr(f32x16* acc, const char* tile, int row0, const f32x16& pv, int lane) {
+    mma_tr_nat<DH>(acc, tile, row0, pv, lane);
+    mma_tr_nat<DH>(acc, tile + BT<DH>::NAT, row0, pv, lane);
+    const f32x16 pl = x3_lo_part(pv);
+    mma_tr_nat<DH>(acc, tile, row0, pl, lane);
+}
+
+// ---- forward (attn_fwd_kernel<float, DH> with split products) -------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(NTH, 2) void attnx_fwd_kernel(AttnP pin) {
+    using A = AT<float, DH>;
+    using X = X3L<DH>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (q0 >= p.Lq) return;
+    const float* Qp = reinterpret_cast<const float*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const float* Kp = reinterpret_cast<const float*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const float* Vp = reinterpret_cast<const float*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
+    const int qrow = q0 + wave * 32 + (lane & 31);
+
+    u32x4 qh[BT<DH>::NS], ql[BT<DH>::NS];
+    x3_row_regs<DH>(qh, ql, Qp, p.ldq, qrow, p.Lq, lane);
+
+    int nsteps = (p.Lk + BSTR - 1) / BSTR;
+    if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+
+    f32x16 oacc[A::NDT];
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl = p.scale * LOG2E;
+    const uint32_t arow = drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow));
+
+    u32x4 st[A::NITEM][4];
+    uint8_t mreg = 0;
+    auto gload = [&](int step) {
+        const int k0 = step * BSTR;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) {
+                const int sb = item % A::NSB;
+                if (item < A::NSB) load_sub<float, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
+                else load_sub<float, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
+            }
+        }
+        if (tid < BSTR) {
+            const int key = k0 + tid;
+            mreg = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * X::BUF_QK;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
+        }
+        if (tid < BSTR) reinterpret_cast<uint8_t*>(base + 2 * X::TILE)[tid] = mreg;
+    };
+
+    if (nsteps > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) gload(step + 1);
+        const char* kt_ = smem + buf * X::BUF_QK;
+        const char* vt_ = kt_ + X::TILE;
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(kt_ + 2 * X::TILE);
+        const int k0 = step * BSTR;
+
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
+            x3_mma_nat<DH>(sacc[kt], kt_, kt * 32, qh, ql, lane);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ko = kt * 32 + 8 * g + 4 * half;
+                const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + ko);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + ko + e;
+                    float x = sacc[kt][4 * g + e] * sl;
+                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
+                    x = masked ? -INFINITY : x;
+                    sacc[kt][4 * g + e] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (__any(mx > m_run + RESCALE_THR)) {                 // deferred rescale, as attn_fwd_kernel
+            const float m_new = fmaxf(m_run, mx);
+            const float ms = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2(m_run - ms);
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            m_run = m_new;
+        }
+        const float m_safe = (m_run == -INFINITY) ? 0.f : m_run;
+        float lsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pe = fast_exp2(sacc[kt][4 * g + e] - m_safe);
+                    lsum += pe;
+                    if (p.drop_thr) {
+                        const uint32_t ck = drop_key_hash(p.drop_seed, (uint32_t)(k0 + kt * 32 + 8 * g + 4 * half + e));
+                        pe = drop_keep2(arow, ck, p.drop_thr) ? pe * p.drop_scale : 0.f;
+                    }
+                    sacc[kt][4 * g + e] = pe;
+                }
+            }
+        l_run += lsum;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) x3_mma_tr<DH>(oacc, vt_, kt * 32, sacc[kt], lane);
+
+        if (step + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    float* Op = reinterpret_cast<float*>(p.o) + (size_t)qoff * p.ldo + h * DH;
+    store_rows<float, DH>(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);
+    if (half == 0 && qrow < p.Lq && p.lse)
+        p.lse[((size_t)b * p.H + h) * pin.Lq + qrow] = l_tot > 0.f ? (m_run + log2f(l_tot)) * LN2 : 0.f;
+}
+
+// ---- backward, dQ (attn_bwd_dq_kernel<float, DH> with split products) ----------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
+    using A = AT<float, DH>;
+    using X = X3L<DH>;
+    constexpr int NS = BT<DH>::NS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (q0 >= p.Lq) return;
+    const float* Qp = reinterpret_cast<const float*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const float* Kp = reinterpret_cast<const float*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const float* Vp = reinterpret_cast<const float*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const float* dOp = reinterpret_cast<const float*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
+    const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
+    const int qrow = q0 + wave * 32 + (lane & 31);
+
+    u32x4 qh[NS], ql[NS], doh[NS], dol[NS];
+    x3_row_regs<DH>(qh, ql, Qp, p.ldq, qrow, p.Lq, lane);
+    x3_row_regs<DH>(doh, dol, dOp, p.lddo, qrow, p.Lq, lane);
+    const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qrow;
+    const float lse2 = (qrow < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
+    const float dlt = (qrow < p.Lq) ? p.delta[srow] : 0.f;
+
+    int nsteps = (p.Lk + BSTR - 1) / BSTR;
+    if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+
+    f32x16 dqacc[A::NDT];
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
+    const float sl = p.scale * LOG2E;
+    const uint32_t arow = drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow));
+
+    u32x4 st[A::NITEM][4];
+    uint8_t mreg = 0;
+    auto gload = [&](int step) {
+        const int k0 = step * BSTR;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) {
+                const int sb = item % A::NSB;
+                if (item < A::NSB) load_sub<float, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
+                else load_sub<float, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
+            }
+        }
+        if (tid < BSTR) {
+            const int key = k0 + tid;
+            mreg = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * X::BUF_QK;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
+        }
+        if (tid < BSTR) reinterpret_cast<uint8_t*>(base + 2 * X::TILE)[tid] = mreg;
+    };
+
+    if (nsteps > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) gload(step + 1);
+        const char* kt_ = smem + buf * X::BUF_QK;
+        const char* vt_ = kt_ + X::TILE;
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(kt_ + 2 * X::TILE);
+        const int k0 = step * BSTR;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+            x3_mma_nat<DH>(sacc, kt_, kt * 32, qh, ql, lane);
+            x3_mma_nat<DH>(dpacc, vt_, kt * 32, doh, dol, lane);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ko = kt * 32 + 8 * g + 4 * half;
+                const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + ko);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + ko + e;
+                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
+                    const float pe = masked ? 0.f : fast_exp2(sacc[4 * g + e] * sl - lse2);
+                    float dp = dpacc[4 * g + e];
+                    if (p.drop_thr)
+                        dp = drop_keep2(arow, drop_key_hash(p.drop_seed, (uint32_t)key), p.drop_thr) ? dp * p.drop_scale : 0.f;
+                    sacc[4 * g + e] = pe * (dp - dlt) * p.scale;          // dS^T
+                }
+            }
+            x3_mma_tr<DH>(dqacc, kt_, kt * 32, sacc, lane);
+        }
+        if (step + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    float* dQp = reinterpret_cast<float*>(p.dq) + (size_t)qoff * p.lddq + h * DH;
+    store_rows<float, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, 1.0f, lane);
+}
+
+// ---- backward, dK / dV (attn_bwd_dkv_kernel<float, DH> with split products) ----------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(NTH, 2) void attnx_bwd_dkv_kernel(AttnP pin) {
+    using A = AT<float, DH>;
+    using X = X3L<DH>;
+    constexpr int NS = BT<DH>::NS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * BOWN;
+    int qoff, koff;
+    const AttnP p = batch_view(pin, b, qoff, koff);
+    if (key0 >= p.Lk) return;
+    const float* Qp = reinterpret_cast<const float*>(p.q) + (size_t)qoff * p.ldq + h * DH;
+    const float* Kp = reinterpret_cast<const float*>(p.k) + (size_t)koff * p.ldk + h * DH;
+    const float* Vp = reinterpret_cast<const float*>(p.v) + (size_t)koff * p.ldv + h * DH;
+    const float* dOp = reinterpret_cast<const float*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
+    const int krow = key0 + wave * 32 + (lane & 31);
+    const bool kmasked = (krow >= p.Lk) || (p.kpm && p.kpm[(size_t)b * pin.Lk + krow]);
+
+    u32x4 kh[NS], kl[NS], vh[NS], vl[NS];
+    x3_row_regs<DH>(kh, kl, Kp, p.ldk, krow, p.Lk, lane);
+    x3_row_regs<DH>(vh, vl, Vp, p.ldv, krow, p.Lk, lane);
+
+    const int nsteps = (p.Lq + BSTR - 1) / BSTR;
+    const int step0 = p.causal ? (key0 / BSTR) : 0;
+
+    f32x16 dkacc[A::NDT], dvacc[A::NDT];
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkacc[dt][r] = 0.f; dvacc[dt][r] = 0.f; }
+    const float sl = p.scale * LOG2E;
+    const uint32_t ckey = drop_key_hash(p.drop_seed, (uint32_t)krow);
+
+    u32x4 st[A::NITEM][4];
+    float lreg = 0.f, dreg = 0.f;
+    auto gload = [&](int step) {
+        const int r0 = step * BSTR;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) {
+                const int sb = item % A::NSB;
+                if (item < A::NSB) load_sub<float, DH>(st[j], Qp, p.ldq, r0, p.Lq, sb);
+                else load_sub<float, DH>(st[j], dOp, p.lddo, r0, p.Lq, sb);
+            }
+        }
+        if (tid < BSTR) {
+            const int qr = r0 + tid;
+            const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qr;
+            lreg = (qr < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
+            dreg = (qr < p.Lq) ? p.delta[srow] : 0.f;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * X::BUF_DKV;
+#pragma unroll
+        for (int j = 0; j < A::NITEM; ++j) {
+            const int item = tid + j * NTH;
+            if (item < 2 * A::NSB) x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
+        }
+        if (tid < BSTR) {
+            float* aux = reinterpret_cast<float*>(base + 2 * X::TILE);
+            aux[tid] = lreg; aux[64 + tid] = dreg;
+        }
+    };
+
+    if (step0 < nsteps) { gload(step0); lstore(0); }
+    __syncthreads();
+
+    for (int step = step0; step < nsteps; ++step) {
+        const int buf = (step - step0) & 1;
+        if (step + 1 < nsteps) gload(step + 1);
+        const char* qt_ = smem + buf * X::BUF_DKV;
+        const char* dot_ = qt_ + X::TILE;
+        const float* aux = reinterpret_cast<const float*>(qt_ + 2 * X::TILE);
+        const int r0 = step * BSTR;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+            x3_mma_nat<DH>(sacc, qt_, qt * 32, kh, kl, lane);        // S[q][key]: rows q (registers), column key (lane)
+            x3_mma_nat<DH>(dpacc, dot_, qt * 32, vh, vl, lane);      // dP[q][key]
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qo = qt * 32 + 8 * g + 4 * half;
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(aux + qo);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(aux + 64 + qo);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qr = r0 + qo + e;
+                    const bool masked = kmasked || (p.causal && krow > qr);
+                    const float pe = masked ? 0.f : fast_exp2(sacc[4 * g + e] * sl - l4[e]);
+                    float dp = dpacc[4 * g + e];
+                    float pd = pe;
+                    if (p.drop_thr) {
+                        const uint32_t ar = drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qr));
+                        const bool keep = drop_keep2(ar, ckey, p.drop_thr);
+                        dp = keep ? dp * p.drop_scale : 0.f;
+                        pd = keep ? pe * p.drop_scale : 0.f;
+                    }
+                    sacc[4 * g + e] = pd;                                   // dropped P  -> dV
+                    dpacc[4 * g + e] = pe * (dp - d4[e]) * p.scale;         // dS         -> dK
+                }
+            }
+            x3_mma_tr<DH>(dvacc, dot_, qt * 32, sacc, lane);
+            x3_mma_tr<DH>(dkacc, qt_, qt * 32, dpacc, lane);
+        }
+        if (step + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    float* dKp = reinterpret_cast<float*>(p.dk) + (size_t)koff * p.lddk + h * DH;
+    float* dVp = reinterpret_cast<float*>(p.dv) + (size_t)koff * p.lddv + h * DH;
+    store_rows<float, DH>(dKp, p.lddk, krow, p.Lk, dkacc, 1.0f, lane);
+    store_rows<float, DH>(dVp, p.lddv, krow, p.Lk, dvacc, 1.0f, lane);
+}

@@ -358,9 +358,13 @@ class PlankModel(nn.Module):
         """'x3': bracket this model's library calls with the process-global bf16x3 GEMM mode (no-op for the other dtypes)."""
         if not self.split3:
             return
+        attn = os.environ.get("PLANK_X3_ATTN", "1") != "0"         # (0: attention stays on the exact-f32 kernels)
         if not on:
             L.check(L.lib().pa_gemm_split_config(0, None, 0), "pa_gemm_split_config")
+            L.check(L.lib().pa_attn_split_config(0), "pa_attn_split_config")
             return
+        if attn:
+            L.check(L.lib().pa_attn_split_config(1), "pa_attn_split_config")
         dev = self._flat.device.index or 0
         ws = PlankModel._x3_scratch.get(dev)
         if ws is None:

@@ -970,3 +970,48 @@ def test_gemm_ln_fused_equals_separate_launches(M, K, drop, res):
         zt = x.float() @ w.float().T + bias + (r.float() if res else 0.0)
         yt = torch.nn.functional.layer_norm(zt, (512,), gamma, beta, 1e-5)
         assert rel_err(y1, yt.cpu()) < tol(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# bf16x3 ("split") attention (csrc/attention_x3.h): the exact-f32 kernels' function with every product as hi*hi + hi*lo + lo*hi
+@pytest.mark.parametrize("B,H,Lq,Lk,use_kpm,causal,drop", [
+    (2, 8, 128, 1199, True, False, 0.0),      # default cross-attention
+    (1, 8, 300, 300, True, False, 0.2),       # self-attention, ragged tiles, dropout (the same decisions as exact f32)
+    (2, 8, 128, 128, True, True, 0.2),        # default decoder self-attention
+    (2, 4, 1024, 1024, True, False, 0.0),     # benchmark length
+])
+def test_attention_x3_equals_exact_f32_to_split_precision(B, H, Lq, Lk, use_kpm, causal, drop):
+    from plankassembly_amd import _lib as L
+    dh, dm = 64, H * 64
+    qkv_q = rnd(B, Lq, 3 * dm, dtype=torch.float32, seed=50).to(DEV)
+    qkv_k = qkv_q if Lq == Lk else rnd(B, Lk, 3 * dm, dtype=torch.float32, seed=51).to(DEV)
+    q, k, v = qkv_q[..., :dm], qkv_k[..., dm:2 * dm], qkv_k[..., 2 * dm:]
+    kpm = None
+    if use_kpm:
+        g = torch.Generator().manual_seed(52)
+        valid = torch.randint(max(1, Lk // 3), Lk + 1, (B,), generator=g)
+        kpm = (torch.arange(Lk)[None, :] >= valid[:, None])
+        kpm[0, 3] = True
+        kpm = kpm.to(DEV)
+    dout = rnd(B, Lq, dm, dtype=torch.float32, seed=53).to(DEV)
+    kw = dict(kpm=kpm, causal=causal, drop_p=drop, drop_seed=77)
+
+    def run(split):
+        L.check(L.lib().pa_attn_split_config(1 if split else 0), "pa_attn_split_config")
+        try:
+            n0 = L.lib().pa_attn_split_taken(1)
+            o, lse = ops.attn_fwd(q, k, v, H, **kw)
+            dq, dk, dv = ops.attn_bwd(dout, q, k, v, o, lse, H, **kw)
+            torch.cuda.synchronize()
+            return (o, lse, dq, dk, dv), int(L.lib().pa_attn_split_taken(1))
+        finally:
+            L.check(L.lib().pa_attn_split_config(0), "pa_attn_split_config")
+
+    exact, n_exact = run(False)
+    x3, n_x3 = run(True)
+    assert n_exact == 0 and n_x3 == 2                         # forward + backward really took the split kernels
+    for name, a, b in zip(("o", "lse", "dq", "dk", "dv"), x3, exact):
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        assert err <= 3e-5 * scale + 1e-6, (name, err, scale)       # three-term split: ~2^-17 per product (plain bf16 would be ~4e-3)
+        assert err > 0.0 or name == "lse"                           # ... and it is not the exact kernel answering
