@@ -135,6 +135,20 @@ def kernel_rooflines(B):
     do = rnd(B, S_IN, D)
     t = time_kernel(lambda: ops.attn_bwd(do, q, k, v, o, lse, H, kpm=kpm, drop_p=0.2, drop_seed=1), iters=10)
     out["attn_bwd_enc_self"] = dict(ms=t * 1e3, tflops=2.5 * fl / t / 1e12, flops=2.5 * fl)
+    # the north_star kernel's other operating points (roofline_attention): no dropout, and a batch of 3 x B - four rounds of its
+    # 1 024-block launch instead of one and a third, i.e. the kernel's steady-state rate without the launch / first-tile / tail share
+    t = time_kernel(lambda: ops.attn_fwd(q, k, v, H, kpm=kpm, drop_p=0.0, drop_seed=1))
+    out["attn_fwd_enc_self_nodrop"] = dict(ms=t * 1e3, tflops=fl / t / 1e12, flops=fl)
+    t = time_kernel(lambda: ops.attn_bwd(do, q, k, v, o, lse, H, kpm=kpm, drop_p=0.0, drop_seed=1), iters=10)
+    out["attn_bwd_enc_self_nodrop"] = dict(ms=t * 1e3, tflops=2.5 * fl / t / 1e12, flops=2.5 * fl)
+    B3 = 3 * B
+    qkv3 = rnd(B3, S_IN, 3 * D)
+    q3, k3, v3 = qkv3[..., :D], qkv3[..., D:2 * D], qkv3[..., 2 * D:]
+    fl3 = 4.0 * S_IN * S_IN * D * B3
+    for tag, dp in (("", 0.2), ("_nodrop", 0.0)):
+        t = time_kernel(lambda: ops.attn_fwd(q3, k3, v3, H, drop_p=dp, drop_seed=1), iters=10)
+        out["attn_fwd_enc_self_steady" + tag] = dict(ms=t * 1e3, tflops=fl3 / t / 1e12, flops=fl3)
+    del qkv3, q3, k3, v3
     # the three GEMM layouts of one encoder Linear (in_proj: [B*S,512] x [1536,512]^T)
     M = B * S_IN
     x, w, dy = rnd(M, D), rnd(3 * D, D), rnd(M, 3 * D)
@@ -221,7 +235,7 @@ def pmc_traffic(kernel_key):
     """HBM bytes per launch of one kernel from the committed rocprofv3 PMC passes (profiles/r0N_pmc_traffic.json,
     made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 return json.load(f)["kernels"][kernel_key]["hbm_bytes_per_launch"]
@@ -242,7 +256,7 @@ def in_step_trace(key):
         return None
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     try:
-        names = sorted((f for f in os.listdir(here) if re.match(r"r\d+\w*_train_kernel_trace_summary\.txt$", f)), reverse=True)
+        names = sorted((f for f in os.listdir(here) if re.match(r"r\d+\w*_train_kernel_trace_summary\.txt$", f) and "x3" not in f), reverse=True)
     except OSError:
         return None
     for name in names:
@@ -278,6 +292,32 @@ def usable_cores():
 
 def log(msg):
     print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def attention_trace():
+    """Average in-step durations (us) of the encoder self-attention kernels from the newest committed rocprofv3 summary: the
+    forward kernel serves nothing else; the backward pair also serves no other launch (cross / decoder self run merged)."""
+    import re
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    try:
+        names = sorted((f for f in os.listdir(here) if re.match(r"r\d+\w*_train_kernel_trace_summary\.txt$", f) and "x3" not in f), reverse=True)
+    except OSError:
+        return None
+    pats = {"fwd_us": r"attn5_fwd_kernelILb1E", "dq_us": r"attn4_bwd_dq_kernelILb1E", "dkv_us": r"attn4_bwd_dkv_kernelILb1E"}
+    for name in names:
+        got = {}
+        with open(os.path.join(here, name)) as f:
+            for line in f:
+                parts = line.split()
+                for k, pat in pats.items():
+                    if len(parts) >= 4 and re.search(pat, parts[0]):
+                        try:
+                            got[k] = float(parts[3])
+                        except ValueError:
+                            pass
+        if len(got) == 3:
+            return dict(got, file="profiles/" + name)
+    return None
 
 
 def attention_census(cfgd, batch, drop_p):
@@ -790,6 +830,35 @@ def main():
                                          "mfma_frac": round(v["flops"] / v["seconds"] / 1e12 / PEAK_BF16_TFLOPS, 4)}
                                      for k, v in census.items()}
         if kern:
+            # The kernel north_star sets a target for (>= 0.70 of the MFMA roofline on the attention at d_model 512, seq 1024): the
+            # encoder self-attention.  Forward with / without dropout, backward, at the padded benchmark shape (dense-equivalent
+            # FLOPs 4 S^2 d B; ~25 % of the key tiles are masked and skipped), the steady-state rate (3 x the batch, no mask), the
+            # packed launches of the training step (HIP events, `kernel_census`) and the archived in-step rocprofv3 durations.
+            def frac(v):
+                return {"us": round(v["ms"] * 1e3, 2), "tflops": round(v["tflops"], 1), "frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4)}
+            ra = {"kernel": "attn5_fwd_kernel<DROP,3,3> (forward; csrc/attention5.h), attn4_bwd_dq_kernel + attn4_bwd_dkv_kernel (backward); dh 64, bf16",
+                  "bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "target_frac": 0.70,
+                  "padded_b16_s1024": {"fwd_dropout": frac(kern["attn_fwd_enc_self"]), "fwd_no_dropout": frac(kern["attn_fwd_enc_self_nodrop"]),
+                                       "bwd_dropout": frac(kern["attn_bwd_enc_self"]), "bwd_no_dropout": frac(kern["attn_bwd_enc_self_nodrop"])},
+                  "steady_state_b48_s1024_unmasked": {"fwd_dropout": frac(kern["attn_fwd_enc_self_steady"]),
+                                                      "fwd_no_dropout": frac(kern["attn_fwd_enc_self_steady_nodrop"])},
+                  "note": "issue-bound at dh 64: per 32 x 32 score chunk 8 MFMAs (256 cycles of the matrix pipe) stand against 16 v_exp_f32, "
+                          "8 v_cvt_pk, 8 packed adds, 12-16 LDS reads and - with dropout - 48 hash / compare / select instructions; a SIMD "
+                          "issues ~one instruction per 4.7 cycles whatever its type (profiles/r04_attn_issue_bound.txt, r05_attention_shape_sweep.txt)"}
+            if census and "attn_enc_self_fwd" in census:
+                ra["in_step_packed"] = {k2: {"launches": round(census[k]["launches"], 2),
+                                             "us": round(census[k]["seconds"] / census[k]["launches"] * 1e6, 2),
+                                             "tflops": round(census[k]["flops"] / census[k]["seconds"] / 1e12, 1),
+                                             "frac": round(census[k]["flops"] / census[k]["seconds"] / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                                        for k, k2 in (("attn_enc_self_fwd", "fwd"), ("attn_enc_self_bwd", "bwd_dq_plus_dkv")) if k in census}
+                ra["all_attention_ms_per_step"] = round(sum(v["seconds"] for k, v in census.items() if k.startswith("attn")) * 1e3, 3)
+                tr5 = attention_trace()
+                if tr5:
+                    flf = census["attn_enc_self_fwd"]["flops"] / census["attn_enc_self_fwd"]["launches"]
+                    ra["in_step_rocprof"] = dict(tr5, archived=True,
+                                                 fwd_frac=round(flf / (tr5["fwd_us"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                                 bwd_frac=round(2.5 * flf / ((tr5["dq_us"] + tr5["dkv_us"]) * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4))
+            line["roofline_attention"] = ra
             line["kernels"] = {k: {"ms": round(v["ms"], 4), "tflops": round(v["tflops"], 1),
                                    "mfma_frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4)} for k, v in kern.items()}
         if cpu:
