@@ -96,6 +96,7 @@ int pa_gemm_effective_splitk(int32_t K, int32_t in_dtype, int32_t splitk);
  * operands, rows / leading dimensions not multiples of 8 / 4, scratch too small) silently runs exact f32 instead; pa_gemm_split_stats
  * counts both.  The setting is process-global; plankassembly_amd.models.PlankModel(compute_dtype="x3") brackets its own calls. */
 int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes);
+int pa_gemm_split_active(void);                               /* 1 while the mode is on */
 int pa_gemm_split_stats(int64_t* out2, int32_t reset);        /* out2[0] GEMMs run as bf16x3, out2[1] asked but run exact */
 /* Measurement hook (bench.py's roofline census; no reference counterpart): pa_gemm_record(1) starts appending every
  * pa_gemm() argument block to a host-side list; pa_gemm_record(0) returns the count so far; pa_gemm_recorded() copies

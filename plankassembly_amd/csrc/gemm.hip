@@ -2404,14 +2404,23 @@ extern "C" int pa_gemm_recorded_kinds(int32_t* out, int32_t cap) {
 // number of NON-EMPTY contraction slices pa_gemm uses for a requested split (slices are whole K tiles of 64 bf16 / 16 f32
 // elements; rounding the slice length up can leave trailing slices empty - those must not exist, their slabs would
 // never be written)
+namespace {
+// bf16x3 mode state (see "bf16x3 (split) products" below)
+struct SplitState { std::atomic<int> on{0}; char* ws = nullptr; long long bytes = 0; std::atomic<long long> taken{0}, declined{0}; };
+SplitState g_split;
+bool split_on() { return g_split.on.load(std::memory_order_relaxed) != 0; }
+}  // namespace
 extern "C" int pa_gemm_effective_splitk(int32_t K, int32_t in_dtype, int32_t splitk) {
-    const int BK = in_dtype == PA_BF16 ? 64 : 16;
-    const int nt = (K + BK - 1) / BK;
+    // (bf16x3 mode: an f32 GEMM runs on the bf16 kernels over a 3 K long contraction - its slices are whole 64-wide tiles of THAT)
+    const bool x3 = in_dtype == PA_F32 && split_on();
+    const int BK = (in_dtype == PA_BF16 || x3) ? 64 : 16;
+    const int nt = ((x3 ? 3 * K : K) + BK - 1) / BK;
     int sk = splitk > 1 ? splitk : 1;
     if (sk > nt) sk = nt;
     const int per = (nt + sk - 1) / sk;
     return (nt + per - 1) / per;
 }
+extern "C" int pa_gemm_split_active(void) { return split_on() ? 1 : 0; }
 
 // CUs the persistent GEMM kernels occupy.  They launch one (or two) blocks per CU that hold the whole register file, so a
 // collective kernel enqueued on another stream (RCCL's all-reduce of a finished gradient slice) finds no CU to run on
@@ -2449,7 +2458,7 @@ extern "C" int pa_get_reserved_cus(void) { return 256 - cus_for_gemm(); }
 // Exact f32 (v_mfma_f32_32x32x2_f32) stays the checker and the fallback for shapes the bf16 fast paths do not take.
 namespace {
 struct SplitJob { const float* src; bf16* dst; int rows, cols, ld, mode; long long sstride, dstride; int batch, pad_; };
-struct SplitTab { SplitJob j[3]; int begin[4]; int n; };
+struct SplitTab { SplitJob j[2 * PA_MAX_GROUP_]; int begin[2 * PA_MAX_GROUP_ + 1]; int n; };
 // mode 0: [rows][cols] -> [rows][3 cols] as (hi, hi, lo);  1: as (hi, lo, hi);  2: -> [3 rows][cols] stacked (hi, hi, lo);
 // 3: stacked (hi, lo, hi);  4: hi only [rows][cols] (the ReLU-backward gate: only its sign is read)
 __global__ __launch_bounds__(256) void split_kernel(SplitTab tb) {
@@ -2485,8 +2494,6 @@ __global__ __launch_bounds__(256) void split_kernel(SplitTab tb) {
         }
     }
 }
-struct SplitState { std::atomic<int> on{0}; char* ws = nullptr; long long bytes = 0; std::atomic<long long> taken{0}, declined{0}; };
-SplitState g_split;
 inline int eff_split(int nt, int sk) { if (sk > nt) sk = nt; if (sk < 1) sk = 1; const int per = (nt + sk - 1) / sk; return (nt + per - 1) / per; }
 }  // namespace
 extern "C" int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes) {
@@ -2519,25 +2526,13 @@ static int gemm_split3(const pa_gemm_args* a, void* stream) {
     if (a_bytes + b_bytes + x_bytes > g_split.bytes) return 0;
     // split-K: the caller sized its slabs with the f32 tiling (pa_gemm_effective_splitk(K, PA_F32, .)); ask the bf16 tiling for
     // exactly as many non-empty slices, or decline
-    int sk_req = a->splitk > 1 ? a->splitk : 1, zero_from = 0, zero_to = 0;
-    if (sk_req > 1) {
-        const int want = eff_split((K + 15) / 16, sk_req), nt3 = (3 * K + 63) / 64;
-        int found = 0, best = 1;
-        for (int s_ = 1; s_ <= nt3 && s_ <= want + 8; ++s_) {
-            const int e_ = eff_split(nt3, s_);
-            if (e_ == want) { found = s_; break; }
-            if (e_ < want && e_ >= eff_split(nt3, best)) best = s_;
-        }
-        if (want <= 1) sk_req = 1;
-        else if (found) sk_req = found;
-        else {
-            // no request yields exactly `want` slices of whole bf16 K tiles: write fewer and (for a deferred reduction, whose
-            // descriptor already says `want`) hand the reducer zeros for the rest
-            sk_req = best;
-            if (a->splitk_defer) { zero_from = eff_split(nt3, best); zero_to = want; }
-            if (!a->ws) return 0;
-        }
-    }
+    // split-K: callers size their slabs with pa_gemm_effective_splitk(K, PA_F32, .), which in this mode already counts whole
+    // 64-wide tiles of the 3 K long bf16 contraction - the request passes through unchanged
+    const int sk_req = a->splitk > 1 ? a->splitk : 1, zero_from = 0, zero_to = 0;
+    if (sk_req > 1 && !a->ws) return 0;
+    static const bool dbg_split = getenv("PA_SPLIT_DEBUG") && atoi(getenv("PA_SPLIT_DEBUG")) >= 2;
+    if (dbg_split) fprintf(stderr, "[pa_gemm x3] M %d N %d K %d batch %d akc %d bkc %d splitk %d -> %d (zero-fill %d..%d) defer %d\n",
+                           M, N, K, nb, (int)akc, (int)bkc, a->splitk, sk_req, zero_from, zero_to, a->splitk_defer);
     bf16* A3 = reinterpret_cast<bf16*>(g_split.ws);
     bf16* B3 = reinterpret_cast<bf16*>(g_split.ws + a_bytes);
     bf16* X1 = reinterpret_cast<bf16*>(g_split.ws + a_bytes + b_bytes);
@@ -2583,6 +2578,27 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         if (r3 < 0) return r3;
         if (r3 == 1) { g_split.taken.fetch_add(1); return 0; }
         g_split.declined.fetch_add(1);
+        if (a->splitk > 1 && a->splitk_defer && a->ws) {
+            // the caller's reduction descriptor counts pa_gemm_effective_splitk(K, PA_F32, splitk) slabs in THIS mode's (bf16)
+            // tiling; the exact kernel below writes the f32 tiling's count: run it with a request that yields no more than that
+            // and hand the reducer zeros for the rest
+            auto eff = [](int nt, int sk) { if (sk > nt) sk = nt; if (sk < 1) sk = 1; const int per = (nt + sk - 1) / sk; return (nt + per - 1) / per; };
+            const int want = eff((3 * a->K + 63) / 64, a->splitk), nt32 = (a->K + 15) / 16;
+            int req = want;
+            while (req > 1 && eff(nt32, req) > want) --req;
+            const int got = eff(nt32, req);
+            pa_gemm_args e = *a; e.splitk = req;
+            g_split.on.store(0, std::memory_order_relaxed);
+            const int rc = pa_gemm(&e, stream);
+            g_split.on.store(1, std::memory_order_relaxed);
+            if (rc) return rc;
+            if (got < want) {
+                const size_t slab = (size_t)a->M * a->N * sizeof(float);
+                if (hipMemsetAsync(static_cast<char*>(a->ws) + (size_t)got * slab, 0, (size_t)(want - got) * slab,
+                                   reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return PA_EINVAL;
+            }
+            return 0;
+        }
         static const bool dbg_split = getenv("PA_SPLIT_DEBUG") && atoi(getenv("PA_SPLIT_DEBUG"));
         if (dbg_split) fprintf(stderr, "[pa_gemm x3 declined] M %d N %d K %d batch %d akc %d bkc %d lda %d ldb %d sA %lld sB %lld splitk %d aux %d ldaux %d\n",
                                a->M, a->N, a->K, a->batch, a->a_kcontig, a->b_kcontig, a->lda, a->ldb, (long long)a->sA, (long long)a->sB, a->splitk, a->aux ? 1 : 0, a->ldaux);
@@ -2872,8 +2888,52 @@ extern "C" int pa_gemm_norm_a(const pa_gemm_args* a, const pa_gemm_norm_ext* x, 
     return 0;
 }
 
+// bf16x3 mode: every member's two operands are cut into their stacked (hi, hi, lo) / (hi, lo, hi) forms by ONE split launch into
+// consecutive regions of the scratch buffer, then the members run as one grouped bf16 launch over 3 K rows each.
+static int gemm_group_split3(const pa_gemm_args* args, int32_t n, void* stream) {
+    pa_gemm_args b[PA_MAX_GROUP];
+    SplitTab tb; tb.n = 0; tb.begin[0] = 0;
+    long long off = 0;
+    auto up = [](long long v) { return (v + 255) / 256 * 256; };
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    for (int i = 0; i < n; ++i) {
+        const pa_gemm_args* a = &args[i];
+        if (a->in_dtype != PA_F32 || a->out_dtype != PA_F32 || a->a_kcontig || a->b_kcontig || a->batch != 1) return 0;
+        if (a->bias || a->R || a->aux || a->relu || a->drop_p > 0.f || a->alpha != 1.f || a->C_lp) return 0;
+        if ((a->M & 7) || (a->N & 7) || (a->lda & 3) || (a->ldb & 3) || !al16(a->A) || !al16(a->B)) return 0;
+        const long long a_el = (long long)a->K * a->M * 3, b_el = (long long)a->K * a->N * 3;
+        if (off + up(a_el * 2) + up(b_el * 2) > g_split.bytes) return 0;
+        bf16* A3 = reinterpret_cast<bf16*>(g_split.ws + off); off += up(a_el * 2);
+        bf16* B3 = reinterpret_cast<bf16*>(g_split.ws + off); off += up(b_el * 2);
+        for (int w = 0; w < 2; ++w) {
+            SplitJob& j = tb.j[tb.n];
+            j.src = static_cast<const float*>(w ? a->B : a->A); j.dst = w ? B3 : A3; j.rows = a->K; j.cols = w ? a->N : a->M;
+            j.ld = w ? a->ldb : a->lda; j.mode = w ? 3 : 2; j.sstride = 0; j.dstride = 0; j.batch = 1; j.pad_ = 0;
+            long long blocks = ((long long)j.rows * (j.cols >> 2) + 1023) / 1024;
+            if (blocks < 1) blocks = 1;
+            if (blocks > 1024) blocks = 1024;
+            tb.begin[tb.n + 1] = tb.begin[tb.n] + (int)blocks;
+            ++tb.n;
+        }
+        b[i] = *a;
+        b[i].in_dtype = PA_BF16; b[i].A = A3; b[i].B = B3; b[i].K = 3 * a->K; b[i].lda = a->M; b[i].ldb = a->N;
+    }
+    PA_LAUNCH(split_kernel, dim3(tb.begin[tb.n]), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tb);
+    g_split.on.store(0, std::memory_order_relaxed);
+    const int rc = pa_gemm_group(b, n, stream);
+    g_split.on.store(1, std::memory_order_relaxed);
+    if (rc) return rc;
+    g_split.taken.fetch_add(n);
+    return 1;
+}
 extern "C" int pa_gemm_group(const pa_gemm_args* args, int32_t n, void* stream) {
     if (!args || n <= 0 || n > PA_MAX_GROUP) return PA_EINVAL;
+    if (split_on() && args[0].in_dtype == PA_F32) {
+        const int r3 = gemm_group_split3(args, n, stream);
+        if (r3 < 0) return r3;
+        if (r3 == 1) return 0;
+        return PA_EINVAL;                                   // the caller launches the members one by one (pa_gemm declines or splits each)
+    }
     static_assert(PA_MAX_GROUP == PA_MAX_GROUP_, "header / kernel table size");
     GemmGroup g; g.n = n; g.begin[0] = 0;
     int valid = 0;

@@ -66,8 +66,9 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
         g.in_dtype = dt(); g.out_dtype = PA_F32;
         g.alpha = 1.f; g.aux_scale = 1.f;
         const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-        const int ktile = dt() == PA_BF16 ? 64 : 16;
-        const int nkt = (M + ktile - 1) / ktile;
+        const bool x3 = dt() == PA_F32 && pa_gemm_split_active();          // bf16x3: the bf16 kernels over 3 M stacked rows
+        const int ktile = (dt() == PA_BF16 || x3) ? 64 : 16;
+        const int nkt = ((x3 ? 3 * M : M) + ktile - 1) / ktile;
         static const bool plan = !(getenv("PA_DW_PLAN") && atoi(getenv("PA_DW_PLAN")) == 0);
         if (plan && m->defer_ok && tiles < 256 && m->ndwq < PA_MAX_GROUP) {
             // member of the segment's grouped launch: its split is chosen at the flush, when all members are known
@@ -523,19 +524,20 @@ int backward_segment_body(pa_model* m, int seg, float gscale, void* st);
 void plan_group(pa_model* m) {
     const int n = m->ndwq;
     int tiles[PA_MAX_GROUP], nkt[PA_MAX_GROUP], cap[PA_MAX_GROUP], sk[PA_MAX_GROUP];
-    const int ktile = m->cfg.dtype == PA_BF16 ? 64 : 16;
+    const bool x3 = m->cfg.dtype == PA_F32 && pa_gemm_split_active();     // bf16x3: planned like the bf16 grouped launch, 3 K rows each
+    const int ktile = (m->cfg.dtype == PA_BF16 || x3) ? 64 : 16;
     int total = 0, planned = 0;
     for (int i = 0; i < n; ++i) {
         const pa_gemm_args& g = m->dwq[i];
         tiles[i] = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-        nkt[i] = (g.K + ktile - 1) / ktile;
+        nkt[i] = ((x3 ? 3 * g.K : g.K) + ktile - 1) / ktile;
         sk[i] = g.splitk > 0 ? g.splitk : 1;
         cap[i] = g.splitk > 0 ? sk[i] : ((g.N & 3) ? 1 : (nkt[i] / 4 < 16 ? (nkt[i] / 4 > 0 ? nkt[i] / 4 : 1) : 16));
         total += tiles[i] * sk[i];
         planned += g.splitk == 0;
     }
     if (!planned) return;
-    if (m->cfg.dtype != PA_BF16) {
+    if (m->cfg.dtype != PA_BF16 && !x3) {
         // f32 (the parity path): pa_gemm_group takes bf16 members only, so flush_segment launches these one by one on the
         // two-blocks-per-CU kernel - each member then wants the whole chip for itself (512 units), not its share of one grouped
         // round.  Rounds 1-3 planned them like a grouped launch: the encoder's out_proj gradient ran on 32 of the 512 block
