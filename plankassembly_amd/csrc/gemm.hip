@@ -2466,31 +2466,35 @@ __global__ __launch_bounds__(256) void split_kernel(SplitTab tb) {
     while (k + 1 < tb.n && (int)blockIdx.x >= tb.begin[k + 1]) ++k;
     const SplitJob& J = tb.j[k];
     const int nb = tb.begin[k + 1] - tb.begin[k], bid = blockIdx.x - tb.begin[k];
-    const int c4 = J.cols >> 2;
-    const long long per = (long long)J.rows * c4, total = per * J.batch;
+    // eight consecutive f32 per thread and pass (every job has cols % 8 == 0): two 16-byte loads, 16-byte stores
+    const int c8 = J.cols >> 3;
+    const long long per = (long long)J.rows * c8, total = per * J.batch;
     for (long long e = (long long)bid * 256 + threadIdx.x; e < total; e += (long long)nb * 256) {
         const int b = (int)(e / per);
         const long long r_ = e - (long long)b * per;
-        const int r = (int)(r_ / c4), c = (int)(r_ - (long long)r * c4) << 2;
-        const f32x4 x = *reinterpret_cast<const f32x4*>(J.src + (size_t)b * J.sstride + (size_t)r * J.ld + c);
-        u32x2 hi, lo;
-        hi[0] = pack_bf16(x[0], x[1]); hi[1] = pack_bf16(x[2], x[3]);
+        const int r = (int)(r_ / c8), c = (int)(r_ - (long long)r * c8) << 3;
+        const float* sp = J.src + (size_t)b * J.sstride + (size_t)r * J.ld + c;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(sp), y = *reinterpret_cast<const f32x4*>(sp + 4);
+        u32x4 hi, lo;
+        hi[0] = pack_bf16(x[0], x[1]); hi[1] = pack_bf16(x[2], x[3]); hi[2] = pack_bf16(y[0], y[1]); hi[3] = pack_bf16(y[2], y[3]);
         lo[0] = pack_bf16(x[0] - bf16_lo(hi[0]), x[1] - bf16_hi(hi[0]));
         lo[1] = pack_bf16(x[2] - bf16_lo(hi[1]), x[3] - bf16_hi(hi[1]));
+        lo[2] = pack_bf16(y[0] - bf16_lo(hi[2]), y[1] - bf16_hi(hi[2]));
+        lo[3] = pack_bf16(y[2] - bf16_lo(hi[3]), y[3] - bf16_hi(hi[3]));
         bf16* d = J.dst + (size_t)b * J.dstride;
-        if (J.mode == 4) { *reinterpret_cast<u32x2*>(d + (size_t)r * J.cols + c) = hi; continue; }
+        if (J.mode == 4) { *reinterpret_cast<u32x4*>(d + (size_t)r * J.cols + c) = hi; continue; }
         const bool a_pat = (J.mode & 1) == 0;                 // (hi, hi, lo) or (hi, lo, hi)
         if (J.mode < 2) {
             bf16* row = d + (size_t)r * 3 * J.cols + c;
-            *reinterpret_cast<u32x2*>(row) = hi;
-            *reinterpret_cast<u32x2*>(row + J.cols) = a_pat ? hi : lo;
-            *reinterpret_cast<u32x2*>(row + 2 * J.cols) = a_pat ? lo : hi;
+            *reinterpret_cast<u32x4*>(row) = hi;
+            *reinterpret_cast<u32x4*>(row + J.cols) = a_pat ? hi : lo;
+            *reinterpret_cast<u32x4*>(row + 2 * J.cols) = a_pat ? lo : hi;
         } else {
             const size_t plane = (size_t)J.rows * J.cols;
             bf16* q = d + (size_t)r * J.cols + c;
-            *reinterpret_cast<u32x2*>(q) = hi;
-            *reinterpret_cast<u32x2*>(q + plane) = a_pat ? hi : lo;
-            *reinterpret_cast<u32x2*>(q + 2 * plane) = a_pat ? lo : hi;
+            *reinterpret_cast<u32x4*>(q) = hi;
+            *reinterpret_cast<u32x4*>(q + plane) = a_pat ? hi : lo;
+            *reinterpret_cast<u32x4*>(q + 2 * plane) = a_pat ? lo : hi;
         }
     }
 }
@@ -2541,7 +2545,7 @@ static int gemm_split3(const pa_gemm_args* a, void* stream) {
         SplitJob& j = tb.j[tb.n];
         j.src = static_cast<const float*>(src); j.dst = dst; j.rows = rows; j.cols = cols; j.ld = ld; j.mode = mode;
         j.sstride = ss; j.dstride = ds; j.batch = batch; j.pad_ = 0;
-        long long blocks = ((long long)rows * (cols >> 2) * batch + 1023) / 1024;       // four vectors per thread
+        long long blocks = ((long long)rows * (cols >> 3) * batch + 511) / 512;         // two 8-element vectors per thread
         if (blocks < 1) blocks = 1;
         if (blocks > 2048) blocks = 2048;
         tb.begin[tb.n + 1] = tb.begin[tb.n] + (int)blocks;
@@ -2909,7 +2913,7 @@ static int gemm_group_split3(const pa_gemm_args* args, int32_t n, void* stream) 
             SplitJob& j = tb.j[tb.n];
             j.src = static_cast<const float*>(w ? a->B : a->A); j.dst = w ? B3 : A3; j.rows = a->K; j.cols = w ? a->N : a->M;
             j.ld = w ? a->ldb : a->lda; j.mode = w ? 3 : 2; j.sstride = 0; j.dstride = 0; j.batch = 1; j.pad_ = 0;
-            long long blocks = ((long long)j.rows * (j.cols >> 2) + 1023) / 1024;
+            long long blocks = ((long long)j.rows * (j.cols >> 3) + 511) / 512;
             if (blocks < 1) blocks = 1;
             if (blocks > 1024) blocks = 1024;
             tb.begin[tb.n + 1] = tb.begin[tb.n] + (int)blocks;
