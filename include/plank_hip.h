@@ -385,6 +385,18 @@ int pa_mixture_nll_bwd(void* dvocab, void* dptr, int32_t out_dtype, float* dsw, 
                        const float* row_lse, const float* vocab, int32_t ldv, const float* ptr, const float* sw,
                        const int64_t* label, int32_t B, int32_t T, int32_t V, int32_t pad, float gscale,
                        void* stream);
+/* The same forward on an EIGHT-float statistics block that the launch zeroes itself: [0] summed NLL, [1] unmasked rows, [2] correct
+ * rows, [3] upstream d(loss) (armed with 1.0), [4] loss = [0] / [1], [5] accuracy = [2] / ([1] + 1e-10) - reference
+ * plankassembly/models.py:226-231 - written by the block that finishes last, [6] its ticket, [7] spare.  The training step returns
+ * views of [4] / [5]: no element-wise launches behind the forward.  pa_mixture_nll_bwd_up: `upstream` (device f32 scalar, or NULL =
+ * stats[3]) is d(loss) from the caller's autograd - read in place instead of being copied into stats[3]. */
+int pa_mixture_nll_fwd_fin(float* stats8, float* row_lse, const float* vocab, int32_t ldv, const float* ptr,
+                           const float* sw, const int64_t* label, int32_t B, int32_t T, int32_t V, int32_t pad,
+                           void* stream);
+int pa_mixture_nll_bwd_up(void* dvocab, void* dptr, int32_t out_dtype, float* dsw, const float* stats,
+                       const float* row_lse, const float* vocab, int32_t ldv, const float* ptr, const float* sw,
+                       const int64_t* label, int32_t B, int32_t T, int32_t V, int32_t pad, float gscale,
+                       const float* upstream, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Adam (torch.optim.Adam defaults; reference trainer_complete.py:127-129), fused over one flat
@@ -486,6 +498,8 @@ int pa_model_train_fwd(pa_model* m, const pa_batch* batch, void* ws, int64_t ws_
  * layers (last first), input embedding.  After segment s returns, the gradients of that
  * segment's parameters are final on `stream` (the shared value-embedding table only after the
  * last segment) - the host can launch their all-reduce on a side stream. */
+/* d(loss) of the next pa_model_train_bwd calls is read from `upstream` (device f32 scalar; NULL = the stats block's own slot). */
+int pa_model_set_upstream(pa_model* m, const float* upstream);
 int pa_model_train_num_segments(const pa_model* m);
 int pa_model_train_bwd(pa_model* m, int32_t seg_lo, int32_t seg_hi, float gscale, void* stream);
 /* Gradient finality lag in segments.  With PA_SIDE_STREAM=1 (experimental, off by default: slower on MI355X) the model

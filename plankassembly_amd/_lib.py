@@ -141,6 +141,9 @@ def lib():
             "pa_switch_bwd": (I, [P, I, P, P, P, P, I, P, P, I64, I, P]),
             "pa_mixture_nll_fwd": (I, [P, P, P, I, P, P, P, I, I, I, I, P]),
             "pa_mixture_nll_bwd": (I, [P, P, I, P, P, P, P, I, P, P, P, I, I, I, I, F, P]),
+            "pa_mixture_nll_fwd_fin": (I, [P, P, P, I, P, P, P, I, I, I, I, P]),
+            "pa_mixture_nll_bwd_up": (I, [P, P, I, P, P, P, P, I, P, P, P, I, I, I, I, F, P, P]),
+            "pa_model_set_upstream": (I, [P, P]),
             "pa_adam_step": (I, [P, P, P, P, P, I64, F, F, F, F, I, F, P]),
             "pa_cast": (I, [P, I, P, I, I64, P]),
             "pa_fake_collective": (I, [P, I64, I, I, F, P]),

@@ -55,6 +55,7 @@ struct pa_model {
     void *memory = nullptr, *hid = nullptr; float *mem_m = nullptr, *mem_r = nullptr, *hid_m = nullptr, *hid_r = nullptr;
     float *vlog = nullptr, *plog = nullptr, *sw = nullptr, *row_lse = nullptr; void* pfeat = nullptr; int ldv = 0;
     float* stats = nullptr;
+    const float* upstream = nullptr;      // d(loss) of the caller's autograd (pa_model_set_upstream), or nullptr = stats[3]
     // backward temporaries
     void *gA, *gB, *gC, *gD, *gE, *gF, *gQ3, *gKV, *dmem, *dvlog, *dplog; float *dsw, *delta, *partial, *splitws;
     void* gPre = nullptr;                        // ACTIVATION gelu: the FFN pre-activation, recomputed by the backward pass (rows x d_ff)

@@ -620,7 +620,7 @@ constexpr int NLL_VSLOTS = 16;   // a lane holds up to 16 vocabulary logits (V <
 constexpr int NLL_PSLOTS = 4;    // all loads are issued up front, unconditionally (clamped index), then reduced in order
 __global__ __launch_bounds__(256) void mixture_nll_fwd_kernel(float* stats, float* row_lse, const float* vocab, int ldv,
                                                               const float* ptr, const float* sw, const int64_t* label,
-                                                              int B, int Tn, int V, int pad) {
+                                                              int B, int Tn, int V, int pad, int fin) {
     __shared__ float red[4][3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float a_nll = 0.f, a_cnt = 0.f, a_hit = 0.f;
@@ -670,13 +670,30 @@ __global__ __launch_bounds__(256) void mixture_nll_fwd_kernel(float* stats, floa
         const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
         if (v != 0.f) atomicAdd(stats + threadIdx.x, v);
     }
+    if (fin) {
+        // stats8 form (pa_mixture_nll_fwd_fin): the block that takes the last ticket turns the three sums into loss = nll / count and
+        // accuracy = hits / (count + 1e-10) (reference models.py:226-231) and arms the upstream gradient with 1.0 - what four tiny
+        // torch launches (two divisions, an add, a fill) did on the step's serial chain before.
+        __threadfence();                                       // this block's three atomics before its ticket
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(stats + 6), 1u);
+            if (t == gridDim.x - 1) {
+                __threadfence();
+                const float s0 = __hip_atomic_load(stats + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float s1 = __hip_atomic_load(stats + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float s2 = __hip_atomic_load(stats + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stats[4] = s0 / s1; stats[5] = s2 / (s1 + 1e-10f); stats[3] = 1.0f;
+            }
+        }
+    }
 }
 
 template <typename TO>
 __global__ __launch_bounds__(256) void mixture_nll_bwd_kernel(TO* dvocab, TO* dptr, float* dsw, const float* stats,
                                                               const float* row_lse, const float* vocab, int ldv,
                                                               const float* ptr, const float* sw, const int64_t* label,
-                                                              int B, int Tn, int V, int pad, float gscale) {
+                                                              int B, int Tn, int V, int pad, float gscale, const float* upstream) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (int64_t)B * Tn) return;
@@ -690,7 +707,7 @@ __global__ __launch_bounds__(256) void mixture_nll_bwd_kernel(TO* dvocab, TO* dp
         if (lane == 0) dsw[row] = 0.f;
         return;
     }
-    const float g = gscale * stats[3] / stats[1];      // stats[3] = upstream d(loss), device resident
+    const float g = gscale * (upstream ? *upstream : stats[3]) / stats[1];      // upstream d(loss), device resident (stats[3] unless given)
     const float prob = 1.0f / (1.0f + expf(-sw[row]));
     if (lab < V) {
         const float lse_v = row_lse[row * 2];
@@ -1126,20 +1143,35 @@ extern "C" int pa_mixture_nll_fwd(float* stats, float* row_lse, const float* voc
                                   void* stream) {
     if (!stats || !row_lse || !vocab || !ptr || !sw || !label || B <= 0 || T <= 0 || V <= 0 || ldv < V) return PA_EINVAL;
     const int grid = (int)(((int64_t)B * T + NLL_ROWS - 1) / NLL_ROWS);
-    PA_LAUNCH(mixture_nll_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad);
+    PA_LAUNCH(mixture_nll_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, 0);
+    return 0;
+}
+extern "C" int pa_mixture_nll_fwd_fin(float* stats8, float* row_lse, const float* vocab, int32_t ldv, const float* ptr,
+                                      const float* sw, const int64_t* label, int32_t B, int32_t T, int32_t V, int32_t pad,
+                                      void* stream) {
+    if (!stats8 || !row_lse || !vocab || !ptr || !sw || !label || B <= 0 || T <= 0 || V <= 0 || ldv < V) return PA_EINVAL;
+    const int grid = (int)(((int64_t)B * T + NLL_ROWS - 1) / NLL_ROWS);
+    if (hipMemsetAsync(stats8, 0, 8 * sizeof(float), ST(stream)) != hipSuccess) return PA_EINVAL;      // sums, ticket (and the rest)
+    PA_LAUNCH(mixture_nll_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), stats8, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, 1);
     return 0;
 }
 
+extern "C" int pa_mixture_nll_bwd_up(void* dvocab, void* dptr, int32_t out_dtype, float* dsw, const float* stats,
+                                  const float* row_lse, const float* vocab, int32_t ldv, const float* ptr,
+                                  const float* sw, const int64_t* label, int32_t B, int32_t T, int32_t V, int32_t pad,
+                                  float gscale, const float* upstream, void* stream) {
+    if (!dvocab || !dptr || !dsw || !stats || !row_lse || !vocab || !ptr || !sw || !label) return PA_EINVAL;
+    if (B <= 0 || T <= 0 || V <= 0 || ldv < V) return PA_EINVAL;
+    const int grid = (int)(((int64_t)B * T + 3) / 4);
+    if (out_dtype == PA_BF16) PA_LAUNCH(mixture_nll_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)dvocab, (bf16*)dptr, dsw, stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, gscale, upstream);
+    else PA_LAUNCH(mixture_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)dvocab, (float*)dptr, dsw, stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, gscale, upstream);
+    return 0;
+}
 extern "C" int pa_mixture_nll_bwd(void* dvocab, void* dptr, int32_t out_dtype, float* dsw, const float* stats,
                                   const float* row_lse, const float* vocab, int32_t ldv, const float* ptr,
                                   const float* sw, const int64_t* label, int32_t B, int32_t T, int32_t V, int32_t pad,
                                   float gscale, void* stream) {
-    if (!dvocab || !dptr || !dsw || !stats || !row_lse || !vocab || !ptr || !sw || !label) return PA_EINVAL;
-    if (B <= 0 || T <= 0 || V <= 0 || ldv < V) return PA_EINVAL;
-    const int grid = (int)(((int64_t)B * T + 3) / 4);
-    if (out_dtype == PA_BF16) PA_LAUNCH(mixture_nll_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)dvocab, (bf16*)dptr, dsw, stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, gscale);
-    else PA_LAUNCH(mixture_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)dvocab, (float*)dptr, dsw, stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, gscale);
-    return 0;
+    return pa_mixture_nll_bwd_up(dvocab, dptr, out_dtype, dsw, stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, gscale, nullptr, stream);
 }
 
 extern "C" int pa_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float b1,

@@ -355,11 +355,9 @@ int pa_train_forward_impl(pa_model* m, void* st) {
         RC(pa_gemm(&g, st));
     }
     RC(pa_switch_fwd(m->sw, m->hid, c.dtype, PF(tl + T_SW_W), PF(tl + T_SW_B), (int64_t)BT, d, st));
-    hipError_t he = hipMemsetAsync(m->stats, 0, 3 * sizeof(float), (hipStream_t)st);
-    if (he != hipSuccess) return (int)he;
-    he = hipMemsetD32Async((hipDeviceptr_t)(m->stats + 3), 0x3f800000, 1, (hipStream_t)st);   // upstream grad = 1.0f
-    if (he != hipSuccess) return (int)he;
-    RC(pa_mixture_nll_fwd(m->stats, m->row_lse, m->vlog, m->ldv, m->plog, m->sw, m->batch.output_label, B, T, c.vocab, c.pad, st));
+    // (one memset inside; loss, accuracy and the upstream 1.0 are written by the kernel's last block: stats is 8 floats)
+    m->upstream = nullptr;
+    RC(pa_mixture_nll_fwd_fin(m->stats, m->row_lse, m->vlog, m->ldv, m->plog, m->sw, m->batch.output_label, B, T, c.vocab, c.pad, st));
     return 0;
 }
 namespace {
@@ -372,8 +370,8 @@ int bwd_heads(pa_model* m, float gscale, void* st) {
     Ctx k{m, st};
     const int d = c.d_model, B = m->B, T = m->T, BT = B * T, tl = m->tail();
     auto G = [&](int i) { return (float*)m->gr[i]; };
-    RC(pa_mixture_nll_bwd(m->dvlog, m->dplog, c.dtype, m->dsw, m->stats, m->row_lse, m->vlog, m->ldv, m->plog, m->sw,
-                          m->batch.output_label, B, T, c.vocab, c.pad, gscale, st));
+    RC(pa_mixture_nll_bwd_up(m->dvlog, m->dplog, c.dtype, m->dsw, m->stats, m->row_lse, m->vlog, m->ldv, m->plog, m->sw,
+                             m->batch.output_label, B, T, c.vocab, c.pad, gscale, m->upstream, st));
     // vocab head
     if (m->plT[tl + T_VOCAB_W])       // padded W^T shadow [d][ldv] (pad columns zero): contraction over the padded width, both k-contiguous
         RC(k.linear_dx(m->dvlog, m->ldv, m->pl[tl + T_VOCAB_W], d, m->gA, d, BT, m->ldv, d, nullptr, 0, nullptr, 0, 1.f,
@@ -792,6 +790,11 @@ extern "C" int pa_model_train_fwd(pa_model* m, const pa_batch* batch, void* ws, 
     return rc;
 }
 
+extern "C" int pa_model_set_upstream(pa_model* m, const float* upstream) {
+    if (!m) return PA_EINVAL;
+    m->upstream = upstream;
+    return 0;
+}
 extern "C" int pa_model_train_num_segments(const pa_model* m) {
     return m ? m->cfg.n_dec + m->cfg.n_enc + 4 : PA_EINVAL;
 }

@@ -114,8 +114,9 @@ class _TrainStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hook, model, stats):
         ctx.model = model
-        loss = stats[0] / stats[1]
-        return loss + 0.0 * hook
+        # stats[4] = loss, written by the forward's last kernel (pa_mixture_nll_fwd_fin): a view, no element-wise launch.  `hook`
+        # (a leaf that requires grad) is what makes this node part of the autograd graph.
+        return stats[4].detach()
 
     @staticmethod
     def backward(ctx, gloss):
@@ -663,7 +664,7 @@ class PlankModel(nn.Module):
         b, keep = self._make_batch(batch, True)
         ws = self._workspace(b.B, b.S, b.T)
         base = (ws.data_ptr() + 255) // 256 * 256
-        stats = torch.empty(4, dtype=torch.float32, device=self._flat.device)
+        stats = torch.empty(8, dtype=torch.float32, device=self._flat.device)      # include/plank_hip.h pa_mixture_nll_fwd_fin
         self._step_seed = (self._step_seed * 1664525 + 1013904223 + int(torch.initial_seed())) & 0xFFFFFFFF
         self._split(True)
         try:
@@ -679,9 +680,8 @@ class PlankModel(nn.Module):
         if torch.is_grad_enabled():
             loss = _TrainStepFn.apply(self._hook_leaf, self, stats)
         else:
-            loss = stats[0] / stats[1]
-        accuracy = stats[2] / (stats[1] + 1e-10)
-        return {"loss": loss, "accuracy": accuracy}
+            loss = stats[4]
+        return {"loss": loss, "accuracy": stats[5]}
 
     def _run_backward(self, gloss):
         self._ensure_grads()
@@ -695,8 +695,13 @@ class PlankModel(nn.Module):
         if self._bound_grads is not target:
             self._rebind(target)
         nseg = int(L.lib().pa_model_train_num_segments(self._handle))
-        stats = self._live[2]
-        stats[3:4].copy_(gloss.reshape(1).to(torch.float32), non_blocking=True)   # upstream grad, no host sync
+        # upstream d(loss): read in place by the first backward kernel (no copy launch, no host sync)
+        up = gloss if (gloss.dtype == torch.float32 and gloss.is_cuda and gloss.numel() == 1) else \
+            gloss.reshape(1).to(device=self._flat.device, dtype=torch.float32)
+        if not up.is_contiguous():
+            up = up.contiguous()
+        self._upstream_keep = up                     # alive until the kernels that read it have been enqueued behind it
+        L.check(L.lib().pa_model_set_upstream(self._handle, L.ptr(up)), "pa_model_set_upstream")
         slices = self.segment_slices()
         # gradient accumulation: the fresh micro-batch contribution (target = _gtmp) is what gets exchanged - the
         # buffer accumulated so far was already summed over the ranks - and is added to _gflat after the last slice
