@@ -83,12 +83,20 @@ template <typename T, int DH>
 __device__ __forceinline__ void load_sub(u32x4* regs, const T* base, int ld, int row0, int nrows, int sb) {
     using A = AT<T, DH>;
     const int cb = sb % A::NCHR, rb = sb / A::NCHR;
+    // unconditional loads on a clamped row (callers have nrows >= 1), zeroed afterwards: a load inside `if (r < nrows)` becomes a
+    // branch with a wait behind it and the four rows cost four dependent memory round trips per tile (round 5: the bf16x3 kernels
+    // spent ~7 us per 64-key step here)
+    u32x4 v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = row0 + rb * 4 + i;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (r < nrows) v = *reinterpret_cast<const u32x4*>(base + (size_t)r * ld + cb * A::EB);
-        regs[i] = v;
+        const int rc = r < nrows ? r : nrows - 1;
+        v[i] = *reinterpret_cast<const u32x4*>(base + (size_t)rc * ld + cb * A::EB);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool in = row0 + rb * 4 + i < nrows;
+        regs[i] = in ? v[i] : u32x4{0u, 0u, 0u, 0u};
     }
 }
 template <typename T, int DH>
@@ -2196,10 +2204,12 @@ template <typename T, int DH> int run_fwd(const AttnP& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) return run_fwd_bf16<DH>(p, st);
     if constexpr (sizeof(T) == 4 && DH == 64) {
         if (g_attn_x3.load(std::memory_order_relaxed)) {
-            const int shm = 2 * X3L<DH>::BUF_QK;
-            static const int rc_ = set_lds(attnx_fwd_kernel<DH>, shm);
+            const int shm = X3L<DH>::SHM;
+            static const int rc_ = set_lds(attnx_fwd_kernel<DH, true>, shm) | set_lds(attnx_fwd_kernel<DH, false>, shm);
             if (rc_) return rc_;
-            PA_LAUNCH((attnx_fwd_kernel<DH>), dim3((p.Lq + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shm, st, p);
+            const dim3 gq((p.Lq + BOWN - 1) / BOWN, p.H, p.B);
+            if (p.drop_thr) PA_LAUNCH((attnx_fwd_kernel<DH, true>), gq, dim3(NTH), shm, st, p);
+            else PA_LAUNCH((attnx_fwd_kernel<DH, false>), gq, dim3(NTH), shm, st, p);
             g_attn_x3_taken.fetch_add(1);
             return 0;
         }
@@ -2217,11 +2227,18 @@ template <typename T, int DH> int run_bwd(const AttnP& p, hipStream_t st) {
     PA_LAUNCH((attn_delta_kernel<T, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
     if constexpr (sizeof(T) == 4 && DH == 64) {
         if (g_attn_x3.load(std::memory_order_relaxed)) {
-            const int shk = 2 * X3L<DH>::BUF_DKV, shq = 2 * X3L<DH>::BUF_QK;
-            static const int rc_ = set_lds(attnx_bwd_dkv_kernel<DH>, shk) | set_lds(attnx_bwd_dq_kernel<DH>, shq);
+            const int shk = X3L<DH>::SHM, shq = X3L<DH>::SHM;
+            static const int rc_ = set_lds(attnx_bwd_dkv_kernel<DH, true>, shk) | set_lds(attnx_bwd_dq_kernel<DH, true>, shq) |
+                                   set_lds(attnx_bwd_dkv_kernel<DH, false>, shk) | set_lds(attnx_bwd_dq_kernel<DH, false>, shq);
             if (rc_) return rc_;
-            PA_LAUNCH((attnx_bwd_dkv_kernel<DH>), dim3((p.Lk + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shk, st, p);
-            PA_LAUNCH((attnx_bwd_dq_kernel<DH>), dim3((p.Lq + BOWN - 1) / BOWN, p.H, p.B), dim3(NTH), shq, st, p);
+            const dim3 gk((p.Lk + BOWN - 1) / BOWN, p.H, p.B), gq((p.Lq + BOWN - 1) / BOWN, p.H, p.B);
+            if (p.drop_thr) {
+                PA_LAUNCH((attnx_bwd_dkv_kernel<DH, true>), gk, dim3(NTH), shk, st, p);
+                PA_LAUNCH((attnx_bwd_dq_kernel<DH, true>), gq, dim3(NTH), shq, st, p);
+            } else {
+                PA_LAUNCH((attnx_bwd_dkv_kernel<DH, false>), gk, dim3(NTH), shk, st, p);
+                PA_LAUNCH((attnx_bwd_dq_kernel<DH, false>), gq, dim3(NTH), shq, st, p);
+            }
             g_attn_x3_taken.fetch_add(1);
             return 0;
         }

@@ -16,10 +16,15 @@
 //     three kernels -> two blocks per CU; the f32 backward kernels need 98 / 132 KB and run one block per CU);
 //   * a lane's own row operand (Q, dO, K, V rows in registers) is cut once per block.
 template <int DH> struct X3L {
-    static constexpr int NAT = BT<DH>::NAT;                  // one 64-row bf16 image
+    static constexpr int RBN = BT<DH>::RBN;
+    static constexpr int NAT = BT<DH>::NAT;                  // one 64-row bf16 image (8 KB at dh 64)
     static constexpr int TILE = 2 * NAT;                     // [hi image | lo image]
-    static constexpr int BUF_QK = 2 * TILE + 64;             // two tiles + 64 mask bytes (forward, dQ)
-    static constexpr int BUF_DKV = 2 * TILE + 2 * 64 * 4;    // two tiles + lse, delta of the 64 streamed queries
+    static constexpr int STG = 2 * TILE;                     // a stage: two tiles (K | V, or Q | dO)
+    static constexpr int AUX0 = 2 * STG;                     // both stages' tiles first, then the stages' aux records
+    // aux record of a stage.  forward, dQ: [64 mask bytes][64 key-hash words (dropout)][flag: the tile contains a masked key];
+    // dK / dV: [64 lse][64 delta][64 row-hash words] of the streamed queries
+    static constexpr int AUX_HASH = 64, AUX_FLAG = 64 + 256, AUXS = 768;
+    static constexpr int SHM = AUX0 + 2 * AUXS;
 };
 
 // four rows x one 16-byte f32 chunk (load_sub<float, DH>) -> hi / lo halves of a bf16 chunk in the two images of `tile`
@@ -61,12 +66,20 @@ __device__ __forceinline__ void x3_row_regs(u32x4* hi, u32x4* lo, const float* b
         lo[s][3] = pack_bf16(v1[2] - bf16_lo(hi[s][3]), v1[3] - bf16_hi(hi[s][3]));
     }
 }
-// acc (32 x 32) += TILE[row0 + (lane & 31)][:] x regs, three terms
+// acc (32 x 32) += TILE[row0 + (lane & 31)][:] x regs, three terms (the hi fragments serve two of them)
 template <int DH>
 __device__ __forceinline__ void x3_mma_nat(f32x16& acc, const char* tile, int row0, const u32x4* rh, const u32x4* rl, int lane) {
-    mma_nat<bf16, DH>(acc, tile, row0, rh, lane);
-    mma_nat<bf16, DH>(acc, tile + BT<DH>::NAT, row0, rh, lane);
-    mma_nat<bf16, DH>(acc, tile, row0, rl, lane);
+    using B = BT<DH>;
+    const int row = row0 + (lane & 31), half = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < B::NS; ++s) {
+        const int off = swz_off<B::RBN>(row, 2 * s + half);
+        const u32x4 ah = *reinterpret_cast<const u32x4*>(tile + off);
+        const u32x4 al = *reinterpret_cast<const u32x4*>(tile + B::NAT + off);
+        mma16B<bf16>(acc, ah, rh[s]);
+        mma16B<bf16>(acc, al, rh[s]);
+        mma16B<bf16>(acc, ah, rl[s]);
+    }
 }
 // what bf16 rounding left of a 32 x 32 accumulator tile: pv - float(bf16(pv)), pairwise as mma_tr_nat packs it
 __device__ __forceinline__ f32x16 x3_lo_part(const f32x16& pv) {
@@ -87,12 +100,29 @@ __device__ __forceinline__ void x3_mma_tr(f32x16* acc, const char* tile, int row
     mma_tr_nat<DH>(acc, tile, row0, pl, lane);
 }
 
+// Score arithmetic as in the tuned bf16 kernels (the first-generation f32 kernels spend ~25 VALU instructions per score): the key /
+// row dropout hash words of a tile are computed ONCE by the 64 staging threads and read from LDS (one multiply + compare + select
+// per score), the mask test only runs on tiles that contain a masked key or touch the causal diagonal, the row maximum is a
+// v_max3_f32 chain, DROP is a template parameter and the survivors' 1 / (1 - p) is folded into the final normalisation (forward)
+// or into one multiply per score (backward).
+// stage aux of the forward / dQ kernels: mask byte, key hash word, "tile has a masked key" flag - written by wave 0
+template <int DH, bool DROP>
+__device__ __forceinline__ void x3_key_aux(char* aux, int tid, uint8_t mreg, uint32_t seed, int key) {
+    using X = X3L<DH>;
+    if (tid < BSTR) {                                           // (exactly wave 0)
+        reinterpret_cast<uint8_t*>(aux)[tid] = mreg;
+        if (DROP) reinterpret_cast<uint32_t*>(aux + X::AUX_HASH)[tid] = drop_key_hash(seed, (uint32_t)key);
+        const unsigned long long any = __ballot(mreg != 0);
+        if (tid == 0) *reinterpret_cast<uint32_t*>(aux + X::AUX_FLAG) = any ? 1u : 0u;
+    }
+}
+
 // ---- forward (attn_fwd_kernel<float, DH> with split products) -------------------------------------------------------------
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(NTH, 2) void attnx_fwd_kernel(AttnP pin) {
     using A = AT<float, DH>;
     using X = X3L<DH>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
     int qoff, koff;
@@ -102,7 +132,7 @@ __global__ __launch_bounds__(NTH, 2) void attnx_fwd_kernel(AttnP pin) {
     const float* Kp = reinterpret_cast<const float*>(p.k) + (size_t)koff * p.ldk + h * DH;
     const float* Vp = reinterpret_cast<const float*>(p.v) + (size_t)koff * p.ldv + h * DH;
     const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
-    const int qrow = q0 + wave * 32 + (lane & 31);
+    const int qw0 = q0 + wave * 32, qrow = qw0 + (lane & 31);
 
     u32x4 qh[BT<DH>::NS], ql[BT<DH>::NS];
     x3_row_regs<DH>(qh, ql, Qp, p.ldq, qrow, p.Lq, lane);
@@ -117,10 +147,12 @@ __global__ __launch_bounds__(NTH, 2) void attnx_fwd_kernel(AttnP pin) {
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float sl = p.scale * LOG2E;
-    const uint32_t arow = drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow));
+    const uint32_t arow = DROP ? drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow)) : 0u;
+    const uint32_t thr = p.drop_thr;
 
     u32x4 st[A::NITEM][4];
     uint8_t mreg = 0;
+    int kreg = 0;
     auto gload = [&](int step) {
         const int k0 = step * BSTR;
 #pragma unroll
@@ -133,55 +165,59 @@ __global__ __launch_bounds__(NTH, 2) void attnx_fwd_kernel(AttnP pin) {
             }
         }
         if (tid < BSTR) {
-            const int key = k0 + tid;
-            mreg = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+            kreg = k0 + tid;
+            mreg = (kreg >= p.Lk) ? 1 : (mp ? mp[kreg] : 0);
         }
     };
     auto lstore = [&](int buf) {
-        char* base = smem + buf * X::BUF_QK;
+        char* base = smem + buf * X::STG;
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
             if (item < 2 * A::NSB) x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
         }
-        if (tid < BSTR) reinterpret_cast<uint8_t*>(base + 2 * X::TILE)[tid] = mreg;
+        x3_key_aux<DH, DROP>(smem + X::AUX0 + buf * X::AUXS, tid, mreg, p.drop_seed, kreg);
     };
 
     if (nsteps > 0) { gload(0); lstore(0); }
     __syncthreads();
 
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
+    auto body = [&](int step, const int S) {                    // S: the stage (0 / 1) this step's tiles are in
         if (step + 1 < nsteps) gload(step + 1);
-        const char* kt_ = smem + buf * X::BUF_QK;
-        const char* vt_ = kt_ + X::TILE;
-        const uint8_t* mk = reinterpret_cast<const uint8_t*>(kt_ + 2 * X::TILE);
+        const char* aux = smem + X::AUX0 + S * X::AUXS;
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(aux);
         const int k0 = step * BSTR;
+        // wave-uniform: this tile needs per-element mask tests (a masked key in it, or keys beyond this wave's first query row)
+        const bool edge = (*reinterpret_cast<const uint32_t*>(aux + X::AUX_FLAG) != 0u) || (p.causal && k0 + BSTR - 1 > qw0);
 
         f32x16 sacc[2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int r = 0; r < 16; ++r) { sacc[0][r] = 0.f; sacc[1][r] = 0.f; }
+        x3_mma_nat<DH>(sacc[0], smem + S * X::STG, 0, qh, ql, lane);
+        x3_mma_nat<DH>(sacc[1], smem + S * X::STG, 32, qh, ql, lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kt][r] = 0.f;
-            x3_mma_nat<DH>(sacc[kt], kt_, kt * 32, qh, ql, lane);
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kt][r] *= sl;
+        if (edge) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ko = kt * 32 + 8 * g + 4 * half;
+                    const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + ko);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && k0 + ko + e > qrow);
+                        sacc[kt][4 * g + e] = masked ? -INFINITY : sacc[kt][4 * g + e];
+                    }
+                }
         }
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ko = kt * 32 + 8 * g + 4 * half;
-                const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + ko);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = k0 + ko + e;
-                    float x = sacc[kt][4 * g + e] * sl;
-                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
-                    x = masked ? -INFINITY : x;
-                    sacc[kt][4 * g + e] = x;
-                    mx = fmaxf(mx, x);
-                }
-            }
+            for (int r = 0; r < 16; r += 2) mx = max3f(mx, sacc[kt][r], sacc[kt][r + 1]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         if (__any(mx > m_run + RESCALE_THR)) {                 // deferred rescale, as attn_fwd_kernel
             const float m_new = fmaxf(m_run, mx);
@@ -200,27 +236,27 @@ __global__ __launch_bounds__(NTH, 2) void attnx_fwd_kernel(AttnP pin) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                u32x4 ck = {0u, 0u, 0u, 0u};
+                if (DROP) ck = *reinterpret_cast<const u32x4*>(aux + X::AUX_HASH + 4 * (kt * 32 + 8 * g + 4 * half));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float pe = fast_exp2(sacc[kt][4 * g + e] - m_safe);
                     lsum += pe;
-                    if (p.drop_thr) {
-                        const uint32_t ck = drop_key_hash(p.drop_seed, (uint32_t)(k0 + kt * 32 + 8 * g + 4 * half + e));
-                        pe = drop_keep2(arow, ck, p.drop_thr) ? pe * p.drop_scale : 0.f;
-                    }
+                    if (DROP) pe = drop_keep2(arow, ck[e], thr) ? pe : 0.f;        // (1 / (1 - p): in the final normalisation)
                     sacc[kt][4 * g + e] = pe;
                 }
             }
         l_run += lsum;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) x3_mma_tr<DH>(oacc, vt_, kt * 32, sacc[kt], lane);
+        x3_mma_tr<DH>(oacc, smem + S * X::STG + X::TILE, 0, sacc[0], lane);
+        x3_mma_tr<DH>(oacc, smem + S * X::STG + X::TILE, 32, sacc[1], lane);
 
-        if (step + 1 < nsteps) lstore(buf ^ 1);
+        if (step + 1 < nsteps) lstore(S ^ 1);
         __syncthreads();
-    }
+    };
+    for (int step = 0; step < nsteps; ++step) body(step, step & 1);
 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const float inv = l_tot > 0.f ? (DROP ? p.drop_scale : 1.0f) / l_tot : 0.f;
     float* Op = reinterpret_cast<float*>(p.o) + (size_t)qoff * p.ldo + h * DH;
     store_rows<float, DH>(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);
     if (half == 0 && qrow < p.Lq && p.lse)
@@ -228,12 +264,12 @@ __global__ __launch_bounds__(NTH, 2) void attnx_fwd_kernel(AttnP pin) {
 }
 
 // ---- backward, dQ (attn_bwd_dq_kernel<float, DH> with split products) ----------------------------------------------------
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
     using A = AT<float, DH>;
     using X = X3L<DH>;
     constexpr int NS = BT<DH>::NS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
     int qoff, koff;
@@ -244,7 +280,7 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
     const float* Vp = reinterpret_cast<const float*>(p.v) + (size_t)koff * p.ldv + h * DH;
     const float* dOp = reinterpret_cast<const float*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
     const uint8_t* mp = p.kpm ? p.kpm + (size_t)b * pin.Lk : nullptr;
-    const int qrow = q0 + wave * 32 + (lane & 31);
+    const int qw0 = q0 + wave * 32, qrow = qw0 + (lane & 31);
 
     u32x4 qh[NS], ql[NS], doh[NS], dol[NS];
     x3_row_regs<DH>(qh, ql, Qp, p.ldq, qrow, p.Lq, lane);
@@ -262,10 +298,13 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[dt][r] = 0.f;
     const float sl = p.scale * LOG2E;
-    const uint32_t arow = drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow));
+    const uint32_t arow = DROP ? drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qrow)) : 0u;
+    const uint32_t thr = p.drop_thr;
+    const float dsc = DROP ? p.drop_scale : 1.0f;
 
     u32x4 st[A::NITEM][4];
     uint8_t mreg = 0;
+    int kreg = 0;
     auto gload = [&](int step) {
         const int k0 = step * BSTR;
 #pragma unroll
@@ -278,68 +317,73 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
             }
         }
         if (tid < BSTR) {
-            const int key = k0 + tid;
-            mreg = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
+            kreg = k0 + tid;
+            mreg = (kreg >= p.Lk) ? 1 : (mp ? mp[kreg] : 0);
         }
     };
     auto lstore = [&](int buf) {
-        char* base = smem + buf * X::BUF_QK;
+        char* base = smem + buf * X::STG;
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
             if (item < 2 * A::NSB) x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
         }
-        if (tid < BSTR) reinterpret_cast<uint8_t*>(base + 2 * X::TILE)[tid] = mreg;
+        x3_key_aux<DH, DROP>(smem + X::AUX0 + buf * X::AUXS, tid, mreg, p.drop_seed, kreg);
     };
 
     if (nsteps > 0) { gload(0); lstore(0); }
     __syncthreads();
 
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
+    auto body = [&](int step, const int S) {                    // S: the stage (0 / 1) this step's tiles are in
         if (step + 1 < nsteps) gload(step + 1);
-        const char* kt_ = smem + buf * X::BUF_QK;
-        const char* vt_ = kt_ + X::TILE;
-        const uint8_t* mk = reinterpret_cast<const uint8_t*>(kt_ + 2 * X::TILE);
+        const char* aux = smem + X::AUX0 + S * X::AUXS;
+        const uint8_t* mk = reinterpret_cast<const uint8_t*>(aux);
         const int k0 = step * BSTR;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        const bool edge = (*reinterpret_cast<const uint32_t*>(aux + X::AUX_FLAG) != 0u) || (p.causal && k0 + BSTR - 1 > qw0);
+        auto sub = [&](auto ktc) {
+            constexpr int kt = decltype(ktc)::value;
             f32x16 sacc, dpacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-            x3_mma_nat<DH>(sacc, kt_, kt * 32, qh, ql, lane);
-            x3_mma_nat<DH>(dpacc, vt_, kt * 32, doh, dol, lane);
+            x3_mma_nat<DH>(sacc, smem + S * X::STG, kt * 32, qh, ql, lane);                      // S^T = K Q^T
+            x3_mma_nat<DH>(dpacc, smem + S * X::STG + X::TILE, kt * 32, doh, dol, lane);         // dP^T = V dO^T
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ko = kt * 32 + 8 * g + 4 * half;
-                const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mk + ko);
+                u32x4 ck = {0u, 0u, 0u, 0u};
+                if (DROP) ck = *reinterpret_cast<const u32x4*>(aux + X::AUX_HASH + 4 * ko);
+                uint32_t m4 = 0u;
+                if (edge) m4 = *reinterpret_cast<const uint32_t*>(mk + ko);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int key = k0 + ko + e;
-                    const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && key > qrow);
-                    const float pe = masked ? 0.f : fast_exp2(sacc[4 * g + e] * sl - lse2);
+                    float pe = fast_exp2(fmaf(sacc[4 * g + e], sl, -lse2));
+                    if (edge) {
+                        const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && k0 + ko + e > qrow);
+                        pe = masked ? 0.f : pe;
+                    }
                     float dp = dpacc[4 * g + e];
-                    if (p.drop_thr)
-                        dp = drop_keep2(arow, drop_key_hash(p.drop_seed, (uint32_t)key), p.drop_thr) ? dp * p.drop_scale : 0.f;
+                    if (DROP) dp = drop_keep2(arow, ck[e], thr) ? dp * dsc : 0.f;
                     sacc[4 * g + e] = pe * (dp - dlt) * p.scale;          // dS^T
                 }
             }
-            x3_mma_tr<DH>(dqacc, kt_, kt * 32, sacc, lane);
-        }
-        if (step + 1 < nsteps) lstore(buf ^ 1);
+            x3_mma_tr<DH>(dqacc, smem + S * X::STG, kt * 32, sacc, lane);                        // dQ^T += K^T dS^T
+        };
+        sub(IC<0>{}); sub(IC<1>{});
+        if (step + 1 < nsteps) lstore(S ^ 1);
         __syncthreads();
-    }
+    };
+    for (int step = 0; step < nsteps; ++step) body(step, step & 1);
     float* dQp = reinterpret_cast<float*>(p.dq) + (size_t)qoff * p.lddq + h * DH;
     store_rows<float, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, 1.0f, lane);
 }
 
 // ---- backward, dK / dV (attn_bwd_dkv_kernel<float, DH> with split products) ----------------------------------------------
-template <int DH>
+template <int DH, bool DROP>
 __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dkv_kernel(AttnP pin) {
     using A = AT<float, DH>;
     using X = X3L<DH>;
     constexpr int NS = BT<DH>::NS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * BOWN;
     int qoff, koff;
@@ -349,7 +393,7 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dkv_kernel(AttnP pin) {
     const float* Kp = reinterpret_cast<const float*>(p.k) + (size_t)koff * p.ldk + h * DH;
     const float* Vp = reinterpret_cast<const float*>(p.v) + (size_t)koff * p.ldv + h * DH;
     const float* dOp = reinterpret_cast<const float*>(p.dout) + (size_t)qoff * p.lddo + h * DH;
-    const int krow = key0 + wave * 32 + (lane & 31);
+    const int kw0 = key0 + wave * 32, krow = kw0 + (lane & 31);
     const bool kmasked = (krow >= p.Lk) || (p.kpm && p.kpm[(size_t)b * pin.Lk + krow]);
 
     u32x4 kh[NS], kl[NS], vh[NS], vl[NS];
@@ -365,10 +409,13 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dkv_kernel(AttnP pin) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkacc[dt][r] = 0.f; dvacc[dt][r] = 0.f; }
     const float sl = p.scale * LOG2E;
-    const uint32_t ckey = drop_key_hash(p.drop_seed, (uint32_t)krow);
+    const uint32_t ckey = DROP ? drop_key_hash(p.drop_seed, (uint32_t)krow) : 0u;
+    const uint32_t thr = p.drop_thr;
+    const float dsc = DROP ? p.drop_scale : 1.0f;
 
     u32x4 st[A::NITEM][4];
     float lreg = 0.f, dreg = 0.f;
+    uint32_t hreg = 0u;
     auto gload = [&](int step) {
         const int r0 = step * BSTR;
 #pragma unroll
@@ -385,66 +432,69 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dkv_kernel(AttnP pin) {
             const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qr;
             lreg = (qr < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
             dreg = (qr < p.Lq) ? p.delta[srow] : 0.f;
+            if (DROP) hreg = drop_row_hash(p.drop_seed, (uint32_t)srow);
         }
     };
     auto lstore = [&](int buf) {
-        char* base = smem + buf * X::BUF_DKV;
+        char* base = smem + buf * X::STG;
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
             if (item < 2 * A::NSB) x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
         }
         if (tid < BSTR) {
-            float* aux = reinterpret_cast<float*>(base + 2 * X::TILE);
+            float* aux = reinterpret_cast<float*>(smem + X::AUX0 + buf * X::AUXS);
             aux[tid] = lreg; aux[64 + tid] = dreg;
+            if (DROP) reinterpret_cast<uint32_t*>(aux)[128 + tid] = hreg;
         }
     };
 
     if (step0 < nsteps) { gload(step0); lstore(0); }
     __syncthreads();
 
-    for (int step = step0; step < nsteps; ++step) {
-        const int buf = (step - step0) & 1;
+    auto body = [&](int step, const int S) {                    // S: the stage (0 / 1) this step's tiles are in
         if (step + 1 < nsteps) gload(step + 1);
-        const char* qt_ = smem + buf * X::BUF_DKV;
-        const char* dot_ = qt_ + X::TILE;
-        const float* aux = reinterpret_cast<const float*>(qt_ + 2 * X::TILE);
+        const float* aux = reinterpret_cast<const float*>(smem + X::AUX0 + S * X::AUXS);
         const int r0 = step * BSTR;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        const bool diag = p.causal && kw0 + 31 > r0;              // wave-uniform: some (query, key) pair of this tile is above the diagonal
+        auto sub = [&](auto qtc) {
+            constexpr int qt = decltype(qtc)::value;
             f32x16 sacc, dpacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-            x3_mma_nat<DH>(sacc, qt_, qt * 32, kh, kl, lane);        // S[q][key]: rows q (registers), column key (lane)
-            x3_mma_nat<DH>(dpacc, dot_, qt * 32, vh, vl, lane);      // dP[q][key]
+            x3_mma_nat<DH>(sacc, smem + S * X::STG, qt * 32, kh, kl, lane);                      // S[q][key]: rows q (registers), column key (lane)
+            x3_mma_nat<DH>(dpacc, smem + S * X::STG + X::TILE, qt * 32, vh, vl, lane);           // dP[q][key]
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int qo = qt * 32 + 8 * g + 4 * half;
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(aux + qo);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(aux + 64 + qo);
+                u32x4 h4 = {0u, 0u, 0u, 0u};
+                if (DROP) h4 = *reinterpret_cast<const u32x4*>(aux + 128 + qo);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int qr = r0 + qo + e;
-                    const bool masked = kmasked || (p.causal && krow > qr);
-                    const float pe = masked ? 0.f : fast_exp2(sacc[4 * g + e] * sl - l4[e]);
+                    float pe = fast_exp2(fmaf(sacc[4 * g + e], sl, -l4[e]));     // (rows past Lq: lse = +inf -> 0)
+                    pe = kmasked ? 0.f : pe;
+                    if (diag) pe = (krow > r0 + qo + e) ? 0.f : pe;
                     float dp = dpacc[4 * g + e];
                     float pd = pe;
-                    if (p.drop_thr) {
-                        const uint32_t ar = drop_row_hash(p.drop_seed, (uint32_t)(((size_t)b * p.H + h) * pin.Lq + qr));
-                        const bool keep = drop_keep2(ar, ckey, p.drop_thr);
-                        dp = keep ? dp * p.drop_scale : 0.f;
-                        pd = keep ? pe * p.drop_scale : 0.f;
+                    if (DROP) {
+                        const bool keep = drop_keep2(h4[e], ckey, thr);
+                        dp = keep ? dp * dsc : 0.f;
+                        pd = keep ? pe * dsc : 0.f;
                     }
                     sacc[4 * g + e] = pd;                                   // dropped P  -> dV
                     dpacc[4 * g + e] = pe * (dp - d4[e]) * p.scale;         // dS         -> dK
                 }
             }
-            x3_mma_tr<DH>(dvacc, dot_, qt * 32, sacc, lane);
-            x3_mma_tr<DH>(dkacc, qt_, qt * 32, dpacc, lane);
-        }
-        if (step + 1 < nsteps) lstore(buf ^ 1);
+            x3_mma_tr<DH>(dvacc, smem + S * X::STG + X::TILE, qt * 32, sacc, lane);              // dV^T += dO^T P
+            x3_mma_tr<DH>(dkacc, smem + S * X::STG, qt * 32, dpacc, lane);                       // dK^T += Q^T dS
+        };
+        sub(IC<0>{}); sub(IC<1>{});
+        if (step + 1 < nsteps) lstore(S ^ 1);
         __syncthreads();
-    }
+    };
+    for (int step = step0; step < nsteps; ++step) body(step, (step - step0) & 1);
     float* dKp = reinterpret_cast<float*>(p.dk) + (size_t)koff * p.lddk + h * DH;
     float* dVp = reinterpret_cast<float*>(p.dv) + (size_t)koff * p.lddv + h * DH;
     store_rows<float, DH>(dKp, p.lddk, krow, p.Lk, dkacc, 1.0f, lane);

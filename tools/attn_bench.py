@@ -13,8 +13,14 @@ dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(1)
 
 
+DT = torch.float32 if os.environ.get("DT", "bf16") == "f32" else torch.bfloat16
+if os.environ.get("X3", "0") == "1":          # f32 inputs, bf16x3 products (csrc/attention_x3.h)
+    from plankassembly_amd import _lib as L
+    L.check(L.lib().pa_attn_split_config(1), "pa_attn_split_config")
+
+
 def rnd(*s):
-    return torch.randn(*s, device=dev, generator=g).to(torch.bfloat16)
+    return torch.randn(*s, device=dev, generator=g).to(DT)
 
 
 def timeit(fn, iters=20, warm=3):
