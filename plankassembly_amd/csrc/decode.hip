@@ -243,9 +243,15 @@ constexpr int MAX_T = 2048;
 template <typename T>
 __global__ __launch_bounds__(256) void dec_sample_kernel(const float* vlog, int ldv, const T* pfeat, const T* h, T* hid_cache,
                                                          const float* sw_w, const float* sw_b, int64_t* tokens,
-                                                         int64_t* attach, int32_t* first_end, const int32_t* t_dev,
-                                                         int Tmax, int d, int V, int end_tok) {
+                                                         int64_t* attach, int32_t* first_end, int32_t* t_dev,
+                                                         int Tmax, int d, int V, int end_tok,
+                                                         // fused tail (PLANK_DECODE_FUSE_TAIL, default on): the NEXT step's input
+                                                         // embedding of this row and the step counter - what dec_embed_kernel and
+                                                         // dec_advance_kernel did as two more launches of the serial chain
+                                                         int fuse, float* x32, T* xT, bf16* x_lp, const float* value,
+                                                         const float* coord, const float* pos, int dof) {
     __shared__ float plog[MAX_T];
+    __shared__ long long s_tok;
     __shared__ float sh[4];
     __shared__ ArgMax sha[4];
     __shared__ float s_sw;
@@ -353,6 +359,70 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(const float* vlog, int 
         tokens[(int64_t)b * Tmax + t] = tok;
         attach[(int64_t)b * Tmax + t] = ptr;
         if (tok == end_tok && first_end[b] < 0) first_end[b] = t;
+        s_tok = tok;
+    }
+    if (!fuse) return;
+    __syncthreads();
+    {   // x(t + 1) = value[token(t)] + coord[t % dof] + pos[t / dof]   (reference models.py:114-123 on the token just sampled)
+        const long long tk = s_tok;
+        for (int c = tid << 2; c < d; c += 1024) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(value + tk * d + c);
+            acc += *reinterpret_cast<const f32x4*>(coord + (int64_t)(t % dof) * d + c);
+            acc += *reinterpret_cast<const f32x4*>(pos + (int64_t)(t / dof) * d + c);
+            if (x32) { *reinterpret_cast<f32x4*>(x32 + (int64_t)b * d + c) = acc; if (x_lp) st4<bf16>(x_lp + (int64_t)b * d + c, acc); }
+            else st4<T>(xT + (int64_t)b * d + c, acc);
+        }
+    }
+    // the block that finishes last advances the step counter: every block has read *t_dev long before its ticket
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned k = atomicAdd(reinterpret_cast<unsigned*>(t_dev + 1), 1u);
+        if (k == gridDim.x - 1) { t_dev[1] = 0; t_dev[0] = t + 1; }
+    }
+}
+
+// last decoder layer's norm3 and decoder.norm back to back on the same rows, plus the bf16 copy of the result (f32-residual step):
+// one wave per row, two-pass statistics in registers - three launches (two LayerNorms, dec_cast_kernel) of the serial chain in one
+__global__ __launch_bounds__(256) void dec_tail_norm_kernel(float* hf, bf16* h, const float* z, const float* g3, const float* b3, float eps3,
+                                                            const float* gf, const float* bf, float epsf, int rows, int d) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    constexpr int NV = 2;                                    // d <= 512: two 4-wide vectors per lane
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + i * 64) << 2;
+        v[i] = c < d ? *reinterpret_cast<const f32x4*>(z + (int64_t)row * d + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    auto norm = [&](const float* g, const float* bb, float eps) {
+        const float mu = wave_sum(s) / d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + i * 64) << 2;
+            if (c < d) for (int j = 0; j < 4; ++j) { const float t = v[i][j] - mu; q += t * t; }
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) / d + eps);          // (the arithmetic of layernorm_fwd_kernel, term for term)
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + i * 64) << 2;
+            if (c < d) {
+                const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c), be = *reinterpret_cast<const f32x4*>(bb + c);
+                for (int j = 0; j < 4; ++j) v[i][j] = (v[i][j] - mu) * rs * gg[j] + be[j];
+                s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+        }
+    };
+    norm(g3, b3, eps3);
+    norm(gf, bf, epsf);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + i * 64) << 2;
+        if (c < d) { *reinterpret_cast<f32x4*>(hf + (int64_t)row * d + c) = v[i]; st4<bf16>(h + (int64_t)row * d + c, v[i]); }
     }
 }
 
@@ -499,7 +569,15 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
     if (part < 0 || part >= n_parts) return PA_EINVAL;
     auto fence_in = [&]() -> int { if (wait_ev) { hipError_t e = hipStreamWaitEvent(s, wait_ev, 0); if (e != hipSuccess) return (int)e; } return 0; };
     auto fence_out = [&]() -> int { if (rec_ev) { hipError_t e = hipEventRecord(rec_ev, s); if (e != hipSuccess) return (int)e; } return 0; };
-    if (part == 0) {
+    // PLANK_DECODE_FUSE_TAIL=1 (default 0): the sampling kernel also writes the next step's input embedding and advances the step
+    // counter, and (f32-residual step) norm3 + decoder.norm + the bf16 copy are one launch: 57 -> 52 launches per step, tokens
+    // identical (tests/test_model_gpu.py decode tests pass either way).  MEASURED NULL on MI355X, round 5, B 256 x 1024 steps under
+    // graph replay, A/B in one session: bf16 1.0905 ms / step fused against 1.0794 unfused, f32 1.9954 against 1.9813 - the five
+    // launches it removes cost ~2 us each inside a replayed graph, and the sampling kernel's longer per-block tail (embedding row,
+    // fence, ticket) costs the same again.  Fourth fusion of this decode step that does not pay.  The embedding
+    // of step 0 is all zeros (models.py:114-123 with no token yet): pa_decode_begin clears x.
+    static const int fuse_tail = getenv("PLANK_DECODE_FUSE_TAIL") ? atoi(getenv("PLANK_DECODE_FUSE_TAIL")) : 0;
+    if (part == 0 && !fuse_tail) {
         const int g1 = (B * (d / 4) + 255) / 256;
         if (L->f32res)
             PA_LAUNCH(dec_embed_kernel<float>, dim3(g1), dim3(256), 0, s, (float*)L->x, PF(P_IN_VALUE), PF(P_Q_COORD), PF(P_Q_POS),
@@ -519,11 +597,18 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
                                L->ff, ff, B, ff, d, act, st));
             RC(gelu_ff());
             RC(linear_res32(m, L->ff, PL(pb + D_L2_W), PF(pb + D_L2_B), xf, zf, L->zb, B, d, ff, st));
-            if (part == n_parts - 1)
+            if (part == n_parts - 1 && !(fuse_tail && d <= 512 && (d & 3) == 0))
                 RC(pa_layernorm_fwd(xf, zf, PF(pb + D_N3_W), PF(pb + D_N3_B), L->mean, L->rstd, B, d, c.eps_layer, PA_F32, st));
         }
         if (part == n_parts - 1) {
-            RC(pa_layernorm_fwd(L->hf, xf, PF(m->dec_norm()), PF(m->dec_norm() + 1), L->mean, L->rstd, B, d, c.eps_final, PA_F32, st));
+            const bool tail_norm = fuse_tail && d <= 512 && (d & 3) == 0;
+            if (tail_norm) {
+                const int pl_ = m->dec_base(c.n_dec - 1);
+                PA_LAUNCH(dec_tail_norm_kernel, dim3((B + 3) / 4), dim3(256), 0, s, L->hf, (bf16*)L->h, (const float*)zf, PF(pl_ + D_N3_W),
+                          PF(pl_ + D_N3_B), c.eps_layer, PF(m->dec_norm()), PF(m->dec_norm() + 1), c.eps_final, B, d);
+            } else {
+                RC(pa_layernorm_fwd(L->hf, xf, PF(m->dec_norm()), PF(m->dec_norm() + 1), L->mean, L->rstd, B, d, c.eps_final, PA_F32, st));
+            }
             const int tl = m->tail(), ldv = (c.vocab + 7) / 8 * 8;
             {   // vocabulary head in f32 on the f32 hidden rows (f32 master weight; the f32 skinny kernel)
                 pa_gemm_args g; memset(&g, 0, sizeof(g));
@@ -533,12 +618,14 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
                 g.alpha = 1.f; g.aux_scale = 1.f; g.splitk = 1;
                 RC(pa_gemm(&g, st));
             }
-            PA_LAUNCH(dec_cast_kernel, dim3((B * d / 4 + 255) / 256), dim3(256), 0, s, (bf16*)L->h, (const float*)L->hf, (int64_t)B * d / 4);
+            if (!tail_norm)
+                PA_LAUNCH(dec_cast_kernel, dim3((B * d / 4 + 255) / 256), dim3(256), 0, s, (bf16*)L->h, (const float*)L->hf, (int64_t)B * d / 4);
             RC(linear(m, L->h, PL(tl + T_PTR_W), PF(tl + T_PTR_B), L->pfeat, d, B, d, d, 0, nullptr, -1, st));
             PA_LAUNCH(dec_sample_kernel<T>, dim3(B), dim3(256), 0, s, L->vlog, ldv, (const T*)L->pfeat, (const T*)L->h,
                                (T*)L->hid_cache, PF(tl + T_SW_W), PF(tl + T_SW_B), L->tokens, L->attach, L->first_end, L->t_dev, Tmax, d,
-                               c.vocab, c.end);
-            PA_LAUNCH(dec_advance_kernel, dim3(1), dim3(64), 0, s, L->t_dev);
+                               c.vocab, c.end, fuse_tail, (float*)L->x, (T*)nullptr, (bf16*)L->xb, PF(P_IN_VALUE), PF(P_Q_COORD), PF(P_Q_POS),
+                               c.out_dof);
+            if (!fuse_tail) PA_LAUNCH(dec_advance_kernel, dim3(1), dim3(64), 0, s, L->t_dev);
             return 0;
         }
         const int i = part / 2, pb = m->dec_base(i);
@@ -591,8 +678,9 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
         RC(linear(m, L->h, PL(tl + T_PTR_W), PF(tl + T_PTR_B), L->pfeat, d, B, d, d, 0, nullptr, -1, st));
         PA_LAUNCH(dec_sample_kernel<T>, dim3(B), dim3(256), 0, s, L->vlog, ldv, (const T*)L->pfeat, (const T*)L->h,
                            (T*)L->hid_cache, PF(tl + T_SW_W), PF(tl + T_SW_B), L->tokens, L->attach, L->first_end, L->t_dev, Tmax, d,
-                           c.vocab, c.end);
-        PA_LAUNCH(dec_advance_kernel, dim3(1), dim3(64), 0, s, L->t_dev);
+                           c.vocab, c.end, fuse_tail, (float*)nullptr, (T*)L->x, (bf16*)nullptr, PF(P_IN_VALUE), PF(P_Q_COORD), PF(P_Q_POS),
+                           c.out_dof);
+        if (!fuse_tail) PA_LAUNCH(dec_advance_kernel, dim3(1), dim3(64), 0, s, L->t_dev);
         return 0;
     }
     const int i = part / 2;
@@ -720,7 +808,11 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
     if (he != hipSuccess) return (int)he;
     he = hipMemsetAsync(L->first_end, 0xFF, (size_t)B * 4, s);
     if (he != hipSuccess) return (int)he;
-    he = hipMemsetAsync(L->t_dev, 0, 4, s);
+    he = hipMemsetAsync(L->t_dev, 0, 8, s);                     // step counter and the sampling kernel's ticket
+    if (he != hipSuccess) return (int)he;
+    he = hipMemsetAsync(L->x, 0, (size_t)B * c.d_model * 4, s);  // input embedding of step 0: zeros (later steps: written by the sampling kernel)
+    if (he != hipSuccess) return (int)he;
+    he = hipMemsetAsync(L->xb, 0, (size_t)B * c.d_model * 2, s);
     if (he != hipSuccess) return (int)he;
     he = hipMemsetAsync(L->tokens, 0, (size_t)B * Tmax * 8, s);
     if (he != hipSuccess) return (int)he;
