@@ -387,7 +387,7 @@ int pa_mixture_nll_bwd(void* dvocab, void* dptr, int32_t out_dtype, float* dsw, 
                        void* stream);
 /* The same forward on an EIGHT-float statistics block that the launch zeroes itself: [0] summed NLL, [1] unmasked rows, [2] correct
  * rows, [3] upstream d(loss) (armed with 1.0), [4] loss = [0] / [1], [5] accuracy = [2] / ([1] + 1e-10) - reference
- * plankassembly/models.py:226-231 - written by the block that finishes last, [6] its ticket, [7] spare.  The training step returns
+ * plankassembly/models.py:226-231 - written by a one-wave finishing launch behind the forward kernel, [6], [7] spare.  The training step returns
  * views of [4] / [5]: no element-wise launches behind the forward.  pa_mixture_nll_bwd_up: `upstream` (device f32 scalar, or NULL =
  * stats[3]) is d(loss) from the caller's autograd - read in place instead of being copied into stats[3]. */
 int pa_mixture_nll_fwd_fin(float* stats8, float* row_lse, const float* vocab, int32_t ldv, const float* ptr,

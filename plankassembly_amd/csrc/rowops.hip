@@ -620,7 +620,7 @@ constexpr int NLL_VSLOTS = 16;   // a lane holds up to 16 vocabulary logits (V <
 constexpr int NLL_PSLOTS = 4;    // all loads are issued up front, unconditionally (clamped index), then reduced in order
 __global__ __launch_bounds__(256) void mixture_nll_fwd_kernel(float* stats, float* row_lse, const float* vocab, int ldv,
                                                               const float* ptr, const float* sw, const int64_t* label,
-                                                              int B, int Tn, int V, int pad, int fin) {
+                                                              int B, int Tn, int V, int pad) {
     __shared__ float red[4][3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float a_nll = 0.f, a_cnt = 0.f, a_hit = 0.f;
@@ -670,22 +670,16 @@ __global__ __launch_bounds__(256) void mixture_nll_fwd_kernel(float* stats, floa
         const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
         if (v != 0.f) atomicAdd(stats + threadIdx.x, v);
     }
-    if (fin) {
-        // stats8 form (pa_mixture_nll_fwd_fin): the block that takes the last ticket turns the three sums into loss = nll / count and
-        // accuracy = hits / (count + 1e-10) (reference models.py:226-231) and arms the upstream gradient with 1.0 - what four tiny
-        // torch launches (two divisions, an add, a fill) did on the step's serial chain before.
-        __threadfence();                                       // this block's three atomics before its ticket
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(stats + 6), 1u);
-            if (t == gridDim.x - 1) {
-                __threadfence();
-                const float s0 = __hip_atomic_load(stats + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float s1 = __hip_atomic_load(stats + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float s2 = __hip_atomic_load(stats + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                stats[4] = s0 / s1; stats[5] = s2 / (s1 + 1e-10f); stats[3] = 1.0f;
-            }
-        }
+}
+// stats8 form (pa_mixture_nll_fwd_fin): loss = nll / count, accuracy = hits / (count + 1e-10) (reference models.py:226-231) and the
+// upstream gradient's default 1.0 in ONE one-wave launch behind the forward kernel - what five tiny torch launches and a memset did
+// on the step's serial chain before.  Two in-kernel forms were measured first and lost: the last block (ticket)
+// finishing the sums behind __threadfence() took the forward kernel from 11.7 to 38.6 us, and with returning device-scope atomics
+// instead of the fence to 33.8 us (512 blocks x 4 returning atomics on four words) - more than the launches they replaced.
+__global__ void mixture_nll_finish_kernel(float* stats) {
+    if (threadIdx.x == 0) {
+        const float s0 = stats[0], s1 = stats[1], s2 = stats[2];
+        stats[4] = s0 / s1; stats[5] = s2 / (s1 + 1e-10f); stats[3] = 1.0f;
     }
 }
 
@@ -1143,7 +1137,7 @@ extern "C" int pa_mixture_nll_fwd(float* stats, float* row_lse, const float* voc
                                   void* stream) {
     if (!stats || !row_lse || !vocab || !ptr || !sw || !label || B <= 0 || T <= 0 || V <= 0 || ldv < V) return PA_EINVAL;
     const int grid = (int)(((int64_t)B * T + NLL_ROWS - 1) / NLL_ROWS);
-    PA_LAUNCH(mixture_nll_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, 0);
+    PA_LAUNCH(mixture_nll_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), stats, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad);
     return 0;
 }
 extern "C" int pa_mixture_nll_fwd_fin(float* stats8, float* row_lse, const float* vocab, int32_t ldv, const float* ptr,
@@ -1152,7 +1146,8 @@ extern "C" int pa_mixture_nll_fwd_fin(float* stats8, float* row_lse, const float
     if (!stats8 || !row_lse || !vocab || !ptr || !sw || !label || B <= 0 || T <= 0 || V <= 0 || ldv < V) return PA_EINVAL;
     const int grid = (int)(((int64_t)B * T + NLL_ROWS - 1) / NLL_ROWS);
     if (hipMemsetAsync(stats8, 0, 8 * sizeof(float), ST(stream)) != hipSuccess) return PA_EINVAL;      // sums, ticket (and the rest)
-    PA_LAUNCH(mixture_nll_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), stats8, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad, 1);
+    PA_LAUNCH(mixture_nll_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), stats8, row_lse, vocab, ldv, ptr, sw, label, B, T, V, pad);
+    PA_LAUNCH(mixture_nll_finish_kernel, dim3(1), dim3(64), 0, ST(stream), stats8);
     return 0;
 }
 

@@ -144,6 +144,31 @@ def test_cli_fit_resume_test_evaluate(tmp_path, monkeypatch):
           f"evaluate.py f1 {f:.3f}")
 
 
+def test_cli_fit_with_bf16x3_products(tmp_path, monkeypatch):
+    """MODEL.COMPUTE_DTYPE: x3 through the command line: the f32 path with split (hi / lo bf16) matrix products trains like the f32
+    path - same first-epoch loss to 1e-3, decreasing afterwards - and its GEMMs really ran split."""
+    import ctypes as C
+    from plankassembly_amd import _lib as L
+    from plankassembly_amd.trainer import Trainer, cli
+    monkeypatch.chdir(tmp_path)
+    config, _ = _write_config(tmp_path, max_epochs=2)
+    ref = cli(Trainer, ["fit", "--config", config])
+    l_ref = [v for _, name, v in ref.logger.history if name == "train/loss"]
+    with open(config) as f:
+        cfg = yaml.safe_load(f)
+    cfg["model"]["hparams"]["MODEL"]["COMPUTE_DTYPE"] = "x3"
+    path = tmp_path / "train_small_x3.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    out = (C.c_int64 * 2)()
+    L.check(L.lib().pa_gemm_split_stats(out, 1), "pa_gemm_split_stats")
+    mod = cli(Trainer, ["fit", "--config", str(path)])
+    L.check(L.lib().pa_gemm_split_stats(out, 0), "pa_gemm_split_stats")
+    assert mod.model.compute_mode == "x3" and int(out[0]) > 100, (mod.model.compute_mode, int(out[0]), int(out[1]))
+    losses = [v for _, name, v in mod.logger.history if name == "train/loss"]
+    assert len(losses) == 2 and losses[1] < losses[0]
+    assert abs(losses[0] - l_ref[0]) < 1e-3 * max(1.0, abs(l_ref[0])), (losses, l_ref)
+
+
 def test_cli_two_ranks_sharing_the_gpu(tmp_path, monkeypatch):
     """The reference trains with `strategy: ddp` on 4 devices (configs/train_complete.yaml:18-21).  Two ranks of this trainer's
     command line - launched as torchrun would, sharing the one GPU of the test box through gloo - run `test` and `fit`:

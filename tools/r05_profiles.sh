@@ -1,21 +1,21 @@
 # Round-3..5 evidence (run on the GPU box from the repo root): kernel traces of the train step and of the decode step, HBM
 # traffic (FETCH_SIZE / WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes) for both, and SQ counters for the
 # GEMM families and the attention kernels inside the step.  Never combines --pmc with hip/hsa/memory-copy tracing.
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp
-BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu --no-decode --no-kernels"
+BENCH="python $R/bench.py --steps 10 --warmup 3 --no-cpu --no-decode --no-kernels --no-f32"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt -o t -- $BENCH > $OUT/kt.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/dec -o t -- python $R/tools/decode_prof.py > $OUT/dec.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --no-decode --no-kernels > $OUT/pmcf.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --no-decode --no-kernels > $OUT/pmcw.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --no-decode --no-kernels --no-f32 > $OUT/pmcf.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o t -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --no-decode --no-kernels --no-f32 > $OUT/pmcw.log 2>&1
 STEPS=24 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/dec_fetch -o t -- python $R/tools/decode_prof.py > $OUT/decf.log 2>&1
 STEPS=24 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/dec_write -o t -- python $R/tools/decode_prof.py > $OUT/decw.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/sq_a -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu --no-decode --no-kernels > $OUT/sqa.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq_b -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu --no-decode --no-kernels > $OUT/sqb.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $OUT/sq_a -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu --no-decode --no-kernels --no-f32 > $OUT/sqa.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq_b -o t -- python $R/bench.py --steps 4 --warmup 2 --no-cpu --no-decode --no-kernels --no-f32 > $OUT/sqb.log 2>&1
 cd $R
 python tools/rocpd_summary.py $(find $OUT/kt -name "*.db" | head -1) > $OUT/train_kernel_trace_summary.txt 2>&1
 python tools/rocpd_summary.py $(find $OUT/dec -name "*.db" | head -1) > $OUT/decode_kernel_trace_summary.txt 2>&1
