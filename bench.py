@@ -590,8 +590,8 @@ def main():
     PARITY_NOTES = {
         "f32": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 activations: the checker path of the 1e-4 parity tests",
         "x3": "f32 activations / parameters / LayerNorm / softmax / loss; every GEMM on the bf16 matrix pipe as hi*hi + hi*lo + lo*hi of "
-              "the operands' bf16 hi / lo parts, f32 accumulation (pa_gemm_split_config); attention products in exact f32; passes the "
-              "f32 gate of tests/test_headline_gpu.py unchanged (test_x3_*)",
+              "the operands' bf16 hi / lo parts, f32 accumulation (pa_gemm_split_config), the attention products likewise "
+              "(csrc/attention_x3.h); passes the f32 gate of tests/test_headline_gpu.py unchanged (test_x3_*)",
     }
 
     def parity_leg(name):
@@ -610,9 +610,9 @@ def main():
             return o
 
         n32 = max(5, min(args.steps, 10))
-        dt32, o32 = timed(raw, fresh=True, steps=n32, warmup=2, tag="train_" + name, mdl=m32, stepper=step32)
+        dt32, o32 = timed(raw, fresh=True, steps=n32, warmup=4, tag="train_" + name, mdl=m32, stepper=step32)
         assert math.isfinite(float(o32["loss"].detach())), name + " training diverged"
-        res = dict(value=n32 * B * world / dt32, unit="samples/s", steps=n32, warmup=2, ms_per_step=dt32 / n32 * 1e3,
+        res = dict(value=n32 * B * world / dt32, unit="samples/s", steps=n32, warmup=4, ms_per_step=dt32 / n32 * 1e3,
                    dtype=name, final_loss=float(o32["loss"].detach()), note=PARITY_NOTES[name])
         log(f"train {name} (parity path): {res['value']:.1f} samples/s, {res['ms_per_step']:.2f} ms/step")
         if sync32 is not None:

@@ -1015,3 +1015,23 @@ def test_attention_x3_equals_exact_f32_to_split_precision(B, H, Lq, Lk, use_kpm,
         err = float((a - b).abs().max())
         assert err <= 3e-5 * scale + 1e-6, (name, err, scale)       # three-term split: ~2^-17 per product (plain bf16 would be ~4e-3)
         assert err > 0.0 or name == "lse"                           # ... and it is not the exact kernel answering
+
+
+def test_attention_mask_order_dispatch_leaves_results_unchanged():
+    """ops.mask_order (longest batch element first, pa_attn_args.order on a padded batch with a key-padding mask): a permutation
+    of the block -> batch-element mapping only - forward and backward outputs are bit-identical to the plain order, with dropout."""
+    B, H, S, dm = 6, 8, 320, 512
+    qkv = rnd(B, S, 3 * dm, dtype=torch.bfloat16, seed=60).to(DEV)
+    q, k, v = qkv[..., :dm], qkv[..., dm:2 * dm], qkv[..., 2 * dm:]
+    valid = torch.tensor([320, 40, 200, 129, 64, 257])
+    kpm = (torch.arange(S)[None, :] >= valid[:, None]).to(DEV)
+    order = ops.mask_order(kpm)
+    assert order.tolist() == [0, 5, 2, 3, 4, 1] and order.dtype == torch.int32
+    do = rnd(B, S, dm, dtype=torch.bfloat16, seed=61).to(DEV)
+    kw = dict(kpm=kpm, drop_p=0.2, drop_seed=9)
+    o0, l0 = ops.attn_fwd(q, k, v, H, **kw)
+    o1, l1 = ops.attn_fwd(q, k, v, H, order=order, **kw)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    g0 = ops.attn_bwd(do, q, k, v, o0, l0, H, **kw)
+    g1 = ops.attn_bwd(do, q, k, v, o0, l0, H, order=order, **kw)
+    assert all(torch.equal(a, b) for a, b in zip(g0, g1))
