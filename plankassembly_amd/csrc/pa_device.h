@@ -144,8 +144,29 @@ __device__ __forceinline__ bool drop_keep2(uint32_t a, uint32_t c, uint32_t thr3
 // three xor-shifts, an add per ELEMENT plus the index arithmetic, ~14 instructions per element - in epilogues that were as long
 // as the K loop at this model's K = 512 (6.9 non-MFMA VALU per MFMA in the two-blocks-per-CU kernel, profiles/r03_gemm_pmc.txt).
 // Here a thread hashes its few rows and its four columns once per pass and spends multiply + compare + select per element.
+// Round 5: ONE 24 x 24-bit product leaves 22 free bits per row / column hash - among 8 192 rows about eight pairs
+// share a row hash and with it their WHOLE mask (correlation 0.9999), column pairs reached 0.85.  The decision is now the SUM of two
+// products, keep <=> low32(A1[row] * C1[col] + A2[row] * C2[col]) >= thr: 32 free bits per side, and two rows that agree
+// in A1 still differ by (A2 - A2') * C2[col], which changes with the column.  One v_mul_u32_u24 + one v_mad_u32_u24 per element
+// (the four hashes are per row / per column and hoisted); tests/dropout_masks.py linear_keep restates it,
+// tests/test_dropout_stats.py bounds every row-row and column-column mask correlation.  (The attention-probability dropout keeps
+// the single product: its kernels are bound by VALU issue, three instructions per score.)
+// (A2 / C2 = the top 24 bits of ONE more xorshift-multiply round on the 32-bit mix A1 / C1 are cut from: 32 free bits per side
+// together.  Bits 8..31 of the same mix do NOT do - rows that agree in A1 then differ by a multiple of 2^16 in A2 and stay
+// correlated at 0.94.  Cost, A/B in one session against a -DPA_DROP_ONE_PRODUCT build, 200 steps twice: 4.617 vs 4.560 ms per bf16
+// train step (+1.2 %; +1.5 % with a second full mix32 per row / column): the extra v_mad per element in every dropout epilogue and in
+// the LayerNorm backward that regenerates the masks.)
+__device__ __forceinline__ uint32_t drop_mix_row(uint32_t seed, uint32_t row) { return mix32(row * 0x9e3779b9u + seed); }
+__device__ __forceinline__ uint32_t drop_mix_key(uint32_t seed, uint32_t key) { return mix32(key * 0x85ebca6bu + (seed ^ 0x5bd1e995u)); }
 __device__ __forceinline__ bool drop_keep_rc(uint32_t seed, uint32_t row, uint32_t col, uint32_t thr32) {
+#ifdef PA_DROP_ONE_PRODUCT      // ablation build (round 4's decision): step-time A/B only, the dropout parity tests fail with it
     return drop_keep2(drop_row_hash(seed, row), drop_key_hash(seed, col), thr32);
+#endif
+    const uint32_t mr = drop_mix_row(seed, row), mc = drop_mix_key(seed, col);
+    const uint32_t mr2 = (mr ^ (mr >> 13)) * 0x846ca68bu, mc2 = (mc ^ (mc >> 13)) * 0x7feb352du;    // one more mixing round
+    const uint32_t h = __umul24((mr & 0xffffffu) | 0x800001u, (mc & 0xffffffu) | 0x800001u) +
+                       __umul24((mr2 >> 8) | 0x800001u, (mc2 >> 8) | 0x800001u);
+    return h >= thr32;
 }
 
 // max(a, b, c) as ONE v_max3_f32.  fmaxf() must quiet signalling NaNs, so hipcc canonicalises every operand that comes out

@@ -31,11 +31,23 @@ def next_step_seed(prev, initial_seed):
 
 
 def linear_keep(seed, rows, n_cols, p):
-    """Epilogue dropout of a Linear whose output is [n_rows][n_cols] (pa_device.h drop_keep_rc, round 4): the separable
-    decision of the attention dropout, keep(row, col) <=> low32(A[row] * C[col]) >= p * 2^32, with A / C the same 24-bit odd
-    hashes of the output row (batch folded in: b * M + m) and the output column.
+    """Epilogue dropout of a Linear whose output is [n_rows][n_cols] (pa_device.h drop_keep_rc, round 5): the SUM of two
+    independent separable products, keep(row, col) <=> low32(A1[row] * C1[col] + A2[row] * C2[col]) >= p * 2^32, with A1 / C1 the
+    attention dropout's 24-bit odd hashes of the output row (batch folded in: b * M + m) and the output column (bits 0..23 of a 32-bit
+    mix) and A2 / C2 the top 24 bits of one more mixing round on those mixes (32 free bits per side: no two rows or columns share a mask).
     ``rows``: the output-row index of every row wanted (packed row numbers for the packed encoder).  bool [len(rows), n_cols]."""
-    return attn_keep(seed, np.asarray(rows, dtype=np.uint64), n_cols, p)
+    thr32 = np.uint64(int(float(np.float32(p)) * 4294967296.0))
+    r = np.asarray(rows, dtype=np.uint64)
+    k = np.arange(n_cols, dtype=np.uint64)
+    odd = lambda x: (x & np.uint64(0xFFFFFF)) | np.uint64(0x800001)
+    mr = mix32((r * np.uint64(0x9E3779B9) + np.uint64(seed)) & M32)
+    mc = mix32((k * np.uint64(0x85EBCA6B) + np.uint64(seed ^ 0x5BD1E995)) & M32)
+    a1, c1 = odd(mr), odd(mc)                                   # bits 0..23 of the mixes: the attention dropout's hashes
+    mr2 = ((mr ^ (mr >> np.uint64(13))) * np.uint64(0x846CA68B)) & M32     # one more xorshift-multiply round each
+    mc2 = ((mc ^ (mc >> np.uint64(13))) * np.uint64(0x7FEB352D)) & M32
+    a2, c2 = odd(mr2 >> np.uint64(8)), odd(mc2 >> np.uint64(8))
+    h = ((a1[..., None] * c1) + (a2[..., None] * c2)) & M32
+    return h >= thr32
 
 
 def linear_scale(p):
