@@ -144,10 +144,15 @@ def spec_for(kind: str, max_input_length=None, max_output_length=None) -> SynthS
 class DevicePrefetcher:
     """Iterate prepared batches one step ahead of the training loop.
 
-    ``model.prepare_batch`` (host -> device copies, encoder row packing, embedding-row groupings; it ends with the one
-    device -> host read of a step, the number of valid encoder rows) runs for batch i + 1 on a side stream while step i
-    computes on the main stream, so that read never drains the main stream.  The reference gets the same overlap from
-    its DataLoader workers (trainer_complete.py:35-43); here the GPU-side part of batch preparation is overlapped too.
+    What runs where (round 5, tools/prep_probe.py on MI355X: 200 headline steps, bf16, batch 16):
+    * the host -> device copies of batch i + 1 always run on a side stream while step i computes (the reference gets the same
+      overlap from its DataLoader workers, trainer_complete.py:35-43);
+    * when the number of valid encoder rows is known on the HOST - the collate function built the padding mask on the CPU (the mask
+      is a CPU tensor: counted here before the copy), or the batch carries ``_n_valid`` - the two preparation launches (row packing,
+      embedding-row grouping) go to the MAIN stream in front of the step: +0.04 ms per step over batches prepared ahead;
+    * otherwise (device-resident batch, count unknown) ``prepare_batch`` runs one step ahead on the side stream, because its device
+      -> host read of the count must not drain the main stream: +0.10 ms per step - not the read (a host-known count on the side
+      stream measures the same) but the two launches sharing the CUs with the step's one-block-per-CU grids.
     """
 
     def __init__(self, model, batches):
@@ -163,10 +168,20 @@ class DevicePrefetcher:
         except StopIteration:
             self.nxt = None
             return
+        msk = raw.get("input_mask")
+        known = raw.get("_n_valid")
+        if known is None and torch.is_tensor(msk) and not msk.is_cuda and getattr(self.model, "unpad", False):
+            known = int(msk.numel() - int(msk.to(torch.bool).sum()))       # CPU collate: the count is free
         # (no wait on the main stream: a collated batch does not depend on the step in flight, and waiting would park
         # prepare_batch's device -> host read behind that whole step)
         with torch.cuda.stream(self.side):
-            self.nxt = self.model.prepare_batch(raw)
+            if known is not None:
+                dev = self.model._flat.device
+                moved = {k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) else v) for k, v in raw.items()}
+                moved["_n_valid"] = known
+                self.nxt = ("main", moved)
+            else:
+                self.nxt = ("done", self.model.prepare_batch(raw))
 
     def __iter__(self):
         return self
@@ -176,9 +191,11 @@ class DevicePrefetcher:
             raise StopIteration
         main = torch.cuda.current_stream()
         main.wait_stream(self.side)
-        cur = self.nxt
+        kind, cur = self.nxt
         for t in _tensors_of(cur):
             t.record_stream(main)                                # allocated on the side stream, consumed on the main one
+        if kind == "main":
+            cur = self.model.prepare_batch(cur)                  # two launches on the main stream, no device -> host read
         self._stage()
         return cur
 

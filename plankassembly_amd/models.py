@@ -580,12 +580,14 @@ class PlankModel(nn.Module):
         b.B, b.S, b.T = B, S, T
         return b, keep
 
-    def _pack(self, mask_u8):
+    def _pack(self, mask_u8, n_valid=None):
+        """``n_valid``: the number of unmasked encoder rows when the caller already knows it on the HOST (a dataloader that
+        padded the batch does; ``batch["_n_valid"]``) - the one device -> host read of a step is then skipped."""
         B, S = mask_u8.shape
         cu = torch.empty(2 * B + 1, dtype=torch.int32, device=mask_u8.device)
         rowmap = torch.empty(B * S, dtype=torch.int32, device=mask_u8.device)
         L.check(L.lib().pa_pack_rows(L.ptr(mask_u8), B, S, L.ptr(cu), L.ptr(rowmap), L.stream()), "pa_pack_rows")
-        return cu, rowmap, int(cu[B])
+        return cu, rowmap, int(cu[B]) if n_valid is None else int(n_valid)
 
     def prepare_batch(self, batch, groups=True):
         """Move a collated batch to the model's device and attach the encoder row packing (``_pack``: valid-row
@@ -599,7 +601,7 @@ class PlankModel(nn.Module):
         if self.unpad:
             msk = out["input_mask"].contiguous()
             msk = msk.view(torch.uint8) if msk.dtype == torch.bool else msk.to(torch.uint8)
-            out["_pack"] = self._pack(msk)
+            out["_pack"] = self._pack(msk, batch.get("_n_valid"))
             # group the token rows by embedding-table row: the table gradients then are segment sums instead of millions
             # of atomics (pa_embed_segment_bwd).  Batch-only information, like the packing: ONE launch for all eight
             # tables (pa_group_rows, a stable counting sort per table), no torch op.
