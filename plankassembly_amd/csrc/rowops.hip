@@ -188,11 +188,18 @@ __global__ __launch_bounds__(1024) void pack_rows_fused_kernel(const uint8_t* ma
     int* cnt = pk_s;
     int* off = pk_s + B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // mask bytes of a batch row: PK_CH x 64 columns per pass, ALL loads of a pass issued before the first ballot (clamped index,
+    // surplus discarded): a load inside `s < S && !mask[..]` is a branch with a wait behind it - 16 dependent round trips per
+    // row and pass at S = 1024, 28 us for this kernel (round 5: on the step's main stream since the prefetcher change)
+    constexpr int PK_CH = 20;
     for (int b = wave; b < B; b += 16) {
         int c = 0;
-        for (int s0 = 0; s0 < S; s0 += 64) {
-            const int s = s0 + lane;
-            c += __popcll(__ballot(s < S && !mask[(size_t)b * S + s]));
+        for (int c0 = 0; c0 < S; c0 += 64 * PK_CH) {
+            uint8_t mv[PK_CH];
+#pragma unroll
+            for (int i = 0; i < PK_CH; ++i) { const int s = c0 + i * 64 + lane; mv[i] = mask[(size_t)b * S + (s < S ? s : S - 1)]; }
+#pragma unroll
+            for (int i = 0; i < PK_CH; ++i) { const int s = c0 + i * 64 + lane; c += __popcll(__ballot(s < S && !mv[i])); }
         }
         if (lane == 0) cnt[b] = c;
     }
@@ -214,12 +221,18 @@ __global__ __launch_bounds__(1024) void pack_rows_fused_kernel(const uint8_t* ma
     for (int b = threadIdx.x; b <= B; b += 1024) cu[b] = off[b];
     for (int b = wave; b < B; b += 16) {
         int base = off[b];
-        for (int s0 = 0; s0 < S; s0 += 64) {
-            const int s = s0 + lane;
-            const bool v = s < S && !mask[(size_t)b * S + s];
-            const unsigned long long bal = __ballot(v);
-            if (v) rowmap[base + __popcll(bal & ((1ull << lane) - 1ull))] = b * S + s;
-            base += __popcll(bal);
+        for (int c0 = 0; c0 < S; c0 += 64 * PK_CH) {
+            uint8_t mv[PK_CH];
+#pragma unroll
+            for (int i = 0; i < PK_CH; ++i) { const int s = c0 + i * 64 + lane; mv[i] = mask[(size_t)b * S + (s < S ? s : S - 1)]; }
+#pragma unroll
+            for (int i = 0; i < PK_CH; ++i) {
+                const int s = c0 + i * 64 + lane;
+                const bool v = s < S && !mv[i];
+                const unsigned long long bal = __ballot(v);
+                if (v) rowmap[base + __popcll(bal & ((1ull << lane) - 1ull))] = b * S + s;
+                base += __popcll(bal);
+            }
         }
     }
     for (int i = threadIdx.x; i < B; i += 1024) {    // dispatch order: descending count, ties in batch order
