@@ -43,6 +43,7 @@ struct AttnP {
     const int32_t* order;                         // batch elements in dispatch order (longest first), or NULL
     int balanced;                                 // self-attention over packed rows with `order`: decode_block_balanced
     int ks_min;                                   // in-block key split (KS = 2 kernels): elements with fewer key tiles run unsplit
+    int parts_q, parts_kv;                        // bf16x3 backward (attention_x3.h): blocks per owned tile, the streamed side cut in ranges
 };
 
 // Variable-length ("unpadded") batches: with cu_q / cu_k given, batch element b owns rows [cu[b], cu[b+1]) of the
@@ -404,6 +405,21 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnP pin) {
     const int b = (int)(i / ((int64_t)pin.Lq * pin.H));
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
+    if constexpr (sizeof(T) == 4) {
+        // range-split bf16x3 backward: its blocks ADD into dq (dk, dv) - zero the rows here, in the launch that runs first anyway
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        if (pin.parts_q > 1 && q < p.Lq) {
+            float* r = reinterpret_cast<float*>(p.dq) + ((size_t)qoff + q) * p.lddq + h * DH;
+#pragma unroll
+            for (int c = 0; c < DH; c += 4) *reinterpret_cast<f32x4*>(r + c) = z4;
+        }
+        if (pin.parts_kv > 1 && q < p.Lk) {          // (the host only splits dK / dV when every key row has a thread: Lk <= Lq)
+            float* rk = reinterpret_cast<float*>(p.dk) + ((size_t)koff + q) * p.lddk + h * DH;
+            float* rv = reinterpret_cast<float*>(p.dv) + ((size_t)koff + q) * p.lddv + h * DH;
+#pragma unroll
+            for (int c = 0; c < DH; c += 4) { *reinterpret_cast<f32x4*>(rk + c) = z4; *reinterpret_cast<f32x4*>(rv + c) = z4; }
+        }
+    }
     if (q >= p.Lq) { p.delta[i] = 0.f; return; }
     const T* o = reinterpret_cast<const T*>(p.o) + ((size_t)qoff + q) * p.ldo + h * DH;
     const T* g = reinterpret_cast<const T*>(p.dout) + ((size_t)qoff + q) * p.lddo + h * DH;
@@ -2059,7 +2075,7 @@ AttnP make_params(const pa_attn_args* a) {
     p.lddo = a->lddo; p.lddq = a->lddq; p.lddk = a->lddk; p.lddv = a->lddv;
     p.cu_q = a->cu_q; p.cu_k = a->cu_k; p.order = a->order;
     static const bool bal_env = !(getenv("PA_ATTN_BALANCED") && atoi(getenv("PA_ATTN_BALANCED")) == 0);
-    p.ks_min = 4;
+    p.ks_min = 4; p.parts_q = 1; p.parts_kv = 1;
     p.balanced = (bal_env && a->order && a->cu_q && a->cu_k && a->H == 8 && a->B <= 64) ? 1 : 0;
     return p;
 }
@@ -2221,17 +2237,36 @@ template <typename T, int DH> int run_fwd(const AttnP& p, hipStream_t st) {
     PA_LAUNCH((attn_fwd_kernel<T, DH>), grid, dim3(NTH), shm, st, p);
     return 0;
 }
-template <typename T, int DH> int run_bwd(const AttnP& p, hipStream_t st) {
-    if constexpr (sizeof(T) == 2) return run_bwd_bf16<DH>(p, st);
+template <typename T, int DH> int run_bwd(const AttnP& p_in, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) return run_bwd_bf16<DH>(p_in, st);
+    AttnP p = p_in;
     const int64_t total = (int64_t)p.B * p.H * p.Lq;
+    bool x3 = false;
+    if constexpr (sizeof(T) == 4 && DH == 64) {
+        x3 = g_attn_x3.load(std::memory_order_relaxed) != 0;
+        if (x3) {
+            // PA_X3_PARTS=n (n >= 2): range-split backward, n blocks per owned tile adding their partial dQ / dK / dV with f32
+            // atomics (attention_x3.h x3_add_rows).  OFF by default - MEASURED on MI355X, round 5, x3 train step: 13.0 ms unsplit,
+            // 16.4 ms with 2 parts, 20.2 ms with 4 (packed encoder backward 360 -> 843 us): the atomic adds of 128 x 64 f32 tiles
+            // at a 6 KB row stride cost several times the chain they shorten.  Results are equal to rounding either way
+            // (tests/test_kernels_gpu.py::test_attention_x3_* pass with PA_X3_PARTS=4).
+            static const int parts_env = getenv("PA_X3_PARTS") ? atoi(getenv("PA_X3_PARTS")) : 0;
+            static const int parts_min = getenv("PA_X3_PARTS_MIN") ? atoi(getenv("PA_X3_PARTS_MIN")) : 512;
+            const int n = parts_env;
+            if (n >= 2) {
+                if (p.Lk >= parts_min) p.parts_q = n;
+                if (p.Lq >= parts_min && p.Lk <= p.Lq && (!p.cu_q || p.cu_q == p.cu_k)) p.parts_kv = n;     // self-attention shapes only
+            }
+        }
+    }
     PA_LAUNCH((attn_delta_kernel<T, DH>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
     if constexpr (sizeof(T) == 4 && DH == 64) {
-        if (g_attn_x3.load(std::memory_order_relaxed)) {
+        if (x3) {
             const int shk = X3L<DH>::SHM, shq = X3L<DH>::SHM;
             static const int rc_ = set_lds(attnx_bwd_dkv_kernel<DH, true>, shk) | set_lds(attnx_bwd_dq_kernel<DH, true>, shq) |
                                    set_lds(attnx_bwd_dkv_kernel<DH, false>, shk) | set_lds(attnx_bwd_dq_kernel<DH, false>, shq);
             if (rc_) return rc_;
-            const dim3 gk((p.Lk + BOWN - 1) / BOWN, p.H, p.B), gq((p.Lq + BOWN - 1) / BOWN, p.H, p.B);
+            const dim3 gk(((p.Lk + BOWN - 1) / BOWN) * p.parts_kv, p.H, p.B), gq(((p.Lq + BOWN - 1) / BOWN) * p.parts_q, p.H, p.B);
             if (p.drop_thr) {
                 PA_LAUNCH((attnx_bwd_dkv_kernel<DH, true>), gk, dim3(NTH), shk, st, p);
                 PA_LAUNCH((attnx_bwd_dq_kernel<DH, true>), gq, dim3(NTH), shq, st, p);

@@ -100,6 +100,23 @@ __device__ __forceinline__ void x3_mma_tr(f32x16* acc, const char* tile, int row
     mma_tr_nat<DH>(acc, tile, row0, pl, lane);
 }
 
+// Range-split backward (AttnP::parts_q / parts_kv > 1): a block covers 1 / parts of the streamed side and ADDS its 128 x dh partial
+// result to rows that attn_delta_kernel zeroed (f32 atomics, fire and forget).  Why: a packed batch's backward launch lasts as
+// long as its longest block - every block is resident from the start, two per CU - and the longest elements stream 16 tiles
+// where the average block streams 8.  Built, correct, and MEASURED SLOWER (attention.hip run_bwd, PA_X3_PARTS): off by default.
+template <int DH>
+__device__ __forceinline__ void x3_add_rows(float* base, int ld, int row, int nrows, const f32x16* acc, int lane) {
+    if (row >= nrows) return;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float* dst = base + (size_t)row * ld + dt * 32 + 8 * g + 4 * (lane >> 5);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, acc[dt][4 * g + e]);
+        }
+}
+
 // Score arithmetic as in the tuned bf16 kernels (the first-generation f32 kernels spend ~25 VALU instructions per score): the key /
 // row dropout hash words of a tile are computed ONCE by the 64 staging threads and read from LDS (one multiply + compare + select
 // per score), the mask test only runs on tiles that contain a masked key or touch the causal diagonal, the row maximum is a
@@ -271,7 +288,8 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
     constexpr int NS = BT<DH>::NS;
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BOWN;
+    const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
+    const int parts = pin.parts_q > 1 ? pin.parts_q : 1, part = blockIdx.x % parts, q0 = (blockIdx.x / parts) * BOWN;
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
     if (q0 >= p.Lq) return;
@@ -291,6 +309,9 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
 
     int nsteps = (p.Lk + BSTR - 1) / BSTR;
     if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+    const int per = (nsteps + parts - 1) / parts, s_lo = part * per;          // this block's key steps [s_lo, nsteps)
+    nsteps = min(nsteps, s_lo + per);
+    if (s_lo >= nsteps) return;                                                // (the rows were zeroed by attn_delta_kernel)
 
     f32x16 dqacc[A::NDT];
 #pragma unroll
@@ -331,7 +352,7 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
         x3_key_aux<DH, DROP>(smem + X::AUX0 + buf * X::AUXS, tid, mreg, p.drop_seed, kreg);
     };
 
-    if (nsteps > 0) { gload(0); lstore(0); }
+    gload(s_lo); lstore(0);
     __syncthreads();
 
     auto body = [&](int step, const int S) {                    // S: the stage (0 / 1) this step's tiles are in
@@ -372,9 +393,10 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
         if (step + 1 < nsteps) lstore(S ^ 1);
         __syncthreads();
     };
-    for (int step = 0; step < nsteps; ++step) body(step, step & 1);
+    for (int step = s_lo; step < nsteps; ++step) body(step, (step - s_lo) & 1);
     float* dQp = reinterpret_cast<float*>(p.dq) + (size_t)qoff * p.lddq + h * DH;
-    store_rows<float, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, 1.0f, lane);
+    if (parts > 1) x3_add_rows<DH>(dQp, p.lddq, qrow, p.Lq, dqacc, lane);
+    else store_rows<float, DH>(dQp, p.lddq, qrow, p.Lq, dqacc, 1.0f, lane);
 }
 
 // ---- backward, dK / dV (attn_bwd_dkv_kernel<float, DH> with split products) ----------------------------------------------
@@ -385,7 +407,8 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dkv_kernel(AttnP pin) {
     constexpr int NS = BT<DH>::NS;
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, key0 = blockIdx.x * BOWN;
+    const int b = pin.order ? pin.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y;
+    const int parts = pin.parts_kv > 1 ? pin.parts_kv : 1, part = blockIdx.x % parts, key0 = (blockIdx.x / parts) * BOWN;
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff);
     if (key0 >= p.Lk) return;
@@ -400,8 +423,14 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dkv_kernel(AttnP pin) {
     x3_row_regs<DH>(kh, kl, Kp, p.ldk, krow, p.Lk, lane);
     x3_row_regs<DH>(vh, vl, Vp, p.ldv, krow, p.Lk, lane);
 
-    const int nsteps = (p.Lq + BSTR - 1) / BSTR;
-    const int step0 = p.causal ? (key0 / BSTR) : 0;
+    int nsteps = (p.Lq + BSTR - 1) / BSTR;
+    int step0 = p.causal ? (key0 / BSTR) : 0;
+    {   // this block's query steps: 1 / parts of [step0, nsteps)
+        const int per = (nsteps - step0 + parts - 1) / parts;
+        step0 += part * per;
+        nsteps = min(nsteps, step0 + per);
+        if (step0 >= nsteps && parts > 1) return;                              // (the rows were zeroed by attn_delta_kernel)
+    }
 
     f32x16 dkacc[A::NDT], dvacc[A::NDT];
 #pragma unroll
@@ -497,6 +526,11 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dkv_kernel(AttnP pin) {
     for (int step = step0; step < nsteps; ++step) body(step, (step - step0) & 1);
     float* dKp = reinterpret_cast<float*>(p.dk) + (size_t)koff * p.lddk + h * DH;
     float* dVp = reinterpret_cast<float*>(p.dv) + (size_t)koff * p.lddv + h * DH;
-    store_rows<float, DH>(dKp, p.lddk, krow, p.Lk, dkacc, 1.0f, lane);
-    store_rows<float, DH>(dVp, p.lddv, krow, p.Lk, dvacc, 1.0f, lane);
+    if (parts > 1) {
+        x3_add_rows<DH>(dKp, p.lddk, krow, p.Lk, dkacc, lane);
+        x3_add_rows<DH>(dVp, p.lddv, krow, p.Lk, dvacc, lane);
+    } else {
+        store_rows<float, DH>(dKp, p.lddk, krow, p.Lk, dkacc, 1.0f, lane);
+        store_rows<float, DH>(dVp, p.lddv, krow, p.Lk, dvacc, 1.0f, lane);
+    }
 }
