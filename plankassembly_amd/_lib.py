@@ -108,6 +108,7 @@ def lib():
             "pa_gemm_effective_splitk": (I, [I, I, I]),
             "pa_gemm_split_config": (I, [I, P, I64]),
             "pa_gemm_split_stats": (I, [P, I]),
+            "pa_gemm_split_reused": (I64, []),
             "pa_gemm_group": (I, [P, I, P]),
             "pa_segment_tail": (I, [P, I, I, P, I, I, P, I, P]),
             "pa_gemm_record": (I, [I]),

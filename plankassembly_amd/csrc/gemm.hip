@@ -2406,7 +2406,14 @@ extern "C" int pa_gemm_recorded_kinds(int32_t* out, int32_t cap) {
 // never be written)
 namespace {
 // bf16x3 mode state (see "bf16x3 (split) products" below)
-struct SplitState { std::atomic<int> on{0}; char* ws = nullptr; long long bytes = 0; std::atomic<long long> taken{0}, declined{0}; };
+struct SplitKeep { const void* src; int rows, cols, ld; bf16* dst; };
+struct SplitState {
+    std::atomic<int> on{0}; char* ws = nullptr; long long bytes = 0; std::atomic<long long> taken{0}, declined{0}, reused{0};
+    // retain mode (pa_gemm_split_config(2, ..): the backward segments): the (hi, hi, lo) image of a k-contiguous A operand stays at
+    // the front of the scratch buffer until the next config call, so that the segment's grouped weight-gradient launch finds dY
+    // already cut (gemm_group_split3) - [rows][3 cols] read as [3 rows][cols] IS the stacked form, planes interleaved by row
+    int retain = 0; long long keep_off = 0; SplitKeep keep[16]; int nkeep = 0;
+};
 SplitState g_split;
 bool split_on() { return g_split.on.load(std::memory_order_relaxed) != 0; }
 }  // namespace
@@ -2503,13 +2510,15 @@ inline int eff_split(int nt, int sk) { if (sk > nt) sk = nt; if (sk < 1) sk = 1;
 extern "C" int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes) {
     if (on && (!ws || bytes <= 0 || (reinterpret_cast<uintptr_t>(ws) & 255))) return PA_EINVAL;
     g_split.ws = static_cast<char*>(ws); g_split.bytes = bytes;
+    g_split.retain = on == 2 ? 1 : 0; g_split.keep_off = 0; g_split.nkeep = 0;
     g_split.on.store(on ? 1 : 0, std::memory_order_relaxed);
     return 0;
 }
 // [0] GEMMs that ran as bf16x3 since the last reset, [1] f32 GEMMs that asked for it and ran exact (shape / alignment / scratch)
+extern "C" int64_t pa_gemm_split_reused(void) { return g_split.reused.load(); }      // dY images the grouped dW launches found already cut
 extern "C" int pa_gemm_split_stats(int64_t* out2, int32_t reset) {
     if (out2) { out2[0] = g_split.taken.load(); out2[1] = g_split.declined.load(); }
-    if (reset) { g_split.taken.store(0); g_split.declined.store(0); }
+    if (reset) { g_split.taken.store(0); g_split.declined.store(0); g_split.reused.store(0); }
     return 0;
 }
 // returns 1 when the GEMM was enqueued as bf16x3, 0 when the caller must run it exact, < 0 on error
@@ -2527,7 +2536,13 @@ static int gemm_split3(const pa_gemm_args* a, void* stream) {
     const long long a_el = (long long)ar * ac * 3, b_el = (long long)br * bc * 3, x_el = a->aux ? (long long)M * N : 0;
     auto up = [](long long v) { return (v + 255) / 256 * 256; };
     const long long a_bytes = up(a_el * 2 * (a_shared ? 1 : nb)), b_bytes = up(b_el * 2 * (b_shared ? 1 : nb)), x_bytes = up(x_el * 2 * nb);
-    if (a_bytes + b_bytes + x_bytes > g_split.bytes) return 0;
+    const bool keep_a = g_split.retain && akc && nb == 1 && g_split.nkeep < 16 &&
+                        g_split.keep_off + a_bytes + b_bytes + x_bytes <= g_split.bytes;
+    if (g_split.keep_off + a_bytes + b_bytes + x_bytes > g_split.bytes) {
+        // does not fit behind what is retained: drop the retained images (stream order keeps their earlier readers safe)
+        g_split.keep_off = 0; g_split.nkeep = 0;
+        if (a_bytes + b_bytes + x_bytes > g_split.bytes) return 0;
+    }
     // split-K: the caller sized its slabs with the f32 tiling (pa_gemm_effective_splitk(K, PA_F32, .)); ask the bf16 tiling for
     // exactly as many non-empty slices, or decline
     // split-K: callers size their slabs with pa_gemm_effective_splitk(K, PA_F32, .), which in this mode already counts whole
@@ -2537,9 +2552,14 @@ static int gemm_split3(const pa_gemm_args* a, void* stream) {
     static const bool dbg_split = getenv("PA_SPLIT_DEBUG") && atoi(getenv("PA_SPLIT_DEBUG")) >= 2;
     if (dbg_split) fprintf(stderr, "[pa_gemm x3] M %d N %d K %d batch %d akc %d bkc %d splitk %d -> %d (zero-fill %d..%d) defer %d\n",
                            M, N, K, nb, (int)akc, (int)bkc, a->splitk, sk_req, zero_from, zero_to, a->splitk_defer);
-    bf16* A3 = reinterpret_cast<bf16*>(g_split.ws);
-    bf16* B3 = reinterpret_cast<bf16*>(g_split.ws + a_bytes);
-    bf16* X1 = reinterpret_cast<bf16*>(g_split.ws + a_bytes + b_bytes);
+    char* w0 = g_split.ws + g_split.keep_off;
+    bf16* A3 = reinterpret_cast<bf16*>(w0);
+    bf16* B3 = reinterpret_cast<bf16*>(w0 + a_bytes);
+    bf16* X1 = reinterpret_cast<bf16*>(w0 + a_bytes + b_bytes);
+    if (keep_a) {
+        g_split.keep[g_split.nkeep++] = SplitKeep{a->A, ar, ac, a->lda, A3};
+        g_split.keep_off += a_bytes;
+    }
     SplitTab tb; tb.n = 0; tb.begin[0] = 0;
     auto add = [&](const void* src, bf16* dst, int rows, int cols, int ld, int mode, long long ss, long long ds, int batch) {
         SplitJob& j = tb.j[tb.n];
@@ -2897,28 +2917,41 @@ extern "C" int pa_gemm_norm_a(const pa_gemm_args* a, const pa_gemm_norm_ext* x, 
 static int gemm_group_split3(const pa_gemm_args* args, int32_t n, void* stream) {
     pa_gemm_args b[PA_MAX_GROUP];
     SplitTab tb; tb.n = 0; tb.begin[0] = 0;
-    long long off = 0;
+    long long off = g_split.keep_off;                      // behind the retained (hi, hi, lo) images of this segment's dY operands
     auto up = [](long long v) { return (v + 255) / 256 * 256; };
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    auto job = [&](const void* src, bf16* dst, int rows, int cols, int ld, int mode) {
+        SplitJob& j = tb.j[tb.n];
+        j.src = static_cast<const float*>(src); j.dst = dst; j.rows = rows; j.cols = cols; j.ld = ld; j.mode = mode;
+        j.sstride = 0; j.dstride = 0; j.batch = 1; j.pad_ = 0;
+        long long blocks = ((long long)rows * (cols >> 3) + 511) / 512;
+        if (blocks < 1) blocks = 1;
+        if (blocks > 1024) blocks = 1024;
+        tb.begin[tb.n + 1] = tb.begin[tb.n] + (int)blocks;
+        ++tb.n;
+    };
+    int hits = 0;
     for (int i = 0; i < n; ++i) {
         const pa_gemm_args* a = &args[i];
         if (a->in_dtype != PA_F32 || a->out_dtype != PA_F32 || a->a_kcontig || a->b_kcontig || a->batch != 1) return 0;
         if (a->bias || a->R || a->aux || a->relu || a->drop_p > 0.f || a->alpha != 1.f || a->C_lp) return 0;
         if ((a->M & 7) || (a->N & 7) || (a->lda & 3) || (a->ldb & 3) || !al16(a->A) || !al16(a->B)) return 0;
         const long long a_el = (long long)a->K * a->M * 3, b_el = (long long)a->K * a->N * 3;
-        if (off + up(a_el * 2) + up(b_el * 2) > g_split.bytes) return 0;
-        bf16* A3 = reinterpret_cast<bf16*>(g_split.ws + off); off += up(a_el * 2);
-        bf16* B3 = reinterpret_cast<bf16*>(g_split.ws + off); off += up(b_el * 2);
-        for (int w = 0; w < 2; ++w) {
-            SplitJob& j = tb.j[tb.n];
-            j.src = static_cast<const float*>(w ? a->B : a->A); j.dst = w ? B3 : A3; j.rows = a->K; j.cols = w ? a->N : a->M;
-            j.ld = w ? a->ldb : a->lda; j.mode = w ? 3 : 2; j.sstride = 0; j.dstride = 0; j.batch = 1; j.pad_ = 0;
-            long long blocks = ((long long)j.rows * (j.cols >> 3) + 511) / 512;
-            if (blocks < 1) blocks = 1;
-            if (blocks > 1024) blocks = 1024;
-            tb.begin[tb.n + 1] = tb.begin[tb.n] + (int)blocks;
-            ++tb.n;
+        // dY (the A operand: [K rows][M features]) was cut for this segment's dX GEMM as a k-contiguous operand: [K][3 M] in the
+        // (hi, hi, lo) pattern, which read as [3 K][M] is the stacked operand with the planes interleaved row by row; X then goes
+        // into the matching (hi, lo, hi) interleaving (split mode 1) instead of the plane-stacked mode 3
+        const SplitKeep* hit = nullptr;
+        for (int k = 0; k < g_split.nkeep; ++k) {
+            const SplitKeep& e = g_split.keep[k];
+            if (e.src == a->A && e.rows == a->K && e.cols == a->M && e.ld == a->lda) { hit = &e; break; }
         }
+        const long long need = (hit ? 0 : up(a_el * 2)) + up(b_el * 2);
+        if (off + need > g_split.bytes) return 0;
+        bf16* A3;
+        if (hit) { A3 = hit->dst; ++hits; }
+        else { A3 = reinterpret_cast<bf16*>(g_split.ws + off); off += up(a_el * 2); job(a->A, A3, a->K, a->M, a->lda, 2); }
+        bf16* B3 = reinterpret_cast<bf16*>(g_split.ws + off); off += up(b_el * 2);
+        job(a->B, B3, a->K, a->N, a->ldb, hit ? 1 : 3);
         b[i] = *a;
         b[i].in_dtype = PA_BF16; b[i].A = A3; b[i].B = B3; b[i].K = 3 * a->K; b[i].lda = a->M; b[i].ldb = a->N;
     }
@@ -2928,6 +2961,7 @@ static int gemm_group_split3(const pa_gemm_args* args, int32_t n, void* stream) 
     g_split.on.store(1, std::memory_order_relaxed);
     if (rc) return rc;
     g_split.taken.fetch_add(n);
+    g_split.reused.fetch_add(hits);
     return 1;
 }
 extern "C" int pa_gemm_group(const pa_gemm_args* args, int32_t n, void* stream) {

@@ -355,7 +355,7 @@ class PlankModel(nn.Module):
     def _pa_dtype(self):
         return L.PA_BF16 if self.compute_dtype == "bf16" else L.PA_F32
 
-    def _split(self, on):
+    def _split(self, on, retain=False):
         """'x3': bracket this model's library calls with the process-global bf16x3 GEMM mode (no-op for the other dtypes)."""
         if not self.split3:
             return
@@ -369,11 +369,13 @@ class PlankModel(nn.Module):
         dev = self._flat.device.index or 0
         ws = PlankModel._x3_scratch.get(dev)
         if ws is None:
-            mb = int(os.environ.get("PLANK_X3_SCRATCH_MB", "384"))
+            mb = int(os.environ.get("PLANK_X3_SCRATCH_MB", "640"))
             ws = torch.empty(mb * (1 << 20) + 256, dtype=torch.uint8, device=self._flat.device)
             PlankModel._x3_scratch[dev] = ws
         base = (ws.data_ptr() + 255) // 256 * 256
-        L.check(L.lib().pa_gemm_split_config(1, C.c_void_p(base), C.c_int64(ws.numel() - (base - ws.data_ptr()))), "pa_gemm_split_config")
+        # backward segments: mode 2 keeps the cut dY of every dX GEMM for the segment's grouped weight-gradient launch
+        mode = 2 if (retain and os.environ.get("PLANK_X3_RETAIN", "1") != "0") else 1
+        L.check(L.lib().pa_gemm_split_config(mode, C.c_void_p(base), C.c_int64(ws.numel() - (base - ws.data_ptr()))), "pa_gemm_split_config")
 
     def _pa_activation(self):
         return {"relu": 1, "gelu": 2}[self.activation]
@@ -712,7 +714,7 @@ class PlankModel(nn.Module):
         # with the library's side stream the gradients of segment s are final once segment s + lag is enqueued
         lag = int(L.lib().pa_model_grad_lag(self._handle))
         for s in range(nseg):
-            self._split(True)
+            self._split(True, retain=True)
             try:
                 L.check(L.lib().pa_model_train_bwd(self._handle, s, s + 1, C.c_float(1.0), L.stream()),
                         "pa_model_train_bwd")
