@@ -2263,15 +2263,21 @@ template <typename T, int DH> int run_bwd(const AttnP& p_in, hipStream_t st) {
     if constexpr (sizeof(T) == 4 && DH == 64) {
         if (x3) {
             const int shk = X3L<DH>::SHM, shq = X3L<DH>::SHM;
-            static const int rc_ = set_lds(attnx_bwd_dkv_kernel<DH, true>, shk) | set_lds(attnx_bwd_dq_kernel<DH, true>, shq) |
-                                   set_lds(attnx_bwd_dkv_kernel<DH, false>, shk) | set_lds(attnx_bwd_dq_kernel<DH, false>, shq);
+            static const int rc_ = set_lds(attnx_bwd_dkv_kernel<DH, true, 2>, shk) | set_lds(attnx_bwd_dq_kernel<DH, true>, shq) |
+                                   set_lds(attnx_bwd_dkv_kernel<DH, false, 2>, shk) | set_lds(attnx_bwd_dq_kernel<DH, false>, shq) |
+                                   set_lds(attnx_bwd_dkv_kernel<DH, true, 1>, shk) | set_lds(attnx_bwd_dkv_kernel<DH, false, 1>, shk);
             if (rc_) return rc_;
+            // dK / dV at two blocks per CU sits at the 256-register limit and spills 160 bytes per lane; allocated for ONE block per CU
+            // (no spills, one wave per SIMD) the x3 step measures 12.72 against 12.82 ms (A/B twice in one session): default 1
+            static const int dkv_occ = getenv("PA_X3_DKV_OCC") ? atoi(getenv("PA_X3_DKV_OCC")) : 1;
             const dim3 gk(((p.Lk + BOWN - 1) / BOWN) * p.parts_kv, p.H, p.B), gq(((p.Lq + BOWN - 1) / BOWN) * p.parts_q, p.H, p.B);
             if (p.drop_thr) {
-                PA_LAUNCH((attnx_bwd_dkv_kernel<DH, true>), gk, dim3(NTH), shk, st, p);
+                if (dkv_occ == 1) PA_LAUNCH((attnx_bwd_dkv_kernel<DH, true, 1>), gk, dim3(NTH), shk, st, p);
+                else PA_LAUNCH((attnx_bwd_dkv_kernel<DH, true, 2>), gk, dim3(NTH), shk, st, p);
                 PA_LAUNCH((attnx_bwd_dq_kernel<DH, true>), gq, dim3(NTH), shq, st, p);
             } else {
-                PA_LAUNCH((attnx_bwd_dkv_kernel<DH, false>), gk, dim3(NTH), shk, st, p);
+                if (dkv_occ == 1) PA_LAUNCH((attnx_bwd_dkv_kernel<DH, false, 1>), gk, dim3(NTH), shk, st, p);
+                else PA_LAUNCH((attnx_bwd_dkv_kernel<DH, false, 2>), gk, dim3(NTH), shk, st, p);
                 PA_LAUNCH((attnx_bwd_dq_kernel<DH, false>), gq, dim3(NTH), shq, st, p);
             }
             g_attn_x3_taken.fetch_add(1);

@@ -400,8 +400,8 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
 }
 
 // ---- backward, dK / dV (attn_bwd_dkv_kernel<float, DH> with split products) ----------------------------------------------
-template <int DH, bool DROP>
-__global__ __launch_bounds__(NTH, 2) void attnx_bwd_dkv_kernel(AttnP pin) {
+template <int DH, bool DROP, int OCC>      // OCC: blocks per CU the register allocation is made for (1: no spills, one wave per SIMD)
+__global__ __launch_bounds__(NTH, OCC) void attnx_bwd_dkv_kernel(AttnP pin) {
     using A = AT<float, DH>;
     using X = X3L<DH>;
     constexpr int NS = BT<DH>::NS;
@@ -482,7 +482,8 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dkv_kernel(AttnP pin) {
     __syncthreads();
 
     auto body = [&](int step, const int S) {                    // S: the stage (0 / 1) this step's tiles are in
-        if (step + 1 < nsteps) gload(step + 1);
+        // (the next tile's global loads are issued between the two 32-row sub-tiles: their 32 staging registers are then live for
+        // half of the step - the kernel sits at the 256-register limit of two blocks per CU)
         const float* aux = reinterpret_cast<const float*>(smem + X::AUX0 + S * X::AUXS);
         const int r0 = step * BSTR;
         const bool diag = p.causal && kw0 + 31 > r0;              // wave-uniform: some (query, key) pair of this tile is above the diagonal
@@ -519,7 +520,9 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dkv_kernel(AttnP pin) {
             x3_mma_tr<DH>(dvacc, smem + S * X::STG + X::TILE, qt * 32, sacc, lane);              // dV^T += dO^T P
             x3_mma_tr<DH>(dkacc, smem + S * X::STG, qt * 32, dpacc, lane);                       // dK^T += Q^T dS
         };
-        sub(IC<0>{}); sub(IC<1>{});
+        sub(IC<0>{});
+        if (step + 1 < nsteps) gload(step + 1);
+        sub(IC<1>{});
         if (step + 1 < nsteps) lstore(S ^ 1);
         __syncthreads();
     };
