@@ -96,10 +96,15 @@ int pa_gemm_effective_splitk(int32_t K, int32_t in_dtype, int32_t splitk);
  * operands, rows / leading dimensions not multiples of 8 / 4, scratch too small) silently runs exact f32 instead; pa_gemm_split_stats
  * counts both.  on = 2 ("retain", the backward segments): the cut image of every k-contiguous A operand - the dY of a dX GEMM -
  * stays in the scratch buffer until the next pa_gemm_split_config call, and pa_gemm_group reuses it for the weight gradients of the
- * same segment instead of cutting dY a second time.  The setting is process-global; plankassembly_amd.models.PlankModel(compute_dtype="x3") brackets its own calls. */
+ * same segment instead of cutting dY a second time.  on = 3 (the forward of a train step): the cut image of every k-contiguous A
+ * operand - the input X of a Linear - stays at the front of the buffer through the following on = 0 / on = 2 calls, until the next
+ * on = 3 or on = 1 call (or until the buffer is needed: at most 3/4 of it is used this way), and the weight gradients find X already
+ * cut as well; images are keyed by (address, rows, cols, leading dimension), so the caller must not rewrite a Linear input
+ * between its forward GEMM and its weight gradient - which a backward pass cannot do anyway.  on = 0 switches the mode off and
+ * leaves the images alone.  The setting is process-global; plankassembly_amd.models.PlankModel(compute_dtype="x3") brackets its own calls. */
 int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes);
 int pa_gemm_split_active(void);                               /* 1 while the mode is on */
-int64_t pa_gemm_split_reused(void);                           /* weight-gradient operands found already cut (on = 2) since the last stats reset */
+int64_t pa_gemm_split_reused(void);                           /* weight-gradient operands found already cut (on = 2 / 3) since the last stats reset */
 int pa_gemm_split_stats(int64_t* out2, int32_t reset);        /* out2[0] GEMMs run as bf16x3, out2[1] asked but run exact */
 /* Measurement hook (bench.py's roofline census; no reference counterpart): pa_gemm_record(1) starts appending every
  * pa_gemm() argument block to a host-side list; pa_gemm_record(0) returns the count so far; pa_gemm_recorded() copies

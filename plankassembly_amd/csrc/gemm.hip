@@ -2406,13 +2406,30 @@ extern "C" int pa_gemm_recorded_kinds(int32_t* out, int32_t cap) {
 // never be written)
 namespace {
 // bf16x3 mode state (see "bf16x3 (split) products" below)
-struct SplitKeep { const void* src; int rows, cols, ld; bf16* dst; };
+struct SplitKeep { const void* src; int rows, cols, ld, pat; bf16* dst; };     // pat 0: (hi, hi, lo) parts, 1: (hi, lo, hi)
 struct SplitState {
     std::atomic<int> on{0}; char* ws = nullptr; long long bytes = 0; std::atomic<long long> taken{0}, declined{0}, reused{0};
-    // retain mode (pa_gemm_split_config(2, ..): the backward segments): the (hi, hi, lo) image of a k-contiguous A operand stays at
-    // the front of the scratch buffer until the next config call, so that the segment's grouped weight-gradient launch finds dY
-    // already cut (gemm_group_split3) - [rows][3 cols] read as [3 rows][cols] IS the stacked form, planes interleaved by row
-    int retain = 0; long long keep_off = 0; SplitKeep keep[16]; int nkeep = 0;
+    // Retained images.  A k-contiguous operand cut as [rows][3 cols] and read as [3 rows][cols] IS its stacked form with the planes
+    // interleaved row by row, so the image one GEMM built serves a later GEMM that contracts over the ROWS of the same buffer:
+    //   retain 1 (pa_gemm_split_config(2, ..): a backward segment): dY of every dX GEMM stays at [long_off, keep_off) until the next
+    //            config call - the segment's grouped weight-gradient launch finds it already cut (gemm_group_split3);
+    //   retain 2 (pa_gemm_split_config(3, ..): the forward): X of every Linear stays at [0, long_off) until the next forward (config 3)
+    //            or a plain config (1) - the same grouped launch finds its OTHER operand already cut as well.
+    // Forward images are (hi, hi, lo); a backward segment cuts dY as (hi, lo, hi) so that the two meet in one product.
+    int retain = 0; long long long_off = 0, keep_off = 0; bool long_closed = false;
+    SplitKeep keep[16]; int nkeep = 0; SplitKeep keepL[128]; int nkeepL = 0;
+    // a weight gradient's dY operand is looked up among this segment's images only, its X operand among the forward's only: backward
+    // buffers may reuse addresses of forward buffers that are dead by then
+    static const SplitKeep* find_in(const SplitKeep* t, int n, const void* src, int rows, int cols, int ld) {
+        for (int k = n - 1; k >= 0; --k) { const SplitKeep& e = t[k]; if (e.src == src && e.rows == rows && e.cols == cols && e.ld == ld) return &e; }
+        return nullptr;
+    }
+    const SplitKeep* find_seg(const void* src, int rows, int cols, int ld) const { return find_in(keep, nkeep, src, rows, cols, ld); }
+    const SplitKeep* find_fwd(const void* src, int rows, int cols, int ld) const { return retain == 2 ? nullptr : find_in(keepL, nkeepL, src, rows, cols, ld); }
+    static void put(SplitKeep* t, int& n, const SplitKeep& e) {       // (a buffer cut again replaces its older image)
+        for (int k = 0; k < n; ++k) if (t[k].src == e.src) { t[k] = e; return; }
+        t[n++] = e;
+    }
 };
 SplitState g_split;
 bool split_on() { return g_split.on.load(std::memory_order_relaxed) != 0; }
@@ -2509,8 +2526,12 @@ inline int eff_split(int nt, int sk) { if (sk > nt) sk = nt; if (sk < 1) sk = 1;
 }  // namespace
 extern "C" int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes) {
     if (on && (!ws || bytes <= 0 || (reinterpret_cast<uintptr_t>(ws) & 255))) return PA_EINVAL;
+    if (on == 0) { g_split.on.store(0, std::memory_order_relaxed); return 0; }       // (retained images stay: forward -> backward)
+    if (on < 0 || on > 3) return PA_EINVAL;
+    if (g_split.ws != static_cast<char*>(ws) || g_split.bytes != bytes) { g_split.long_off = 0; g_split.nkeepL = 0; }
     g_split.ws = static_cast<char*>(ws); g_split.bytes = bytes;
-    g_split.retain = on == 2 ? 1 : 0; g_split.keep_off = 0; g_split.nkeep = 0;
+    if (on != 2) { g_split.long_off = 0; g_split.nkeepL = 0; g_split.long_closed = false; }
+    g_split.retain = on == 2 ? 1 : on == 3 ? 2 : 0; g_split.keep_off = g_split.long_off; g_split.nkeep = 0;
     g_split.on.store(on ? 1 : 0, std::memory_order_relaxed);
     return 0;
 }
@@ -2535,13 +2556,43 @@ static int gemm_split3(const pa_gemm_args* a, void* stream) {
     const bool a_shared = nb > 1 && a->sA == 0, b_shared = nb > 1 && a->sB == 0;
     const long long a_el = (long long)ar * ac * 3, b_el = (long long)br * bc * 3, x_el = a->aux ? (long long)M * N : 0;
     auto up = [](long long v) { return (v + 255) / 256 * 256; };
-    const long long a_bytes = up(a_el * 2 * (a_shared ? 1 : nb)), b_bytes = up(b_el * 2 * (b_shared ? 1 : nb)), x_bytes = up(x_el * 2 * nb);
-    const bool keep_a = g_split.retain && akc && nb == 1 && g_split.nkeep < 16 &&
-                        g_split.keep_off + a_bytes + b_bytes + x_bytes <= g_split.bytes;
-    if (g_split.keep_off + a_bytes + b_bytes + x_bytes > g_split.bytes) {
-        // does not fit behind what is retained: drop the retained images (stream order keeps their earlier readers safe)
-        g_split.keep_off = 0; g_split.nkeep = 0;
-        if (a_bytes + b_bytes + x_bytes > g_split.bytes) return 0;
+    // parts pattern: the forward and plain mode cut A as (hi, hi, lo) and B as (hi, lo, hi), a backward segment the other way round
+    // (its retained dY images then meet the forward's retained X images in the weight-gradient product)
+    int pa = g_split.retain == 1 ? 1 : 0;
+    // both operands with a strided contraction index (a weight gradient): either may have been cut before, as the k-contiguous
+    // operand of an earlier GEMM, and kept (SplitState) - the other one is then cut into the same row-interleaved stacking
+    const bool stacked2 = !akc && !bkc && nb == 1;
+    const SplitKeep* ha = stacked2 ? g_split.find_seg(a->A, ar, ac, a->lda) : nullptr;
+    const SplitKeep* hb = stacked2 ? g_split.find_fwd(a->B, br, bc, a->ldb) : nullptr;
+    if (ha) pa = ha->pat; else if (hb) pa = 1 - hb->pat;
+    if (hb && hb->pat == pa) hb = nullptr;
+    long long a_bytes = ha ? 0 : up(a_el * 2 * (a_shared ? 1 : nb)), b_bytes = hb ? 0 : up(b_el * 2 * (b_shared ? 1 : nb));
+    const long long x_bytes = up(x_el * 2 * nb);
+    auto forget_hits = [&]() {                               // (images dropped below may be the ones found above)
+        ha = hb = nullptr; pa = g_split.retain == 1 ? 1 : 0;
+        a_bytes = up(a_el * 2 * (a_shared ? 1 : nb)); b_bytes = up(b_el * 2 * (b_shared ? 1 : nb));
+    };
+    bool keep_a = false;
+    if (g_split.retain == 2) {
+        // forward: images are kept while a quarter of the buffer stays free for the backward segments' own cuts
+        if (g_split.long_off + a_bytes + b_bytes + x_bytes > g_split.bytes) {
+            g_split.long_off = 0; g_split.nkeepL = 0; g_split.long_closed = true; forget_hits();
+            if (a_bytes + b_bytes + x_bytes > g_split.bytes) return 0;
+        }
+        keep_a = akc && nb == 1 && !g_split.long_closed && g_split.nkeepL < 128 &&
+                 g_split.long_off + a_bytes + b_bytes + x_bytes <= g_split.bytes - g_split.bytes / 4;
+        g_split.keep_off = g_split.long_off;
+    } else {
+        if (g_split.keep_off + a_bytes + b_bytes + x_bytes > g_split.bytes) {
+            // does not fit behind what is retained: drop this segment's images, then the forward's (stream order keeps their
+            // earlier readers safe)
+            g_split.keep_off = g_split.long_off; g_split.nkeep = 0; forget_hits();
+            if (g_split.keep_off + a_bytes + b_bytes + x_bytes > g_split.bytes) {
+                g_split.long_off = 0; g_split.nkeepL = 0; g_split.keep_off = 0;
+                if (a_bytes + b_bytes + x_bytes > g_split.bytes) return 0;
+            }
+        }
+        keep_a = g_split.retain == 1 && akc && nb == 1 && g_split.nkeep < 16;
     }
     // split-K: the caller sized its slabs with the f32 tiling (pa_gemm_effective_splitk(K, PA_F32, .)); ask the bf16 tiling for
     // exactly as many non-empty slices, or decline
@@ -2556,10 +2607,16 @@ static int gemm_split3(const pa_gemm_args* a, void* stream) {
     bf16* A3 = reinterpret_cast<bf16*>(w0);
     bf16* B3 = reinterpret_cast<bf16*>(w0 + a_bytes);
     bf16* X1 = reinterpret_cast<bf16*>(w0 + a_bytes + b_bytes);
+    if (ha) A3 = ha->dst;
+    if (hb) B3 = hb->dst;
     if (keep_a) {
-        g_split.keep[g_split.nkeep++] = SplitKeep{a->A, ar, ac, a->lda, A3};
+        const SplitKeep e{a->A, ar, ac, a->lda, pa, A3};
+        if (g_split.retain == 2) { SplitState::put(g_split.keepL, g_split.nkeepL, e); g_split.long_off += a_bytes; }
+        else SplitState::put(g_split.keep, g_split.nkeep, e);
         g_split.keep_off += a_bytes;
     }
+    if (ha || hb) g_split.reused.fetch_add((ha ? 1 : 0) + (hb ? 1 : 0));
+    const bool inter = ha || hb;                             // row-interleaved stacking: split modes 0 / 1 instead of 2 / 3
     SplitTab tb; tb.n = 0; tb.begin[0] = 0;
     auto add = [&](const void* src, bf16* dst, int rows, int cols, int ld, int mode, long long ss, long long ds, int batch) {
         SplitJob& j = tb.j[tb.n];
@@ -2571,10 +2628,10 @@ static int gemm_split3(const pa_gemm_args* a, void* stream) {
         tb.begin[tb.n + 1] = tb.begin[tb.n] + (int)blocks;
         ++tb.n;
     };
-    add(a->A, A3, ar, ac, a->lda, akc ? 0 : 2, a->sA, a_el, a_shared ? 1 : nb);
-    add(a->B, B3, br, bc, a->ldb, bkc ? 1 : 3, a->sB, b_el, b_shared ? 1 : nb);
+    if (!ha) add(a->A, A3, ar, ac, a->lda, (akc || inter ? 0 : 2) + pa, a->sA, a_el, a_shared ? 1 : nb);
+    if (!hb) add(a->B, B3, br, bc, a->ldb, (bkc || inter ? 0 : 2) + (1 - pa), a->sB, b_el, b_shared ? 1 : nb);
     if (a->aux) add(a->aux, X1, M, N, a->ldaux, 4, a->sAux, x_el, nb);
-    PA_LAUNCH(split_kernel, dim3(tb.begin[tb.n]), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tb);
+    if (tb.n) PA_LAUNCH(split_kernel, dim3(tb.begin[tb.n]), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tb);
     pa_gemm_args b = *a;
     b.in_dtype = PA_BF16;
     b.A = A3; b.B = B3; b.K = 3 * K;
@@ -2937,25 +2994,26 @@ static int gemm_group_split3(const pa_gemm_args* args, int32_t n, void* stream) 
         if (a->bias || a->R || a->aux || a->relu || a->drop_p > 0.f || a->alpha != 1.f || a->C_lp) return 0;
         if ((a->M & 7) || (a->N & 7) || (a->lda & 3) || (a->ldb & 3) || !al16(a->A) || !al16(a->B)) return 0;
         const long long a_el = (long long)a->K * a->M * 3, b_el = (long long)a->K * a->N * 3;
-        // dY (the A operand: [K rows][M features]) was cut for this segment's dX GEMM as a k-contiguous operand: [K][3 M] in the
-        // (hi, hi, lo) pattern, which read as [3 K][M] is the stacked operand with the planes interleaved row by row; X then goes
-        // into the matching (hi, lo, hi) interleaving (split mode 1) instead of the plane-stacked mode 3
-        const SplitKeep* hit = nullptr;
-        for (int k = 0; k < g_split.nkeep; ++k) {
-            const SplitKeep& e = g_split.keep[k];
-            if (e.src == a->A && e.rows == a->K && e.cols == a->M && e.ld == a->lda) { hit = &e; break; }
-        }
-        const long long need = (hit ? 0 : up(a_el * 2)) + up(b_el * 2);
+        // dY (the A operand: [K rows][M features]) was cut for this segment's dX GEMM as a k-contiguous operand: [K][3 M], which
+        // read as [3 K][M] is the stacked operand with the planes interleaved row by row; X (the B operand) was cut the same way
+        // by the forward's Linear, in the opposite parts pattern.  Whichever is missing goes into the matching interleaving
+        // (split modes 0 / 1) instead of the plane-stacked modes 2 / 3.
+        const SplitKeep* ha = g_split.find_seg(a->A, a->K, a->M, a->lda);
+        const SplitKeep* hb = g_split.find_fwd(a->B, a->K, a->N, a->ldb);
+        const int pa = ha ? ha->pat : hb ? 1 - hb->pat : 0;
+        if (hb && hb->pat == pa) hb = nullptr;
+        const bool inter = ha || hb;
+        const long long need = (ha ? 0 : up(a_el * 2)) + (hb ? 0 : up(b_el * 2));
         if (off + need > g_split.bytes) return 0;
-        bf16* A3;
-        if (hit) { A3 = hit->dst; ++hits; }
-        else { A3 = reinterpret_cast<bf16*>(g_split.ws + off); off += up(a_el * 2); job(a->A, A3, a->K, a->M, a->lda, 2); }
-        bf16* B3 = reinterpret_cast<bf16*>(g_split.ws + off); off += up(b_el * 2);
-        job(a->B, B3, a->K, a->N, a->ldb, hit ? 1 : 3);
+        bf16 *A3, *B3;
+        if (ha) { A3 = ha->dst; ++hits; }
+        else { A3 = reinterpret_cast<bf16*>(g_split.ws + off); off += up(a_el * 2); job(a->A, A3, a->K, a->M, a->lda, (inter ? 0 : 2) + pa); }
+        if (hb) { B3 = hb->dst; ++hits; }
+        else { B3 = reinterpret_cast<bf16*>(g_split.ws + off); off += up(b_el * 2); job(a->B, B3, a->K, a->N, a->ldb, (inter ? 0 : 2) + 1 - pa); }
         b[i] = *a;
         b[i].in_dtype = PA_BF16; b[i].A = A3; b[i].B = B3; b[i].K = 3 * a->K; b[i].lda = a->M; b[i].ldb = a->N;
     }
-    PA_LAUNCH(split_kernel, dim3(tb.begin[tb.n]), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tb);
+    if (tb.n) PA_LAUNCH(split_kernel, dim3(tb.begin[tb.n]), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tb);
     g_split.on.store(0, std::memory_order_relaxed);
     const int rc = pa_gemm_group(b, n, stream);
     g_split.on.store(1, std::memory_order_relaxed);

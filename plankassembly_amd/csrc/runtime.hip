@@ -611,7 +611,9 @@ int backward_segment(pa_model* m, int seg, float gscale, void* st) {
     RC(backward_segment_body(m, seg, gscale, st));
     m->defer_ok = false;
     const bool queued = m->ndwq > 0 || m->nlnq > 0 || m->ncs > 0 || m->ndefer > 0;
-    if (queued && m->side_on) {
+    // (bf16x3 mode: the queued GEMMs cut their operands into the process-wide split scratch, which the next segment's GEMMs on
+    // the main stream reuse - the queued work stays on the main stream)
+    if (queued && m->side_on && !pa_gemm_split_active()) {
         HC(hipEventRecord((hipEvent_t)m->ev_ready[par], (hipStream_t)st));
         HC(hipStreamWaitEvent((hipStream_t)m->side, (hipEvent_t)m->ev_ready[par], 0));
         RC(flush_segment(m, m->side));

@@ -369,12 +369,16 @@ class PlankModel(nn.Module):
         dev = self._flat.device.index or 0
         ws = PlankModel._x3_scratch.get(dev)
         if ws is None:
-            mb = int(os.environ.get("PLANK_X3_SCRATCH_MB", "640"))
+            # the cut operands of one GEMM at a time, plus (retain modes) the forward's Linear inputs for the backward's weight
+            # gradients: 1.1 GB at the benchmark batch; what does not fit is simply cut again
+            mb = int(os.environ.get("PLANK_X3_SCRATCH_MB", "2048"))
             ws = torch.empty(mb * (1 << 20) + 256, dtype=torch.uint8, device=self._flat.device)
             PlankModel._x3_scratch[dev] = ws
         base = (ws.data_ptr() + 255) // 256 * 256
-        # backward segments: mode 2 keeps the cut dY of every dX GEMM for the segment's grouped weight-gradient launch
-        mode = 2 if (retain and os.environ.get("PLANK_X3_RETAIN", "1") != "0") else 1
+        # backward segments: mode 2 keeps the cut dY of every dX GEMM for the segment's grouped weight-gradient launch; the
+        # forward: mode 3 keeps the cut input of every Linear for the same launch (include/plank_hip.h pa_gemm_split_config)
+        keep = os.environ.get("PLANK_X3_RETAIN", "1")
+        mode = 1 if (not retain or keep == "0") else 3 if (retain == "fwd" and keep != "bwd") else 1 if retain == "fwd" else 2
         L.check(L.lib().pa_gemm_split_config(mode, C.c_void_p(base), C.c_int64(ws.numel() - (base - ws.data_ptr()))), "pa_gemm_split_config")
 
     def _pa_activation(self):
@@ -670,7 +674,7 @@ class PlankModel(nn.Module):
         base = (ws.data_ptr() + 255) // 256 * 256
         stats = torch.empty(8, dtype=torch.float32, device=self._flat.device)      # include/plank_hip.h pa_mixture_nll_fwd_fin
         self._step_seed = (self._step_seed * 1664525 + 1013904223 + int(torch.initial_seed())) & 0xFFFFFFFF
-        self._split(True)
+        self._split(True, retain="fwd")
         try:
             L.check(L.lib().pa_model_train_fwd(self._handle, C.byref(b), C.c_void_p(base),
                                                C.c_int64(ws.numel() - (base - ws.data_ptr())),

@@ -682,8 +682,9 @@ def test_x3_b16_step_matches_oracle(which):
     assert taken >= 150 and declined <= taken // 8, (taken, declined)
     from plankassembly_amd import _lib as L
     reused = int(L.lib().pa_gemm_split_reused())
-    # the grouped weight-gradient launches found the dY of (nearly) every layer Linear already cut by its dX GEMM (retain mode)
-    assert reused >= 4 * c["ne"] + 5 * c["nd"], reused
+    # the grouped weight-gradient launches found the dY of (nearly) every layer Linear already cut by its dX GEMM, and its X already
+    # cut by the forward's Linear (pa_gemm_split_config modes 2 and 3)
+    assert reused >= 2 * (4 * c["ne"] + 5 * c["nd"]), reused
     f32_gate(f"b16-{which}-x3", c, sd, batch, m, out, mem, hid, grads)
 
 
