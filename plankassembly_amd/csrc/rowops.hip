@@ -508,6 +508,100 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(T* dz, T* ddrop, con
     }
 }
 
+// d = 512 (the benchmarked width): every row of a wave's share is requested before the first one is reduced - a lane holds 8
+// columns of a row (bf16: ONE 16-byte load per tensor and row, columns 8 lane ..; f32: two, columns 4 lane .. and 256 + 4 lane ..),
+// LNB_ROWS / 4 rows per wave - so the stores of a row leave while the loads of the following rows are still arriving
+// (the generic kernel above keeps two rows in flight and walks the rest one pair after the other).
+template <typename T> struct LnRaw;
+template <> struct LnRaw<bf16> {
+    u32x4 v;
+    __device__ __forceinline__ void load(const bf16* row, int lane) { v = *reinterpret_cast<const u32x4*>(row + lane * 8); }
+    __device__ __forceinline__ float get(int j) const { return (j & 1) ? bf16_hi(v[j >> 1]) : bf16_lo(v[j >> 1]); }
+    static __device__ __forceinline__ int col(int lane, int j) { return lane * 8 + j; }
+    static __device__ __forceinline__ void store(bf16* row, int lane, const float* o) {
+        u32x4 u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = pack_bf16(o[2 * k], o[2 * k + 1]);
+        *reinterpret_cast<u32x4*>(row + lane * 8) = u;
+    }
+};
+template <> struct LnRaw<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* row, int lane) {
+        a = *reinterpret_cast<const f32x4*>(row + lane * 4); b = *reinterpret_cast<const f32x4*>(row + 256 + lane * 4);
+    }
+    __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
+    static __device__ __forceinline__ int col(int lane, int j) { return j < 4 ? lane * 4 + j : 256 + lane * 4 + (j - 4); }
+    static __device__ __forceinline__ void store(float* row, int lane, const float* o) {
+        *reinterpret_cast<f32x4*>(row + lane * 4) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(row + 256 + lane * 4) = f32x4{o[4], o[5], o[6], o[7]};
+    }
+};
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd512_kernel(T* dz, T* ddrop, const T* dy, const T* z, const float* gamma,
+                                                               const float* mean, const float* rstd, float* partial,
+                                                               int64_t rows, uint32_t drop_thr, float drop_scale,
+                                                               uint32_t drop_seed, int want_dzsum) {
+    constexpr int D = 512, RW = LNB_ROWS / 4;                     // rows per wave
+    static_assert(LNB_ROWS % 4 == 0, "whole rows per wave");
+    __shared__ __attribute__((aligned(16))) float red[4 * 3 * D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * LNB_ROWS;
+    LnRaw<T> zz[RW], dd[RW];
+    float mu[RW], rs[RW];
+#pragma unroll
+    for (int u = 0; u < RW; ++u) {
+        const int64_t row = r0 + wave + 4 * u, rowc = row < rows ? row : rows - 1;        // (clamped: no branch between the loads)
+        zz[u].load(z + rowc * D, lane); dd[u].load(dy + rowc * D, lane);
+        mu[u] = mean[rowc]; rs[u] = rstd[rowc];
+    }
+    float gm[8], ag[8], ab[8], as[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gm[j] = gamma[LnRaw<T>::col(lane, j)]; ag[j] = 0.f; ab[j] = 0.f; as[j] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < RW; ++u) {
+        const int64_t row = r0 + wave + 4 * u;
+        if (row >= rows) continue;                                   // (wave-uniform)
+        float xh[8], g[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d_ = dd[u].get(j);
+            xh[j] = (zz[u].get(j) - mu[u]) * rs[u];
+            g[j] = d_ * gm[j];
+            s1 += g[j]; s2 += g[j] * xh[j];
+            ag[j] += d_ * xh[j]; ab[j] += d_;
+        }
+        s1 = wave_sum(s1) / D;
+        s2 = wave_sum(s2) / D;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs[u] * (g[j] - s1 - xh[j] * s2);
+        LnRaw<T>::store(dz + row * D, lane, o);
+        if (drop_thr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j] = drop_keep_rc(drop_seed, (uint32_t)row, (uint32_t)LnRaw<T>::col(lane, j), drop_thr) ? o[j] * drop_scale : 0.f;
+            LnRaw<T>::store(ddrop + row * D, lane, o);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) as[j] += o[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = LnRaw<T>::col(lane, j);
+        red[(wave * 3 + 0) * D + c] = ag[j]; red[(wave * 3 + 1) * D + c] = ab[j]; red[(wave * 3 + 2) * D + c] = as[j];
+    }
+    __syncthreads();
+    const int nq = want_dzsum ? 3 : 2;
+    float* po = partial + (size_t)blockIdx.x * 3 * D;
+    for (int e = threadIdx.x * 4; e < nq * D; e += 1024) {
+        f32x4 sum = *reinterpret_cast<const f32x4*>(red + e);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4*>(red + w * 3 * D + e);
+        *reinterpret_cast<f32x4*>(po + e) = sum;
+    }
+}
+
 // sums `nparts` partial rows and ACCUMULATES into up to three outputs.  Block = 64 columns x 4 part lanes
 // (each lane strides over the parts with independent, coalesced loads), LDS combine.
 __global__ __launch_bounds__(256) void partial_finish_kernel(const float* partial, int nparts, int part_stride, int q_stride,
@@ -1041,6 +1135,17 @@ extern "C" int pa_layernorm_bwd_partial(void* dz, void* ddrop, const void* dy, c
         (const T_*)dy, (const T_*)z, gamma, mean, rstd, partial, rows, d, thr, scale, drop_seed, want_dzsum ? 1 : 0)
 #define LNB_NV(T_) do { if (d <= 256) LNB_GO(T_, 1); else if (d <= 512) LNB_GO(T_, 2); else if (d <= 1024) LNB_GO(T_, 4); \
         else LNB_GO(T_, 8); } while (0)
+    static const bool v512 = !(getenv("PA_LNB_512") && atoi(getenv("PA_LNB_512")) == 0);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (d == 512 && v512 && al16(dz) && al16(dy) && al16(z) && al16(gamma) && al16(partial) && (!thr || al16(ddrop))) {
+        if (dtype == PA_BF16)
+            PA_LAUNCH(layernorm_bwd512_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)dz, (bf16*)ddrop, (const bf16*)dy,
+                      (const bf16*)z, gamma, mean, rstd, partial, rows, thr, scale, drop_seed, want_dzsum ? 1 : 0);
+        else
+            PA_LAUNCH(layernorm_bwd512_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)dz, (float*)ddrop, (const float*)dy,
+                      (const float*)z, gamma, mean, rstd, partial, rows, thr, scale, drop_seed, want_dzsum ? 1 : 0);
+        return 0;
+    }
     if (dtype == PA_BF16) LNB_NV(bf16); else LNB_NV(float);
 #undef LNB_NV
 #undef LNB_GO
