@@ -106,6 +106,26 @@ int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes);
 int pa_gemm_split_active(void);                               /* 1 while the mode is on */
 int64_t pa_gemm_split_reused(void);                           /* weight-gradient operands found already cut (on = 2 / 3) since the last stats reset */
 int pa_gemm_split_stats(int64_t* out2, int32_t reset);        /* out2[0] GEMMs run as bf16x3, out2[1] asked but run exact */
+/* Images written by the PRODUCER of an operand (bf16x3 mode, retain modes 2 / 3).  pa_gemm_split_reserve: the kernel about to write
+ * the f32 matrix `src` ([rows][cols], leading dimension ld, cols % 8 == 0) also writes its cut image - [rows][3 cols] bf16, parts
+ * pattern *pat: 0 = (hi, hi, lo), 1 = (hi, lo, hi), hi = bf16(x), lo = bf16(x - hi) - to the returned address, and the pa_gemm call
+ * that consumes `src` as its k-contiguous A operand (and, in a backward segment, the grouped weight-gradient launch) skips its own
+ * cut.  NULL: no image wanted (mode off, no retain mode, no room); the consumer then cuts as before.  Used by
+ * pa_layernorm_fwd_img (csrc/runtime.hip Ctx::ln_fwd). */
+void* pa_gemm_split_reserve(const void* src, int32_t rows, int32_t cols, int32_t ld, int32_t* pat);
+int64_t pa_gemm_split_made_hits(void);                        /* A operands found written by their producer since the last stats reset */
+/* Images of the constant operands (the weights), owned by one model: a cache over a caller-owned device buffer (256-byte aligned;
+ * 12 bytes per parameter + 32 KiB holds W and W^T of every Linear).  While a cache is in use (pa_gemm_split_cache_use, inside the
+ * model's own pa_gemm_split_config bracket) every unbatched k-contiguous B operand of a bf16x3 GEMM is looked up in it; a miss is
+ * cut INTO the cache (the first step learns the list).  pa_gemm_split_cache_refresh cuts every image again from its source in one
+ * launch: call it whenever the parameters (or their transposed copies) changed.  The sources must stay alive and in place for as
+ * long as the cache exists; destroy it before freeing them. */
+int pa_gemm_split_cache_create(void* buf, int64_t bytes, void** out);
+void pa_gemm_split_cache_destroy(void* cache);
+int pa_gemm_split_cache_use(void* cache);                     /* NULL: none */
+int32_t pa_gemm_split_cache_entries(void* cache);
+int pa_gemm_split_cache_refresh(void* cache, void* stream);
+int64_t pa_gemm_split_cache_hits(void);
 /* Measurement hook (bench.py's roofline census; no reference counterpart): pa_gemm_record(1) starts appending every
  * pa_gemm() argument block to a host-side list; pa_gemm_record(0) returns the count so far; pa_gemm_recorded() copies
  * up to `cap` recorded blocks out and stops recording.  Replaying the blocks re-launches the same GEMMs. */
@@ -293,6 +313,16 @@ int pa_layernorm_bwd(void* dz, void* ddrop, const void* dy, const void* z, const
 int pa_layernorm_bwd_partial(void* dz, void* ddrop, const void* dy, const void* z, const float* gamma,
                              const float* mean, const float* rstd, int32_t want_dzsum, float* partial,
                              int64_t rows, int32_t d, int32_t dtype, float drop_p, uint32_t drop_seed, void* stream);
+/* pa_layernorm_fwd that also writes the bf16x3 image of y (f32 only; img from pa_gemm_split_reserve, NULL = none) */
+int pa_layernorm_fwd_img(void* y, const void* z, const float* gamma, const float* beta, float* mean, float* rstd,
+                         int64_t rows, int32_t d, float eps, int32_t dtype, void* img, int32_t img_pat, void* stream);
+/* pa_layernorm_bwd_partial that also writes the bf16x3 image of its output (ddrop, or dz when drop_p == 0) for the dX GEMM that
+ * consumes it; only where pa_layernorm_bwd_can_img(d, dtype) says so (f32, d = 512). */
+int pa_layernorm_bwd_can_img(int32_t d, int32_t dtype);
+int pa_layernorm_bwd_partial_img(void* dz, void* ddrop, const void* dy, const void* z, const float* gamma,
+                                 const float* mean, const float* rstd, int32_t want_dzsum, float* partial,
+                                 int64_t rows, int32_t d, int32_t dtype, float drop_p, uint32_t drop_seed,
+                                 void* img, int32_t img_pat, void* stream);
 int32_t pa_layernorm_bwd_nparts(int64_t rows);
 #define PA_MAX_LN_FINISH 4
 typedef struct {

@@ -109,6 +109,17 @@ def lib():
             "pa_gemm_split_config": (I, [I, P, I64]),
             "pa_gemm_split_stats": (I, [P, I]),
             "pa_gemm_split_reused": (I64, []),
+            "pa_gemm_split_made_hits": (I64, []),
+            "pa_gemm_split_cache_hits": (I64, []),
+            "pa_gemm_split_reserve": (P, [P, I, I, I, P]),
+            "pa_gemm_split_cache_create": (I, [P, I64, P]),
+            "pa_gemm_split_cache_destroy": (None, [P]),
+            "pa_gemm_split_cache_use": (I, [P]),
+            "pa_gemm_split_cache_entries": (I, [P]),
+            "pa_gemm_split_cache_refresh": (I, [P, P]),
+            "pa_layernorm_fwd_img": (I, [P, P, P, P, P, P, I64, I, F, I, P, I, P]),
+            "pa_layernorm_bwd_can_img": (I, [I, I]),
+            "pa_layernorm_bwd_partial_img": (I, [P, P, P, P, P, P, P, I, P, I64, I, I, F, U, P, I, P]),
             "pa_gemm_group": (I, [P, I, P]),
             "pa_segment_tail": (I, [P, I, I, P, I, I, P, I, P]),
             "pa_gemm_record": (I, [I]),

@@ -2406,9 +2406,16 @@ extern "C" int pa_gemm_recorded_kinds(int32_t* out, int32_t cap) {
 // never be written)
 namespace {
 // bf16x3 mode state (see "bf16x3 (split) products" below)
-struct SplitKeep { const void* src; int rows, cols, ld, pat; bf16* dst; };     // pat 0: (hi, hi, lo) parts, 1: (hi, lo, hi)
+struct SplitKeep { const void* src; int rows, cols, ld, pat; bf16* dst; int made; };     // pat 0: (hi, hi, lo) parts, 1: (hi, lo, hi);
+                                                                                          // made 1: written by its producer (pa_gemm_split_reserve)
+// Images of the CONSTANT operands (the weights: every k-contiguous B operand of an unbatched GEMM in this mode), owned by one model
+// (pa_gemm_split_cache_*): learnt during the first step - a miss cuts the operand into the cache instead of the scratch - and from
+// then on re-cut all at once whenever the parameters changed (pa_gemm_split_cache_refresh), so that a Linear whose input image
+// was written by its producer needs no split launch at all.
+constexpr int SPLIT_CACHE_MAX = 320, SPLIT_CACHE_HEAD = 32768;         // (the head of the buffer holds the device copy of the job table)
+struct SplitCache { char* buf; long long bytes, used; int n; bool table_stale; SplitKeep e[SPLIT_CACHE_MAX]; };
 struct SplitState {
-    std::atomic<int> on{0}; char* ws = nullptr; long long bytes = 0; std::atomic<long long> taken{0}, declined{0}, reused{0};
+    std::atomic<int> on{0}; char* ws = nullptr; long long bytes = 0; std::atomic<long long> taken{0}, declined{0}, reused{0}, made_hits{0}, cache_hits{0};
     // Retained images.  A k-contiguous operand cut as [rows][3 cols] and read as [3 rows][cols] IS its stacked form with the planes
     // interleaved row by row, so the image one GEMM built serves a later GEMM that contracts over the ROWS of the same buffer:
     //   retain 1 (pa_gemm_split_config(2, ..): a backward segment): dY of every dX GEMM stays at [long_off, keep_off) until the next
@@ -2417,7 +2424,7 @@ struct SplitState {
     //            or a plain config (1) - the same grouped launch finds its OTHER operand already cut as well.
     // Forward images are (hi, hi, lo); a backward segment cuts dY as (hi, lo, hi) so that the two meet in one product.
     int retain = 0; long long long_off = 0, keep_off = 0; bool long_closed = false;
-    SplitKeep keep[16]; int nkeep = 0; SplitKeep keepL[128]; int nkeepL = 0;
+    SplitKeep keep[16]; int nkeep = 0; SplitKeep keepL[128]; int nkeepL = 0; SplitCache* cache = nullptr;
     // a weight gradient's dY operand is looked up among this segment's images only, its X operand among the forward's only: backward
     // buffers may reuse addresses of forward buffers that are dead by then
     static const SplitKeep* find_in(const SplitKeep* t, int n, const void* src, int rows, int cols, int ld) {
@@ -2485,11 +2492,7 @@ struct SplitJob { const float* src; bf16* dst; int rows, cols, ld, mode; long lo
 struct SplitTab { SplitJob j[2 * PA_MAX_GROUP_]; int begin[2 * PA_MAX_GROUP_ + 1]; int n; };
 // mode 0: [rows][cols] -> [rows][3 cols] as (hi, hi, lo);  1: as (hi, lo, hi);  2: -> [3 rows][cols] stacked (hi, hi, lo);
 // 3: stacked (hi, lo, hi);  4: hi only [rows][cols] (the ReLU-backward gate: only its sign is read)
-__global__ __launch_bounds__(256) void split_kernel(SplitTab tb) {
-    int k = 0;
-    while (k + 1 < tb.n && (int)blockIdx.x >= tb.begin[k + 1]) ++k;
-    const SplitJob& J = tb.j[k];
-    const int nb = tb.begin[k + 1] - tb.begin[k], bid = blockIdx.x - tb.begin[k];
+__device__ __forceinline__ void split_job(const SplitJob& J, int bid, int nb) {
     // eight consecutive f32 per thread and pass (every job has cols % 8 == 0): two 16-byte loads, 16-byte stores
     const uint32_t c8 = (uint32_t)J.cols >> 3;
     const uint32_t per = (uint32_t)J.rows * c8, total = per * (uint32_t)J.batch;          // (< 2^31: checked by the launchers)
@@ -2522,6 +2525,18 @@ __global__ __launch_bounds__(256) void split_kernel(SplitTab tb) {
         }
     }
 }
+__global__ __launch_bounds__(256) void split_kernel(SplitTab tb) {
+    int k = 0;
+    while (k + 1 < tb.n && (int)blockIdx.x >= tb.begin[k + 1]) ++k;
+    split_job(tb.j[k], blockIdx.x - tb.begin[k], tb.begin[k + 1] - tb.begin[k]);
+}
+// the same over a job table in device memory (pa_gemm_split_cache_refresh: every weight of a model in one launch)
+__global__ __launch_bounds__(256) void split_many_kernel(const SplitJob* jobs, const int* begin, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)blockIdx.x >= begin[mid]) lo = mid; else hi = mid - 1; }
+    const SplitJob J = jobs[lo];
+    split_job(J, blockIdx.x - begin[lo], begin[lo + 1] - begin[lo]);
+}
 inline int eff_split(int nt, int sk) { if (sk > nt) sk = nt; if (sk < 1) sk = 1; const int per = (nt + sk - 1) / sk; return (nt + per - 1) / per; }
 }  // namespace
 extern "C" int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes) {
@@ -2537,9 +2552,84 @@ extern "C" int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes) {
 }
 // [0] GEMMs that ran as bf16x3 since the last reset, [1] f32 GEMMs that asked for it and ran exact (shape / alignment / scratch)
 extern "C" int64_t pa_gemm_split_reused(void) { return g_split.reused.load(); }      // dY images the grouped dW launches found already cut
+extern "C" int64_t pa_gemm_split_made_hits(void) { return g_split.made_hits.load(); }   // A images found written by their producer
+extern "C" int64_t pa_gemm_split_cache_hits(void) { return g_split.cache_hits.load(); } // B (weight) images found in the model's cache
+// Producer side of a retained image: the kernel about to write the f32 matrix `src` ([rows][cols], leading dimension ld) also writes
+// its cut image ([rows][3 cols], parts pattern *pat: 0 (hi, hi, lo), 1 (hi, lo, hi)) to the returned address, and the GEMM that
+// consumes `src` as its k-contiguous A operand skips its own cut.  NULL: no image wanted (mode off, no retain mode, no room).
+extern "C" void* pa_gemm_split_reserve(const void* src, int32_t rows, int32_t cols, int32_t ld, int32_t* pat) {
+    if (!split_on() || !g_split.retain || !src || rows <= 0 || cols <= 0 || (cols & 7)) return nullptr;
+    static const bool off = getenv("PA_SPLIT_RESERVE") && atoi(getenv("PA_SPLIT_RESERVE")) == 0;
+    if (off) return nullptr;
+    const long long bytes = ((long long)rows * cols * 6 + 255) / 256 * 256;
+    bf16* dst;
+    if (g_split.retain == 2) {
+        if (g_split.long_closed || g_split.nkeepL >= 128 || g_split.long_off + bytes > g_split.bytes - g_split.bytes / 4) return nullptr;
+        dst = reinterpret_cast<bf16*>(g_split.ws + g_split.long_off);
+        SplitState::put(g_split.keepL, g_split.nkeepL, SplitKeep{src, rows, cols, ld, 0, dst, 1});
+        g_split.long_off += bytes; g_split.keep_off = g_split.long_off;
+        if (pat) *pat = 0;
+    } else {
+        if (g_split.nkeep >= 16 || g_split.keep_off + bytes > g_split.bytes - g_split.bytes / 8) return nullptr;
+        dst = reinterpret_cast<bf16*>(g_split.ws + g_split.keep_off);
+        SplitState::put(g_split.keep, g_split.nkeep, SplitKeep{src, rows, cols, ld, 1, dst, 1});
+        g_split.keep_off += bytes;
+        if (pat) *pat = 1;
+    }
+    return dst;
+}
+extern "C" int pa_gemm_split_cache_create(void* buf, int64_t bytes, void** out) {
+    if (!buf || !out || bytes <= SPLIT_CACHE_HEAD || (reinterpret_cast<uintptr_t>(buf) & 255)) return PA_EINVAL;
+    SplitCache* c = new (std::nothrow) SplitCache();
+    if (!c) return PA_EINVAL;
+    c->buf = static_cast<char*>(buf); c->bytes = bytes; c->used = SPLIT_CACHE_HEAD; c->n = 0; c->table_stale = false;
+    *out = c;
+    return 0;
+}
+extern "C" void pa_gemm_split_cache_destroy(void* h) {
+    if (!h) return;
+    if (g_split.cache == h) g_split.cache = nullptr;
+    delete static_cast<SplitCache*>(h);
+}
+extern "C" int pa_gemm_split_cache_use(void* h) { g_split.cache = static_cast<SplitCache*>(h); return 0; }
+extern "C" int32_t pa_gemm_split_cache_entries(void* h) { return h ? static_cast<SplitCache*>(h)->n : 0; }
+// the parameters changed: every image of the cache is cut again from its source, in one launch
+extern "C" int pa_gemm_split_cache_refresh(void* h, void* stream) {
+    SplitCache* c = static_cast<SplitCache*>(h);
+    if (!c) return PA_EINVAL;
+    if (c->n == 0) return 0;
+    static_assert(SPLIT_CACHE_MAX * sizeof(SplitJob) + (SPLIT_CACHE_MAX + 1) * sizeof(int) <= SPLIT_CACHE_HEAD, "job table fits the head");
+    SplitJob* dj = reinterpret_cast<SplitJob*>(c->buf);
+    int* db = reinterpret_cast<int*>(c->buf + SPLIT_CACHE_MAX * sizeof(SplitJob));
+    std::vector<int> begin(c->n + 1, 0);
+    std::vector<SplitJob> jobs(c->n);
+    for (int k = 0; k < c->n; ++k) {
+        const SplitKeep& e = c->e[k];
+        SplitJob& j = jobs[k];
+        j.src = static_cast<const float*>(e.src); j.dst = e.dst; j.rows = e.rows; j.cols = e.cols; j.ld = e.ld; j.mode = e.pat;
+        j.sstride = 0; j.dstride = 0; j.batch = 1; j.pad_ = 0;
+        long long blocks = ((long long)e.rows * (e.cols >> 3) + 255) / 256;
+        if (blocks < 1) blocks = 1;
+        if (blocks > 4096) blocks = 4096;
+        begin[k + 1] = begin[k] + (int)blocks;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static const bool dbg = getenv("PA_SPLIT_DEBUG") && atoi(getenv("PA_SPLIT_DEBUG"));
+    if (dbg) fprintf(stderr, "[pa_gemm x3 cache] refresh: %d images, %lld of %lld bytes, table %s, %d blocks\n", c->n, c->used, c->bytes,
+                     c->table_stale ? "uploaded" : "resident", begin[c->n]);
+    if (c->table_stale) {
+        // (only while the list is still growing: the first two steps)
+        if (hipMemcpyAsync(dj, jobs.data(), jobs.size() * sizeof(SplitJob), hipMemcpyHostToDevice, st) != hipSuccess) return PA_EINVAL;
+        if (hipMemcpyAsync(db, begin.data(), begin.size() * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) return PA_EINVAL;
+        if (hipStreamSynchronize(st) != hipSuccess) return PA_EINVAL;          // (the host vectors die with this call)
+        c->table_stale = false;
+    }
+    PA_LAUNCH(split_many_kernel, dim3(begin[c->n]), dim3(256), 0, st, dj, db, c->n);
+    return 0;
+}
 extern "C" int pa_gemm_split_stats(int64_t* out2, int32_t reset) {
     if (out2) { out2[0] = g_split.taken.load(); out2[1] = g_split.declined.load(); }
-    if (reset) { g_split.taken.store(0); g_split.declined.store(0); g_split.reused.store(0); }
+    if (reset) { g_split.taken.store(0); g_split.declined.store(0); g_split.reused.store(0); g_split.made_hits.store(0); g_split.cache_hits.store(0); }
     return 0;
 }
 // returns 1 when the GEMM was enqueued as bf16x3, 0 when the caller must run it exact, < 0 on error
@@ -2567,11 +2657,32 @@ static int gemm_split3(const pa_gemm_args* a, void* stream) {
     const SplitKeep* hb = stacked2 ? g_split.find_fwd(a->B, br, bc, a->ldb) : nullptr;
     if (ha) pa = ha->pat; else if (hb) pa = 1 - hb->pat;
     if (hb && hb->pat == pa) hb = nullptr;
-    long long a_bytes = ha ? 0 : up(a_el * 2 * (a_shared ? 1 : nb)), b_bytes = hb ? 0 : up(b_el * 2 * (b_shared ? 1 : nb));
+    // a k-contiguous A whose image was written by the kernel that produced A (pa_gemm_split_reserve) ..
+    if (akc && nb == 1 && g_split.retain) {
+        const SplitKeep* e = g_split.retain == 2 ? SplitState::find_in(g_split.keepL, g_split.nkeepL, a->A, ar, ac, a->lda)
+                                                 : g_split.find_seg(a->A, ar, ac, a->lda);
+        if (e && e->made && e->pat == pa) { ha = e; g_split.made_hits.fetch_add(1); }
+    }
+    // .. and a constant k-contiguous B (a weight) held in the model's cache; a miss is cut INTO the cache
+    SplitCache* const wc = g_split.cache;
+    bf16* cache_b = nullptr; bool cache_cut = false;
+    if (wc && bkc && nb == 1) {
+        for (int k = 0; k < wc->n && !cache_b; ++k) {
+            const SplitKeep& e = wc->e[k];
+            if (e.src == a->B && e.rows == br && e.cols == bc && e.ld == a->ldb && e.pat == 1 - pa) cache_b = e.dst;
+        }
+        if (cache_b) g_split.cache_hits.fetch_add(1);
+        else if (wc->n < SPLIT_CACHE_MAX && wc->used + up(b_el * 2) <= wc->bytes) {
+            cache_b = reinterpret_cast<bf16*>(wc->buf + wc->used); wc->used += up(b_el * 2);
+            wc->e[wc->n++] = SplitKeep{a->B, br, bc, a->ldb, 1 - pa, cache_b, 0};
+            wc->table_stale = true; cache_cut = true;
+        }
+    }
+    long long a_bytes = ha ? 0 : up(a_el * 2 * (a_shared ? 1 : nb)), b_bytes = (hb || cache_b) ? 0 : up(b_el * 2 * (b_shared ? 1 : nb));
     const long long x_bytes = up(x_el * 2 * nb);
     auto forget_hits = [&]() {                               // (images dropped below may be the ones found above)
-        ha = hb = nullptr; pa = g_split.retain == 1 ? 1 : 0;
-        a_bytes = up(a_el * 2 * (a_shared ? 1 : nb)); b_bytes = up(b_el * 2 * (b_shared ? 1 : nb));
+        ha = hb = nullptr; if (stacked2) pa = g_split.retain == 1 ? 1 : 0;
+        a_bytes = up(a_el * 2 * (a_shared ? 1 : nb)); b_bytes = cache_b ? 0 : up(b_el * 2 * (b_shared ? 1 : nb));
     };
     bool keep_a = false;
     if (g_split.retain == 2) {
@@ -2610,14 +2721,15 @@ static int gemm_split3(const pa_gemm_args* a, void* stream) {
     bf16* X1 = reinterpret_cast<bf16*>(w0 + a_bytes + b_bytes);
     if (ha) A3 = ha->dst;
     if (hb) B3 = hb->dst;
-    if (keep_a) {
-        const SplitKeep e{a->A, ar, ac, a->lda, pa, A3};
+    if (cache_b) B3 = cache_b;
+    if (keep_a && !ha) {
+        const SplitKeep e{a->A, ar, ac, a->lda, pa, A3, 0};
         if (g_split.retain == 2) { SplitState::put(g_split.keepL, g_split.nkeepL, e); g_split.long_off += a_bytes; }
         else SplitState::put(g_split.keep, g_split.nkeep, e);
         g_split.keep_off += a_bytes;
     }
-    if (ha || hb) g_split.reused.fetch_add((ha ? 1 : 0) + (hb ? 1 : 0));
-    const bool inter = ha || hb;                             // row-interleaved stacking: split modes 0 / 1 instead of 2 / 3
+    if (stacked2 && (ha || hb)) g_split.reused.fetch_add((ha ? 1 : 0) + (hb ? 1 : 0));
+    const bool inter = stacked2 && (ha || hb);               // row-interleaved stacking: split modes 0 / 1 instead of 2 / 3
     SplitTab tb; tb.n = 0; tb.begin[0] = 0;
     auto add = [&](const void* src, bf16* dst, int rows, int cols, int ld, int mode, long long ss, long long ds, int batch) {
         SplitJob& j = tb.j[tb.n];
@@ -2632,7 +2744,7 @@ static int gemm_split3(const pa_gemm_args* a, void* stream) {
         ++tb.n;
     };
     if (!ha) add(a->A, A3, ar, ac, a->lda, (akc || inter ? 0 : 2) + pa, a->sA, a_el, a_shared ? 1 : nb);
-    if (!hb) add(a->B, B3, br, bc, a->ldb, (bkc || inter ? 0 : 2) + (1 - pa), a->sB, b_el, b_shared ? 1 : nb);
+    if (!hb && (!cache_b || cache_cut)) add(a->B, B3, br, bc, a->ldb, (bkc || inter ? 0 : 2) + (1 - pa), a->sB, b_el, b_shared ? 1 : nb);
     if (a->aux) add(a->aux, X1, M, N, a->ldaux, 4, a->sAux, x_el, nb);
     if (tb.n) PA_LAUNCH(split_kernel, dim3(tb.begin[tb.n]), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tb);
     pa_gemm_args b = *a;

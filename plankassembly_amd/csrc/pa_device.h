@@ -75,6 +75,18 @@ template <> __device__ __forceinline__ void st4<bf16>(bf16* p, f32x4 v) {
 #endif
 }
 
+// bf16x3 image of four consecutive f32 values (gemm.hip "bf16x3 (split) products"; pa_gemm_split_reserve): hi = bf16(x),
+// lo = bf16(x - hi) written as the three parts of a [rows][3 cols] image row - pat 0: (hi, hi, lo), pat 1: (hi, lo, hi)
+__device__ __forceinline__ void split_store4(bf16* img_row, int cols, int c, f32x4 v, int pat) {
+    u32x2 hi, lo;
+    hi[0] = pack_bf16(v[0], v[1]); hi[1] = pack_bf16(v[2], v[3]);
+    lo[0] = pack_bf16(v[0] - bf16_lo(hi[0]), v[1] - bf16_hi(hi[0]));
+    lo[1] = pack_bf16(v[2] - bf16_lo(hi[1]), v[3] - bf16_hi(hi[1]));
+    *reinterpret_cast<u32x2*>(img_row + c) = hi;
+    *reinterpret_cast<u32x2*>(img_row + cols + c) = pat ? lo : hi;
+    *reinterpret_cast<u32x2*>(img_row + 2 * cols + c) = pat ? hi : lo;
+}
+
 // ---------------------------------------------------------------------------------------------
 // One "16-byte step" of a 32x32 MFMA tile.  Lane l = (i = l & 31, h = l >> 5) supplies for the A
 // operand row i and for the B operand column i the EB contraction elements [EB*h, EB*h+EB) of

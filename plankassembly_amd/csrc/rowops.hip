@@ -2,6 +2,7 @@
 // backward), LayerNorm fwd/bwd, switch head, fused mixture-NLL fwd/bwd, Adam, casts.
 // One 64-lane wave per row with 16-byte (4 x f32 / 4 x bf16 = 8-byte) vector accesses and
 // shuffle reductions; parameter-gradient column sums go through per-block partials (deterministic).
+#include <type_traits>
 #include "pa_device.h"
 #include "../../include/plank_hip.h"
 
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(1024) void group_rows_kernel(GroupTab tab) {
 // ================================================================================ LayerNorm
 template <typename T, int NV>   // NV = ceil(d / 256): 4-wide vectors per lane per row
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(T* y, const T* z, const float* gamma, const float* beta,
-                                                            float* mean, float* rstd, int64_t rows, int d, float eps) {
+                                                            float* mean, float* rstd, int64_t rows, int d, float eps,
+                                                            bf16* img, int img_pat) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -392,6 +394,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(T* y, const T* z, co
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[i][j] + b[i][j];
             st4<T>(yr + c, o);
+            if (std::is_same<T, float>::value && img) split_store4(img + row * 3 * d, d, c, o, img_pat);   // (bf16x3 mode: the consumer's cut)
         }
     }
 }
@@ -541,7 +544,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd512_kernel(T* dz, T* ddrop, const T* dy, const T* z, const float* gamma,
                                                                const float* mean, const float* rstd, float* partial,
                                                                int64_t rows, uint32_t drop_thr, float drop_scale,
-                                                               uint32_t drop_seed, int want_dzsum) {
+                                                               uint32_t drop_seed, int want_dzsum, bf16* img, int img_pat) {
     constexpr int D = 512, RW = LNB_ROWS / 4;                     // rows per wave
     static_assert(LNB_ROWS % 4 == 0, "whole rows per wave");
     __shared__ __attribute__((aligned(16))) float red[4 * 3 * D];
@@ -582,6 +585,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd512_kernel(T* dz, T* ddrop, 
             for (int j = 0; j < 8; ++j)
                 o[j] = drop_keep_rc(drop_seed, (uint32_t)row, (uint32_t)LnRaw<T>::col(lane, j), drop_thr) ? o[j] * drop_scale : 0.f;
             LnRaw<T>::store(ddrop + row * D, lane, o);
+        }
+        if (std::is_same<T, float>::value && img) {                  // bf16x3 mode: the cut image of the dX GEMM's operand (ddrop, or dz without dropout)
+            split_store4(img + row * 3 * D, D, lane * 4, f32x4{o[0], o[1], o[2], o[3]}, img_pat);
+            split_store4(img + row * 3 * D, D, 256 + lane * 4, f32x4{o[4], o[5], o[6], o[7]}, img_pat);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) as[j] += o[j];
@@ -1109,11 +1116,19 @@ extern "C" int64_t pa_layernorm_ws_floats(int64_t rows, int32_t d) {
     return ((rows + LNB_ROWS - 1) / LNB_ROWS) * 3 * (int64_t)d;
 }
 
+extern "C" int pa_layernorm_fwd_img(void* y, const void* z, const float* gamma, const float* beta, float* mean, float* rstd,
+                                    int64_t rows, int32_t d, float eps, int32_t dtype, void* img, int32_t img_pat, void* stream);
 extern "C" int pa_layernorm_fwd(void* y, const void* z, const float* gamma, const float* beta, float* mean, float* rstd,
                                 int64_t rows, int32_t d, float eps, int32_t dtype, void* stream) {
+    return pa_layernorm_fwd_img(y, z, gamma, beta, mean, rstd, rows, d, eps, dtype, nullptr, 0, stream);
+}
+extern "C" int pa_layernorm_fwd_img(void* y, const void* z, const float* gamma, const float* beta, float* mean, float* rstd,
+                                    int64_t rows, int32_t d, float eps, int32_t dtype, void* img_, int32_t img_pat, void* stream) {
     if (!y || !z || !gamma || !beta || !mean || !rstd || rows <= 0 || (d & 3) || d > 256 * MAXV) return PA_EINVAL;
+    if (img_ && (dtype != PA_F32 || (reinterpret_cast<uintptr_t>(img_) & 7))) return PA_EINVAL;
+    bf16* img = static_cast<bf16*>(img_);
     const int grid = (int)((rows + 3) / 4);
-#define LNF_GO(T_, NV_) PA_LAUNCH((layernorm_fwd_kernel<T_, NV_>), dim3(grid), dim3(256), 0, ST(stream), (T_*)y, (const T_*)z, gamma, beta, mean, rstd, rows, d, eps)
+#define LNF_GO(T_, NV_) PA_LAUNCH((layernorm_fwd_kernel<T_, NV_>), dim3(grid), dim3(256), 0, ST(stream), (T_*)y, (const T_*)z, gamma, beta, mean, rstd, rows, d, eps, img, img_pat)
 #define LNF_NV(T_) do { if (d <= 256) LNF_GO(T_, 1); else if (d <= 512) LNF_GO(T_, 2); else if (d <= 1024) LNF_GO(T_, 4); else LNF_GO(T_, 8); } while (0)
     if (dtype == PA_BF16) LNF_NV(bf16); else LNF_NV(float);
 #undef LNF_NV
@@ -1121,10 +1136,27 @@ extern "C" int pa_layernorm_fwd(void* y, const void* z, const float* gamma, cons
     return 0;
 }
 
+extern "C" int pa_layernorm_bwd_partial_img(void* dz, void* ddrop, const void* dy, const void* z, const float* gamma,
+                                            const float* mean, const float* rstd, int32_t want_dzsum, float* partial,
+                                            int64_t rows, int32_t d, int32_t dtype, float drop_p, uint32_t drop_seed,
+                                            void* img, int32_t img_pat, void* stream);
 extern "C" int pa_layernorm_bwd_partial(void* dz, void* ddrop, const void* dy, const void* z, const float* gamma,
                                         const float* mean, const float* rstd, int32_t want_dzsum, float* partial,
                                         int64_t rows, int32_t d, int32_t dtype, float drop_p, uint32_t drop_seed, void* stream) {
+    return pa_layernorm_bwd_partial_img(dz, ddrop, dy, z, gamma, mean, rstd, want_dzsum, partial, rows, d, dtype, drop_p, drop_seed,
+                                        nullptr, 0, stream);
+}
+// 1 when pa_layernorm_bwd_partial_img can write the bf16x3 image of its output for these arguments (the d = 512 f32 kernel)
+extern "C" int pa_layernorm_bwd_can_img(int32_t d, int32_t dtype) {
+    static const bool v512 = !(getenv("PA_LNB_512") && atoi(getenv("PA_LNB_512")) == 0);
+    return (d == 512 && dtype == PA_F32 && v512) ? 1 : 0;
+}
+extern "C" int pa_layernorm_bwd_partial_img(void* dz, void* ddrop, const void* dy, const void* z, const float* gamma,
+                                            const float* mean, const float* rstd, int32_t want_dzsum, float* partial,
+                                            int64_t rows, int32_t d, int32_t dtype, float drop_p, uint32_t drop_seed,
+                                            void* img_, int32_t img_pat, void* stream) {
     if (!dz || !dy || !z || !gamma || !mean || !rstd || !partial) return PA_EINVAL;
+    bf16* img = static_cast<bf16*>(img_);
     if (rows <= 0 || (d & 3) || d > 256 * MAXV || drop_p < 0.f || drop_p >= 1.f) return PA_EINVAL;
     const uint32_t thr = (uint32_t)((double)drop_p * 4294967296.0);        // as pa_gemm: keep <=> 32-bit product >= thr (drop_keep_rc)
     if (thr && !ddrop) return PA_EINVAL;
@@ -1138,14 +1170,16 @@ extern "C" int pa_layernorm_bwd_partial(void* dz, void* ddrop, const void* dy, c
     static const bool v512 = !(getenv("PA_LNB_512") && atoi(getenv("PA_LNB_512")) == 0);
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     if (d == 512 && v512 && al16(dz) && al16(dy) && al16(z) && al16(gamma) && al16(partial) && (!thr || al16(ddrop))) {
+        if (img && (dtype != PA_F32 || (reinterpret_cast<uintptr_t>(img) & 7))) return PA_EINVAL;
         if (dtype == PA_BF16)
             PA_LAUNCH(layernorm_bwd512_kernel<bf16>, dim3(grid), dim3(256), 0, ST(stream), (bf16*)dz, (bf16*)ddrop, (const bf16*)dy,
-                      (const bf16*)z, gamma, mean, rstd, partial, rows, thr, scale, drop_seed, want_dzsum ? 1 : 0);
+                      (const bf16*)z, gamma, mean, rstd, partial, rows, thr, scale, drop_seed, want_dzsum ? 1 : 0, nullptr, 0);
         else
             PA_LAUNCH(layernorm_bwd512_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (float*)dz, (float*)ddrop, (const float*)dy,
-                      (const float*)z, gamma, mean, rstd, partial, rows, thr, scale, drop_seed, want_dzsum ? 1 : 0);
+                      (const float*)z, gamma, mean, rstd, partial, rows, thr, scale, drop_seed, want_dzsum ? 1 : 0, img, img_pat);
         return 0;
     }
+    if (img) return PA_EINVAL;                             // (callers ask pa_layernorm_bwd_can_img first)
     if (dtype == PA_BF16) LNB_NV(bf16); else LNB_NV(float);
 #undef LNB_NV
 #undef LNB_GO

@@ -141,14 +141,25 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
         return ln_fwd(y, z, g, b, mean, rstd, M, eps);
     }
     int ln_fwd(void* y, const void* z, const float* g, const float* b, float* mean, float* rstd, int64_t rows, float eps) const {
-        return pa_layernorm_fwd(y, z, g, b, mean, rstd, rows, m->cfg.d_model, eps, dt(), st);
+        // bf16x3 mode: the Linear that consumes y finds its cut image written here (pa_gemm_split_reserve)
+        int32_t pat = 0;
+        void* img = dt() == PA_F32 ? pa_gemm_split_reserve(y, (int32_t)rows, m->cfg.d_model, m->cfg.d_model, &pat) : nullptr;
+        return pa_layernorm_fwd_img(y, z, g, b, mean, rstd, rows, m->cfg.d_model, eps, dt(), img, pat, st);
     }
     int ln_bwd(void* dz, void* ddrop, const void* dy, const void* z, const float* g, const float* mean, const float* rstd,
                float* dg, float* db, float* dzsum, int64_t rows, float drop_p, uint32_t seed) const {
         if (m->defer_ok && m->nlnq < PA_MAX_LN_FINISH && m->nlnq < 3) {
             // inside a layer segment: partial sums now (own buffer), one finishing launch for all of them at the end
             float* part = m->lnp[m->nlnq];
-            RC(pa_layernorm_bwd_partial(dz, ddrop, dy, z, g, mean, rstd, dzsum ? 1 : 0, part, rows, m->cfg.d_model, dt(), drop_p, seed, st));
+            // bf16x3 mode: the dX GEMM that consumes ddrop (dz without dropout) finds its cut image written here
+            int32_t pat = 0;
+            void* const out = ddrop ? ddrop : dz;
+            const bool al = ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(z) |
+                              reinterpret_cast<uintptr_t>(ddrop)) & 15) == 0;
+            void* img = (al && pa_layernorm_bwd_can_img(m->cfg.d_model, dt())) ?
+                        pa_gemm_split_reserve(out, (int32_t)rows, m->cfg.d_model, m->cfg.d_model, &pat) : nullptr;
+            RC(pa_layernorm_bwd_partial_img(dz, ddrop, dy, z, g, mean, rstd, dzsum ? 1 : 0, part, rows, m->cfg.d_model, dt(), drop_p, seed,
+                                            img, pat, st));
             pa_ln_finish_desc& fd = m->lnq[m->nlnq++];
             fd.partial = part; fd.nparts = pa_layernorm_bwd_nparts(rows); fd.pad_ = 0; fd.dgamma = dg; fd.dbeta = db; fd.dzsum = dzsum;
             return 0;

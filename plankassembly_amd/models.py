@@ -290,6 +290,13 @@ class PlankModel(nn.Module):
             self._handle = None
         self._ws = None
         self._decoder = None
+        self._drop_x3_cache()
+
+    def _drop_x3_cache(self):
+        cache = getattr(self, "_x3_cache", None)
+        if cache is not None:
+            L.lib().pa_gemm_split_cache_destroy(cache[0])
+        self._x3_cache = None
 
     def __del__(self):
         try:
@@ -363,6 +370,7 @@ class PlankModel(nn.Module):
         if not on:
             L.check(L.lib().pa_gemm_split_config(0, None, 0), "pa_gemm_split_config")
             L.check(L.lib().pa_attn_split_config(0), "pa_attn_split_config")
+            L.check(L.lib().pa_gemm_split_cache_use(None), "pa_gemm_split_cache_use")
             return
         if attn:
             L.check(L.lib().pa_attn_split_config(1), "pa_attn_split_config")
@@ -380,6 +388,24 @@ class PlankModel(nn.Module):
         keep = os.environ.get("PLANK_X3_RETAIN", "1")
         mode = 1 if (not retain or keep == "0") else 3 if (retain == "fwd" and keep != "bwd") else 1 if retain == "fwd" else 2
         L.check(L.lib().pa_gemm_split_config(mode, C.c_void_p(base), C.c_int64(ws.numel() - (base - ws.data_ptr()))), "pa_gemm_split_config")
+        # this model's weight images: learnt by the first step, re-cut by refresh_transposed() whenever the parameters changed
+        if retain and getattr(self, "_x3_cache", None) is None:
+            # OFF by default (PLANK_X3_WCACHE_MB=0): measured on MI355X the split launches it removes (28.0 -> 21.8 ms over 23 steps)
+            # cost less than what the GEMMs lose reading weight images cut a whole step earlier instead of just before the launch
+            # (pair GEMM 54.9 -> 62.6 us, gemm3s 18.2 -> 23.3 us): 12.07 -> 12.57 ms per step.  -1: sized from the parameters.
+            mb = int(os.environ.get("PLANK_X3_WCACHE_MB", "0"))
+            if mb < 0:
+                mb = max(64, (self._numel * 12 >> 20) + 64)
+            if mb > 0:
+                buf = torch.empty(mb * (1 << 20) + 256, dtype=torch.uint8, device=self._flat.device)
+                cb = (buf.data_ptr() + 255) // 256 * 256
+                h = C.c_void_p()
+                L.check(L.lib().pa_gemm_split_cache_create(C.c_void_p(cb), C.c_int64(buf.numel() - (cb - buf.data_ptr())), C.byref(h)),
+                        "pa_gemm_split_cache_create")
+                self._x3_cache = (h, buf)
+        cache = getattr(self, "_x3_cache", None)
+        if retain and cache is not None:
+            L.check(L.lib().pa_gemm_split_cache_use(cache[0]), "pa_gemm_split_cache_use")
 
     def _pa_activation(self):
         return {"relu": 1, "gelu": 2}[self.activation]
@@ -495,11 +521,14 @@ class PlankModel(nn.Module):
 
     def refresh_transposed(self):
         """Re-derive the W^T shadow from the bf16 shadow (one batched transpose launch)."""
-        if self._tr_descs is None:
-            return
-        d, n, tiles = self._tr_descs
-        L.check(L.lib().pa_transpose_many(L.ptr(d), n, tiles, L.PA_BF16 if self.compute_dtype == "bf16" else L.PA_F32, L.stream()),
-                "pa_transpose_many")
+        if self._tr_descs is not None:
+            d, n, tiles = self._tr_descs
+            L.check(L.lib().pa_transpose_many(L.ptr(d), n, tiles, L.PA_BF16 if self.compute_dtype == "bf16" else L.PA_F32, L.stream()),
+                    "pa_transpose_many")
+        # 'x3': the cut images of the weights (and of their transposes) follow the parameters (pa_gemm_split_cache_refresh)
+        cache = getattr(self, "_x3_cache", None)
+        if cache is not None:
+            L.check(L.lib().pa_gemm_split_cache_refresh(cache[0], L.stream()), "pa_gemm_split_cache_refresh")
 
     def _ensure_grads(self):
         if self._gflat is None:
