@@ -685,7 +685,55 @@ def test_x3_b16_step_matches_oracle(which):
     # the grouped weight-gradient launches found the dY of (nearly) every layer Linear already cut by its dX GEMM, and its X already
     # cut by the forward's Linear (pa_gemm_split_config modes 2 and 3)
     assert reused >= 2 * (4 * c["ne"] + 5 * c["nd"]), reused
+    # the Linears behind a LayerNorm (forward) and the dX GEMMs behind a LayerNorm backward took the image their producer wrote
+    # (pa_gemm_split_reserve; d_model = 512: both kernels can write it)
+    made = int(L.lib().pa_gemm_split_made_hits())
+    assert made >= 2 * c["ne"] + 3 * c["nd"], made
     f32_gate(f"b16-{which}-x3", c, sd, batch, m, out, mem, hid, grads)
+
+
+def test_x3_weight_image_cache_leaves_the_step_unchanged(monkeypatch):
+    """PLANK_X3_WCACHE_MB=-1 (opt-in): the weight images come from the per-model cache - learnt in the first step, re-cut in one
+    launch whenever the parameters changed - instead of the split launch in front of each GEMM.  Same cut, same kernels: two
+    steps with a parameter change in between must give the same losses and gradients either way (to the rounding of the step's
+    unordered sums)."""
+    from plankassembly_amd import _lib as L
+    c = LC.CASES["headline"]
+    sd, batch = LC.case_state_dict(c), LC.case_batch(c)
+
+    def two_steps(cache_mb):
+        monkeypatch.setenv("PLANK_X3_WCACHE_MB", cache_mb)
+        m = hip_model(c, "x3", sd).train()
+        pb = m.prepare_batch(batch)
+        losses = []
+        for it in range(2):
+            for p in m.parameters():
+                p.grad = None
+            out = m(pb)
+            out["loss"].backward()
+            losses.append(float(out["loss"].detach()))
+            g = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+            if it == 0:
+                # the same parameter change on both sides (an optimizer would amplify the rounding of the first step's unordered
+                # sums: Adam's first update is lr * sign(g)); in-place through the parameters, as torch.optim does
+                with torch.no_grad():
+                    for p in m.parameters():
+                        p.mul_(1.01)
+        torch.cuda.synchronize()
+        n = int(L.lib().pa_gemm_split_cache_entries(m._x3_cache[0])) if getattr(m, "_x3_cache", None) else 0
+        return losses, g, n
+
+    _split_stats(reset=True)
+    l0, g0, n0 = two_steps("0")
+    assert n0 == 0 and int(L.lib().pa_gemm_split_cache_hits()) == 0
+    _split_stats(reset=True)
+    l1, g1, n1 = two_steps("-1")
+    hits = int(L.lib().pa_gemm_split_cache_hits())
+    assert n1 >= 2 * (4 * c["ne"] + 6 * c["nd"]) and hits >= n1, (n1, hits)      # second step: every weight image found in the cache
+    assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-6 + 1e-5 * scale, k
 
 
 def test_x3_train_step_under_dropout_matches_oracle_given_the_same_decisions():
