@@ -155,7 +155,7 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
             int32_t pat = 0;
             void* const out = ddrop ? ddrop : dz;
             const bool al = ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(z) |
-                              reinterpret_cast<uintptr_t>(ddrop)) & 15) == 0;
+                              reinterpret_cast<uintptr_t>(ddrop) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(part)) & 15) == 0;
             void* img = (al && pa_layernorm_bwd_can_img(m->cfg.d_model, dt())) ?
                         pa_gemm_split_reserve(out, (int32_t)rows, m->cfg.d_model, m->cfg.d_model, &pat) : nullptr;
             RC(pa_layernorm_bwd_partial_img(dz, ddrop, dy, z, g, mean, rstd, dzsum ? 1 : 0, part, rows, m->cfg.d_model, dt(), drop_p, seed,
