@@ -692,6 +692,28 @@ def test_x3_b16_step_matches_oracle(which):
     f32_gate(f"b16-{which}-x3", c, sd, batch, m, out, mem, hid, grads)
 
 
+def test_x3_b16_step_with_a_small_scratch_buffer_still_passes_the_gate(monkeypatch):
+    """256 MB of split scratch instead of 2 GB: the forward can keep only a few of its cut Linear inputs, segments drop their images
+    when a GEMM's own cuts need the room - every fallback path of gemm.hip gemm_split3 / pa_gemm_split_reserve - and the step
+    must come out the same (the images are an optimisation, never a source of data)."""
+    from plankassembly_amd.models import PlankModel
+    c, batch, _ = _b16_case("above")
+    sd = LC.case_state_dict(c)
+    saved = dict(PlankModel._x3_scratch)
+    PlankModel._x3_scratch.clear()
+    monkeypatch.setenv("PLANK_X3_SCRATCH_MB", "256")
+    try:
+        m = hip_model(c, "x3", sd)
+        _split_stats(reset=True)
+        out, mem, hid, grads = run_hip_train(m, batch)
+        taken, declined = _split_stats()
+        assert taken >= 150, (taken, declined)
+        f32_gate("b16-above-x3-small-scratch", c, sd, batch, m, out, mem, hid, grads)
+    finally:
+        PlankModel._x3_scratch.clear()
+        PlankModel._x3_scratch.update(saved)
+
+
 def test_x3_weight_image_cache_leaves_the_step_unchanged(monkeypatch):
     """PLANK_X3_WCACHE_MB=-1 (opt-in): the weight images come from the per-model cache - learnt in the first step, re-cut in one
     launch whenever the parameters changed - instead of the split launch in front of each GEMM.  Same cut, same kernels: two
