@@ -1035,3 +1035,145 @@ def test_attention_mask_order_dispatch_leaves_results_unchanged():
     g0 = ops.attn_bwd(do, q, k, v, o0, l0, H, **kw)
     g1 = ops.attn_bwd(do, q, k, v, o0, l0, H, order=order, **kw)
     assert all(torch.equal(a, b) for a, b in zip(g0, g1))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# bf16x3 ("split") GEMMs at the C ABI (csrc/gemm.hip gemm_split3 / gemm_group_split3; include/plank_hip.h pa_gemm_split_config):
+# f32 in / f32 out, every product as hi*hi + hi*lo + lo*hi on the bf16 matrix pipe.  Reference: float64 on the CPU.
+class _SplitMode:
+    """pa_gemm_split_config bracket over a scratch tensor owned by the test."""
+
+    def __init__(self, mode, mb=256):
+        import ctypes as C
+        from plankassembly_amd import _lib as L
+        self.C, self.L, self.mode = C, L, mode
+        self.buf = torch.empty(mb * (1 << 20) + 256, dtype=torch.uint8, device=DEV)
+        self.base = (self.buf.data_ptr() + 255) // 256 * 256
+        self.bytes = self.buf.numel() - (self.base - self.buf.data_ptr())
+
+    def config(self, mode):
+        L, C = self.L, self.C
+        L.check(L.lib().pa_gemm_split_config(mode, C.c_void_p(self.base) if mode else None, C.c_int64(self.bytes if mode else 0)),
+                "pa_gemm_split_config")
+
+    def __enter__(self):
+        out = (self.C.c_int64 * 2)()
+        self.L.lib().pa_gemm_split_stats(out, 1)
+        self.config(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        self.config(0)
+
+    def stats(self):
+        out = (self.C.c_int64 * 2)()
+        self.L.lib().pa_gemm_split_stats(out, 0)
+        return int(out[0]), int(out[1])
+
+    def image_view(self, ptr, rows, cols):
+        """[rows][3 cols] bf16 view of an image address inside the scratch buffer (pa_gemm_split_reserve)."""
+        off = ptr - self.buf.data_ptr()
+        return self.buf[off: off + rows * cols * 6].view(torch.bfloat16).view(rows, 3 * cols)
+
+
+def _x3_err(got, a64, b64_t):
+    """max |got - a b| over max(|a| |b|): the split drops lo*lo (2^-16 of a term) and rounds lo to 8 bits (2^-17)."""
+    ref = a64 @ b64_t
+    bound = (a64.abs() @ b64_t.abs()).max()
+    return float((got.detach().cpu().double() - ref).abs().max() / bound)
+
+
+@pytest.mark.parametrize("akc,bkc", [(True, True), (True, False), (False, False), (False, True)])
+@pytest.mark.parametrize("M,N,K", [(256, 192, 128), (2048, 512, 512), (264, 520, 64), (1200, 1536, 512)])
+def test_gemm_x3_layouts_match_float64_to_split_precision(akc, bkc, M, N, K):
+    a = rnd(M, K, seed=1)
+    b = rnd(N, K, seed=2)
+    bias = rnd(N, seed=3).to(DEV)
+    A = (a if akc else a.t().contiguous()).to(DEV)
+    Bm = (b if bkc else b.t().contiguous()).to(DEV)
+    exact = ops.gemm(A, Bm, a_kcontig=akc, b_kcontig=bkc, bias=bias)
+    with _SplitMode(1) as sm:
+        got = ops.gemm(A, Bm, a_kcontig=akc, b_kcontig=bkc, bias=bias)
+        taken, declined = sm.stats()
+    torch.cuda.synchronize()
+    assert (taken, declined) == (1, 0), (taken, declined)
+    bias64 = bias.cpu().double()
+    e3 = _x3_err(got - bias, a.double(), b.double().t())
+    e32 = _x3_err(exact - bias, a.double(), b.double().t())
+    assert e3 < 2.0 ** -15, e3                      # measured ~2^-17.5 .. 2^-16.5 of max |a||b|; plain bf16 sits at ~2^-9
+    assert e32 < 2.0 ** -20, e32
+    assert not torch.equal(got, exact)               # (really a different arithmetic, not the exact kernel again)
+    del bias64
+
+
+def test_gemm_x3_epilogues_batch_and_splitk():
+    """ReLU-backward gate (from a bf16 copy of the gate tensor: only its sign is read), residual, alpha, a batch with a shared
+    A operand, deferred split-K through the split-aware slab count."""
+    M, N, K = 512, 256, 256
+    a, b = rnd(M, K, seed=4), rnd(N, K, seed=5)
+    gate, res = rnd(M, N, seed=6), rnd(M, N, seed=7)
+    ref = (a.double() @ b.double().t()) * 0.5
+    ref = torch.where(gate.double() > 0, ref * 1.25, torch.zeros_like(ref)) + res.double()
+    with _SplitMode(1) as sm:
+        got = ops.gemm(a.to(DEV), b.to(DEV), aux=gate.to(DEV), aux_scale=1.25, residual=res.to(DEV), alpha=0.5)
+        # batch of 3 weights against one shared activation matrix (the cross-attention K/V projection of all layers)
+        wb = rnd(3, N, K, seed=8)
+        A1 = a.to(DEV)
+        gb = ops.gemm(A1[None].expand(3, M, K), wb.to(DEV))
+        # split-K over the rows (a weight gradient): slabs sized by pa_gemm_effective_splitk in THIS mode, reduced afterwards
+        dy, x = rnd(4096, 192, seed=9), rnd(4096, 128, seed=10)
+        dw, ws, sk = ops.gemm(dy.to(DEV), x.to(DEV), a_kcontig=False, b_kcontig=False, splitk=4, defer=True)
+        ops.splitk_reduce_many([(ws, dw, sk)])
+        taken, declined = sm.stats()
+    torch.cuda.synchronize()
+    assert declined == 0 and taken == 3, (taken, declined)
+    bound = float((a.double().abs() @ b.double().abs().t()).max())
+    assert float((got.cpu().double() - ref).abs().max()) < 2.0 ** -15 * bound
+    for i in range(3):
+        assert _x3_err(gb[i], a.double(), wb[i].double().t()) < 2.0 ** -15
+    assert sk > 1 and _x3_err(dw, dy.double().t(), x.double()) < 2.0 ** -15
+
+
+def test_gemm_x3_retained_images_serve_the_weight_gradient():
+    """The life of a Linear in retain modes 3 (forward) and 2 (backward segment): Y = X W^T keeps the cut X, dX = dY W keeps the cut dY,
+    and dW = dY^T X - alone (pa_gemm) and inside a grouped launch (pa_gemm_group) - finds BOTH operands already cut.  A producer-written
+    image (pa_gemm_split_reserve) is taken as it is: an image of 2 X in place of X doubles the product."""
+    import ctypes as C
+    from plankassembly_amd import _lib as L
+    rows, din, dout = 1024, 256, 384
+    x, w, dy = rnd(rows, din, seed=11), rnd(dout, din, seed=12), rnd(rows, dout, seed=13)
+    X, W, DY = x.to(DEV), w.to(DEV), dy.to(DEV)
+    WT = W.t().contiguous()
+    sm = _SplitMode(3)
+    with sm:
+        y = ops.gemm(X, W)                                            # forward: A = X retained as (hi, hi, lo)
+        sm.config(0)
+        sm.config(2)                                                  # a backward segment
+        dx = ops.gemm(DY, WT)                                         # dX = dY W as a k-contiguous GEMM over W^T: dY retained as (hi, lo, hi)
+        r0 = int(L.lib().pa_gemm_split_reused())
+        dw = ops.gemm(DY, X, a_kcontig=False, b_kcontig=False)        # lone weight gradient: both operands found
+        r1 = int(L.lib().pa_gemm_split_reused())
+        (dwg, dwg2) = ops.dw_group([(DY, X, 1), (DY, X, 1)])          # grouped: both members, both operands
+        r2 = int(L.lib().pa_gemm_split_reused())
+        sm.config(0)
+        # producer-written image: reserve in a fresh forward, write the image of 2 X by hand, run the Linear on X
+        sm.config(3)
+        pat = C.c_int32(-1)
+        ptr = L.lib().pa_gemm_split_reserve(C.c_void_p(X.data_ptr()), rows, din, din, C.byref(pat))
+        assert ptr and pat.value == 0
+        x2 = 2.0 * X
+        hi = x2.to(torch.bfloat16)
+        lo = (x2 - hi.float()).to(torch.bfloat16)
+        sm.image_view(ptr, rows, din).copy_(torch.cat([hi, hi, lo], dim=1))
+        m0 = int(L.lib().pa_gemm_split_made_hits())
+        y2 = ops.gemm(X, W)
+        m1 = int(L.lib().pa_gemm_split_made_hits())
+    torch.cuda.synchronize()
+    assert r1 - r0 == 2 and r2 - r1 == 4, (r0, r1, r2)
+    assert m1 - m0 == 1
+    x64, w64, dy64 = x.double(), w.double(), dy.double()
+    assert _x3_err(y, x64, w64.t()) < 2.0 ** -15
+    assert _x3_err(dx, dy64, w64) < 2.0 ** -15
+    for g in (dw, dwg, dwg2):
+        assert _x3_err(g, dy64.t(), x64) < 2.0 ** -15
+    assert _x3_err(y2, 2.0 * x64, w64.t()) < 2.0 ** -15               # the hand-written image was what the GEMM multiplied
