@@ -575,6 +575,14 @@ int pa_decode_step(pa_model* m, void* stream);
  * Experimental: on MI355X / ROCm 7.2 the cross-queue event edges cost more than the overlap. */
 int pa_decode_step_pair(pa_model* a, pa_model* b, void* stream_a, void* stream_b);
 int pa_decode_buffers(pa_model* m, void** tokens, void** attach, void** first_end, void** t_dev);
+/* Cross-attention of one decode step in absorbed ("multi-query") form (reference plankassembly/models.py:284-307, the
+ * cross-attention of nn.TransformerDecoderLayer with K = W_k memory + b_k, V = W_v memory + b_v): per batch element and head
+ * ctx[b][h][:] = sum_s softmax_s(qt[b][h] . mem[s]) mem[s] over the element's memory rows, where the caller has put
+ * qt_h = scale log2(e) W_k,h^T q_h into `qt` and applies W_v,h (+ b_v,h) to ctx afterwards.  bf16, d == 512, H <= 8
+ * (PA_ESHAPE otherwise).  qt, ctx: [B][H][512]; mem: dense [B][S][512] with optional kpm [B][S] (1 = PAD) or packed rows
+ * with cu [B + 1]. */
+int pa_dec_cross_mq(void* ctx, const void* qt, const void* mem, const uint8_t* kpm, const int32_t* cu, int32_t B, int32_t S,
+                    int32_t H, int32_t d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,12 +38,21 @@ struct DecodeLayout {
     bool f32res = false;
     void *zb = nullptr, *z2b = nullptr, *xb = nullptr;
     float* hf = nullptr;
+    // Absorbed ("multi-query") cross-attention (csrc/decode_mq.h; bf16, d_model 512, <= 8 heads, with `fold`): the step attends over a
+    // copy of the encoder output rows (`mem`) instead of per-layer K / V caches.  qt / ctx: [B][H][d] query / context rows of a step;
+    // wo_t / bo_t per layer: W_o,h W_v,h as one [d][H d] bf16 matrix and b_o + W_o b_v.
+    bool mq = false;
+    void *mem = nullptr, *qt = nullptr, *ctx = nullptr;
+    std::vector<void*> wo_t; std::vector<float*> bo_t;
 };
 
 namespace {
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 constexpr float LOG2E_F = 1.4426950408889634f;
+}  // namespace
+#include "decode_mq.h"
+namespace {
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -496,17 +505,55 @@ int linear_norm_a32(pa_model* m, const void* Zb, const float* Zf, const void* Wf
     return pa_gemm_norm_a(&g, &x, st);
 }
 
+// Which forms the step takes (shared by the workspace layout and pa_decode_begin).
+// fold: LayerNorm folded into its consumer Linear (bf16 decode): 17 LayerNorm launches fewer per step.
+// On the ring kernel (gemm3s_kernel's prologue statistics pass) this was MEASURED NULL on MI355X (B 256, 1024 steps, one lane:
+// 1.228 ms / step folded against 1.210 - the statistics pass pays the memory round trips the LayerNorm launch paid).  On
+// gemm_skinny_kernel the Z tile is resident in LDS and the statistics cost no round trip: 1.072 against 1.089 ms / step.  So: on by
+// default exactly where pa_gemm_norm_a takes the skinny kernel (d_model 512, at most 512 rows); PLANK_DECODE_FOLD_LN=0 / 1 forces.
+// The exact-f32 step folds too since round 4 (pa_ln_fold_weights_f32 + the f32 skinny kernel with the statistics taken from
+// the rows themselves): 17 LayerNorm launches fewer per step - measured +0.5 % only (B 256: 1.995 vs 2.005 ms / step; the folded
+// Linears re-read their rows for the statistics), token-exact against the reference in every decode test.  d_model 512, <= 512 rows.
+// f32res: f32 residual stream inside the bf16 step (see DecodeLayout::f32res): on wherever every Linear of the step takes the skinny
+// kernel (d_model 512, at most 512 rows).  tests/bf16_decode_sim.py / profiles/r04_bf16_decode_rounding_sim.txt: exact-prefix
+// agreement with the f32 tokens 0.40 -> 0.63-0.70 on 32 rows x 128 steps.  PLANK_DECODE_F32_RESID=0 restores the all-bf16 step.
+// mq: absorbed cross-attention (csrc/decode_mq.h) wherever the fold is on in bf16 with at most 8 heads; PLANK_DECODE_MQ=0 restores
+// the per-layer K / V caches.
+struct DecodeModes { bool fold, f32res, mq; };
+DecodeModes decode_modes(const pa_model_cfg& c, int B, int S) {
+    const int d = c.d_model;
+    static const int fold_force = getenv("PLANK_DECODE_FOLD_LN") ? atoi(getenv("PLANK_DECODE_FOLD_LN")) : -1;
+    static const int f32res_env = getenv("PLANK_DECODE_F32_RESID") ? atoi(getenv("PLANK_DECODE_F32_RESID")) : 1;
+    static const int mq_env = getenv("PLANK_DECODE_MQ") ? atoi(getenv("PLANK_DECODE_MQ")) : 1;
+    const bool fold_env = fold_force >= 0 ? fold_force != 0 : (d == 512 && B <= 512);
+    DecodeModes r;
+    r.fold = fold_env && c.dtype == PA_BF16 && d % 64 == 0 && c.d_ff % 32 == 0 && c.d_ff >= d && (size_t)((B + 63) / 64) * ((3 * d + 63) / 64) <= 512;
+    if (c.dtype == PA_F32) r.fold = fold_env && d == 512 && B <= 512 && c.d_ff % 32 == 0 && c.d_ff >= d;   // (N < K: pa_gemm_norm_a's f32 form cannot materialise y - ADVICE r4)
+    r.f32res = r.fold && c.dtype == PA_BF16 && f32res_env != 0 && d == 512 && B <= 512 && c.d_ff % 512 == 0;
+    r.mq = r.fold && c.dtype == PA_BF16 && mq_env != 0 && d == MQ_D && B <= 512 && c.n_head >= 1 && c.n_head <= MQ_MAXH && d % c.n_head == 0 && S <= MQ_MAXS;
+    return r;
+}
+
 size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tmax) {
     const pa_model_cfg& c = m->cfg;
     const size_t e = c.dtype == PA_BF16 ? 2 : 4, d = c.d_model, ff = c.d_ff;
+    const DecodeModes md = decode_modes(c, B, S);
     Arena a{base, 0};
     L->B = B; L->S = S; L->Tmax = Tmax;
-    L->cross_k.resize(c.n_dec); L->cross_v.resize(c.n_dec); L->self_k.resize(c.n_dec); L->self_v.resize(c.n_dec);
+    L->cross_k.assign(c.n_dec, nullptr); L->cross_v.assign(c.n_dec, nullptr); L->self_k.resize(c.n_dec); L->self_v.resize(c.n_dec);
+    L->wo_t.assign(c.n_dec, nullptr); L->bo_t.assign(c.n_dec, nullptr);
     for (int i = 0; i < c.n_dec; ++i) {
-        L->cross_k[i] = a.take((size_t)B * S * d * e); L->cross_v[i] = a.take((size_t)B * S * d * e);
+        if (!md.mq) { L->cross_k[i] = a.take((size_t)B * S * d * e); L->cross_v[i] = a.take((size_t)B * S * d * e); }
         L->self_k[i] = a.take((size_t)B * Tmax * d * e); L->self_v[i] = a.take((size_t)B * Tmax * d * e);
     }
-    L->kv_tmp = a.take((size_t)B * S * 2 * d * e);
+    L->mem = L->qt = L->ctx = nullptr;
+    if (md.mq) {
+        const size_t H = c.n_head;
+        L->mem = a.take((size_t)B * S * d * 2);
+        L->qt = a.take((size_t)B * H * d * 2); L->ctx = a.take((size_t)B * H * d * 2);
+        for (int i = 0; i < c.n_dec; ++i) { L->wo_t[i] = a.take(d * H * d * 2); L->bo_t[i] = (float*)a.take(d * 4); }
+    }
+    L->kv_tmp = md.mq ? nullptr : a.take((size_t)B * S * 2 * d * e);
     L->hid_cache = a.take((size_t)B * Tmax * d * e);
     // (x / y / z / z2 are sized for f32 rows: the bf16 step keeps its residual stream in f32, `f32res`)
     L->x = a.take(B * d * 4); L->qkv = a.take(B * 3 * d * e); L->ao = a.take(B * d * e); L->z = a.take(B * d * 4);
@@ -569,6 +616,18 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
     if (part < 0 || part >= n_parts) return PA_EINVAL;
     auto fence_in = [&]() -> int { if (wait_ev) { hipError_t e = hipStreamWaitEvent(s, wait_ev, 0); if (e != hipSuccess) return (int)e; } return 0; };
     auto fence_out = [&]() -> int { if (rec_ev) { hipError_t e = hipEventRecord(rec_ev, s); if (e != hipSuccess) return (int)e; } return 0; };
+    // absorbed cross-attention of layer i (csrc/decode_mq.h): q~_h = scale log2e W_k,h^T q_h for all heads, then attention over the
+    // memory rows themselves; the Linear behind it applies W_o,h W_v,h to the context rows (wo_t)
+    auto cross_mq = [&](pa_model* mm, int i, hipStream_t ss) -> int {
+        const int H = c.n_head, pbi = mm->dec_base(i);
+        const bf16* Wk = (const bf16*)mm->pl[pbi + D_CA_IN_W] + (size_t)d * d;
+        const float sl = LOG2E_F / sqrtf((float)(d / H));
+        if (d / H == 64) PA_LAUNCH(mq_expand_q_kernel<64>, dim3((B + MQ_XR - 1) / MQ_XR, H), dim3(512), 0, ss, (bf16*)L->qt, (const bf16*)L->q, d, Wk, B, d, H, sl);
+        else PA_LAUNCH(mq_expand_q_kernel<0>, dim3((B + MQ_XR - 1) / MQ_XR, H), dim3(512), 0, ss, (bf16*)L->qt, (const bf16*)L->q, d, Wk, B, d, H, sl);
+        RC(fence_in());
+        RC(launch_cross_mq((bf16*)L->ctx, (const bf16*)L->qt, (const bf16*)L->mem, L->cu ? nullptr : L->kpm, L->cu, B, S, H, d, ss));
+        return fence_out();
+    };
     // PLANK_DECODE_FUSE_TAIL=1 (default 0): the sampling kernel also writes the next step's input embedding and advances the step
     // counter, and (f32-residual step) norm3 + decoder.norm + the bf16 copy are one launch: 57 -> 52 launches per step, tokens
     // identical (tests/test_model_gpu.py decode tests pass either way).  MEASURED NULL on MI355X, round 5, B 256 x 1024 steps under
@@ -592,7 +651,8 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
         float* xf = (float*)L->x; float* yf = (float*)L->y; float* zf = (float*)L->z; float* z2f = (float*)L->z2;
         if (part >= 2 && (part & 1) == 0) {    // feed-forward block of the previous layer
             const int j = part / 2 - 1, pb = m->dec_base(j);
-            RC(linear_res32(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), yf, z2f, L->z2b, B, d, d, st));
+            if (L->mq) RC(linear_res32(m, L->ctx, L->wo_t[j], L->bo_t[j], yf, z2f, L->z2b, B, d, c.n_head * d, st));     // W_o,h W_v,h on the context rows
+            else RC(linear_res32(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), yf, z2f, L->z2b, B, d, d, st));
             RC(linear_norm_a32(m, L->z2b, z2f, L->fw[2][j], L->fu[2][j], L->fv[2][j], PF(pb + D_N2_W), PF(pb + D_N2_B), c.eps_layer, xf,
                                L->ff, ff, B, ff, d, act, st));
             RC(gelu_ff());
@@ -645,6 +705,7 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
             RC(linear_res32(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), xf, z2f, L->z2b, B, d, d, st));
             RC(linear_norm_a32(m, L->z2b, z2f, L->fw[1][i], L->fu[1][i], L->fv[1][i], PF(pb + D_N1_W), PF(pb + D_N1_B), c.eps_layer, yf,
                                L->q, d, B, d, d, 0, st));
+            if (L->mq) { RC(cross_mq(m, i, s)); return 0; }
             RC(fence_in());
             RC(launch_attn<T>(m, (T*)L->ao, (const T*)L->q, d, (T*)L->cross_k[i], (T*)L->cross_v[i], S, L->cu ? nullptr : L->kpm, S,
                               L->t_dev, B, st, L->cu));
@@ -657,7 +718,8 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
         const int j = part / 2 - 1, pb = m->dec_base(j);
         if (fold) {
             // z2 = ao Wo^T + b + y1;  ff = relu(norm2(z2) W1^T + b1), y2 -> x;  z3 = ff W2^T + b2 + y2 -> z
-            RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z2, d, B, d, d, 0, L->y, -1, st));
+            if (L->mq) RC(linear(m, L->ctx, L->wo_t[j], L->bo_t[j], L->z2, d, B, d, c.n_head * d, 0, L->y, -1, st));
+            else RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z2, d, B, d, d, 0, L->y, -1, st));
             RC(linear_norm_a(m, L->z2, L->fw[2][j], L->fu[2][j], L->fv[2][j], PF(pb + D_N2_W), PF(pb + D_N2_B), c.eps_layer, L->x,
                              L->ff, ff, B, ff, d, act, st));
             RC(gelu_ff());
@@ -703,6 +765,7 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
             RC(linear(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), L->z2, d, B, d, d, 0, x, -1, st));
             RC(linear_norm_a(m, L->z2, L->fw[1][i], L->fu[1][i], L->fv[1][i], PF(pb + D_N1_W), PF(pb + D_N1_B), c.eps_layer, L->y,
                              L->q, d, B, d, d, 0, st));
+            if (L->mq) { RC(cross_mq(m, i, s)); return 0; }
         } else {
             RC(linear_ln(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), x, L->z, L->y, PF(pb + D_N1_W), PF(pb + D_N1_B), c.eps_layer, B, d, st));
             RC(linear(m, L->y, PL(pb + D_CA_IN_W), PF(pb + D_CA_IN_B), L->q, d, B, d, d, 0, nullptr, -1, st));
@@ -752,7 +815,14 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
     const size_t e = c.dtype == PA_BF16 ? 2 : 4;
     const void* memory = c.has_enc_norm ? m->memory : m->X[c.n_enc];
     hipStream_t s = (hipStream_t)stream;
-    for (int i = 0; i < c.n_dec; ++i) {       // cross-attention K/V of the memory: once per sequence, not per step
+    const DecodeModes md = decode_modes(c, B, S);
+    L->fold = md.fold; L->f32res = md.f32res; L->mq = md.mq;           // (what each is and where it was measured: decode_modes)
+    if (L->mq) {
+        // absorbed cross-attention: the step reads the encoder output rows themselves - no K / V projection of the memory at all
+        hipError_t hm = hipMemcpyAsync(L->mem, memory, (size_t)m->NE * d * 2, hipMemcpyDeviceToDevice, s);
+        if (hm != hipSuccess) return (int)hm;
+    }
+    for (int i = 0; i < c.n_dec && !L->mq; ++i) {       // cross-attention K/V of the memory: once per sequence, not per step
         const int pb = m->dec_base(i);
         RC(linear(m, memory, (const char*)m->pl[pb + D_CA_IN_W] + (size_t)d * d * e, (const float*)m->pf[pb + D_CA_IN_B] + d,
                   L->kv_tmp, 2 * d, m->NE, 2 * d, d, 0, nullptr, -1, stream));
@@ -763,25 +833,7 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
             PA_LAUNCH(dec_split_heads_kernel<float>, dim3(2048), dim3(256), 0, s, (float*)L->cross_k[i], (float*)L->cross_v[i],
                       (const float*)L->kv_tmp, (int64_t)m->NE, S, d, c.n_head, m->batch.cu_in, m->batch.rowmap);
     }
-    // LayerNorm folded into its consumer Linear (bf16 decode): 17 LayerNorm launches fewer per step.
-    // On the ring kernel (gemm3s_kernel's prologue statistics pass) this was MEASURED NULL on MI355X (B 256, 1024 steps, one lane:
-    // 1.228 ms / step folded against 1.210 - the statistics pass pays the memory round trips the LayerNorm launch paid).  On
-    // gemm_skinny_kernel the Z tile is resident in LDS and the statistics cost no round trip: 1.072 against 1.089 ms / step.  So: on by
-    // default exactly where pa_gemm_norm_a takes the skinny kernel (d_model 512, at most 512 rows); PLANK_DECODE_FOLD_LN=0 / 1 forces.
-    static const int fold_force = getenv("PLANK_DECODE_FOLD_LN") ? atoi(getenv("PLANK_DECODE_FOLD_LN")) : -1;
-    const bool fold_env = fold_force >= 0 ? fold_force != 0 : (d == 512 && B <= 512);
-    L->fold = fold_env && c.dtype == PA_BF16 && d % 64 == 0 && c.d_ff % 32 == 0 && c.d_ff >= d && (size_t)((B + 63) / 64) * ((3 * d + 63) / 64) <= 512;
-    // The exact-f32 step folds too since round 4 (pa_ln_fold_weights_f32 + the f32 skinny kernel with the statistics taken from
-    // the rows themselves): 17 LayerNorm launches fewer per step - measured +0.5 % only (B 256: 1.995 vs 2.005 ms / step; the folded
-    // Linears re-read their rows for the statistics), token-exact against the reference in every decode test.  d_model 512, <= 512 rows.
-    // PLANK_DECODE_FOLD_LN=0 disables it as it does for bf16.
-    if (c.dtype == PA_F32) L->fold = fold_env && d == 512 && B <= 512 && c.d_ff % 32 == 0 && c.d_ff >= d;   // (N < K: pa_gemm_norm_a's f32 form cannot materialise y - ADVICE r4)
     const bool fold32 = L->fold && c.dtype == PA_F32;
-    // f32 residual stream inside the bf16 step (see DecodeLayout::f32res): on wherever every Linear of the step takes the skinny
-    // kernel (d_model 512, at most 512 rows).  tests/bf16_decode_sim.py / profiles/r04_bf16_decode_rounding_sim.txt: exact-prefix
-    // agreement with the f32 tokens 0.40 -> 0.63-0.70 on 32 rows x 128 steps.  PLANK_DECODE_F32_RESID=0 restores the all-bf16 step.
-    static const int f32res_env = getenv("PLANK_DECODE_F32_RESID") ? atoi(getenv("PLANK_DECODE_F32_RESID")) : 1;
-    L->f32res = L->fold && c.dtype == PA_BF16 && f32res_env != 0 && d == 512 && B <= 512 && c.d_ff % 512 == 0;
     if (L->fold) {
         for (int i = 0; i < c.n_dec; ++i) {
             const int pb = m->dec_base(i);
@@ -795,6 +847,9 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
                 RC(foldw(L->fw[0][i], L->fu[0][i], L->fv[0][i], F(pb + D_SA_IN_W), F(pb + D_SA_IN_B), F(pp + D_N3_W), F(pp + D_N3_B), 3 * d));
             }
             RC(foldw(L->fw[1][i], L->fu[1][i], L->fv[1][i], F(pb + D_CA_IN_W), F(pb + D_CA_IN_B), F(pb + D_N1_W), F(pb + D_N1_B), d));
+            if (L->mq)      // W~o = W_o,h W_v,h, b~o = b_o + W_o b_v for the Linear behind the absorbed attention (csrc/decode_mq.h)
+                PA_LAUNCH(mq_absorb_o_kernel, dim3(d), dim3(256), 0, s, (bf16*)L->wo_t[i], L->bo_t[i], F(pb + D_CA_OUT_W), F(pb + D_CA_OUT_B),
+                          F(pb + D_CA_IN_W), F(pb + D_CA_IN_B), d, c.n_head);
             RC(foldw(L->fw[2][i], L->fu[2][i], L->fv[2][i], F(pb + D_L1_W), F(pb + D_L1_B), F(pb + D_N2_W), F(pb + D_N2_B), c.d_ff));
         }
     }
@@ -851,6 +906,16 @@ extern "C" int pa_decode_step_pair(pa_model* a, pa_model* b, void* stream_a, voi
     RC(step_part_any(a, n, stream_a, nullptr, nullptr));
     RC(step_part_any(b, n, stream_b, nullptr, nullptr));
     return 0;
+}
+
+// The absorbed cross-attention launch on its own (csrc/decode_mq.h; kernel tests / tools): ctx [B][H][512] (bf16) = per head the
+// softmax(qt_h . m_s)-weighted sum of the memory rows m_s; qt [B][H][512] carries scale * log2 e; mem [rows][512] bf16 - dense
+// [B][S] rows with the optional key-padding mask kpm [B][S] (1 = PAD), or packed rows with cu [B + 1].
+extern "C" int pa_dec_cross_mq(void* ctx, const void* qt, const void* mem, const uint8_t* kpm, const int32_t* cu, int32_t B,
+                               int32_t S, int32_t H, int32_t d, void* stream) {
+    if (!ctx || !qt || !mem) return PA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(mem)) & 15) return PA_EALIGN;
+    return launch_cross_mq((bf16*)ctx, (const bf16*)qt, (const bf16*)mem, kpm, cu, B, S, H, d, (hipStream_t)stream);
 }
 
 extern "C" int pa_decode_buffers(pa_model* m, void** tokens, void** attach, void** first_end, void** t_dev) {

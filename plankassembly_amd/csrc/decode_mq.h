@@ -1,0 +1,302 @@
+// Cross-attention of the greedy decode step in ABSORBED ("multi-query") form - bf16, d_model 512, at most 8 heads.
+//
+// Reference: plankassembly/models.py:284-307 runs nn.TransformerDecoderLayer's cross-attention with K = W_k memory + b_k and
+// V = W_v memory + b_v.  The K/V-cache form of it (dec_attn_kernel) streams 2 x [B][S][d] per layer and step: at B 256, S 1024 that
+// is 537 MB per launch, 3.2 of the 4.9 GB a decode step moves, and the kernel sits at the HBM wall.  The projections are linear, so
+//     q_h . k_s  =  (W_k,h^T q_h) . m_s  +  q_h . b_k,h          (the second term is constant over s: it cancels in the softmax)
+//     sum_s p_s v_s  =  W_v,h (sum_s p_s m_s)  +  b_v,h           (sum_s p_s = 1)
+// i.e. every head can attend over the ENCODER OUTPUT ROWS m_s themselves with a 512-wide query qt_h = W_k,h^T q_h, and the value
+// projection moves behind the softmax.  All heads of a batch element then read the same rows: one [S][d] stream per layer and step
+// (268 MB) instead of two - half the bytes of the kernel that bounds the step - for 8 x the (tiny) arithmetic, which goes to the
+// matrix pipe: per 16-key tile S^T[16 keys][16 head slots] = M_tile[16][512] Qt^T (16 x v_mfma_f32_16x16x32_bf16) and
+// O^T[512][16 head slots] += M_tile^T P^T (32 x v_mfma_f32_16x16x16_bf16, the A operand read from the same natural LDS image with
+// ds_read_b64_tr_b16).  The value side is folded into the Linear behind the attention (pa_decode_begin: W~o = W_o,h W_v,h, one
+// [d][H d] matrix per layer); the query side is a small launch of its own (mq_expand_q_kernel).
+//
+// One block per batch element, four waves.  All waves walk every 16-key tile: a wave recomputes the tile's 16 x 16 scores (the
+// matrix pipe has the room) and owns 128 of the 512 output dims (8 accumulator blocks = 32 registers), so there is no per-wave
+// partial to merge and the registers stay free for read-ahead.  Tiles are DMA'd straight into an 8-stage LDS ring
+// (global_load_lds, 16 KB per tile, a wave issues 4 of a tile's 16 rows): 7 tiles = 112 KB per CU are in flight while one is
+// multiplied; one raw s_barrier per tile (counted s_waitcnt vmcnt - a __syncthreads() would drain the DMA queue).
+#pragma once
+
+namespace {
+typedef short mq_s16x4 __attribute__((ext_vector_type(4)));
+constexpr int MQ_D = 512, MQ_KT = 16, MQ_ROW = MQ_D * 2, MQ_TILE = MQ_KT * MQ_ROW, MQ_NS = 8, MQ_MAXH = 8;
+constexpr int MQ_MAXS = 16384;                // key-padding mask bytes kept in LDS behind the ring
+
+// LDS image of a tile: row r (key) at r * 1024; its 16-byte chunk c sits at position (c & 48) | ((c ^ r) & 15) so that the 16 rows a
+// fragment read touches fall into 16 different bank groups.
+// max / sum over the four 16-lane rows of a wave (same column = head slot): gfx950's v_permlane16_swap / v_permlane32_swap exchange
+// whole rows between two registers in the VALU (SWAP), against two ds_bpermute round trips through the LDS crossbar.
+template <bool SWAP> __device__ __forceinline__ float mq_rows_max(float v) {
+    if constexpr (SWAP) {
+        const unsigned u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        const float a = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+        const unsigned ua = __float_as_uint(a);
+        const auto r2 = __builtin_amdgcn_permlane32_swap(ua, ua, false, false);
+        return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+    } else {
+        v = fmaxf(v, __shfl_xor(v, 16));
+        return fmaxf(v, __shfl_xor(v, 32));
+    }
+}
+
+template <int AUX, bool SWAP, bool MASK>
+__global__ __launch_bounds__(256, 1) void dec_cross_mq_kernel(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* kpm,
+                                                              const int32_t* cu, int S, int H) {
+    extern __shared__ __attribute__((aligned(256))) char mq_smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int row0 = cu ? cu[b] : b * S;
+    const int Lk = cu ? cu[b + 1] - row0 : S;
+    bf16* out = ctx + (size_t)b * H * MQ_D;
+    if (Lk <= 0) {                                                      // (block-uniform) no key: zeros, as dec_attn_kernel
+        for (int idx = tid; idx < H * MQ_D; idx += 256) out[idx] = (bf16)0.f;
+        return;
+    }
+    const uint8_t* mk = MASK ? kpm + (size_t)b * S : nullptr;      // (MASK: dense rows with a key-padding mask)
+    uint8_t* mlds = reinterpret_cast<uint8_t*>(mq_smem + MQ_NS * MQ_TILE);
+    const int ntiles = (Lk + MQ_KT - 1) / MQ_KT;
+    if constexpr (MASK) {
+        for (int s = tid; s < ntiles * MQ_KT; s += 256) mlds[s] = s < Lk ? mk[s] : (uint8_t)1;
+        __syncthreads();
+    }
+    // query fragments (B operand of the score product): head slot n, dims 32 ks + 8 g .. + 7; slots >= H are zero
+    u32x4 qf[16];
+    {
+        const bf16* qrow = qt + ((size_t)b * H + min(n, H - 1)) * MQ_D + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            u32x4 v = *reinterpret_cast<const u32x4*>(qrow + 32 * ks);
+            if (n >= H) v = u32x4{0u, 0u, 0u, 0u};
+            qf[ks] = v;
+        }
+        // the query is complete HERE, in front of the DMA prologue: left to itself hipcc waits for it with vmcnt(0) behind the
+        // prologue, i.e. for all seven tiles, before the first MFMA
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]),
+                     "+v"(qf[8]), "+v"(qf[9]), "+v"(qf[10]), "+v"(qf[11]), "+v"(qf[12]), "+v"(qf[13]), "+v"(qf[14]), "+v"(qf[15]) :: "memory");
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)mq_smem;
+    const uint32_t abase = (uint32_t)n * MQ_ROW + (uint32_t)((g ^ n) << 4);                 // score A operand: row n, chunk 4 ks + g
+    const int keyt = 4 * g + (n >> 2);
+    // transposing read of this wave's dims 128 wave + 16 nb + 4 (n & 3) ..: row keyt, chunk 16 wave + 2 nb + ((n >> 1) & 1)
+    const uint32_t tbase = (uint32_t)keyt * MQ_ROW + (uint32_t)((((n >> 1) & 1) ^ keyt) << 4) + (uint32_t)(n & 1) * 8u;
+    uint32_t toffr[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) toffr[nb] = (uint32_t)wave * 256u + (tbase ^ (uint32_t)(nb << 5));
+    const char* const mbase = reinterpret_cast<const char*>(mem + (size_t)row0 * MQ_D);
+    const uint32_t lch = (uint32_t)(lane & 48);
+    // The DMA is inline asm on purpose: as a builtin hipcc knows an LDS-DMA write is in flight and, unable to tell which reads it
+    // may alias, puts s_waitcnt vmcnt(0) in front of the transposing LDS reads - the whole ring would be waited for every tile.
+    // Ordering is ours: counted s_waitcnt vmcnt + s_barrier below (the compiler's own vmcnt waits only become more conservative).
+    // (m0 is set and consumed inside one asm statement; it is a reserved register that hipcc never keeps a value in across code.)
+    auto issue = [&](int t) {
+        const uint32_t dst = lds0 + (uint32_t)(t & (MQ_NS - 1)) * MQ_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * wave + i;                                 // (wave-uniform) this wave's rows of the tile
+            const int row = min(t * MQ_KT + r, Lk - 1);                 // rows past the end re-read the last row; masked below
+            const uint32_t c = lch | (uint32_t)((lane ^ r) & 15);
+            const char* src = mbase + (size_t)row * MQ_ROW + c * 16u;
+            const uint32_t ldst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dst + (uint32_t)r * MQ_ROW));
+            if constexpr (AUX == 2)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(src), "s"(ldst) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(ldst) : "memory");
+        }
+    };
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 fa[16];                                                       // the 16 score fragments of a tile, read one tile ahead
+    auto read_scores = [&](int t) {
+        const char* base = mq_smem + (t & (MQ_NS - 1)) * MQ_TILE;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            fa[ks] = *reinterpret_cast<const u32x4*>(base + (abase ^ (uint32_t)((ks & 3) << 6)) + (ks >> 2) * 256);
+        __builtin_amdgcn_sched_barrier(0);                              // all reads issued here, not re-serialised in front of their MFMAs
+    };
+    auto scores = [&]() -> f32x4 {
+        f32x4 sp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            sp[ks & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&fa[ks]), *reinterpret_cast<const bf16x8*>(&qf[ks]),
+                                                                 sp[ks & 3], 0, 0, 0);
+        return (sp[0] + sp[1]) + (sp[2] + sp[3]);
+    };
+    // softmax update + O^T += M^T P^T for tile t; s4[i]: key t * 16 + 4 g + i, head slot n (scale * log2 e came in through the query)
+    // the tile's transposed fragments (A operand of O^T += M^T P^T: dims 128 wave + 16 nb .., keys 4 g ..): requested right behind the
+    // score MFMAs, in FRONT of the next tile's 16 score fragments (LDS returns in order: they land first)
+    mq_s16x4 ta[8];
+    auto read_tr = [&](int t) {
+        const uint32_t soff = (uint32_t)(t & (MQ_NS - 1)) * MQ_TILE;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+            ta[nb] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) mq_s16x4*)(mq_smem + soff + toffr[nb]));
+    };
+    auto finish = [&](int t, const f32x4& s4, uint32_t m4) {
+        const int key0 = t * MQ_KT + 4 * g;
+        float s[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool valid = (key0 + i < Lk) && !((m4 >> (8 * i)) & 0xffu);
+            s[i] = valid ? s4[i] : -INFINITY;
+        }
+        const float mx = mq_rows_max<SWAP>(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+        float p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = __builtin_amdgcn_exp2f(s[i] - m_safe);
+        l_run = l_run * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {               // (wave-uniform) a reference point moved: rescale
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) acc[nb] *= alpha;
+        }
+        u32x2 pbu; pbu[0] = pack_bf16(p[0], p[1]); pbu[1] = pack_bf16(p[2], p[3]);
+        const mq_s16x4 pb = *reinterpret_cast<const mq_s16x4*>(&pbu);
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ta[nb], pb, acc[nb], 0, 0, 0);   // O^T[128 wave + 16 nb + 4 g + i][n]
+    };
+
+    // Ring schedule (8 stages, tile t in stage t & 7): tiles 0..6 are requested up front; in the middle of iteration t - behind the
+    // score MFMAs of tile t - a wave waits for ITS rows of tile t + 1 (at most the 5 younger tiles' 20 DMAs still outstanding),
+    // the barrier makes that true for every wave's rows and says every wave is through with tile t - 1, whose stage then takes tile
+    // t + 7; the score fragments of tile t + 1 are read there, one tile ahead, so their LDS latency hides behind tile t's softmax.
+#pragma unroll
+    for (int t = 0; t < MQ_NS - 1; ++t)
+        if (t < ntiles) issue(t);
+    if (ntiles >= MQ_NS - 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_scores(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const f32x4 s4 = scores();
+        uint32_t m4 = 0;                                                // mask bytes of this lane's 4 keys (read ahead of the next tile's fragments)
+        if constexpr (MASK) m4 = *reinterpret_cast<const uint32_t*>(mlds + t * MQ_KT + 4 * g);
+        read_tr(t);
+        if (t + 1 < ntiles) {
+            if (t + MQ_NS - 2 < ntiles) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");      // tiles t + 1 .. t + 6 outstanding
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + MQ_NS - 1 < ntiles) issue(t + MQ_NS - 1);
+            read_scores(t + 1);
+        }
+        finish(t, s4, m4);
+    }
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    if (n < H) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        bf16* orow = out + (size_t)n * MQ_D + 128 * wave + 4 * g;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            u32x2 u; u[0] = pack_bf16(acc[nb][0] * inv, acc[nb][1] * inv); u[1] = pack_bf16(acc[nb][2] * inv, acc[nb][3] * inv);
+            *reinterpret_cast<u32x2*>(orow + 16 * nb) = u;
+        }
+    }
+}
+
+// qt[b][h][j] = sl * sum_c q[b][h dh + c] * W_k[h dh + c][j]  (q = the step's cross-attention query rows, bias included; W_k = rows
+// d .. 2d of the layer's bf16 in_proj weight, [d][d]).  A launch of its own behind the (LayerNorm-folded) query Linear: folding
+// W_k,h^T W_q,h into that Linear instead makes it a [B][512] x [512][H 512] product - measured 18 us per layer on the 32 x 32-tile
+// skinny kernel (four rounds of 1 024 blocks) against 6 + ~4 us for the two launches.  grid (B / 8, H), 512 threads: a thread owns
+// one column j of 8 rows; the weights are read once per block (coalesced over j), the 8 x dh query values come from LDS.
+constexpr int MQ_XR = 8;
+template <int DH>        // DH = head dim when it is 64 (every weight load of a thread issued before the first use: one round trip), else 0
+__global__ __launch_bounds__(512) void mq_expand_q_kernel(bf16* qt, const bf16* q, int ldq, const bf16* Wk, int B, int d, int H, float sl) {
+    __shared__ __attribute__((aligned(16))) float qs[MQ_XR][MQ_D];                 // (dh <= d)
+    const int h = blockIdx.y, r0 = blockIdx.x * MQ_XR, dh = DH ? DH : d / H, tid = threadIdx.x;
+    for (int e = tid; e < MQ_XR * dh; e += 512) {
+        const int r = e / dh, c = e - r * dh;
+        qs[r][c] = r0 + r < B ? (float)q[(size_t)(r0 + r) * ldq + h * dh + c] * sl : 0.f;
+    }
+    const int j = min(tid, d - 1);                    // this thread's column (d <= 512 = the block)
+    const bf16* w = Wk + (size_t)h * dh * d + j;
+    if constexpr (DH > 0) {
+        float wf[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) wf[c] = (float)w[(size_t)c * d];
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < MQ_XR; ++r) {             // (rolled: unrolled, hipcc hoists all 8 x DH LDS reads and spills)
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; c += 4) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(&qs[r][c]);
+                a += (q4[0] * wf[c] + q4[1] * wf[c + 1]) + (q4[2] * wf[c + 2] + q4[3] * wf[c + 3]);
+            }
+            if (tid < d && r0 + r < B) qt[((size_t)(r0 + r) * H + h) * d + j] = (bf16)a;
+        }
+    } else {
+        __syncthreads();
+        float a0[MQ_XR];
+#pragma unroll
+        for (int r = 0; r < MQ_XR; ++r) a0[r] = 0.f;
+#pragma unroll 4
+        for (int c = 0; c < dh; ++c) {
+            const float f0 = (float)w[(size_t)c * d];
+#pragma unroll
+            for (int r = 0; r < MQ_XR; ++r) a0[r] += qs[r][c] * f0;
+        }
+        if (tid < d) {
+#pragma unroll
+            for (int r = 0; r < MQ_XR; ++r)
+                if (r0 + r < B) qt[((size_t)(r0 + r) * H + h) * d + j] = (bf16)a0[r];
+        }
+    }
+}
+// W~o (bf16 [d][H d]) and b~o (f32 [d]):  W~o[n][h d + j] = sum_c W_o[n][h dh + c] W_v[h dh + c][j];  b~o = b_o + W_o b_v.  grid d blocks.
+__global__ __launch_bounds__(256) void mq_absorb_o_kernel(bf16* Wt, float* bt, const float* Wo, const float* bo, const float* Win,
+                                                          const float* bin, int d, int H) {
+    const int nrow = blockIdx.x, dh = d / H;
+    const float* Wv = Win + (size_t)2 * d * d;
+    const float* bv = bin + 2 * d;
+    for (int col = threadIdx.x; col < H * d; col += 256) {
+        const int h = col / d, j = col - h * d;
+        float a = 0.f;
+        for (int c = 0; c < dh; ++c) a += Wo[(size_t)nrow * d + h * dh + c] * Wv[(size_t)(h * dh + c) * d + j];
+        Wt[(size_t)nrow * H * d + col] = (bf16)a;
+    }
+    if (threadIdx.x == 0) {
+        float a = bo[nrow];
+        for (int k = 0; k < d; ++k) a += Wo[(size_t)nrow * d + k] * bv[k];
+        bt[nrow] = a;
+    }
+}
+
+int launch_cross_mq(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* kpm, const int32_t* cu, int B, int S, int H, int d,
+                    hipStream_t s) {
+    if (d != MQ_D || H < 1 || H > MQ_MAXH || B <= 0 || S <= 0 || S > MQ_MAXS) return PA_ESHAPE;
+    const int lds = MQ_NS * MQ_TILE + ((!cu && kpm) ? (S + 31) / 16 * 16 : 0);
+    // PLANK_DECODE_MQ_NT=0: default-policy DMA instead of non-temporal (aux 2; measured in the step, B 256 x 1024: 0.958 vs 0.989 ms); PLANK_DECODE_MQ_SWAP=0: ds_bpermute row reductions instead of v_permlane*_swap
+    static const int nt = getenv("PLANK_DECODE_MQ_NT") ? atoi(getenv("PLANK_DECODE_MQ_NT")) : 1;
+    static const int swap = getenv("PLANK_DECODE_MQ_SWAP") ? atoi(getenv("PLANK_DECODE_MQ_SWAP")) : 1;
+    static bool attr_done = false;
+    constexpr int MAXLDS = MQ_NS * MQ_TILE + MQ_MAXS + 32;
+    typedef void (*KernT)(bf16*, const bf16*, const bf16*, const uint8_t*, const int32_t*, int, int);
+    static const KernT ks[8] = {dec_cross_mq_kernel<0, false, false>, dec_cross_mq_kernel<0, false, true>, dec_cross_mq_kernel<0, true, false>,
+                                dec_cross_mq_kernel<0, true, true>,   dec_cross_mq_kernel<2, false, false>, dec_cross_mq_kernel<2, false, true>,
+                                dec_cross_mq_kernel<2, true, false>,  dec_cross_mq_kernel<2, true, true>};
+    if (!attr_done) {
+        for (KernT k : ks) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
+            if (e != hipSuccess) return (int)e;
+        }
+        attr_done = true;
+    }
+    const bool mask = !cu && kpm;
+    PA_LAUNCH(ks[(nt ? 4 : 0) + (swap ? 2 : 0) + (mask ? 1 : 0)], dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H);
+    return 0;
+}
+
+}  // namespace

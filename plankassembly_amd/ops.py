@@ -413,3 +413,16 @@ def attn_varlen_bwd(dout, q, k, v, o, lse, H, cu_q, cu_k, B, Lq_max, Lk_max, cau
     a.lddo, a.lddq, a.lddk, a.lddv = dout.stride(-2), dq.stride(-2), dk.stride(-2), dv.stride(-2)
     L.check(L.lib().pa_attn_bwd(C.byref(a), L.stream()), "pa_attn_bwd")
     return dq, dk, dv
+
+
+def dec_cross_mq(qt, mem, *, kpm=None, cu=None, S=None):
+    """Absorbed ("multi-query") cross-attention of one decode step (csrc/decode_mq.h, pa_dec_cross_mq): qt [B, H, 512] bf16 (already
+    carrying scale * log2 e), mem dense [B, S, 512] (optional kpm [B, S] uint8, 1 = PAD) or packed [rows, 512] with cu int32 [B + 1].
+    Returns ctx [B, H, 512] bf16: per head the softmax-weighted sum of the element's memory rows."""
+    B, H, d = qt.shape
+    if cu is None:
+        S = mem.shape[1]
+    ctx = torch.empty(B, H, d, dtype=torch.bfloat16, device=qt.device)
+    L.check(L.lib().pa_dec_cross_mq(L.ptr(ctx), L.ptr(qt), L.ptr(mem), L.ptr(kpm), L.ptr(cu), B, int(S), H, d, L.stream()),
+            "pa_dec_cross_mq")
+    return ctx

@@ -1,0 +1,139 @@
+"""Absorbed ("multi-query") cross-attention of the decode step (csrc/decode_mq.h) at the C ABI (pa_dec_cross_mq) against float64:
+dense rows with and without a key-padding mask, packed rows, ragged / tiny / tile-edge lengths, fewer than 8 heads, and the
+algebra it rests on - attention over the memory rows with q~ = W_k^T q equals the reference's attention over K = W_k m + b_k,
+V = W_v m + b_v (plankassembly/models.py:284-307 -> nn.MultiheadAttention)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LN2 = math.log(2.0)
+
+
+def _ref(qt, mem_rows, valid):
+    """qt [H, d] (log2 domain), mem_rows [L, d], valid [L] bool -> ctx [H, d] (float64)."""
+    x = qt.double() @ mem_rows.double().T * LN2
+    x = x.masked_fill(~valid[None, :], float("-inf"))
+    p = torch.softmax(x, dim=-1)
+    return p @ mem_rows.double()
+
+
+def _check(ctx, ref, tol=2e-2):
+    err = (ctx.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= tol * max(scale, 1e-3), (err, scale)
+
+
+@pytest.mark.parametrize("B,S,H", [(3, 16, 8), (2, 48, 8), (4, 200, 8), (2, 1024, 8), (3, 130, 4), (2, 17, 1), (5, 7, 8)])
+@pytest.mark.parametrize("swap", ["1", "0"])
+def test_dense_rows_no_mask(B, S, H, swap, monkeypatch):
+    from plankassembly_amd import ops
+    torch.manual_seed(B * 1000 + S + H)
+    mem = torch.randn(B, S, 512, device="cuda").bfloat16()
+    qt = (torch.randn(B, H, 512, device="cuda") * 0.15).bfloat16()
+    ctx = ops.dec_cross_mq(qt, mem)
+    torch.cuda.synchronize()
+    for b in range(B):
+        _check(ctx[b], _ref(qt[b], mem[b], torch.ones(S, dtype=torch.bool, device="cuda")))
+
+
+@pytest.mark.parametrize("B,S", [(4, 64), (3, 299), (2, 1024), (3, 33)])
+def test_dense_rows_with_key_padding_mask(B, S):
+    from plankassembly_amd import ops
+    torch.manual_seed(S)
+    mem = torch.randn(B, S, 512, device="cuda").bfloat16()
+    qt = (torch.randn(B, 8, 512, device="cuda") * 0.15).bfloat16()
+    lens = torch.randint(1, S + 1, (B,))
+    lens[0] = S
+    kpm = (torch.arange(S)[None, :] >= lens[:, None]).to(torch.uint8).cuda()
+    kpm[1, 0] = 1                                            # a hole in front of a valid key: the mask is per key, not a length
+    ctx = ops.dec_cross_mq(qt, mem, kpm=kpm)
+    torch.cuda.synchronize()
+    for b in range(B):
+        _check(ctx[b], _ref(qt[b], mem[b], kpm[b] == 0))
+
+
+def test_all_keys_masked_gives_zeros():
+    from plankassembly_amd import ops
+    mem = torch.randn(2, 40, 512, device="cuda").bfloat16()
+    qt = torch.randn(2, 8, 512, device="cuda").bfloat16()
+    kpm = torch.zeros(2, 40, dtype=torch.uint8, device="cuda")
+    kpm[1] = 1
+    ctx = ops.dec_cross_mq(qt, mem, kpm=kpm)
+    assert torch.isfinite(ctx.float()).all() and float(ctx[1].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("lens", [[16, 1, 1024, 333], [5, 0, 129], [1024] * 3, [112, 113, 127, 128, 96]])
+def test_packed_rows(lens):
+    from plankassembly_amd import ops
+    torch.manual_seed(sum(lens))
+    B = len(lens)
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = torch.tensor(lens).cumsum(0)
+    rows = int(cu[-1])
+    mem = torch.randn(max(rows, 1), 512, device="cuda").bfloat16()
+    qt = (torch.randn(B, 8, 512, device="cuda") * 0.15).bfloat16()
+    ctx = ops.dec_cross_mq(qt, mem, cu=cu.cuda(), S=max(lens))
+    torch.cuda.synchronize()
+    for b in range(B):
+        if lens[b] == 0:
+            assert float(ctx[b].float().abs().max()) == 0.0
+            continue
+        m = mem[int(cu[b]):int(cu[b + 1])]
+        _check(ctx[b], _ref(qt[b], m, torch.ones(lens[b], dtype=torch.bool, device="cuda")))
+
+
+def test_large_scores_and_moving_reference_point():
+    """Scores spanning +-60 in the log2 domain with the largest key LAST: every tile moves the running reference point (the
+    accumulator rescale path) and the early tiles' probabilities underflow - the result must still be the exact softmax."""
+    from plankassembly_amd import ops
+    torch.manual_seed(3)
+    S = 256
+    mem = torch.randn(1, S, 512, device="cuda").bfloat16()
+    q = torch.randn(8, 512, device="cuda")
+    q = q / q.norm(dim=-1, keepdim=True)
+    # the score of key s grows with s: add a multiple of q to the rows
+    ramp = torch.linspace(-60, 60, S, device="cuda")
+    mem = (mem.float() * 0.05 + ramp[None, :, None] * q[0][None, None, :]).bfloat16()
+    qt = q[None].bfloat16()
+    ctx = ops.dec_cross_mq(qt, mem)
+    torch.cuda.synchronize()
+    _check(ctx[0], _ref(qt[0], mem[0], torch.ones(S, dtype=torch.bool, device="cuda")))
+
+
+def test_absorbed_form_equals_attention_over_projected_keys_and_values():
+    """float64 algebra + the kernel: softmax(q_h . (W_k m + b_k)_h / sqrt(dh)) (W_v m + b_v)_h == W_v,h ctx_h + b_v,h with
+    ctx from pa_dec_cross_mq on q~_h = scale log2e W_k,h^T q_h."""
+    from plankassembly_amd import ops
+    torch.manual_seed(11)
+    B, S, H, d = 3, 150, 8, 512
+    dh = d // H
+    mem = torch.randn(B, S, d, device="cuda").bfloat16()
+    q = torch.randn(B, d, device="cuda", dtype=torch.float64) * 0.5
+    Wk = torch.randn(d, d, device="cuda", dtype=torch.float64) / math.sqrt(d)
+    Wv = torch.randn(d, d, device="cuda", dtype=torch.float64) / math.sqrt(d)
+    bk = torch.randn(d, device="cuda", dtype=torch.float64)
+    bv = torch.randn(d, device="cuda", dtype=torch.float64)
+    m64 = mem.double()
+    K = m64 @ Wk.T + bk
+    V = m64 @ Wv.T + bv
+    qh = q.view(B, H, dh)
+    Kh = K.view(B, S, H, dh).permute(0, 2, 1, 3)
+    Vh = V.view(B, S, H, dh).permute(0, 2, 1, 3)
+    att = torch.softmax(torch.einsum("bhc,bhsc->bhs", qh, Kh) / math.sqrt(dh), dim=-1)
+    want = torch.einsum("bhs,bhsc->bhc", att, Vh).reshape(B, d)
+    sl = 1.0 / math.sqrt(dh) / LN2
+    qt = torch.einsum("bhc,bhcj->bhj", qh, Wk.view(H, dh, d)[None].expand(B, H, dh, d)) * sl
+    # (i) the algebra, in float64: attention over the memory rows with q~, W_v applied behind the softmax
+    p64 = torch.softmax(torch.einsum("bhj,bsj->bhs", qt, m64) * LN2, dim=-1)
+    ctx64 = torch.einsum("bhs,bsj->bhj", p64, m64)
+    alg = torch.einsum("bhj,hcj->bhc", ctx64, Wv.view(H, dh, d)).reshape(B, d) + bv
+    assert (alg - want).abs().max().item() <= 1e-9 * max(1.0, want.abs().max().item())
+    # (ii) the kernel on the bf16-rounded q~ against float64 on the same rounded q~
+    qtb = qt.bfloat16()
+    ctx = ops.dec_cross_mq(qtb, mem).double()
+    pr = torch.softmax(torch.einsum("bhj,bsj->bhs", qtb.double(), m64) * LN2, dim=-1)
+    ctxr = torch.einsum("bhs,bsj->bhj", pr, m64)
+    assert (ctx - ctxr).abs().max().item() <= 2e-2 * ctxr.abs().max().item()
