@@ -720,12 +720,26 @@ def main():
             # algorithmic HBM bytes per step averaged over t: weights + cross K/V + self K/V
             w_bytes = (ND * (4 * D * D + 4 * D * D + 2 * D * FF) + V * D + D * D) * esz
             kv_bytes = 2 * ND * B_DEC * (S_IN + T_DEC / 2) * D * esz
+            kv_cache_form_bytes = w_bytes + kv_bytes
+            # bf16 default since round 5: cross-attention in absorbed form (csrc/decode_mq.h) - every head attends over the encoder
+            # output rows themselves: ONE [S][d] stream per layer and step instead of K and V; W_o,h W_v,h is one [d][H d] matrix
+            mq = (ddtype == "bf16" and D == 512 and H <= 8 and B_DEC <= 512 and os.environ.get("PLANK_DECODE_MQ", "1") != "0"
+                  and os.environ.get("PLANK_DECODE_FOLD_LN", "1") != "0")
+            if mq:
+                w_bytes = (ND * ((6 + H) * D * D + 2 * D * FF) + V * D + D * D) * esz
+                kv_bytes = ND * B_DEC * (S_IN + 2 * T_DEC / 2) * D * esz
             decode[ddtype] = dict(value=B_DEC * T_DEC * world / ddt, unit="tokens/s", batch=B_DEC, max_len=T_DEC, seq_in=S_IN,
                                   ms_per_step=ddt / T_DEC * 1e3, graph=bool(dec.use_graph),
                                   hbm_gbs=(w_bytes + kv_bytes) * T_DEC / ddt / 1e9,
                                   hbm_frac=(w_bytes + kv_bytes) * T_DEC / ddt / 1e9 / PEAK_HBM_GBS,
                                   token_exact=None,      # filled in by the CPU leg (cpu_decode_check); None = not checked
                                   includes="encoder + cross-K/V projection + 1024 decode steps")
+            if mq:
+                decode[ddtype]["cross_attention"] = ("absorbed: q~_h = W_k,h^T q_h attends over the memory rows, W_v behind the softmax "
+                                                     "(no cross-K/V projection, one [S][d] stream per layer and step)")
+                decode[ddtype]["includes"] = "encoder + 1024 decode steps"
+                # the same time against the bytes the K/V-cache form moves (what rounds 1-4 quoted hbm_frac on)
+                decode[ddtype]["kv_cache_form_equiv_gbs"] = kv_cache_form_bytes * T_DEC / ddt / 1e9
             log(f"decode {ddtype}: {decode[ddtype]['value']:.0f} tokens/s, {decode[ddtype]['ms_per_step']:.3f} ms/step")
             del dec, dm, db
             torch.cuda.empty_cache()

@@ -583,6 +583,9 @@ int pa_decode_buffers(pa_model* m, void** tokens, void** attach, void** first_en
  * with cu [B + 1]. */
 int pa_dec_cross_mq(void* ctx, const void* qt, const void* mem, const uint8_t* kpm, const int32_t* cu, int32_t B, int32_t S,
                     int32_t H, int32_t d, void* stream);
+/* The same in exact f32 (f32 ctx / qt / mem; v_mfma_f32_16x16x4_f32): the cross-attention of the parity (token-exact) decode. */
+int pa_dec_cross_mq32(float* ctx, const float* qt, const float* mem, const uint8_t* kpm, const int32_t* cu, int32_t B, int32_t S,
+                      int32_t H, int32_t d, void* stream);
 
 #ifdef __cplusplus
 }

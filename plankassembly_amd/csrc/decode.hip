@@ -517,20 +517,21 @@ int linear_norm_a32(pa_model* m, const void* Zb, const float* Zf, const void* Wf
 // f32res: f32 residual stream inside the bf16 step (see DecodeLayout::f32res): on wherever every Linear of the step takes the skinny
 // kernel (d_model 512, at most 512 rows).  tests/bf16_decode_sim.py / profiles/r04_bf16_decode_rounding_sim.txt: exact-prefix
 // agreement with the f32 tokens 0.40 -> 0.63-0.70 on 32 rows x 128 steps.  PLANK_DECODE_F32_RESID=0 restores the all-bf16 step.
-// mq: absorbed cross-attention (csrc/decode_mq.h) wherever the fold is on in bf16 with at most 8 heads; PLANK_DECODE_MQ=0 restores
-// the per-layer K / V caches.
+// mq: absorbed cross-attention (csrc/decode_mq.h) wherever the fold is on, with at most 8 heads; PLANK_DECODE_MQ=0 (bf16) /
+// PLANK_DECODE_MQ_F32=0 (exact f32) restore the per-layer K / V caches.
 struct DecodeModes { bool fold, f32res, mq; };
 DecodeModes decode_modes(const pa_model_cfg& c, int B, int S) {
     const int d = c.d_model;
     static const int fold_force = getenv("PLANK_DECODE_FOLD_LN") ? atoi(getenv("PLANK_DECODE_FOLD_LN")) : -1;
     static const int f32res_env = getenv("PLANK_DECODE_F32_RESID") ? atoi(getenv("PLANK_DECODE_F32_RESID")) : 1;
     static const int mq_env = getenv("PLANK_DECODE_MQ") ? atoi(getenv("PLANK_DECODE_MQ")) : 1;
+    static const int mq32_env = getenv("PLANK_DECODE_MQ_F32") ? atoi(getenv("PLANK_DECODE_MQ_F32")) : 1;
     const bool fold_env = fold_force >= 0 ? fold_force != 0 : (d == 512 && B <= 512);
     DecodeModes r;
     r.fold = fold_env && c.dtype == PA_BF16 && d % 64 == 0 && c.d_ff % 32 == 0 && c.d_ff >= d && (size_t)((B + 63) / 64) * ((3 * d + 63) / 64) <= 512;
     if (c.dtype == PA_F32) r.fold = fold_env && d == 512 && B <= 512 && c.d_ff % 32 == 0 && c.d_ff >= d;   // (N < K: pa_gemm_norm_a's f32 form cannot materialise y - ADVICE r4)
     r.f32res = r.fold && c.dtype == PA_BF16 && f32res_env != 0 && d == 512 && B <= 512 && c.d_ff % 512 == 0;
-    r.mq = r.fold && c.dtype == PA_BF16 && mq_env != 0 && d == MQ_D && B <= 512 && c.n_head >= 1 && c.n_head <= MQ_MAXH && d % c.n_head == 0 && S <= MQ_MAXS;
+    r.mq = r.fold && (c.dtype == PA_BF16 ? mq_env != 0 : mq32_env != 0) && d == MQ_D && B <= 512 && c.n_head >= 1 && c.n_head <= MQ_MAXH && d % c.n_head == 0 && S <= MQ_MAXS;
     return r;
 }
 
@@ -549,9 +550,9 @@ size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tm
     L->mem = L->qt = L->ctx = nullptr;
     if (md.mq) {
         const size_t H = c.n_head;
-        L->mem = a.take((size_t)B * S * d * 2);
-        L->qt = a.take((size_t)B * H * d * 2); L->ctx = a.take((size_t)B * H * d * 2);
-        for (int i = 0; i < c.n_dec; ++i) { L->wo_t[i] = a.take(d * H * d * 2); L->bo_t[i] = (float*)a.take(d * 4); }
+        L->mem = a.take((size_t)B * S * d * e);
+        L->qt = a.take((size_t)B * H * d * e); L->ctx = a.take((size_t)B * H * d * e);
+        for (int i = 0; i < c.n_dec; ++i) { L->wo_t[i] = a.take(d * H * d * e); L->bo_t[i] = (float*)a.take(d * 4); }
     }
     L->kv_tmp = md.mq ? nullptr : a.take((size_t)B * S * 2 * d * e);
     L->hid_cache = a.take((size_t)B * Tmax * d * e);
@@ -620,12 +621,16 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
     // memory rows themselves; the Linear behind it applies W_o,h W_v,h to the context rows (wo_t)
     auto cross_mq = [&](pa_model* mm, int i, hipStream_t ss) -> int {
         const int H = c.n_head, pbi = mm->dec_base(i);
-        const bf16* Wk = (const bf16*)mm->pl[pbi + D_CA_IN_W] + (size_t)d * d;
+        const T* Wk = (const T*)mm->pl[pbi + D_CA_IN_W] + (size_t)d * d;
         const float sl = LOG2E_F / sqrtf((float)(d / H));
-        if (d / H == 64) PA_LAUNCH(mq_expand_q_kernel<64>, dim3((B + MQ_XR - 1) / MQ_XR, H), dim3(512), 0, ss, (bf16*)L->qt, (const bf16*)L->q, d, Wk, B, d, H, sl);
-        else PA_LAUNCH(mq_expand_q_kernel<0>, dim3((B + MQ_XR - 1) / MQ_XR, H), dim3(512), 0, ss, (bf16*)L->qt, (const bf16*)L->q, d, Wk, B, d, H, sl);
+        const dim3 xg((B + MQ_XR - 1) / MQ_XR, H);
+        if (d / H == 64) PA_LAUNCH((mq_expand_q_kernel<64, T>), xg, dim3(512), 0, ss, (T*)L->qt, (const T*)L->q, d, Wk, B, d, H, sl);
+        else PA_LAUNCH((mq_expand_q_kernel<0, T>), xg, dim3(512), 0, ss, (T*)L->qt, (const T*)L->q, d, Wk, B, d, H, sl);
         RC(fence_in());
-        RC(launch_cross_mq((bf16*)L->ctx, (const bf16*)L->qt, (const bf16*)L->mem, L->cu ? nullptr : L->kpm, L->cu, B, S, H, d, ss));
+        if constexpr (sizeof(T) == 2)
+            RC(launch_cross_mq((bf16*)L->ctx, (const bf16*)L->qt, (const bf16*)L->mem, L->cu ? nullptr : L->kpm, L->cu, B, S, H, d, ss));
+        else
+            RC(launch_cross_mq32((float*)L->ctx, (const float*)L->qt, (const float*)L->mem, L->cu ? nullptr : L->kpm, L->cu, B, S, H, d, ss));
         return fence_out();
     };
     // PLANK_DECODE_FUSE_TAIL=1 (default 0): the sampling kernel also writes the next step's input embedding and advances the step
@@ -819,7 +824,7 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
     L->fold = md.fold; L->f32res = md.f32res; L->mq = md.mq;           // (what each is and where it was measured: decode_modes)
     if (L->mq) {
         // absorbed cross-attention: the step reads the encoder output rows themselves - no K / V projection of the memory at all
-        hipError_t hm = hipMemcpyAsync(L->mem, memory, (size_t)m->NE * d * 2, hipMemcpyDeviceToDevice, s);
+        hipError_t hm = hipMemcpyAsync(L->mem, memory, (size_t)m->NE * d * e, hipMemcpyDeviceToDevice, s);
         if (hm != hipSuccess) return (int)hm;
     }
     for (int i = 0; i < c.n_dec && !L->mq; ++i) {       // cross-attention K/V of the memory: once per sequence, not per step
@@ -847,9 +852,14 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
                 RC(foldw(L->fw[0][i], L->fu[0][i], L->fv[0][i], F(pb + D_SA_IN_W), F(pb + D_SA_IN_B), F(pp + D_N3_W), F(pp + D_N3_B), 3 * d));
             }
             RC(foldw(L->fw[1][i], L->fu[1][i], L->fv[1][i], F(pb + D_CA_IN_W), F(pb + D_CA_IN_B), F(pb + D_N1_W), F(pb + D_N1_B), d));
-            if (L->mq)      // W~o = W_o,h W_v,h, b~o = b_o + W_o b_v for the Linear behind the absorbed attention (csrc/decode_mq.h)
-                PA_LAUNCH(mq_absorb_o_kernel, dim3(d), dim3(256), 0, s, (bf16*)L->wo_t[i], L->bo_t[i], F(pb + D_CA_OUT_W), F(pb + D_CA_OUT_B),
-                          F(pb + D_CA_IN_W), F(pb + D_CA_IN_B), d, c.n_head);
+            if (L->mq) {    // W~o = W_o,h W_v,h, b~o = b_o + W_o b_v for the Linear behind the absorbed attention (csrc/decode_mq.h)
+                if (c.dtype == PA_BF16)
+                    PA_LAUNCH(mq_absorb_o_kernel<bf16>, dim3(d), dim3(256), 0, s, (bf16*)L->wo_t[i], L->bo_t[i], F(pb + D_CA_OUT_W), F(pb + D_CA_OUT_B),
+                              F(pb + D_CA_IN_W), F(pb + D_CA_IN_B), d, c.n_head);
+                else
+                    PA_LAUNCH(mq_absorb_o_kernel<float>, dim3(d), dim3(256), 0, s, (float*)L->wo_t[i], L->bo_t[i], F(pb + D_CA_OUT_W), F(pb + D_CA_OUT_B),
+                              F(pb + D_CA_IN_W), F(pb + D_CA_IN_B), d, c.n_head);
+            }
             RC(foldw(L->fw[2][i], L->fu[2][i], L->fv[2][i], F(pb + D_L1_W), F(pb + D_L1_B), F(pb + D_N2_W), F(pb + D_N2_B), c.d_ff));
         }
     }
@@ -916,6 +926,13 @@ extern "C" int pa_dec_cross_mq(void* ctx, const void* qt, const void* mem, const
     if (!ctx || !qt || !mem) return PA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(mem)) & 15) return PA_EALIGN;
     return launch_cross_mq((bf16*)ctx, (const bf16*)qt, (const bf16*)mem, kpm, cu, B, S, H, d, (hipStream_t)stream);
+}
+
+extern "C" int pa_dec_cross_mq32(float* ctx, const float* qt, const float* mem, const uint8_t* kpm, const int32_t* cu, int32_t B,
+                                 int32_t S, int32_t H, int32_t d, void* stream) {
+    if (!ctx || !qt || !mem) return PA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(mem) | reinterpret_cast<uintptr_t>(ctx)) & 15) return PA_EALIGN;
+    return launch_cross_mq32(ctx, qt, mem, kpm, cu, B, S, H, d, (hipStream_t)stream);
 }
 
 extern "C" int pa_decode_buffers(pa_model* m, void** tokens, void** attach, void** first_end, void** t_dev) {

@@ -206,14 +206,178 @@ __global__ __launch_bounds__(256, 1) void dec_cross_mq_kernel(bf16* ctx, const b
     }
 }
 
+// ---- exact-f32 form (the parity path of the greedy decode: token indices bit-exact against the reference) ---------------------------
+// Same algebra, f32 memory rows (2 KB per key), v_mfma_f32_16x16x4_f32 (1/16 of the bf16 rate: the score product cannot be recomputed
+// by every wave).  A wave takes the 128 dims it owns in BOTH products: its partial scores S_w^T[16 keys][16 head slots] over those dims
+// go through a 1 KB LDS slot per wave, every wave adds the four partials in the same order (identical statistics in all waves), and
+// O^T[128 w ..][head] += M^T P^T with key <-> k-slot mapping key = 4 g + kk so that a lane's own four probabilities ARE the B operand of
+// k-step kk (no exchange).  The contraction / row indices of the MFMAs are assigned so that a lane's operands are CONTIGUOUS in a row:
+// scores - lane group g contracts dims 128 w + 32 g .. + 31 (8 ds_read_b128 instead of 32 scalar reads); P^T M - row m of accumulator
+// block nb is dim 128 w + 8 m + nb (two ds_read_b128 per key).  With scalar reads the launch took 147 us (latency of 64 dependent LDS
+// reads per tile), level with the K / V-cache kernel it replaces.  4-stage ring of 32 KB tiles; software pipeline: iteration t finishes tile t (softmax, P^T M) and forms the
+// partial scores of tile t + 1, so one barrier per tile serves the ring and the partial-score hand-over.
+constexpr int MQF_ROW = MQ_D * 4, MQF_TILE = MQ_KT * MQF_ROW, MQF_NS = 4, MQF_SCR = 2 * 4 * 1024;
+template <bool MASK>
+__global__ __launch_bounds__(256, 1) void dec_cross_mq32_kernel(float* ctx, const float* qt, const float* mem, const uint8_t* kpm,
+                                                                const int32_t* cu, int S, int H) {
+    extern __shared__ __attribute__((aligned(256))) char mq_smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int row0 = cu ? cu[b] : b * S;
+    const int Lk = cu ? cu[b + 1] - row0 : S;
+    float* out = ctx + (size_t)b * H * MQ_D;
+    if (Lk <= 0) {
+        for (int idx = tid; idx < H * MQ_D; idx += 256) out[idx] = 0.f;
+        return;
+    }
+    const uint8_t* mk = MASK ? kpm + (size_t)b * S : nullptr;
+    char* scr = mq_smem + MQF_NS * MQF_TILE;                            // [2][4 waves][64 lanes] f32x4
+    uint8_t* mlds = reinterpret_cast<uint8_t*>(scr + MQF_SCR);
+    const int ntiles = (Lk + MQ_KT - 1) / MQ_KT;
+    if constexpr (MASK) {
+        for (int s = tid; s < ntiles * MQ_KT; s += 256) mlds[s] = s < Lk ? mk[s] : (uint8_t)1;
+        __syncthreads();
+    }
+    // query values (B operand of the partial score product): head slot n, k-step 4 j + e <-> dim 128 wave + 32 g + 4 j + e
+    f32x4 qf[8];
+    {
+        const float* qrow = qt + ((size_t)b * H + min(n, H - 1)) * MQ_D + 128 * wave + 32 * g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[j] = n < H ? *reinterpret_cast<const f32x4*>(qrow + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]) :: "memory");
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)mq_smem;
+    // LDS image of a tile: row r (key) at r * 2048; 16-byte chunk c (4 dims) at position (c & ~15) | ((c ^ r) & 15).
+    // score A operand (row = key n, dims 128 wave + 32 g + 4 j ..): chunk 32 wave + 8 g + j
+    const uint32_t sbase = (uint32_t)n * MQF_ROW + 512u * (uint32_t)wave + 256u * (uint32_t)(g >> 1) + ((((uint32_t)n) ^ (8u * (uint32_t)(g & 1))) << 4);
+    // P^T M A operand for k-step kk (k <-> key 4 g + kk; row m = n <-> dims 128 wave + 8 n + 0..7): chunks 32 wave + 2 n + {0, 1}
+    uint32_t pbase[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const uint32_t key = 4u * (uint32_t)g + (uint32_t)kk;
+        pbase[kk] = key * MQF_ROW + 512u * (uint32_t)wave + 256u * (uint32_t)(n >> 3) + ((((2u * (uint32_t)(n & 7)) ^ key) & 15u) << 4);
+    }
+    const char* const mbase = reinterpret_cast<const char*>(mem + (size_t)row0 * MQ_D);
+    auto issue = [&](int t) {
+        const uint32_t dst = lds0 + (uint32_t)(t & (MQF_NS - 1)) * MQF_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * wave + i;
+            const int row = min(t * MQ_KT + r, Lk - 1);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const uint32_t pz = 64u * hh + (uint32_t)lane;
+                const uint32_t c = (pz & ~15u) | ((pz ^ (uint32_t)r) & 15u);
+                const char* src = mbase + (size_t)row * MQF_ROW + c * 16u;
+                const uint32_t ldst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dst + (uint32_t)r * MQF_ROW + 1024u * hh));
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(src), "s"(ldst) : "memory");
+            }
+        }
+    };
+    auto wait_vm = [&](int tiles_younger) {                             // (wave-uniform) at most that many younger tiles (8 DMAs each) outstanding
+        if (tiles_younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (tiles_younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    // partial scores of tile t over this wave's 128 dims -> this wave's slot of scratch buffer t & 1
+    auto partial_scores = [&](int t) {
+        const char* base = mq_smem + (t & (MQF_NS - 1)) * MQF_TILE;
+        f32x4 av[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) av[j] = *reinterpret_cast<const f32x4*>(base + (sbase ^ (uint32_t)(j << 4)));
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 sp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sp[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], qf[j][e], sp[e], 0, 0, 0);
+        const f32x4 s4 = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        *reinterpret_cast<f32x4*>(scr + (t & 1) * 4096 + wave * 1024 + lane * 16) = s4;
+    };
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int npro = min(ntiles, MQF_NS - 1);
+    for (int t = 0; t < npro; ++t) issue(t);
+    wait_vm(npro - 1);
+    __builtin_amdgcn_s_barrier();
+    partial_scores(0);
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) wait_vm(t + 2 < ntiles ? 1 : 0);            // my rows of tile t + 1 (tile t + 2 may still be on its way)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // my partial scores of tile t are written
+        __builtin_amdgcn_s_barrier();                                   // ... everyone's; tile t + 1 landed; stage of tile t - 1 free
+        asm volatile("" ::: "memory");
+        if (t + MQF_NS - 1 < ntiles) issue(t + MQF_NS - 1);
+        f32x4 s4;
+        {
+            const char* sb = scr + (t & 1) * 4096 + lane * 16;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(sb), p1 = *reinterpret_cast<const f32x4*>(sb + 1024);
+            const f32x4 p2 = *reinterpret_cast<const f32x4*>(sb + 2048), p3 = *reinterpret_cast<const f32x4*>(sb + 3072);
+            s4 = (p0 + p1) + (p2 + p3);
+        }
+        uint32_t m4 = 0;
+        if constexpr (MASK) m4 = *reinterpret_cast<const uint32_t*>(mlds + t * MQ_KT + 4 * g);
+        if (t + 1 < ntiles) partial_scores(t + 1);
+        // s4[i]: key t * 16 + 4 g + i, head slot n (log2 domain)
+        const int key0 = t * MQ_KT + 4 * g;
+        float s[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool valid = (key0 + i < Lk) && !((m4 >> (8 * i)) & 0xffu);
+            s[i] = valid ? s4[i] : -INFINITY;
+        }
+        const float mx = mq_rows_max<true>(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_safe);
+        float p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = exp2f(s[i] - m_safe);
+        l_run = l_run * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) acc[nb] *= alpha;
+        }
+        const char* base = mq_smem + (t & (MQF_NS - 1)) * MQF_TILE;
+        f32x4 pv[4][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) pv[kk][e] = *reinterpret_cast<const f32x4*>(base + (pbase[kk] ^ (uint32_t)(e << 4)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb)                              // O^T[128 wave + 8 (4 g + i) + nb][n]
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[kk][nb >> 2][nb & 3], p[kk], acc[nb], 0, 0, 0);
+    }
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    if (n < H) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        float* orow = out + (size_t)n * MQ_D + 128 * wave + 32 * g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(orow + 8 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]} * inv;
+            *reinterpret_cast<f32x4*>(orow + 8 * i + 4) = f32x4{acc[4][i], acc[5][i], acc[6][i], acc[7][i]} * inv;
+        }
+    }
+}
+
 // qt[b][h][j] = sl * sum_c q[b][h dh + c] * W_k[h dh + c][j]  (q = the step's cross-attention query rows, bias included; W_k = rows
 // d .. 2d of the layer's bf16 in_proj weight, [d][d]).  A launch of its own behind the (LayerNorm-folded) query Linear: folding
 // W_k,h^T W_q,h into that Linear instead makes it a [B][512] x [512][H 512] product - measured 18 us per layer on the 32 x 32-tile
 // skinny kernel (four rounds of 1 024 blocks) against 6 + ~4 us for the two launches.  grid (B / 8, H), 512 threads: a thread owns
 // one column j of 8 rows; the weights are read once per block (coalesced over j), the 8 x dh query values come from LDS.
 constexpr int MQ_XR = 8;
-template <int DH>        // DH = head dim when it is 64 (every weight load of a thread issued before the first use: one round trip), else 0
-__global__ __launch_bounds__(512) void mq_expand_q_kernel(bf16* qt, const bf16* q, int ldq, const bf16* Wk, int B, int d, int H, float sl) {
+template <int DH, typename T>        // DH = head dim when it is 64 (every weight load of a thread issued before the first use: one round trip), else 0
+__global__ __launch_bounds__(512) void mq_expand_q_kernel(T* qt, const T* q, int ldq, const T* Wk, int B, int d, int H, float sl) {
     __shared__ __attribute__((aligned(16))) float qs[MQ_XR][MQ_D];                 // (dh <= d)
     const int h = blockIdx.y, r0 = blockIdx.x * MQ_XR, dh = DH ? DH : d / H, tid = threadIdx.x;
     for (int e = tid; e < MQ_XR * dh; e += 512) {
@@ -221,7 +385,7 @@ __global__ __launch_bounds__(512) void mq_expand_q_kernel(bf16* qt, const bf16* 
         qs[r][c] = r0 + r < B ? (float)q[(size_t)(r0 + r) * ldq + h * dh + c] * sl : 0.f;
     }
     const int j = min(tid, d - 1);                    // this thread's column (d <= 512 = the block)
-    const bf16* w = Wk + (size_t)h * dh * d + j;
+    const T* w = Wk + (size_t)h * dh * d + j;
     if constexpr (DH > 0) {
         float wf[DH];
 #pragma unroll
@@ -235,7 +399,7 @@ __global__ __launch_bounds__(512) void mq_expand_q_kernel(bf16* qt, const bf16* 
                 const f32x4 q4 = *reinterpret_cast<const f32x4*>(&qs[r][c]);
                 a += (q4[0] * wf[c] + q4[1] * wf[c + 1]) + (q4[2] * wf[c + 2] + q4[3] * wf[c + 3]);
             }
-            if (tid < d && r0 + r < B) qt[((size_t)(r0 + r) * H + h) * d + j] = (bf16)a;
+            if (tid < d && r0 + r < B) qt[((size_t)(r0 + r) * H + h) * d + j] = (T)a;
         }
     } else {
         __syncthreads();
@@ -251,12 +415,13 @@ __global__ __launch_bounds__(512) void mq_expand_q_kernel(bf16* qt, const bf16* 
         if (tid < d) {
 #pragma unroll
             for (int r = 0; r < MQ_XR; ++r)
-                if (r0 + r < B) qt[((size_t)(r0 + r) * H + h) * d + j] = (bf16)a0[r];
+                if (r0 + r < B) qt[((size_t)(r0 + r) * H + h) * d + j] = (T)a0[r];
         }
     }
 }
 // W~o (bf16 [d][H d]) and b~o (f32 [d]):  W~o[n][h d + j] = sum_c W_o[n][h dh + c] W_v[h dh + c][j];  b~o = b_o + W_o b_v.  grid d blocks.
-__global__ __launch_bounds__(256) void mq_absorb_o_kernel(bf16* Wt, float* bt, const float* Wo, const float* bo, const float* Win,
+template <typename T>
+__global__ __launch_bounds__(256) void mq_absorb_o_kernel(T* Wt, float* bt, const float* Wo, const float* bo, const float* Win,
                                                           const float* bin, int d, int H) {
     const int nrow = blockIdx.x, dh = d / H;
     const float* Wv = Win + (size_t)2 * d * d;
@@ -265,7 +430,7 @@ __global__ __launch_bounds__(256) void mq_absorb_o_kernel(bf16* Wt, float* bt, c
         const int h = col / d, j = col - h * d;
         float a = 0.f;
         for (int c = 0; c < dh; ++c) a += Wo[(size_t)nrow * d + h * dh + c] * Wv[(size_t)(h * dh + c) * d + j];
-        Wt[(size_t)nrow * H * d + col] = (bf16)a;
+        Wt[(size_t)nrow * H * d + col] = (T)a;
     }
     if (threadIdx.x == 0) {
         float a = bo[nrow];
@@ -296,6 +461,24 @@ int launch_cross_mq(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* k
     }
     const bool mask = !cu && kpm;
     PA_LAUNCH(ks[(nt ? 4 : 0) + (swap ? 2 : 0) + (mask ? 1 : 0)], dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H);
+    return 0;
+}
+
+int launch_cross_mq32(float* ctx, const float* qt, const float* mem, const uint8_t* kpm, const int32_t* cu, int B, int S, int H, int d,
+                      hipStream_t s) {
+    if (d != MQ_D || H < 1 || H > MQ_MAXH || B <= 0 || S <= 0 || S > MQ_MAXS) return PA_ESHAPE;
+    const bool mask = !cu && kpm;
+    const int lds = MQF_NS * MQF_TILE + MQF_SCR + (mask ? (S + 31) / 16 * 16 : 0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        constexpr int MAXLDS = MQF_NS * MQF_TILE + MQF_SCR + MQ_MAXS + 32;
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_mq32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_mq32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
+        if (e0 != hipSuccess || e1 != hipSuccess) return (int)(e0 != hipSuccess ? e0 : e1);
+        attr_done = true;
+    }
+    if (mask) PA_LAUNCH(dec_cross_mq32_kernel<true>, dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H);
+    else PA_LAUNCH(dec_cross_mq32_kernel<false>, dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H);
     return 0;
 }
 

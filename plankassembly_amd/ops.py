@@ -422,6 +422,11 @@ def dec_cross_mq(qt, mem, *, kpm=None, cu=None, S=None):
     B, H, d = qt.shape
     if cu is None:
         S = mem.shape[1]
+    if qt.dtype == torch.float32:                      # the exact-f32 form (pa_dec_cross_mq32)
+        ctx = torch.empty(B, H, d, dtype=torch.float32, device=qt.device)
+        L.check(L.lib().pa_dec_cross_mq32(L.ptr(ctx), L.ptr(qt), L.ptr(mem), L.ptr(kpm), L.ptr(cu), B, int(S), H, d, L.stream()),
+                "pa_dec_cross_mq32")
+        return ctx
     ctx = torch.empty(B, H, d, dtype=torch.bfloat16, device=qt.device)
     L.check(L.lib().pa_dec_cross_mq(L.ptr(ctx), L.ptr(qt), L.ptr(mem), L.ptr(kpm), L.ptr(cu), B, int(S), H, d, L.stream()),
             "pa_dec_cross_mq")

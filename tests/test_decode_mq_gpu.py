@@ -137,3 +137,70 @@ def test_absorbed_form_equals_attention_over_projected_keys_and_values():
     pr = torch.softmax(torch.einsum("bhj,bsj->bhs", qtb.double(), m64) * LN2, dim=-1)
     ctxr = torch.einsum("bhs,bsj->bhj", pr, m64)
     assert (ctx - ctxr).abs().max().item() <= 2e-2 * ctxr.abs().max().item()
+
+
+# ---- exact-f32 form (pa_dec_cross_mq32): the cross-attention of the token-exact decode ------------------------------------------------
+def _check32(ctx, ref):
+    err = (ctx.double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(ref.abs().max().item(), 1e-3), err
+
+
+@pytest.mark.parametrize("B,S,H", [(3, 16, 8), (2, 48, 8), (4, 200, 8), (2, 1024, 8), (3, 130, 4), (2, 17, 1), (5, 7, 8), (2, 33, 8)])
+def test_f32_dense_rows_no_mask(B, S, H):
+    from plankassembly_amd import ops
+    torch.manual_seed(B * 1000 + S + H)
+    mem = torch.randn(B, S, 512, device="cuda")
+    qt = torch.randn(B, H, 512, device="cuda") * 0.15
+    ctx = ops.dec_cross_mq(qt, mem)
+    torch.cuda.synchronize()
+    for b in range(B):
+        _check32(ctx[b], _ref(qt[b], mem[b], torch.ones(S, dtype=torch.bool, device="cuda")))
+
+
+@pytest.mark.parametrize("B,S", [(4, 64), (3, 299), (2, 1024), (3, 33)])
+def test_f32_dense_rows_with_key_padding_mask(B, S):
+    from plankassembly_amd import ops
+    torch.manual_seed(S)
+    mem = torch.randn(B, S, 512, device="cuda")
+    qt = torch.randn(B, 8, 512, device="cuda") * 0.15
+    lens = torch.randint(1, S + 1, (B,))
+    lens[0] = S
+    kpm = (torch.arange(S)[None, :] >= lens[:, None]).to(torch.uint8).cuda()
+    kpm[1, 0] = 1
+    ctx = ops.dec_cross_mq(qt, mem, kpm=kpm)
+    torch.cuda.synchronize()
+    for b in range(B):
+        _check32(ctx[b], _ref(qt[b], mem[b], kpm[b] == 0))
+
+
+@pytest.mark.parametrize("lens", [[16, 1, 1024, 333], [5, 0, 129], [112, 113, 127, 128, 96], [31, 32, 33, 47, 48, 49, 63, 64, 65]])
+def test_f32_packed_rows(lens):
+    from plankassembly_amd import ops
+    torch.manual_seed(sum(lens))
+    B = len(lens)
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = torch.tensor(lens).cumsum(0)
+    mem = torch.randn(max(int(cu[-1]), 1), 512, device="cuda")
+    qt = torch.randn(B, 8, 512, device="cuda") * 0.15
+    ctx = ops.dec_cross_mq(qt, mem, cu=cu.cuda(), S=max(lens))
+    torch.cuda.synchronize()
+    for b in range(B):
+        if lens[b] == 0:
+            assert float(ctx[b].abs().max()) == 0.0
+            continue
+        m = mem[int(cu[b]):int(cu[b + 1])]
+        _check32(ctx[b], _ref(qt[b], m, torch.ones(lens[b], dtype=torch.bool, device="cuda")))
+
+
+def test_f32_moving_reference_point():
+    from plankassembly_amd import ops
+    torch.manual_seed(3)
+    S = 256
+    q = torch.randn(8, 512, device="cuda")
+    q = q / q.norm(dim=-1, keepdim=True)
+    ramp = torch.linspace(-60, 60, S, device="cuda")
+    mem = (torch.randn(1, S, 512, device="cuda") * 0.05 + ramp[None, :, None] * q[0][None, None, :]).contiguous()
+    qt = q[None].contiguous()
+    ctx = ops.dec_cross_mq(qt, mem)
+    torch.cuda.synchronize()
+    _check32(ctx[0], _ref(qt[0], mem[0], torch.ones(S, dtype=torch.bool, device="cuda")))

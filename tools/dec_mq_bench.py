@@ -16,16 +16,18 @@ def t(fn, iters=30, warm=5):
     e1.record(); e1.synchronize()
     return e0.elapsed_time(e1) * 1e3 / iters
 # several memories so that consecutive launches do not find their rows in the Infinity Cache
-mems = [torch.randn(B, S, 512, device="cuda").bfloat16() for _ in range(6)]
+DT = torch.float32 if os.environ.get("DTYPE") == "f32" else torch.bfloat16
+mems = [torch.randn(B, S, 512, device="cuda").to(DT) for _ in range(6)]
+qt = qt.to(DT)
 i = [0]
 def run():
     i[0] = (i[0] + 1) % len(mems)
     ops.dec_cross_mq(qt, mems[i[0]])
 us = t(run)
-gb = B * S * 512 * 2 / 1e9
+gb = B * S * 512 * mems[0].element_size() / 1e9
 print(f"dec_cross_mq B {B} S {S} NT {os.environ.get('PLANK_DECODE_MQ_NT', '0')} SWAP {os.environ.get('PLANK_DECODE_MQ_SWAP', '1')}: {us:.1f} us  {gb / us * 1e6 / 1e3:.2f} TB/s of memory rows")
 lens = torch.randint(300, S + 1, (B,))
 cu = torch.zeros(B + 1, dtype=torch.int32); cu[1:] = lens.cumsum(0)
-pm = torch.randn(int(cu[-1]), 512, device="cuda").bfloat16(); cud = cu.cuda()
+pm = torch.randn(int(cu[-1]), 512, device="cuda").to(DT); cud = cu.cuda()
 us2 = t(lambda: ops.dec_cross_mq(qt, pm, cu=cud, S=S))
-print(f"   packed rows, lengths 300..{S} ({int(cu[-1])} rows): {us2:.1f} us  {int(cu[-1]) * 1024 / us2 / 1e6:.2f} TB/s")
+print(f"   packed rows, lengths 300..{S} ({int(cu[-1])} rows): {us2:.1f} us  {int(cu[-1]) * 512 * pm.element_size() / us2 / 1e6:.2f} TB/s")
