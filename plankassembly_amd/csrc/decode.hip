@@ -42,6 +42,7 @@ struct DecodeLayout {
     // copy of the encoder output rows (`mem`) instead of per-layer K / V caches.  qt / ctx: [B][H][d] query / context rows of a step;
     // wo_t / bo_t per layer: W_o,h W_v,h as one [d][H d] bf16 matrix and b_o + W_o b_v.
     bool mq = false;
+    bool mq_contract = false;                  // exact f32, dh 64: W_v as its own launch + the ordinary out-projection instead of wo_t (decode_mq.h)
     void *mem = nullptr, *qt = nullptr, *ctx = nullptr;
     std::vector<void*> wo_t; std::vector<float*> bo_t;
 };
@@ -656,7 +657,11 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
         float* xf = (float*)L->x; float* yf = (float*)L->y; float* zf = (float*)L->z; float* z2f = (float*)L->z2;
         if (part >= 2 && (part & 1) == 0) {    // feed-forward block of the previous layer
             const int j = part / 2 - 1, pb = m->dec_base(j);
-            if (L->mq) RC(linear_res32(m, L->ctx, L->wo_t[j], L->bo_t[j], yf, z2f, L->z2b, B, d, c.n_head * d, st));     // W_o,h W_v,h on the context rows
+            if (L->mq && L->mq_contract) {
+                PA_LAUNCH(mq_contract_v_kernel<bf16>, dim3((B + MQ_XR - 1) / MQ_XR, c.n_head), dim3(512), 0, s, (bf16*)L->ao, d, (const bf16*)L->ctx,
+                          (const bf16*)PL(pb + D_CA_IN_W) + (size_t)2 * d * d, PF(pb + D_CA_IN_B) + 2 * d, B, d, c.n_head);
+                RC(linear_res32(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), yf, z2f, L->z2b, B, d, d, st));
+            } else if (L->mq) RC(linear_res32(m, L->ctx, L->wo_t[j], L->bo_t[j], yf, z2f, L->z2b, B, d, c.n_head * d, st));     // W_o,h W_v,h on the context rows
             else RC(linear_res32(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), yf, z2f, L->z2b, B, d, d, st));
             RC(linear_norm_a32(m, L->z2b, z2f, L->fw[2][j], L->fu[2][j], L->fv[2][j], PF(pb + D_N2_W), PF(pb + D_N2_B), c.eps_layer, xf,
                                L->ff, ff, B, ff, d, act, st));
@@ -723,7 +728,11 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
         const int j = part / 2 - 1, pb = m->dec_base(j);
         if (fold) {
             // z2 = ao Wo^T + b + y1;  ff = relu(norm2(z2) W1^T + b1), y2 -> x;  z3 = ff W2^T + b2 + y2 -> z
-            if (L->mq) RC(linear(m, L->ctx, L->wo_t[j], L->bo_t[j], L->z2, d, B, d, c.n_head * d, 0, L->y, -1, st));
+            if (L->mq && L->mq_contract) {
+                PA_LAUNCH(mq_contract_v_kernel<T>, dim3((B + MQ_XR - 1) / MQ_XR, c.n_head), dim3(512), 0, s, (T*)L->ao, d, (const T*)L->ctx,
+                          (const T*)PL(pb + D_CA_IN_W) + (size_t)2 * d * d, PF(pb + D_CA_IN_B) + 2 * d, B, d, c.n_head);
+                RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z2, d, B, d, d, 0, L->y, -1, st));
+            } else if (L->mq) RC(linear(m, L->ctx, L->wo_t[j], L->bo_t[j], L->z2, d, B, d, c.n_head * d, 0, L->y, -1, st));
             else RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z2, d, B, d, d, 0, L->y, -1, st));
             RC(linear_norm_a(m, L->z2, L->fw[2][j], L->fu[2][j], L->fv[2][j], PF(pb + D_N2_W), PF(pb + D_N2_B), c.eps_layer, L->x,
                              L->ff, ff, B, ff, d, act, st));
@@ -822,6 +831,8 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
     hipStream_t s = (hipStream_t)stream;
     const DecodeModes md = decode_modes(c, B, S);
     L->fold = md.fold; L->f32res = md.f32res; L->mq = md.mq;           // (what each is and where it was measured: decode_modes)
+    static const int contract_env = getenv("PLANK_DECODE_MQ_CONTRACT") ? atoi(getenv("PLANK_DECODE_MQ_CONTRACT")) : -1;
+    L->mq_contract = L->mq && d / c.n_head == 64 && (contract_env >= 0 ? contract_env != 0 : c.dtype == PA_F32);
     if (L->mq) {
         // absorbed cross-attention: the step reads the encoder output rows themselves - no K / V projection of the memory at all
         hipError_t hm = hipMemcpyAsync(L->mem, memory, (size_t)m->NE * d * e, hipMemcpyDeviceToDevice, s);

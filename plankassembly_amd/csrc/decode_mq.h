@@ -419,6 +419,46 @@ __global__ __launch_bounds__(512) void mq_expand_q_kernel(T* qt, const T* q, int
         }
     }
 }
+// The value side as a launch of its own (exact f32, dh = 64): ao[b][h dh + c] = b_v[h dh + c] + sum_j ctx[b][h][j] W_v[h dh + c][j], followed by
+// the layer's ordinary out-projection.  In f32 the folded form (W~o = W_o,h W_v,h, one [B][H d] x [H d][d] product) costs 4 x the flops of the
+// two steps on the 1/16-rate f32 matrix pipe: 27 us on the skinny kernel against ~8 + 7.  grid (B / 8, H), 512 threads: thread (c, jp) holds
+// 64 weights of row h dh + c (columns 64 jp ..), the 8 context rows come from LDS (broadcast reads), the 8 column parts meet in LDS.
+template <typename T>
+__global__ __launch_bounds__(512) void mq_contract_v_kernel(T* ao, int ldo, const T* ctx, const T* Wv, const float* bv, int B, int d, int H) {
+    __shared__ __attribute__((aligned(16))) float cs[MQ_XR][MQ_D];
+    __shared__ float part[MQ_XR][8][64];
+    const int h = blockIdx.y, r0 = blockIdx.x * MQ_XR, tid = threadIdx.x, c = tid & 63, jp = tid >> 6;
+    float wf[64];
+    {
+        const T* w = Wv + (size_t)(h * 64 + c) * d + 64 * jp;
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) { const f32x4 v = ld4<T>(w + k); wf[k] = v[0]; wf[k + 1] = v[1]; wf[k + 2] = v[2]; wf[k + 3] = v[3]; }
+    }
+    for (int e = tid; e < MQ_XR * MQ_D; e += 512) {
+        const int r = e >> 9, j = e & (MQ_D - 1);
+        cs[r][j] = r0 + r < B ? (float)ctx[((size_t)(r0 + r) * H + h) * MQ_D + j] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < MQ_XR; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(&cs[r][64 * jp + k]);
+            a += (q4[0] * wf[k] + q4[1] * wf[k + 1]) + (q4[2] * wf[k + 2] + q4[3] * wf[k + 3]);
+        }
+        part[r][jp][c] = a;
+    }
+    __syncthreads();
+    const int r = tid >> 6;
+    if (r0 + r < B) {
+        float a = bv[h * 64 + c];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a += part[r][q][c];
+        ao[(size_t)(r0 + r) * ldo + h * 64 + c] = (T)a;
+    }
+}
+
 // W~o (bf16 [d][H d]) and b~o (f32 [d]):  W~o[n][h d + j] = sum_c W_o[n][h dh + c] W_v[h dh + c][j];  b~o = b_o + W_o b_v.  grid d blocks.
 template <typename T>
 __global__ __launch_bounds__(256) void mq_absorb_o_kernel(T* Wt, float* bt, const float* Wo, const float* bo, const float* Win,
