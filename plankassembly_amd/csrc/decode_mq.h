@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256, 1) void dec_cross_mq_kernel(bf16* ctx, const b
 // k-step kk (no exchange).  The contraction / row indices of the MFMAs are assigned so that a lane's operands are CONTIGUOUS in a row:
 // scores - lane group g contracts dims 128 w + 32 g .. + 31 (8 ds_read_b128 instead of 32 scalar reads); P^T M - row m of accumulator
 // block nb is dim 128 w + 8 m + nb (two ds_read_b128 per key).  With scalar reads the launch took 147 us (latency of 64 dependent LDS
-// reads per tile), level with the K / V-cache kernel it replaces.  4-stage ring of 32 KB tiles; software pipeline: iteration t finishes tile t (softmax, P^T M) and forms the
+// reads per tile), level with the K / V-cache kernel it replaces.  Requesting ALL of an iteration's LDS reads at its top (partials,
+// next tile's score operands, this tile's P^T M operands) was measured slower: 148 vs 135 us stand-alone, 1.873 vs 1.849 ms per step.  4-stage ring of 32 KB tiles; software pipeline: iteration t finishes tile t (softmax, P^T M) and forms the
 // partial scores of tile t + 1, so one barrier per tile serves the ring and the partial-score hand-over.
 constexpr int MQF_ROW = MQ_D * 4, MQF_TILE = MQ_KT * MQF_ROW, MQF_NS = 4, MQF_SCR = 2 * 4 * 1024;
 template <bool MASK>
