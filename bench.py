@@ -114,6 +114,31 @@ def time_kernel(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
+def decode_cross_roofline(ddtype):
+    """The decode step's dominant launch since round 5 - the absorbed cross-attention (csrc/decode_mq.h, pa_dec_cross_mq / _mq32) - timed
+    under HIP events at the benchmark's shape over rotating memories (so a launch does not find its rows in the Infinity Cache).
+    HBM-bound: algorithmic bytes = the memory rows once + query / context rows."""
+    from plankassembly_amd import ops
+    dt = torch.bfloat16 if ddtype == "bf16" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(3)
+    mems = [torch.randn(B_DEC, S_IN, D, device="cuda", generator=g).to(dt) for _ in range(4)]
+    qt = (torch.randn(B_DEC, H, D, device="cuda", generator=g) * 0.1).to(dt)
+    i = [0]
+
+    def run():
+        i[0] = (i[0] + 1) % len(mems)
+        ops.dec_cross_mq(qt, mems[i[0]])
+    t = time_kernel(run, iters=24, warm=4)
+    esz = mems[0].element_size()
+    nbytes = (B_DEC * S_IN * D + 2 * B_DEC * H * D) * esz
+    del mems
+    torch.cuda.empty_cache()
+    return {"kernel": "dec_cross_mq_kernel" if ddtype == "bf16" else "dec_cross_mq32_kernel", "bound": "hbm", "avg_launch_us": t * 1e6,
+            "algorithmic_bytes_per_launch": nbytes, "achieved": nbytes / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": nbytes / t / 1e9 / PEAK_HBM_GBS, "launches_per_step": ND,
+            "replaces": "dec_attn_kernel over the per-layer K / V caches: %.0f MB per launch" % (2 * B_DEC * S_IN * D * esz / 1e6)}
+
+
 def kernel_rooflines(B):
     """HIP-event timing of the hot kernels at the workload's shapes (random bf16 data)."""
     from plankassembly_amd import ops
@@ -725,8 +750,12 @@ def main():
             # output rows themselves: ONE [S][d] stream per layer and step instead of K and V; W_o,h W_v,h is one [d][H d] matrix
             mq = (ddtype == "bf16" and D == 512 and H <= 8 and B_DEC <= 512 and os.environ.get("PLANK_DECODE_MQ", "1") != "0"
                   and os.environ.get("PLANK_DECODE_FOLD_LN", "1") != "0")
+            mqf = (ddtype == "f32" and D == 512 and H <= 8 and B_DEC <= 512 and os.environ.get("PLANK_DECODE_MQ_F32", "1") != "0"
+                   and os.environ.get("PLANK_DECODE_FOLD_LN", "1") != "0")
             if mq:
                 w_bytes = (ND * ((6 + H) * D * D + 2 * D * FF) + V * D + D * D) * esz
+                kv_bytes = ND * B_DEC * (S_IN + 2 * T_DEC / 2) * D * esz
+            if mqf:        # (f32: W_v as its own launch, the weights are the reference's)
                 kv_bytes = ND * B_DEC * (S_IN + 2 * T_DEC / 2) * D * esz
             decode[ddtype] = dict(value=B_DEC * T_DEC * world / ddt, unit="tokens/s", batch=B_DEC, max_len=T_DEC, seq_in=S_IN,
                                   ms_per_step=ddt / T_DEC * 1e3, graph=bool(dec.use_graph),
@@ -734,7 +763,7 @@ def main():
                                   hbm_frac=(w_bytes + kv_bytes) * T_DEC / ddt / 1e9 / PEAK_HBM_GBS,
                                   token_exact=None,      # filled in by the CPU leg (cpu_decode_check); None = not checked
                                   includes="encoder + cross-K/V projection + 1024 decode steps")
-            if mq:
+            if mq or mqf:
                 decode[ddtype]["cross_attention"] = ("absorbed: q~_h = W_k,h^T q_h attends over the memory rows, W_v behind the softmax "
                                                      "(no cross-K/V projection, one [S][d] stream per layer and step)")
                 decode[ddtype]["includes"] = "encoder + 1024 decode steps"
@@ -743,6 +772,10 @@ def main():
             log(f"decode {ddtype}: {decode[ddtype]['value']:.0f} tokens/s, {decode[ddtype]['ms_per_step']:.3f} ms/step")
             del dec, dm, db
             torch.cuda.empty_cache()
+            mq32 = ddtype == "f32" and D == 512 and H <= 8 and B_DEC <= 512 and os.environ.get("PLANK_DECODE_MQ_F32", "1") != "0" \
+                and os.environ.get("PLANK_DECODE_FOLD_LN", "1") != "0"
+            if (mq or mq32) and rank == 0 and not args.no_kernels:
+                decode[ddtype]["roofline_cross_attention"] = decode_cross_roofline(ddtype)
 
     kern = None
     if rank == 0 and not args.no_kernels and headline:

@@ -23,6 +23,8 @@ KEYS = [  # json key -> regex on the demangled kernel name
     ("gemm_small_tt", r"gemm3s_kernel"),
     ("gemm_wide_tt", r"gemm3w_kernel"),
     ("dec_attn", r"dec_attn_kernel"),
+    ("dec_cross_mq", r"dec_cross_mq_kernel"),
+    ("dec_cross_mq32", r"dec_cross_mq32_kernel"),
     ("dec_sample", r"dec_sample_kernel"),
     # (rocprofv3's demangler leaves names with the __bf16 template argument mangled)
     ("gemm_pair_tt", r"gemm_kernel<__bf16, 64, 2, true, true, true, true, false, 2>|gemm_kernelIDF16bLi64ELi2ELb1ELb1ELb1ELb1ELb0ELi2E"),
@@ -60,6 +62,11 @@ def main():
     # (`fetch_bytes_corrected`), the raw numbers are kept next to it.
     cf = None
     fcorr = wcorr = 1.0
+    # PMC_FETCH_FACTOR: a run without a calibration kernel (the exact-f32 decode never casts parameters) takes the factor measured by
+    # the same script on the same box in the pass next to it
+    if os.environ.get("PMC_FETCH_FACTOR"):
+        fcorr = float(os.environ["PMC_FETCH_FACTOR"])
+        print(f"# no calibration kernel in this run: FETCH correction factor {fcorr:.3f} taken from PMC_FETCH_FACTOR (measured in the bf16 pass of the same session)")
     for name, (n, tot, grid) in fetch.items():
         is_cast = "cast_kernel" in name
         is_torch = "bfloat16_copy_kernel_cuda" in name and "lambda(float)" in name
