@@ -260,17 +260,25 @@ __global__ __launch_bounds__(256, 1) void dec_cross_mq32_kernel(float* ctx, cons
         pbase[kk] = key * MQF_ROW + 512u * (uint32_t)wave + 256u * (uint32_t)(n >> 3) + ((((2u * (uint32_t)(n & 7)) ^ key) & 15u) << 4);
     }
     const char* const mbase = reinterpret_cast<const char*>(mem + (size_t)row0 * MQ_D);
+    // per-lane byte offset of the chunk this lane fetches for row 4 wave + i, half hh (loop-invariant: 8 registers)
+    uint32_t coff[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const uint32_t pz = 64u * hh + (uint32_t)lane, r = 4u * (uint32_t)wave + (uint32_t)i;
+            coff[i][hh] = ((pz & ~15u) | ((pz ^ r) & 15u)) * 16u;
+        }
     auto issue = [&](int t) {
         const uint32_t dst = lds0 + (uint32_t)(t & (MQF_NS - 1)) * MQF_TILE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * wave + i;
             const int row = min(t * MQ_KT + r, Lk - 1);
+            const char* rowp = mbase + (size_t)row * MQF_ROW;            // (wave-uniform)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const uint32_t pz = 64u * hh + (uint32_t)lane;
-                const uint32_t c = (pz & ~15u) | ((pz ^ (uint32_t)r) & 15u);
-                const char* src = mbase + (size_t)row * MQF_ROW + c * 16u;
+                const char* src = rowp + coff[i][hh];
                 const uint32_t ldst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dst + (uint32_t)r * MQF_ROW + 1024u * hh));
                 asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(src), "s"(ldst) : "memory");
             }
@@ -335,10 +343,10 @@ __global__ __launch_bounds__(256, 1) void dec_cross_mq32_kernel(float* ctx, cons
         const float mx = mq_rows_max<true>(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
         const float m_new = fmaxf(m_run, mx);
         const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_safe);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);       // (v_exp_f32, 1 ulp; arguments <= 0)
         float p[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p[i] = exp2f(s[i] - m_safe);
+        for (int i = 0; i < 4; ++i) p[i] = __builtin_amdgcn_exp2f(s[i] - m_safe);
         l_run = l_run * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
         m_run = m_new;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
