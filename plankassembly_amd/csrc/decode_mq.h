@@ -379,6 +379,175 @@ __global__ __launch_bounds__(256, 1) void dec_cross_mq32_kernel(float* ctx, cons
     }
 }
 
+// ---- exact f32, eight waves (two per SIMD) ----------------------------------------------------------------------------------------
+// The four-wave kernel above keeps the f32 matrix pipe 43 % busy (profiles/r05_decode_f32_cross_mq_sq_counters.txt): with one wave per
+// SIMD the LDS round trips, the softmax and the barrier of a tile are all exposed between its two MFMA batches.  Here a wave owns 64
+// dims (16 + 16 MFMAs per tile) and the two waves of a SIMD (w and w + 4: a workgroup's waves go to the SIMDs in cyclic order) run the
+// iteration's two halves in OPPOSITE order - one forms the next tile's partial scores while the other is in its softmax / LDS phase.
+constexpr int MQ8_SCR = 2 * 8 * 1024;
+template <bool MASK>
+__global__ __launch_bounds__(512, 1) void dec_cross_mq32w8_kernel(float* ctx, const float* qt, const float* mem, const uint8_t* kpm,
+                                                                  const int32_t* cu, int S, int H) {
+    extern __shared__ __attribute__((aligned(256))) char mq_smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int row0 = cu ? cu[b] : b * S;
+    const int Lk = cu ? cu[b + 1] - row0 : S;
+    float* out = ctx + (size_t)b * H * MQ_D;
+    if (Lk <= 0) {
+        for (int idx = tid; idx < H * MQ_D; idx += 512) out[idx] = 0.f;
+        return;
+    }
+    const uint8_t* mk = MASK ? kpm + (size_t)b * S : nullptr;
+    char* scr = mq_smem + MQF_NS * MQF_TILE;                            // [2][8 waves][64 lanes] f32x4
+    uint8_t* mlds = reinterpret_cast<uint8_t*>(scr + MQ8_SCR);
+    const int ntiles = (Lk + MQ_KT - 1) / MQ_KT;
+    if constexpr (MASK) {
+        for (int s = tid; s < ntiles * MQ_KT; s += 512) mlds[s] = s < Lk ? mk[s] : (uint8_t)1;
+        __syncthreads();
+    }
+    // query values: head slot n, k-step 4 j + e <-> dim 64 wave + 16 g + 4 j + e
+    f32x4 qf[4];
+    {
+        const float* qrow = qt + ((size_t)b * H + min(n, H - 1)) * MQ_D + 64 * wave + 16 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qf[j] = n < H ? *reinterpret_cast<const f32x4*>(qrow + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) :: "memory");
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)mq_smem;
+    // tile image as above: row r at r * 2048, chunk c at position (c & ~15) | ((c ^ r) & 15).  Scores: row n, chunks 16 wave + 4 g + j
+    const uint32_t sbase = (uint32_t)n * MQF_ROW + 256u * (uint32_t)wave + ((((uint32_t)n) ^ (4u * (uint32_t)g)) << 4);
+    // P^T M: k <-> key 4 g + kk, row m = n <-> dims 64 wave + 4 n + 0..3: chunk 16 wave + n
+    uint32_t pbase[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const uint32_t key = 4u * (uint32_t)g + (uint32_t)kk;
+        pbase[kk] = key * MQF_ROW + 256u * (uint32_t)wave + ((((uint32_t)n) ^ key) << 4);
+    }
+    const char* const mbase = reinterpret_cast<const char*>(mem + (size_t)row0 * MQ_D);
+    uint32_t coff[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const uint32_t pz = 64u * hh + (uint32_t)lane, r = 2u * (uint32_t)wave + (uint32_t)i;
+            coff[i][hh] = ((pz & ~15u) | ((pz ^ r) & 15u)) * 16u;
+        }
+    auto issue = [&](int t) {
+        const uint32_t dst = lds0 + (uint32_t)(t & (MQF_NS - 1)) * MQF_TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 2 * wave + i;
+            const int row = min(t * MQ_KT + r, Lk - 1);
+            const char* rowp = mbase + (size_t)row * MQF_ROW;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const char* src = rowp + coff[i][hh];
+                const uint32_t ldst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(dst + (uint32_t)r * MQF_ROW + 1024u * hh));
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(src), "s"(ldst) : "memory");
+            }
+        }
+    };
+    auto wait_vm = [&](int tiles_younger) {                             // (wave-uniform) 4 DMAs per tile and wave
+        if (tiles_younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (tiles_younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto partial_scores = [&](int t) {
+        const char* base = mq_smem + (t & (MQF_NS - 1)) * MQF_TILE;
+        f32x4 av[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(base + (sbase ^ (uint32_t)(j << 4)));
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 sp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sp[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], qf[j][e], sp[e], 0, 0, 0);
+        const f32x4 s4 = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+        *reinterpret_cast<f32x4*>(scr + (t & 1) * 8192 + wave * 1024 + lane * 16) = s4;
+    };
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // softmax update of tile t from the summed scores, then O^T += M^T P^T on this wave's 64 dims
+    auto finish = [&](int t, const f32x4& s4, uint32_t m4) {
+        const int key0 = t * MQ_KT + 4 * g;
+        float s[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool valid = (key0 + i < Lk) && !((m4 >> (8 * i)) & 0xffu);
+            s[i] = valid ? s4[i] : -INFINITY;
+        }
+        const float mx = mq_rows_max<true>(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+        float p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = __builtin_amdgcn_exp2f(s[i] - m_safe);
+        l_run = l_run * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[nb] *= alpha;
+        }
+        const char* base = mq_smem + (t & (MQF_NS - 1)) * MQF_TILE;
+        f32x4 pv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) pv[kk] = *reinterpret_cast<const f32x4*>(base + pbase[kk]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)                              // O^T[64 wave + 4 (4 g + i) + nb][n]
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[kk][nb], p[kk], acc[nb], 0, 0, 0);
+    };
+
+    const int npro = min(ntiles, MQF_NS - 1);
+    for (int t = 0; t < npro; ++t) issue(t);
+    wait_vm(npro - 1);
+    __builtin_amdgcn_s_barrier();
+    partial_scores(0);
+    const bool first_half = wave < 4;                                    // (wave-uniform) which order this wave runs an iteration in
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) wait_vm(t + 2 < ntiles ? 1 : 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + MQF_NS - 1 < ntiles) issue(t + MQF_NS - 1);
+        f32x4 s4;
+        {
+            const char* sb = scr + (t & 1) * 8192 + lane * 16;
+            f32x4 pp[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) pp[w] = *reinterpret_cast<const f32x4*>(sb + w * 1024);
+            s4 = ((pp[0] + pp[1]) + (pp[2] + pp[3])) + ((pp[4] + pp[5]) + (pp[6] + pp[7]));
+        }
+        uint32_t m4 = 0;
+        if constexpr (MASK) m4 = *reinterpret_cast<const uint32_t*>(mlds + t * MQ_KT + 4 * g);
+        if (first_half) {
+            if (t + 1 < ntiles) partial_scores(t + 1);
+            finish(t, s4, m4);
+        } else {
+            finish(t, s4, m4);
+            if (t + 1 < ntiles) partial_scores(t + 1);
+        }
+    }
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    if (n < H) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        float* orow = out + (size_t)n * MQ_D + 64 * wave + 16 * g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(orow + 4 * i) = f32x4{acc[0][i], acc[1][i], acc[2][i], acc[3][i]} * inv;
+    }
+}
+
 // qt[b][h][j] = sl * sum_c q[b][h dh + c] * W_k[h dh + c][j]  (q = the step's cross-attention query rows, bias included; W_k = rows
 // d .. 2d of the layer's bf16 in_proj weight, [d][d]).  A launch of its own behind the (LayerNorm-folded) query Linear: folding
 // W_k,h^T W_q,h into that Linear instead makes it a [B][512] x [512][H 512] product - measured 18 us per layer on the 32 x 32-tile
@@ -515,19 +684,32 @@ int launch_cross_mq(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* k
 
 int launch_cross_mq32(float* ctx, const float* qt, const float* mem, const uint8_t* kpm, const int32_t* cu, int B, int S, int H, int d,
                       hipStream_t s) {
-    if (d != MQ_D || H < 1 || H > MQ_MAXH || B <= 0 || S <= 0 || S > MQ_MAXS) return PA_ESHAPE;
+    constexpr int MAXS32 = 16000;                 // (ring + partial-score slots + mask bytes within 160 KB)
+    if (d != MQ_D || H < 1 || H > MQ_MAXH || B <= 0 || S <= 0 || S > MAXS32) return PA_ESHAPE;
     const bool mask = !cu && kpm;
-    const int lds = MQF_NS * MQF_TILE + MQF_SCR + (mask ? (S + 31) / 16 * 16 : 0);
+    // PLANK_DECODE_MQ32_W8=0: the four-wave kernel (one wave per SIMD) instead of eight waves with skewed halves
+    static const int w8 = getenv("PLANK_DECODE_MQ32_W8") ? atoi(getenv("PLANK_DECODE_MQ32_W8")) : 1;
     static bool attr_done = false;
     if (!attr_done) {
-        constexpr int MAXLDS = MQF_NS * MQF_TILE + MQF_SCR + MQ_MAXS + 32;
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_mq32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_mq32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
-        if (e0 != hipSuccess || e1 != hipSuccess) return (int)(e0 != hipSuccess ? e0 : e1);
+        constexpr int MAXLDS = MQF_NS * MQF_TILE + MQ8_SCR + MAXS32 + 32;
+        const void* ks[4] = {reinterpret_cast<const void*>(dec_cross_mq32_kernel<false>), reinterpret_cast<const void*>(dec_cross_mq32_kernel<true>),
+                             reinterpret_cast<const void*>(dec_cross_mq32w8_kernel<false>), reinterpret_cast<const void*>(dec_cross_mq32w8_kernel<true>)};
+        for (const void* k : ks) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, MAXLDS);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_done = true;
     }
-    if (mask) PA_LAUNCH(dec_cross_mq32_kernel<true>, dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H);
-    else PA_LAUNCH(dec_cross_mq32_kernel<false>, dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H);
+    const int mbytes = mask ? (S + 31) / 16 * 16 : 0;
+    if (w8) {
+        const int lds = MQF_NS * MQF_TILE + MQ8_SCR + mbytes;
+        if (mask) PA_LAUNCH(dec_cross_mq32w8_kernel<true>, dim3(B), dim3(512), lds, s, ctx, qt, mem, kpm, cu, S, H);
+        else PA_LAUNCH(dec_cross_mq32w8_kernel<false>, dim3(B), dim3(512), lds, s, ctx, qt, mem, kpm, cu, S, H);
+    } else {
+        const int lds = MQF_NS * MQF_TILE + MQF_SCR + mbytes;
+        if (mask) PA_LAUNCH(dec_cross_mq32_kernel<true>, dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H);
+        else PA_LAUNCH(dec_cross_mq32_kernel<false>, dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H);
+    }
     return 0;
 }
 
