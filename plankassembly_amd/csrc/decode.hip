@@ -659,7 +659,7 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
             const int j = part / 2 - 1, pb = m->dec_base(j);
             if (L->mq && L->mq_contract) {
                 PA_LAUNCH(mq_contract_v_kernel<bf16>, dim3((B + MQ_XR - 1) / MQ_XR, c.n_head), dim3(512), 0, s, (bf16*)L->ao, d, (const bf16*)L->ctx,
-                          (const bf16*)PL(pb + D_CA_IN_W) + (size_t)2 * d * d, PF(pb + D_CA_IN_B) + 2 * d, B, d, c.n_head);
+                          (const bf16*)L->wo_t[j], PF(pb + D_CA_IN_B) + 2 * d, B, d, c.n_head);
                 RC(linear_res32(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), yf, z2f, L->z2b, B, d, d, st));
             } else if (L->mq) RC(linear_res32(m, L->ctx, L->wo_t[j], L->bo_t[j], yf, z2f, L->z2b, B, d, c.n_head * d, st));     // W_o,h W_v,h on the context rows
             else RC(linear_res32(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), yf, z2f, L->z2b, B, d, d, st));
@@ -730,7 +730,7 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
             // z2 = ao Wo^T + b + y1;  ff = relu(norm2(z2) W1^T + b1), y2 -> x;  z3 = ff W2^T + b2 + y2 -> z
             if (L->mq && L->mq_contract) {
                 PA_LAUNCH(mq_contract_v_kernel<T>, dim3((B + MQ_XR - 1) / MQ_XR, c.n_head), dim3(512), 0, s, (T*)L->ao, d, (const T*)L->ctx,
-                          (const T*)PL(pb + D_CA_IN_W) + (size_t)2 * d * d, PF(pb + D_CA_IN_B) + 2 * d, B, d, c.n_head);
+                          (const T*)L->wo_t[j], PF(pb + D_CA_IN_B) + 2 * d, B, d, c.n_head);
                 RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z2, d, B, d, d, 0, L->y, -1, st));
             } else if (L->mq) RC(linear(m, L->ctx, L->wo_t[j], L->bo_t[j], L->z2, d, B, d, c.n_head * d, 0, L->y, -1, st));
             else RC(linear(m, L->ao, PL(pb + D_CA_OUT_W), PF(pb + D_CA_OUT_B), L->z2, d, B, d, d, 0, L->y, -1, st));
@@ -863,7 +863,13 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
                 RC(foldw(L->fw[0][i], L->fu[0][i], L->fv[0][i], F(pb + D_SA_IN_W), F(pb + D_SA_IN_B), F(pp + D_N3_W), F(pp + D_N3_B), 3 * d));
             }
             RC(foldw(L->fw[1][i], L->fu[1][i], L->fv[1][i], F(pb + D_CA_IN_W), F(pb + D_CA_IN_B), F(pb + D_N1_W), F(pb + D_N1_B), d));
-            if (L->mq) {    // W~o = W_o,h W_v,h, b~o = b_o + W_o b_v for the Linear behind the absorbed attention (csrc/decode_mq.h)
+            if (L->mq && L->mq_contract) {     // the head-transposed copy of W_v for mq_contract_v_kernel (in the wo_t buffer, unused in this form)
+                if (c.dtype == PA_BF16)
+                    PA_LAUNCH(mq_transpose_v_kernel<bf16>, dim3(1024), dim3(256), 0, s, (bf16*)L->wo_t[i], (const bf16*)m->pl[pb + D_CA_IN_W] + (size_t)2 * d * d, d, c.n_head);
+                else
+                    PA_LAUNCH(mq_transpose_v_kernel<float>, dim3(1024), dim3(256), 0, s, (float*)L->wo_t[i], (const float*)m->pl[pb + D_CA_IN_W] + (size_t)2 * d * d, d, c.n_head);
+            }
+            if (L->mq && !L->mq_contract) {    // W~o = W_o,h W_v,h, b~o = b_o + W_o b_v for the Linear behind the absorbed attention (csrc/decode_mq.h)
                 if (c.dtype == PA_BF16)
                     PA_LAUNCH(mq_absorb_o_kernel<bf16>, dim3(d), dim3(256), 0, s, (bf16*)L->wo_t[i], L->bo_t[i], F(pb + D_CA_OUT_W), F(pb + D_CA_OUT_B),
                               F(pb + D_CA_IN_W), F(pb + D_CA_IN_B), d, c.n_head);

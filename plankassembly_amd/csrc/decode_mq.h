@@ -600,17 +600,28 @@ __global__ __launch_bounds__(512) void mq_expand_q_kernel(T* qt, const T* q, int
 // The value side as a launch of its own (exact f32, dh = 64): ao[b][h dh + c] = b_v[h dh + c] + sum_j ctx[b][h][j] W_v[h dh + c][j], followed by
 // the layer's ordinary out-projection.  In f32 the folded form (W~o = W_o,h W_v,h, one [B][H d] x [H d][d] product) costs 4 x the flops of the
 // two steps on the 1/16-rate f32 matrix pipe: 27 us on the skinny kernel against ~8 + 7.  grid (B / 8, H), 512 threads: thread (c, jp) holds
-// 64 weights of row h dh + c (columns 64 jp ..), the 8 context rows come from LDS (broadcast reads), the 8 column parts meet in LDS.
+// 64 weights of row h dh + c (columns 64 jp ..; read from the transposed copy WvT), the 8 context rows come from LDS (broadcast reads), the 8 column
+// parts meet in LDS.
+// WvT[h][j][c] = W_v[h 64 + c][j]: the value weights with the head's 64 output columns contiguous, so that the 64 lanes (c) of a wave of
+// mq_contract_v_kernel read 256 contiguous bytes per load (from W_v itself every lane would start its own 2 KB-strided row).  Once per sequence.
 template <typename T>
-__global__ __launch_bounds__(512) void mq_contract_v_kernel(T* ao, int ldo, const T* ctx, const T* Wv, const float* bv, int B, int d, int H) {
+__global__ __launch_bounds__(256) void mq_transpose_v_kernel(T* WvT, const T* Wv, int d, int H) {
+    const int64_t total = (int64_t)H * d * 64;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int c = (int)(e & 63), j = (int)((e >> 6) % d), h = (int)(e / ((int64_t)64 * d));
+        WvT[e] = Wv[(size_t)(h * 64 + c) * d + j];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(512) void mq_contract_v_kernel(T* ao, int ldo, const T* ctx, const T* WvT, const float* bv, int B, int d, int H) {
     __shared__ __attribute__((aligned(16))) float cs[MQ_XR][MQ_D];
     __shared__ float part[MQ_XR][8][64];
     const int h = blockIdx.y, r0 = blockIdx.x * MQ_XR, tid = threadIdx.x, c = tid & 63, jp = tid >> 6;
     float wf[64];
     {
-        const T* w = Wv + (size_t)(h * 64 + c) * d + 64 * jp;
+        const T* w = WvT + ((size_t)h * d + 64 * jp) * 64 + c;
 #pragma unroll
-        for (int k = 0; k < 64; k += 4) { const f32x4 v = ld4<T>(w + k); wf[k] = v[0]; wf[k + 1] = v[1]; wf[k + 2] = v[2]; wf[k + 3] = v[3]; }
+        for (int k = 0; k < 64; ++k) wf[k] = (float)w[(size_t)k * 64];
     }
     for (int e = tid; e < MQ_XR * MQ_D; e += 512) {
         const int r = e >> 9, j = e & (MQ_D - 1);
