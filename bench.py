@@ -755,8 +755,9 @@ def main():
             if mq:
                 w_bytes = (ND * ((6 + H) * D * D + 2 * D * FF) + V * D + D * D) * esz
                 kv_bytes = ND * B_DEC * (S_IN + 2 * T_DEC / 2) * D * esz
-            if mqf:        # (f32: W_v as its own launch, the weights are the reference's)
-                kv_bytes = ND * B_DEC * (S_IN + 2 * T_DEC / 2) * D * esz
+            if mqf:        # (f32: W_v as its own launch, the weights are the reference's; the SELF-attention is absorbed too - layer-input rows cached)
+                self_rows = 1 if os.environ.get("PLANK_DECODE_MQ_SELF", "1") != "0" else 2
+                kv_bytes = ND * B_DEC * (S_IN + self_rows * T_DEC / 2) * D * esz
             decode[ddtype] = dict(value=B_DEC * T_DEC * world / ddt, unit="tokens/s", batch=B_DEC, max_len=T_DEC, seq_in=S_IN,
                                   ms_per_step=ddt / T_DEC * 1e3, graph=bool(dec.use_graph),
                                   hbm_gbs=(w_bytes + kv_bytes) * T_DEC / ddt / 1e9,
@@ -767,6 +768,8 @@ def main():
                 decode[ddtype]["cross_attention"] = ("absorbed: q~_h = W_k,h^T q_h attends over the memory rows, W_v behind the softmax "
                                                      "(no cross-K/V projection, one [S][d] stream per layer and step)")
                 decode[ddtype]["includes"] = "encoder + 1024 decode steps"
+                if mqf and os.environ.get("PLANK_DECODE_MQ_SELF", "1") != "0":
+                    decode[ddtype]["self_attention"] = "absorbed too: the step caches the layer-input rows instead of K and V (exact f32 only)"
                 # the same time against the bytes the K/V-cache form moves (what rounds 1-4 quoted hbm_frac on)
                 decode[ddtype]["kv_cache_form_equiv_gbs"] = kv_cache_form_bytes * T_DEC / ddt / 1e9
             log(f"decode {ddtype}: {decode[ddtype]['value']:.0f} tokens/s, {decode[ddtype]['ms_per_step']:.3f} ms/step")

@@ -42,6 +42,8 @@ struct DecodeLayout {
     // copy of the encoder output rows (`mem`) instead of per-layer K / V caches.  qt / ctx: [B][H][d] query / context rows of a step;
     // wo_t / bo_t per layer: W_o,h W_v,h as one [d][H d] bf16 matrix and b_o + W_o b_v.
     bool mq = false;
+    bool mq_self = false;                      // exact f32: the SELF-attention absorbed too - self_k[i] caches the layer-input rows [B][Tmax][d]
+    std::vector<void*> wvt_self;               // per layer: head-transposed W_v of the self-attention (mq_contract_v_kernel)
     bool mq_contract = false;                  // exact f32, dh 64: W_v as its own launch + the ordinary out-projection instead of wo_t (decode_mq.h)
     void *mem = nullptr, *qt = nullptr, *ctx = nullptr;
     std::vector<void*> wo_t; std::vector<float*> bo_t;
@@ -554,6 +556,8 @@ size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tm
         L->mem = a.take((size_t)B * S * d * e);
         L->qt = a.take((size_t)B * H * d * e); L->ctx = a.take((size_t)B * H * d * e);
         for (int i = 0; i < c.n_dec; ++i) { L->wo_t[i] = a.take(d * H * d * e); L->bo_t[i] = (float*)a.take(d * 4); }
+        L->wvt_self.assign(c.n_dec, nullptr);
+        if (c.dtype == PA_F32) for (int i = 0; i < c.n_dec; ++i) L->wvt_self[i] = a.take(d * d * e);
     }
     L->kv_tmp = md.mq ? nullptr : a.take((size_t)B * S * 2 * d * e);
     L->hid_cache = a.take((size_t)B * Tmax * d * e);
@@ -651,6 +655,25 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
             PA_LAUNCH(dec_embed_kernel<T>, dim3(g1), dim3(256), 0, s, (T*)L->x, PF(P_IN_VALUE), PF(P_Q_COORD), PF(P_Q_POS),
                                L->tokens, Tmax, L->t_dev, B, d, c.out_dof, (bf16*)nullptr);
     }
+    // absorbed SELF-attention of layer i (exact f32): q in L->q, the layer input rows in `xin`; the row cache is self_k[i]
+    auto self_mq = [&](pa_model* mm, int i, const void* xin, hipStream_t ss) -> int {
+        if constexpr (sizeof(T) == 4) {
+            const int H = c.n_head, pbi = mm->dec_base(i);
+            const float* Wk = (const float*)mm->pl[pbi + D_SA_IN_W] + (size_t)d * d;
+            const float sl = LOG2E_F / sqrtf((float)(d / H));
+            PA_LAUNCH((mq_expand_q_kernel<64, float>), dim3((B + MQ_XR - 1) / MQ_XR, H), dim3(512), 0, ss, (float*)L->qt, (const float*)L->q, d, Wk, B, d, H, sl,
+                      (const float*)xin, (float*)L->self_k[i], (const int32_t*)L->t_dev, Tmax);
+            RC(fence_in());
+            RC(launch_cross_mq32((float*)L->ctx, (const float*)L->qt, (const float*)L->self_k[i], nullptr, nullptr, B, Tmax, H, d, ss, L->t_dev));
+            RC(fence_out());
+            PA_LAUNCH(mq_contract_v_kernel<float>, dim3((B + MQ_XR - 1) / MQ_XR, H), dim3(512), 0, ss, (float*)L->ao, d, (const float*)L->ctx,
+                      (const float*)L->wvt_self[i], (const float*)mm->pf[pbi + D_SA_IN_B] + 2 * d, B, d, H);
+            return 0;
+        } else {
+            (void)mm; (void)i; (void)xin; (void)ss;
+            return PA_EINVAL;
+        }
+    };
     const bool fold = L->fold;
     if (L->f32res) {
         // ---- bf16 step with an f32 residual stream: x / y / z / z2 are f32 rows, zb / z2b / xb their bf16 copies (matrix operands)
@@ -762,6 +785,16 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
     const int i = part / 2;
     const int pb = m->dec_base(i);
     if ((part & 1) == 0) {
+        if (L->mq_self) {                      // only the query rows are projected; K / V never exist (self_mq)
+            if (fold && i > 0) {
+                const int pp = m->dec_base(i - 1);
+                RC(linear_norm_a(m, L->z, L->fw[0][i], L->fu[0][i], L->fv[0][i], PF(pp + D_N3_W), PF(pp + D_N3_B), c.eps_layer, L->x,
+                                 L->q, d, B, d, d, 0, st));
+            } else {
+                RC(linear(m, x, PL(pb + D_SA_IN_W), PF(pb + D_SA_IN_B), L->q, d, B, d, d, 0, nullptr, -1, st));
+            }
+            return self_mq(m, i, L->x, s);
+        }
         if (fold && i > 0) {                   // x = norm3(z) of the layer before, materialised by this launch for the residual add
             const int pp = m->dec_base(i - 1);
             RC(linear_norm_a(m, L->z, L->fw[0][i], L->fu[0][i], L->fv[0][i], PF(pp + D_N3_W), PF(pp + D_N3_B), c.eps_layer, L->x,
@@ -833,6 +866,10 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
     L->fold = md.fold; L->f32res = md.f32res; L->mq = md.mq;           // (what each is and where it was measured: decode_modes)
     static const int contract_env = getenv("PLANK_DECODE_MQ_CONTRACT") ? atoi(getenv("PLANK_DECODE_MQ_CONTRACT")) : -1;
     L->mq_contract = L->mq && d / c.n_head == 64 && (contract_env >= 0 ? contract_env != 0 : c.dtype == PA_F32);
+    // exact f32: the self-attention in the same form - the step caches the layer-input rows x_t instead of K and V (half the bytes of what is
+    // then the largest stream of the f32 step), q~ = W_k^T q, W_v behind the softmax (q . b_k cancels, b_v is added once).  PLANK_DECODE_MQ_SELF=0.
+    static const int self_env = getenv("PLANK_DECODE_MQ_SELF") ? atoi(getenv("PLANK_DECODE_MQ_SELF")) : 1;
+    L->mq_self = L->mq && L->mq_contract && c.dtype == PA_F32 && self_env != 0 && Tmax <= 16000;
     if (L->mq) {
         // absorbed cross-attention: the step reads the encoder output rows themselves - no K / V projection of the memory at all
         hipError_t hm = hipMemcpyAsync(L->mem, memory, (size_t)m->NE * d * e, hipMemcpyDeviceToDevice, s);
@@ -869,6 +906,8 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
                 else
                     PA_LAUNCH(mq_transpose_v_kernel<float>, dim3(1024), dim3(256), 0, s, (float*)L->wo_t[i], (const float*)m->pl[pb + D_CA_IN_W] + (size_t)2 * d * d, d, c.n_head);
             }
+            if (L->mq_self)
+                PA_LAUNCH(mq_transpose_v_kernel<float>, dim3(1024), dim3(256), 0, s, (float*)L->wvt_self[i], (const float*)m->pl[pb + D_SA_IN_W] + (size_t)2 * d * d, d, c.n_head);
             if (L->mq && !L->mq_contract) {    // W~o = W_o,h W_v,h, b~o = b_o + W_o b_v for the Linear behind the absorbed attention (csrc/decode_mq.h)
                 if (c.dtype == PA_BF16)
                     PA_LAUNCH(mq_absorb_o_kernel<bf16>, dim3(d), dim3(256), 0, s, (bf16*)L->wo_t[i], L->bo_t[i], F(pb + D_CA_OUT_W), F(pb + D_CA_OUT_B),

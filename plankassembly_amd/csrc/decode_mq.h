@@ -220,13 +220,13 @@ __global__ __launch_bounds__(256, 1) void dec_cross_mq_kernel(bf16* ctx, const b
 constexpr int MQF_ROW = MQ_D * 4, MQF_TILE = MQ_KT * MQF_ROW, MQF_NS = 4, MQF_SCR = 2 * 4 * 1024;
 template <bool MASK>
 __global__ __launch_bounds__(256, 1) void dec_cross_mq32_kernel(float* ctx, const float* qt, const float* mem, const uint8_t* kpm,
-                                                                const int32_t* cu, int S, int H) {
+                                                                const int32_t* cu, int S, int H, const int32_t* t_dev) {
     extern __shared__ __attribute__((aligned(256))) char mq_smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
     const int row0 = cu ? cu[b] : b * S;
-    const int Lk = cu ? cu[b + 1] - row0 : S;
+    const int Lk = t_dev ? *t_dev + 1 : (cu ? cu[b + 1] - row0 : S);     // (t_dev: rows 0 .. t of a [B][S] cache - the self-attention form)
     float* out = ctx + (size_t)b * H * MQ_D;
     if (Lk <= 0) {
         for (int idx = tid; idx < H * MQ_D; idx += 256) out[idx] = 0.f;
@@ -387,13 +387,13 @@ __global__ __launch_bounds__(256, 1) void dec_cross_mq32_kernel(float* ctx, cons
 constexpr int MQ8_SCR = 2 * 8 * 1024;
 template <bool MASK>
 __global__ __launch_bounds__(512, 1) void dec_cross_mq32w8_kernel(float* ctx, const float* qt, const float* mem, const uint8_t* kpm,
-                                                                  const int32_t* cu, int S, int H) {
+                                                                  const int32_t* cu, int S, int H, const int32_t* t_dev) {
     extern __shared__ __attribute__((aligned(256))) char mq_smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
     const int row0 = cu ? cu[b] : b * S;
-    const int Lk = cu ? cu[b + 1] - row0 : S;
+    const int Lk = t_dev ? *t_dev + 1 : (cu ? cu[b + 1] - row0 : S);
     float* out = ctx + (size_t)b * H * MQ_D;
     if (Lk <= 0) {
         for (int idx = tid; idx < H * MQ_D; idx += 512) out[idx] = 0.f;
@@ -555,9 +555,17 @@ __global__ __launch_bounds__(512, 1) void dec_cross_mq32w8_kernel(float* ctx, co
 // one column j of 8 rows; the weights are read once per block (coalesced over j), the 8 x dh query values come from LDS.
 constexpr int MQ_XR = 8;
 template <int DH, typename T>        // DH = head dim when it is 64 (every weight load of a thread issued before the first use: one round trip), else 0
-__global__ __launch_bounds__(512) void mq_expand_q_kernel(T* qt, const T* q, int ldq, const T* Wk, int B, int d, int H, float sl) {
+__global__ __launch_bounds__(512) void mq_expand_q_kernel(T* qt, const T* q, int ldq, const T* Wk, int B, int d, int H, float sl,
+                                                          const T* xrow = nullptr, T* xcache = nullptr, const int32_t* t_dev = nullptr, int Tmax = 0) {
     __shared__ __attribute__((aligned(16))) float qs[MQ_XR][MQ_D];                 // (dh <= d)
     const int h = blockIdx.y, r0 = blockIdx.x * MQ_XR, dh = DH ? DH : d / H, tid = threadIdx.x;
+    if (xcache && h == 0) {                            // self-attention form: this step's layer-input rows join the row cache (row t of [B][Tmax][d])
+        const int t = *t_dev;
+        for (int e = tid; e < MQ_XR * d; e += 512) {
+            const int r = e / d, j = e - r * d;
+            if (r0 + r < B) xcache[((size_t)(r0 + r) * Tmax + t) * d + j] = xrow[(size_t)(r0 + r) * d + j];
+        }
+    }
     for (int e = tid; e < MQ_XR * dh; e += 512) {
         const int r = e / dh, c = e - r * dh;
         qs[r][c] = r0 + r < B ? (float)q[(size_t)(r0 + r) * ldq + h * dh + c] * sl : 0.f;
@@ -694,7 +702,7 @@ int launch_cross_mq(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* k
 }
 
 int launch_cross_mq32(float* ctx, const float* qt, const float* mem, const uint8_t* kpm, const int32_t* cu, int B, int S, int H, int d,
-                      hipStream_t s) {
+                      hipStream_t s, const int32_t* t_dev = nullptr) {
     constexpr int MAXS32 = 16000;                 // (ring + partial-score slots + mask bytes within 160 KB)
     if (d != MQ_D || H < 1 || H > MQ_MAXH || B <= 0 || S <= 0 || S > MAXS32) return PA_ESHAPE;
     const bool mask = !cu && kpm;
@@ -714,12 +722,12 @@ int launch_cross_mq32(float* ctx, const float* qt, const float* mem, const uint8
     const int mbytes = mask ? (S + 31) / 16 * 16 : 0;
     if (w8) {
         const int lds = MQF_NS * MQF_TILE + MQ8_SCR + mbytes;
-        if (mask) PA_LAUNCH(dec_cross_mq32w8_kernel<true>, dim3(B), dim3(512), lds, s, ctx, qt, mem, kpm, cu, S, H);
-        else PA_LAUNCH(dec_cross_mq32w8_kernel<false>, dim3(B), dim3(512), lds, s, ctx, qt, mem, kpm, cu, S, H);
+        if (mask) PA_LAUNCH(dec_cross_mq32w8_kernel<true>, dim3(B), dim3(512), lds, s, ctx, qt, mem, kpm, cu, S, H, t_dev);
+        else PA_LAUNCH(dec_cross_mq32w8_kernel<false>, dim3(B), dim3(512), lds, s, ctx, qt, mem, kpm, cu, S, H, t_dev);
     } else {
         const int lds = MQF_NS * MQF_TILE + MQF_SCR + mbytes;
-        if (mask) PA_LAUNCH(dec_cross_mq32_kernel<true>, dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H);
-        else PA_LAUNCH(dec_cross_mq32_kernel<false>, dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H);
+        if (mask) PA_LAUNCH(dec_cross_mq32_kernel<true>, dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H, t_dev);
+        else PA_LAUNCH(dec_cross_mq32_kernel<false>, dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H, t_dev);
     }
     return 0;
 }
