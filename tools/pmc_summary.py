@@ -24,7 +24,7 @@ KEYS = [  # json key -> regex on the demangled kernel name
     ("gemm_wide_tt", r"gemm3w_kernel"),
     ("dec_attn", r"dec_attn_kernel"),
     ("dec_cross_mq", r"dec_cross_mq_kernel"),
-    ("dec_cross_mq32", r"dec_cross_mq32_kernel"),
+    ("dec_cross_mq32", r"dec_cross_mq32(w8)?_kernel"),
     ("dec_sample", r"dec_sample_kernel"),
     # (rocprofv3's demangler leaves names with the __bf16 template argument mangled)
     ("gemm_pair_tt", r"gemm_kernel<__bf16, 64, 2, true, true, true, true, false, 2>|gemm_kernelIDF16bLi64ELi2ELb1ELb1ELb1ELb1ELb0ELi2E"),
