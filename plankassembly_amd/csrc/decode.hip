@@ -534,7 +534,7 @@ DecodeModes decode_modes(const pa_model_cfg& c, int B, int S) {
     r.fold = fold_env && c.dtype == PA_BF16 && d % 64 == 0 && c.d_ff % 32 == 0 && c.d_ff >= d && (size_t)((B + 63) / 64) * ((3 * d + 63) / 64) <= 512;
     if (c.dtype == PA_F32) r.fold = fold_env && d == 512 && B <= 512 && c.d_ff % 32 == 0 && c.d_ff >= d;   // (N < K: pa_gemm_norm_a's f32 form cannot materialise y - ADVICE r4)
     r.f32res = r.fold && c.dtype == PA_BF16 && f32res_env != 0 && d == 512 && B <= 512 && c.d_ff % 512 == 0;
-    r.mq = r.fold && (c.dtype == PA_BF16 ? mq_env != 0 : mq32_env != 0) && d == MQ_D && B <= 512 && c.n_head >= 1 && c.n_head <= MQ_MAXH && d % c.n_head == 0 && S <= MQ_MAXS;
+    r.mq = r.fold && (c.dtype == PA_BF16 ? mq_env != 0 : mq32_env != 0) && d == MQ_D && B <= 512 && c.n_head >= 1 && c.n_head <= MQ_MAXH && d % c.n_head == 0 && S <= (c.dtype == PA_F32 ? 16000 : MQ_MAXS);     // (f32: launch_cross_mq32 keeps 16 KB of partial-score slots beside the ring)
     return r;
 }
 
