@@ -586,6 +586,11 @@ int pa_dec_cross_mq(void* ctx, const void* qt, const void* mem, const uint8_t* k
 /* The same in exact f32 (f32 ctx / qt / mem; v_mfma_f32_16x16x4_f32): the cross-attention of the parity (token-exact) decode. */
 int pa_dec_cross_mq32(float* ctx, const float* qt, const float* mem, const uint8_t* kpm, const int32_t* cu, int32_t B, int32_t S,
                       int32_t H, int32_t d, void* stream);
+/* The self-attention form of the same launch (exact f32; what the token-exact decode step runs on its cache of layer-input rows):
+ * rows [B][Tmax][512], of which element b attends over rows 0 .. *t_dev (the key count t + 1 is read on the device, so the launch can
+ * sit in a captured graph). */
+int pa_dec_self_mq32(float* ctx, const float* qt, const float* xcache, const int32_t* t_dev, int32_t B, int32_t Tmax, int32_t H,
+                     int32_t d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -179,6 +179,7 @@ def lib():
             "pa_decode_buffers": (I, [P, P, P, P, P]),
             "pa_dec_cross_mq": (I, [P, P, P, P, P, I, I, I, I, P]),
             "pa_dec_cross_mq32": (I, [P, P, P, P, P, I, I, I, I, P]),
+            "pa_dec_self_mq32": (I, [P, P, P, P, I, I, I, I, P]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)

@@ -991,6 +991,13 @@ extern "C" int pa_dec_cross_mq32(float* ctx, const float* qt, const float* mem, 
     return launch_cross_mq32(ctx, qt, mem, kpm, cu, B, S, H, d, (hipStream_t)stream);
 }
 
+extern "C" int pa_dec_self_mq32(float* ctx, const float* qt, const float* xcache, const int32_t* t_dev, int32_t B, int32_t Tmax,
+                                int32_t H, int32_t d, void* stream) {
+    if (!ctx || !qt || !xcache || !t_dev) return PA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(xcache) | reinterpret_cast<uintptr_t>(ctx)) & 15) return PA_EALIGN;
+    return launch_cross_mq32(ctx, qt, xcache, nullptr, nullptr, B, Tmax, H, d, (hipStream_t)stream, t_dev);
+}
+
 extern "C" int pa_decode_buffers(pa_model* m, void** tokens, void** attach, void** first_end, void** t_dev) {
     if (!m || !m->dec || !tokens || !attach || !first_end || !t_dev) return PA_EINVAL;
     *tokens = m->dec->tokens; *attach = m->dec->attach; *first_end = m->dec->first_end; *t_dev = m->dec->t_dev;

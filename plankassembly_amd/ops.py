@@ -431,3 +431,13 @@ def dec_cross_mq(qt, mem, *, kpm=None, cu=None, S=None):
     L.check(L.lib().pa_dec_cross_mq(L.ptr(ctx), L.ptr(qt), L.ptr(mem), L.ptr(kpm), L.ptr(cu), B, int(S), H, d, L.stream()),
             "pa_dec_cross_mq")
     return ctx
+
+
+def dec_self_mq32(qt, xcache, t_dev):
+    """Self-attention form of the absorbed decode attention (pa_dec_self_mq32): qt [B, H, 512] f32, xcache [B, Tmax, 512] f32, t_dev int32
+    device scalar (element b attends over rows 0 .. t).  Returns ctx [B, H, 512] f32."""
+    B, H, d = qt.shape
+    ctx = torch.empty(B, H, d, dtype=torch.float32, device=qt.device)
+    L.check(L.lib().pa_dec_self_mq32(L.ptr(ctx), L.ptr(qt), L.ptr(xcache), L.ptr(t_dev), B, xcache.shape[1], H, d, L.stream()),
+            "pa_dec_self_mq32")
+    return ctx

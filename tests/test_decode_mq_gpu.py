@@ -205,6 +205,22 @@ def test_f32_moving_reference_point():
     _check32(ctx[0], _ref(qt[0], mem[0], torch.ones(S, dtype=torch.bool, device="cuda")))
 
 
+@pytest.mark.parametrize("B,Tmax,t", [(3, 128, 0), (2, 128, 15), (4, 256, 16), (2, 1024, 1023), (5, 64, 40)])
+def test_f32_self_attention_form_reads_its_length_from_the_device(B, Tmax, t):
+    """pa_dec_self_mq32: rows 0 .. t of a [B][Tmax] cache, t in device memory (rows behind t hold NaN: they must not be touched)."""
+    from plankassembly_amd import ops
+    torch.manual_seed(Tmax + t)
+    x = torch.randn(B, Tmax, 512, device="cuda")
+    x[:, t + 1:] = float("nan")                                    # (rows past the end are never fetched: the last tile re-reads row t)
+    qt = torch.randn(B, 8, 512, device="cuda") * 0.15
+    td = torch.tensor([t, 0], dtype=torch.int32, device="cuda")
+    ctx = ops.dec_self_mq32(qt, x, td)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ctx).all()
+    for b in range(B):
+        _check32(ctx[b], _ref(qt[b], x[b, :t + 1], torch.ones(t + 1, dtype=torch.bool, device="cuda")))
+
+
 def test_kv_cache_form_of_the_decode_step_still_passes_the_token_exact_gate():
     """The per-layer K / V-cache form of the cross-attention (PLANK_DECODE_MQ=0 / PLANK_DECODE_MQ_F32=0, read once per process) stays a
     tested path: the headline-shape f32 decode test in a child process with both switches off (in this process the same test runs on
