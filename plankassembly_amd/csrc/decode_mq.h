@@ -416,14 +416,18 @@ __global__ __launch_bounds__(512, 1) void dec_cross_mq32w8_kernel(float* ctx, co
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) :: "memory");
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)mq_smem;
-    // tile image as above: row r at r * 2048, chunk c at position (c & ~15) | ((c ^ r) & 15).  Scores: row n, chunks 16 wave + 4 g + j
-    const uint32_t sbase = (uint32_t)n * MQF_ROW + 256u * (uint32_t)wave + ((((uint32_t)n) ^ (4u * (uint32_t)g)) << 4);
+    // tile image: row r at r * 2048, chunk c at position (c & ~15) | ((c ^ f(r)) & 15) with f(r) = r ^ ((r & 4) << 1): a ds_read_b128 is
+    // served in four groups of 16 lanes that each take lanes of TWO 16-lane rows ({0-3, 12-15, 20-27}, ..), so the rows a group
+    // touches must land in disjoint bank quads - with the plain key r both products had 2-way conflicts in every group.
+    // Scores: row n, chunks 16 wave + 4 g + j
+    auto fz = [](uint32_t r) { return r ^ ((r & 4u) << 1); };
+    const uint32_t sbase = (uint32_t)n * MQF_ROW + 256u * (uint32_t)wave + ((fz((uint32_t)n) ^ (4u * (uint32_t)g)) << 4);
     // P^T M: k <-> key 4 g + kk, row m = n <-> dims 64 wave + 4 n + 0..3: chunk 16 wave + n
     uint32_t pbase[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         const uint32_t key = 4u * (uint32_t)g + (uint32_t)kk;
-        pbase[kk] = key * MQF_ROW + 256u * (uint32_t)wave + ((((uint32_t)n) ^ key) << 4);
+        pbase[kk] = key * MQF_ROW + 256u * (uint32_t)wave + ((((uint32_t)n) ^ fz(key)) << 4);
     }
     const char* const mbase = reinterpret_cast<const char*>(mem + (size_t)row0 * MQ_D);
     uint32_t coff[2][2];
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(512, 1) void dec_cross_mq32w8_kernel(float* ctx, co
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const uint32_t pz = 64u * hh + (uint32_t)lane, r = 2u * (uint32_t)wave + (uint32_t)i;
-            coff[i][hh] = ((pz & ~15u) | ((pz ^ r) & 15u)) * 16u;
+            coff[i][hh] = ((pz & ~15u) | ((pz ^ fz(r)) & 15u)) * 16u;
         }
     auto issue = [&](int t) {
         const uint32_t dst = lds0 + (uint32_t)(t & (MQF_NS - 1)) * MQF_TILE;
