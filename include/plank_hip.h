@@ -524,11 +524,16 @@ int pa_model_bind_transposed(pa_model* m, void* const* params_lpT);
  * backward pass forms d(memory) with ONE GEMM over all layers instead of n_dec accumulating ones.  NULL unbinds. */
 int pa_model_bind_cross_kv_t(pa_model* m, const void* kvT_all);
 int64_t pa_model_train_ws_bytes(pa_model* m, int32_t B, int32_t S, int32_t T);
-/* stats (device, f32[4]): [0] sum of -log p(label) over non-PAD labels, [1] #non-PAD, [2] #correct.
+/* stats (device, f32[PA_MODEL_STATS_FLOATS] = f32[8]; the forward zeroes all eight itself - pa_mixture_nll_fwd_fin):
+ * [0] sum of -log p(label) over non-PAD labels, [1] #non-PAD, [2] #correct.
  * loss = stats[0]/stats[1] (reference models.py:221), accuracy = stats[2]/(stats[1]+1e-10) (:227);
  * [3] upstream gradient d(objective)/d(loss), initialised to 1 by the forward and read (on the
- * device, no host sync) by the backward.
+ * device, no host sync) by the backward; [4] loss, [5] accuracy (written by the forward's last launch), [6], [7] spare.
+ * A caller that sized the block for the four-float layout of rounds 1-4 gets a 16-byte out-of-bounds write: size it with
+ * pa_model_stats_floats().
  * `seed` keys this step's dropout masks (training != 0 and cfg.dropout > 0). */
+#define PA_MODEL_STATS_FLOATS 8
+int32_t pa_model_stats_floats(void);                           /* = PA_MODEL_STATS_FLOATS of the loaded library */
 int pa_model_train_fwd(pa_model* m, const pa_batch* batch, void* ws, int64_t ws_bytes, uint32_t seed,
                        int32_t training, float* stats, void* stream);
 /* Backward in execution-ordered segments [seg_lo, seg_hi): 0 = heads + decoder.norm,

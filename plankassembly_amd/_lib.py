@@ -169,6 +169,7 @@ def lib():
             "pa_model_train_ws_bytes": (I64, [P, I, I, I]),
             "pa_model_train_fwd": (I, [P, P, P, I64, U, I, P, P]),
             "pa_model_train_num_segments": (I, [P]),
+            "pa_model_stats_floats": (I, []),
             "pa_model_train_bwd": (I, [P, I, I, F, P]),
             "pa_model_grad_lag": (I, [P]),
             "pa_model_tensor": (I, [P, I, P, P]),

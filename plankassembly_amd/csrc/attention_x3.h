@@ -311,7 +311,9 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
     if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
     const int per = (nsteps + parts - 1) / parts, s_lo = part * per;          // this block's key steps [s_lo, nsteps)
     nsteps = min(nsteps, s_lo + per);
-    if (s_lo >= nsteps) return;                                                // (the rows were zeroed by attn_delta_kernel)
+    // split launches: attn_delta_kernel zeroed the rows.  Unsplit: an element without keys (cu_k[b + 1] == cu_k[b]) must
+    // still store its zero dQ rows - fall through to the store with an empty loop
+    if (s_lo >= nsteps && parts > 1) return;
 
     f32x16 dqacc[A::NDT];
 #pragma unroll
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
         x3_key_aux<DH, DROP>(smem + X::AUX0 + buf * X::AUXS, tid, mreg, p.drop_seed, kreg);
     };
 
-    gload(s_lo); lstore(0);
+    if (s_lo < nsteps) { gload(s_lo); lstore(0); }                             // (block-uniform)
     __syncthreads();
 
     auto body = [&](int step, const int S) {                    // S: the stage (0 / 1) this step's tiles are in

@@ -2633,7 +2633,11 @@ extern "C" int pa_gemm_split_stats(int64_t* out2, int32_t reset) {
     return 0;
 }
 // returns 1 when the GEMM was enqueued as bf16x3, 0 when the caller must run it exact, < 0 on error
-static int gemm_split3(const pa_gemm_args* a, void* stream) {
+// Returns 0 and *taken = true when the product ran as bf16x3, 0 and *taken = false when the caller must run it exact, or an error
+// (a negative PA_E* or a positive hipError_t of the cut / inner launch - ADVICE r5: the status used to share the return value
+// with the 'taken' flag, so hipErrorInvalidValue = 1 read as success).
+static int gemm_split3(const pa_gemm_args* a, void* stream, bool* taken) {
+    *taken = false;
     const bool akc = a->a_kcontig != 0, bkc = a->b_kcontig != 0;
     const int M = a->M, N = a->N, K = a->K, nb = a->batch;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -2763,16 +2767,18 @@ static int gemm_split3(const pa_gemm_args* a, void* stream) {
         if (hipMemsetAsync(static_cast<char*>(a->ws) + (size_t)zero_from * slab, 0, (size_t)(zero_to - zero_from) * slab,
                            reinterpret_cast<hipStream_t>(stream)) != hipSuccess) return PA_EINVAL;
     }
-    return 1;
+    *taken = true;
+    return 0;
 }
 
 extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return PA_EINVAL;
     if (a->in_dtype == PA_F32 && g_split.on.load(std::memory_order_relaxed)) {
         if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch <= 0) return PA_EINVAL;
-        const int r3 = gemm_split3(a, stream);
-        if (r3 < 0) return r3;
-        if (r3 == 1) { g_split.taken.fetch_add(1); return 0; }
+        bool took = false;
+        const int r3 = gemm_split3(a, stream, &took);
+        if (r3) return r3;
+        if (took) { g_split.taken.fetch_add(1); return 0; }
         g_split.declined.fetch_add(1);
         if (a->splitk > 1 && a->splitk_defer && a->ws) {
             // the caller's reduction descriptor counts pa_gemm_effective_splitk(K, PA_F32, splitk) slabs in THIS mode's (bf16)
@@ -3086,7 +3092,9 @@ extern "C" int pa_gemm_norm_a(const pa_gemm_args* a, const pa_gemm_norm_ext* x, 
 
 // bf16x3 mode: every member's two operands are cut into their stacked (hi, hi, lo) / (hi, lo, hi) forms by ONE split launch into
 // consecutive regions of the scratch buffer, then the members run as one grouped bf16 launch over 3 K rows each.
-static int gemm_group_split3(const pa_gemm_args* args, int32_t n, void* stream) {
+// (status / 'taken' separated as in gemm_split3: 0 + *taken, 0 + !*taken = declined, or an error code)
+static int gemm_group_split3(const pa_gemm_args* args, int32_t n, void* stream, bool* taken) {
+    *taken = false;
     pa_gemm_args b[PA_MAX_GROUP];
     SplitTab tb; tb.n = 0; tb.begin[0] = 0;
     long long off = g_split.keep_off;                      // behind the retained (hi, hi, lo) images of this segment's dY operands
@@ -3136,14 +3144,16 @@ static int gemm_group_split3(const pa_gemm_args* args, int32_t n, void* stream) 
     if (rc) return rc;
     g_split.taken.fetch_add(n);
     g_split.reused.fetch_add(hits);
-    return 1;
+    *taken = true;
+    return 0;
 }
 extern "C" int pa_gemm_group(const pa_gemm_args* args, int32_t n, void* stream) {
     if (!args || n <= 0 || n > PA_MAX_GROUP) return PA_EINVAL;
     if (split_on() && args[0].in_dtype == PA_F32) {
-        const int r3 = gemm_group_split3(args, n, stream);
-        if (r3 < 0) return r3;
-        if (r3 == 1) return 0;
+        bool took = false;
+        const int r3 = gemm_group_split3(args, n, stream, &took);
+        if (r3) return r3;
+        if (took) return 0;
         return PA_EINVAL;                                   // the caller launches the members one by one (pa_gemm declines or splits each)
     }
     static_assert(PA_MAX_GROUP == PA_MAX_GROUP_, "header / kernel table size");

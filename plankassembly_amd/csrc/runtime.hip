@@ -808,6 +808,7 @@ extern "C" int pa_model_set_upstream(pa_model* m, const float* upstream) {
     m->upstream = upstream;
     return 0;
 }
+extern "C" int32_t pa_model_stats_floats(void) { return PA_MODEL_STATS_FLOATS; }
 extern "C" int pa_model_train_num_segments(const pa_model* m) {
     return m ? m->cfg.n_dec + m->cfg.n_enc + 4 : PA_EINVAL;
 }

@@ -58,7 +58,7 @@ class _Lane:
         if self.enc_ws is None or self.enc_ws.numel() < need + 256:
             self.enc_ws = torch.empty(need + 512, dtype=torch.uint8, device=dev)
         base = (self.enc_ws.data_ptr() + 255) // 256 * 256
-        stats = torch.empty(4, dtype=torch.float32, device=dev)
+        stats = torch.empty(L.lib().pa_model_stats_floats(), dtype=torch.float32, device=dev)   # include/plank_hip.h: f32[8]
         L.check(lib.pa_model_train_fwd(self.h(), C.byref(b), C.c_void_p(base),
                                        C.c_int64(self.enc_ws.numel() - (base - self.enc_ws.data_ptr())), C.c_uint32(0), 0,
                                        L.ptr(stats), L.stream()), "pa_model_train_fwd(encoder)")

@@ -372,6 +372,18 @@ class PlankModel(nn.Module):
             L.check(L.lib().pa_attn_split_config(0), "pa_attn_split_config")
             L.check(L.lib().pa_gemm_split_cache_use(None), "pa_gemm_split_cache_use")
             return
+        try:
+            self._split_on(attn, retain)
+        except BaseException:
+            #  a failure half way - scratch allocation, cache creation - must not leave the process-global mode on
+            # for every other f32 model of the process
+            try:
+                self._split(False)
+            except Exception:
+                pass
+            raise
+
+    def _split_on(self, attn, retain):
         if attn:
             L.check(L.lib().pa_attn_split_config(1), "pa_attn_split_config")
         dev = self._flat.device.index or 0
@@ -617,12 +629,24 @@ class PlankModel(nn.Module):
 
     def _pack(self, mask_u8, n_valid=None):
         """``n_valid``: the number of unmasked encoder rows when the caller already knows it on the HOST (a dataloader that
-        padded the batch does; ``batch["_n_valid"]``) - the one device -> host read of a step is then skipped."""
+        padded the batch does; ``batch["_n_valid"]``) - the one device -> host read of a step is then skipped.  Contract: it
+        must equal ``(~input_mask).sum()`` of THIS batch."""
         B, S = mask_u8.shape
         cu = torch.empty(2 * B + 1, dtype=torch.int32, device=mask_u8.device)
         rowmap = torch.empty(B * S, dtype=torch.int32, device=mask_u8.device)
         L.check(L.lib().pa_pack_rows(L.ptr(mask_u8), B, S, L.ptr(cu), L.ptr(rowmap), L.stream()), "pa_pack_rows")
-        return cu, rowmap, int(cu[B]) if n_valid is None else int(n_valid)
+        if n_valid is None:
+            return cu, rowmap, int(cu[B])
+        # A host-supplied count sizes every packed encoder launch: a stale one (batch edited after collation) reads / writes
+        # past the packed rows.  Checked against the device's own count on a model's first uses (a device -> host read each;
+        # PLANK_CHECK_NVALID=1: always, 0: never) - ADVICE r5.
+        chk = os.environ.get("PLANK_CHECK_NVALID")
+        self._nvalid_checks = getattr(self, "_nvalid_checks", 0) + 1
+        if chk != "0" and (chk == "1" or self._nvalid_checks <= 4):
+            got = int(cu[B])
+            if got != int(n_valid):
+                raise ValueError(f"batch['_n_valid'] = {int(n_valid)} but input_mask has {got} unmasked rows")
+        return cu, rowmap, int(n_valid)
 
     def prepare_batch(self, batch, groups=True):
         """Move a collated batch to the model's device and attach the encoder row packing (``_pack``: valid-row
@@ -701,7 +725,7 @@ class PlankModel(nn.Module):
         b, keep = self._make_batch(batch, True)
         ws = self._workspace(b.B, b.S, b.T)
         base = (ws.data_ptr() + 255) // 256 * 256
-        stats = torch.empty(8, dtype=torch.float32, device=self._flat.device)      # include/plank_hip.h pa_mixture_nll_fwd_fin
+        stats = torch.empty(L.lib().pa_model_stats_floats(), dtype=torch.float32, device=self._flat.device)   # include/plank_hip.h: f32[8]
         self._step_seed = (self._step_seed * 1664525 + 1013904223 + int(torch.initial_seed())) & 0xFFFFFFFF
         self._split(True, retain="fwd")
         try:
