@@ -374,9 +374,22 @@ typedef struct {
      * lasts as long as the CU that drew the longest elements; in this order every CU gets a long, a medium and a short
      * block.  Results do not depend on it.  NULL = batch order. */
     const int32_t* order;
+    /* optional scratch (device, 256-byte aligned; NULL = none) for packed bf16 self-attention launches (cu_q == cu_k, order given,
+     * H = 8, dh = 64): the key range of a long batch element - resp. its query range in the dK / dV launch - is then cut across
+     * several blocks whose partial results meet in this buffer (csrc/attention.hip decode_unit_split), so that the launch lasts
+     * as long as its work instead of as long as its longest element's serial chain.  OPT-IN (PA_ATTN_SPLIT=1): on MI355X every
+     * extra block costs ~6 us of slot time (lookup, first tile, publish + merge) and the split launches measured 15-20 % SLOWER
+     * than one block per tile (profiles/r06_attn_split.txt).  Size: pa_attn_ws_bytes() (0 while the split is off).  Contract: its
+     * first pa_attn_ws_ticket_bytes(ws_bytes) bytes are ZERO before the first launch that uses the buffer; every launch leaves them
+     * zero.  Launches that share a buffer must be ordered on one stream.  Results do not depend on it beyond f32 summation order. */
+    void* ws; int64_t ws_bytes;
 } pa_attn_args;
 int pa_attn_fwd(const pa_attn_args* a, void* stream);
 int pa_attn_bwd(const pa_attn_args* a, void* stream);
+/* scratch for pa_attn_args.ws: rows_total packed rows of B batch elements, the longest L_max rows (0 bytes when no launch of that
+ * shape would use it: split not enabled - PA_ATTN_SPLIT=1 -, H != 8, or L_max short enough for one block per tile) */
+int64_t pa_attn_ws_bytes(int32_t rows_total, int32_t B, int32_t H, int32_t L_max);
+int64_t pa_attn_ws_ticket_bytes(int64_t ws_bytes);
 /* bf16x3 ("split") attention, the companion of pa_gemm_split_config: while `on`, f32 launches with dh = 64 compute every matrix
  * product of torch's F.multi_head_attention_forward (reference plankassembly/models.py:60-69: S = Q K^T, O = P V) and of its
  * backward as hi*hi + hi*lo + lo*hi of the operands' bf16 hi / lo parts with f32 accumulation (csrc/attention_x3.h); inputs,

@@ -61,7 +61,8 @@ class AttnArgs(C.Structure):
                 ("dout", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
                 ("delta", C.c_void_p),
                 ("lddo", C.c_int32), ("lddq", C.c_int32), ("lddk", C.c_int32), ("lddv", C.c_int32),
-                ("cu_q", C.c_void_p), ("cu_k", C.c_void_p), ("order", C.c_void_p)]
+                ("cu_q", C.c_void_p), ("cu_k", C.c_void_p), ("order", C.c_void_p),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
 
 
 class GroupDesc(C.Structure):
@@ -145,6 +146,8 @@ def lib():
             "pa_layernorm_finish_many": (I, [P, I, I, P]),
             "pa_attn_fwd": (I, [P, P]),
             "pa_attn_bwd": (I, [P, P]),
+            "pa_attn_ws_bytes": (I64, [I, I, I, I]),
+            "pa_attn_ws_ticket_bytes": (I64, [I64]),
             "pa_attn_split_config": (I, [I]),
             "pa_attn_split_taken": (I64, [I]),
             "pa_gelu_fwd": (I, [P, P, I64, I, I, I, F, C.c_uint32, P]),

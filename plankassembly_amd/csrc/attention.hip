@@ -15,7 +15,9 @@
 // [row][dh] image and/or a transposed [dh][row] image (4 x EB register blocks transposed in
 // flight).  LDS images are XOR-swizzled in 16-byte chunks.  Scores never touch HBM.
 // Softmax runs in the log2 domain (exp2), f32 statistics.
+#include <stdio.h>
 #include <atomic>
+#include <algorithm>
 #include "pa_device.h"
 #include "../../include/plank_hip.h"
 
@@ -44,7 +46,17 @@ struct AttnP {
     int balanced;                                 // self-attention over packed rows with `order`: decode_block_balanced
     int ks_min;                                   // in-block key split (KS = 2 kernels): elements with fewer key tiles run unsplit
     int parts_q, parts_kv;                        // bf16x3 backward (attention_x3.h): blocks per owned tile, the streamed side cut in ranges
+    // balanced == 2 (round 6, packed self-attention): the STREAMED side of a long element is cut into up to sp_pmax ranges of at
+    // most sp_kmax 64-row tiles, one block each (decode_unit_split); the range blocks of an owned tile meet at a ticket and
+    // the last one to arrive merges the others' partial results (split_publish / split_arrive)
+    int* sp_tick; char* sp_part; int sp_slots, sp_pmax, sp_kmax;
 };
+#ifdef PA_SPLIT_FENCE
+constexpr bool SPLIT_FENCE = true;       // probe build: acquire fence + sc1 loads
+#else
+constexpr bool SPLIT_FENCE = false;
+#endif
+constexpr int SP_BYTES = 64 * 1024;               // partial results of one (owned tile, range) block
 
 // Variable-length ("unpadded") batches: with cu_q / cu_k given, batch element b owns rows [cu[b], cu[b+1]) of the
 // packed Q resp. K/V matrices; Lq / Lk in the launch parameters are then only the maxima (grid size, layout of the
@@ -704,11 +716,11 @@ __device__ __forceinline__ int dispatch_batch(const int32_t* order, int b) { ret
 // Blocks past the last valid one exit.  Every wave computes the same mapping from B <= 64 lanes (no LDS, no barrier).
 // `off` / `len`: the element's first row and row count in `cu`, from the lane that loaded them (saves the caller a second,
 // dependent round of loads - ~800 cycles of every block's prologue).
-__device__ __forceinline__ bool decode_block_balanced(const AttnP& pin, const int32_t* cu, int& tile, int& h, int& b, int& off, int& len, int L = blockIdx.x) {
+__device__ __forceinline__ bool decode_block_balanced(const AttnP& pin, const int32_t* cu, int& tile, int& h, int& b, int& off, int& len, int L = blockIdx.x, int rows = BOWN) {
     const int x = L & 7, j = L >> 3;
     const int lane = threadIdx.x & 63;
     int o = 0, t = 0, c0 = 0, cl = 0;
-    if (lane < pin.B) { o = pin.order[lane]; c0 = cu[o]; cl = cu[o + 1] - c0; t = (cl + BOWN - 1) / BOWN; }
+    if (lane < pin.B) { o = pin.order[lane]; c0 = cu[o]; cl = cu[o + 1] - c0; t = (cl + rows - 1) / rows; }
     int inc = t;                                             // inclusive prefix of the tile counts over the ranks
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
@@ -726,6 +738,98 @@ __device__ __forceinline__ bool decode_block_balanced(const AttnP& pin, const in
     h = x;
     return true;
 }
+
+
+// ---- balanced == 2: units = (element, owned 128-row tile, range of the streamed side), longest elements first -------------
+// Why (profiles/r05_attention_shape_sweep.txt item 4, profiles/r06_attn_split.txt): every block of the packed launch is resident
+// from the start, so the launch lasts as long as the serial chain of its longest block - 15-16 key tiles for a 1 000-row element
+// against ~8 on average - while the CUs that drew short blocks idle.  Cutting the long chains makes the launch's duration its
+// WORK: an element with kt >= sp_kmax + 1 streamed tiles runs as np = min(sp_pmax, ceil(kt / sp_kmax)) blocks per owned tile.
+// Blocks are numbered longest element first (LPT; the hardware hands blocks to CU slots in index order as slots free up), the
+// ranges of one owned tile are neighbours (they finish together: the merge rarely waits for data to become visible - it never
+// WAITS at all, the last arriver merges).  Every wave computes the mapping from B <= 64 lanes, as decode_block_balanced does.
+struct SplitUnit { int tile, h, b, off, len, part, nparts, slot; };
+__device__ __forceinline__ bool decode_unit_split(const AttnP& pin, const int32_t* cu, SplitUnit& u, int L = blockIdx.x) {
+    const int x = L & 7, j = L >> 3;
+    const int lane = threadIdx.x & 63;
+    int o = 0, c0 = 0, cl = 0, tq = 0, np = 1;
+    if (lane < pin.B) {
+        o = pin.order[lane]; c0 = cu[o]; cl = cu[o + 1] - c0; tq = (cl + BOWN - 1) / BOWN;
+        const int ks = (cl + BSTR - 1) / BSTR;
+        if (ks > pin.sp_kmax) np = min(pin.sp_pmax, (ks + pin.sp_kmax - 1) / pin.sp_kmax);
+    }
+    int sinc = np > 1 ? tq : 0;                              // inclusive prefix of the split elements' owned tiles: merge slots
+    const int spl = sinc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(sinc, d); if (lane >= d) sinc += v; }
+    if (sinc > pin.sp_slots) np = 1;                          // no slot left (scratch sized for fewer rows): this element runs unsplit
+    const int t = tq * np;
+    int inc = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
+    // units in descending work, dealt to the XCD's 32 CUs boustrophedon like decode_block_balanced's blocks (the first rows are
+    // all resident from the start - placement IS the balance there; later rows go to whichever slot frees up)
+    const int n = __shfl(inc, 63);
+    const int row = j >> 5, pos = j & 31, left = n - (row << 5);
+    if (left <= 0) return false;
+    const int rowlen = left < 32 ? left : 32;
+    if (pos >= rowlen) return false;
+    const int k = (row << 5) + ((row & 1) ? rowlen - 1 - pos : pos);
+    const int rank = __popcll(__ballot(inc <= k));           // elements whose blocks all come before block k
+    const int local = k - (__shfl(inc, rank) - __shfl(t, rank));
+    const int npr = __shfl(np, rank);
+    u.nparts = __builtin_amdgcn_readfirstlane(npr);
+    u.tile = __builtin_amdgcn_readfirstlane(local / npr);
+    u.part = __builtin_amdgcn_readfirstlane(local % npr);
+    u.b = __builtin_amdgcn_readfirstlane(__shfl(o, rank));
+    u.off = __builtin_amdgcn_readfirstlane(__shfl(c0, rank));
+    u.len = __builtin_amdgcn_readfirstlane(__shfl(cl, rank));
+    u.slot = __builtin_amdgcn_readfirstlane(((__shfl(sinc, rank) - __shfl(spl, rank)) + u.tile) * 8 + x);
+    u.h = x;
+    return true;
+}
+// this range block's tiles [lo, hi) of the element's n streamed tiles
+__device__ __forceinline__ void split_range(int n, int part, int nparts, int& lo, int& hi) {
+    const int per = (n + nparts - 1) / nparts;
+    lo = min(n, part * per); hi = min(n, lo + per);
+}
+// Partial results travel through HBM/L2 between blocks that may sit on different XCDs (private, mutually incoherent L2s):
+// cdna_hip_programming.md Guideline 16, form R1 - payload stored WRITE-THROUGH (16-byte sc1 buffer stores), every storing wave
+// drains them (s_waitcnt vmcnt(0)), the block meets, ONE lane takes a ticket (relaxed agent-scope atomic); the block that
+// draws the last ticket does ONE agent-scope acquire (drops its CU's / XCD's stale lines), the block meets again, then plain loads.
+// Tickets are zero between launches: the last arriver puts the word back (the scratch is zeroed once by its owner).
+struct SplitOut {
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ SplitOut(char* base) : rs(__builtin_amdgcn_make_buffer_rsrc(base, 0, SP_BYTES, 0x00020000)) {}
+    // vector j of this thread ([j][thread] layout: a wave's store covers 1 KB)
+    __device__ __forceinline__ void put(int j, int nthreads, f32x4 v) const {
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), rs, (j * nthreads + (int)threadIdx.x) * 16, 0, 16);   // aux 16 = sc1
+    }
+};
+// (sc1 loads - L1 bypassed, served from the memory side like the sc1 stores that wrote the data: valid WITHOUT an acquire fence
+//  when the producer stored sc1, cdna_hip_programming.md Guideline 16; the fence - buffer_inv sc1 - was measured first and made
+//  every range-block launch slower than the unsplit one: profiles/r06_attn_split.txt)
+__device__ __forceinline__ f32x4 split_get(const char* base, int j, int nthreads) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, SP_BYTES, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (j * nthreads + (int)threadIdx.x) * 16, 0, 16);
+    return *reinterpret_cast<const f32x4*>(&v);
+}
+__device__ __forceinline__ bool split_arrive(int* tick, int nparts, int* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave: its write-through stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == nparts - 1;
+        if (last) {
+            if (SPLIT_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(tick, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *s_flag = last;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
 
 
 template <int DH> struct BT {
@@ -1752,7 +1856,13 @@ __device__ __forceinline__ void attn4_dq_body(const AttnP& pin, int bid, char* s
     const int kh = KS == 2 ? (wave_all >> 3) : 0;
     const int wave = wave_all & 7, tid = threadIdx.x & (NT4 - 1);
     int tile_, h, b, off_ = 0, len_ = -1;
-    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_, bid)) return; }
+    int part = 0, nparts = 1, slot = 0;                      // balanced == 2 (KS == 1 launches): this block's range of the key tiles
+    if (KS == 1 && pin.balanced == 2) {
+        SplitUnit su;
+        if (!decode_unit_split(pin, pin.cu_q, su, bid)) return;
+        tile_ = su.tile; h = su.h; b = su.b; off_ = su.off; len_ = su.len; part = su.part; nparts = su.nparts; slot = su.slot;
+    }
+    else if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_, bid)) return; }
     else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b, bid); b = dispatch_batch(pin.order, b); }
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff, off_, len_);
@@ -1783,7 +1893,7 @@ __device__ __forceinline__ void attn4_dq_body(const AttnP& pin, int bid, char* s
             for (int w = 0; w < 4; ++w)
                 dsum += bf16_lo(oreg[s_][w]) * bf16_lo(doreg[s_][w]) + bf16_hi(oreg[s_][w]) * bf16_hi(doreg[s_][w]);
         dsum = quad_sum(dsum);
-        if (g == 0 && qrow < p.Lq && kh == 0) p.delta[srow] = dsum;
+        if (g == 0 && qrow < p.Lq && kh == 0 && part == 0) p.delta[srow] = dsum;
     }
     const float dlt = (qrow < p.Lq) ? dsum * keep_p : 0.f;
     const TileSrc srcK = tile_src(Kp, p.ldk, p.Lk, DH), srcV = tile_src(Vp, p.ldv, p.Lk, DH);
@@ -1798,7 +1908,9 @@ __device__ __forceinline__ void attn4_dq_body(const AttnP& pin, int bid, char* s
     const bool split = KS == 2 && ksteps >= pin.ks_min;                    // block-uniform
     if (KS == 2 && kh == 1 && !split) return;
     const int s0 = split ? (ksteps + 1) / 2 : ksteps;
-    const int kbase = kh * s0 * BSTR, nst_h = KS == 2 ? (kh ? ksteps - s0 : s0) : 0;
+    int r_lo = 0, r_hi = ksteps;
+    if (KS == 1 && nparts > 1) split_range(ksteps, part, nparts, r_lo, r_hi);
+    const int kbase = KS == 2 ? kh * s0 * BSTR : r_lo * BSTR, nst_h = KS == 2 ? (kh ? ksteps - s0 : s0) : 0;
     auto issue = [&](int step, int buf, int kfirst_) {
         char* base = smem + kh * 2 * BUF + buf * BUF;
         const int k0 = kbase + step * BSTR;
@@ -1815,11 +1927,12 @@ __device__ __forceinline__ void attn4_dq_body(const AttnP& pin, int bid, char* s
             if (DROP) reinterpret_cast<uint32_t*>(base + AUX + 64)[tid] = drop_key_hash(p.drop_seed, (uint32_t)(k0 + tid));
         }
     };
-    if (KS == 1 || nst_h > 0) issue(0, 0, 0);
+    if (KS == 1 ? r_hi > r_lo : nst_h > 0) issue(0, 0, 0);
     int kfirst = p.Lk, klast = p.Lk;
     if (KS == 1 && mp) scan_key_mask4(mp, p.Lk, tid, reinterpret_cast<int*>(smem + 2 * BUF), kfirst, klast);
     int nsteps = (klast + BSTR - 1) / BSTR;
     if (p.causal) nsteps = min(nsteps, (min(q0 + BOWN, p.Lq) + BSTR - 1) / BSTR);
+    if (KS == 1) nsteps = max(0, min(nsteps, r_hi) - r_lo);          // steps of this block's range (all of them when unsplit)
     const int my_steps = KS == 2 ? nst_h : nsteps;
     if (KS == 2) nsteps = s0;
 
@@ -1887,6 +2000,19 @@ __device__ __forceinline__ void attn4_dq_body(const AttnP& pin, int bid, char* s
 #pragma unroll
         for (int db = 0; db < 4; ++db) dqacc[db] += xo[db * 64 + lane];
     }
+    if (KS == 1 && nparts > 1) {
+        // range block: publish the partial dQ^T; the tile's last range block to arrive adds the others to its own and stores
+        char* const pbase = pin.sp_part + (size_t)slot * pin.sp_pmax * SP_BYTES;
+        const SplitOut so(pbase + (size_t)part * SP_BYTES);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) so.put(db, NT4, dqacc[db]);
+        if (!split_arrive(pin.sp_tick + slot, nparts, reinterpret_cast<int*>(smem + 2 * BUF))) return;
+        for (int pp = 0; pp < nparts; ++pp) {
+            if (pp == part) continue;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) dqacc[db] += split_get(pbase + (size_t)pp * SP_BYTES, db, NT4);
+        }
+    }
     bf16* dQp = reinterpret_cast<bf16*>(p.dq) + (size_t)qoff * p.lddq + h * DH;
     store_rows4(dQp, p.lddq, qrow, p.Lq, dqacc, p.scale * (DROP ? p.drop_scale : 1.0f), lane);
 }
@@ -1908,7 +2034,13 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b, off_ = 0, len_ = -1;
-    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_k, tile_, h, b, off_, len_, bid)) return; }
+    int part = 0, nparts = 1, slot = 0;                      // balanced == 2: this block's range of the query tiles
+    if (!SELF_DELTA && pin.balanced == 2) {
+        SplitUnit su;
+        if (!decode_unit_split(pin, pin.cu_k, su, bid)) return;
+        tile_ = su.tile; h = su.h; b = su.b; off_ = su.off; len_ = su.len; part = su.part; nparts = su.nparts; slot = su.slot;
+    }
+    else if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_k, tile_, h, b, off_, len_, bid)) return; }
     else { decode_block((pin.Lk + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b, bid); b = dispatch_batch(pin.order, b); }
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff, off_, len_);
@@ -1925,8 +2057,9 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
     u32x4 kreg[2], vreg[2];
     load_row4(kreg, Kp, p.ldk, krow, p.Lk, lane);
     load_row4(vreg, Vp, p.ldv, krow, p.Lk, lane);
-    const int nsteps = (p.Lq + BSTR - 1) / BSTR;
-    const int step0 = CAUSAL ? (key0 / BSTR) : 0;
+    int nsteps = (p.Lq + BSTR - 1) / BSTR;
+    int step0 = CAUSAL ? (key0 / BSTR) : 0;
+    if (nparts > 1) split_range(nsteps, part, nparts, step0, nsteps);
 
     f32x4 dkacc[4], dvacc[4];
 #pragma unroll
@@ -2036,6 +2169,22 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
         body(step, IC<0>{});
         if (step + 1 < nsteps) body(step + 1, IC<1>{});
     }
+    if (nparts > 1) {
+        // range block: publish the partial dK^T / dV^T; the tile's last range block to arrive adds the others to its own and stores
+        char* const pbase = pin.sp_part + (size_t)slot * pin.sp_pmax * SP_BYTES;
+        const SplitOut so(pbase + (size_t)part * SP_BYTES);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) { so.put(db, NT4, dkacc[db]); so.put(4 + db, NT4, dvacc[db]); }
+        if (!split_arrive(pin.sp_tick + slot, nparts, reinterpret_cast<int*>(smem + 2 * BUF))) return;
+        for (int pp = 0; pp < nparts; ++pp) {
+            if (pp == part) continue;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                dkacc[db] += split_get(pbase + (size_t)pp * SP_BYTES, db, NT4);
+                dvacc[db] += split_get(pbase + (size_t)pp * SP_BYTES, 4 + db, NT4);
+            }
+        }
+    }
     bf16* dKp = reinterpret_cast<bf16*>(p.dk) + (size_t)koff * p.lddk + h * DH;
     bf16* dVp = reinterpret_cast<bf16*>(p.dv) + (size_t)koff * p.lddv + h * DH;
     const float ds = DROP ? p.drop_scale : 1.0f;
@@ -2062,6 +2211,8 @@ __global__ __launch_bounds__(NT4, 4) void attn4_bwd_merged_kernel(AttnP pin, int
 #include "attention_x3.h"
 
 // =====================================================================================================
+static int split_kmax() { static const int v = getenv("PA_ATTN_SPLIT_KMAX") ? atoi(getenv("PA_ATTN_SPLIT_KMAX")) : 8; return v < 1 ? 1 : v; }
+static int split_pmax() { static const int v = getenv("PA_ATTN_SPLIT_PMAX") ? atoi(getenv("PA_ATTN_SPLIT_PMAX")) : 2; return v < 1 ? 1 : v > 8 ? 8 : v; }
 AttnP make_params(const pa_attn_args* a) {
     AttnP p;
     p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o; p.lse = a->lse; p.kpm = a->kpm;
@@ -2077,7 +2228,26 @@ AttnP make_params(const pa_attn_args* a) {
     static const bool bal_env = !(getenv("PA_ATTN_BALANCED") && atoi(getenv("PA_ATTN_BALANCED")) == 0);
     p.ks_min = 4; p.parts_q = 1; p.parts_kv = 1;
     p.balanced = (bal_env && a->order && a->cu_q && a->cu_k && a->H == 8 && a->B <= 64) ? 1 : 0;
+    // range blocks (balanced == 2, set by the launchers whose kernels know it): packed self-attention with scratch from the caller.
+    // PA_ATTN_SPLIT=1 enables (default off); PA_ATTN_SPLIT_KMAX (8) longest unsplit chain in 64-row tiles; PA_ATTN_SPLIT_PMAX (2) most ranges.
+    p.sp_tick = nullptr; p.sp_part = nullptr; p.sp_slots = 0; p.sp_pmax = split_pmax(); p.sp_kmax = split_kmax();
+    static const bool sp_env = getenv("PA_ATTN_SPLIT") && atoi(getenv("PA_ATTN_SPLIT")) != 0;     // opt-in: measured slower (profiles/r06_attn_split.txt)
+    if (sp_env && p.balanced && a->ws && a->cu_q == a->cu_k && !a->kpm && !a->causal && a->dtype == PA_BF16 && a->dh == 64 &&
+        (reinterpret_cast<uintptr_t>(a->ws) & 255) == 0 && p.sp_pmax > 1) {
+        const int64_t per = (int64_t)p.sp_pmax * SP_BYTES + 64;          // one (owned tile, head): its range blocks' partials + ticket
+        const int64_t total = a->ws_bytes / per;
+        p.sp_slots = (int)(total / 8 < (1 << 20) ? total / 8 : (1 << 20));
+        p.sp_tick = static_cast<int*>(a->ws);
+        p.sp_part = static_cast<char*>(a->ws) + ((int64_t)p.sp_slots * 8 * 4 + 255) / 256 * 256;
+        if ((int64_t)p.sp_slots * 8 * per > a->ws_bytes || p.sp_slots < 1) { p.sp_slots = 0; p.sp_tick = nullptr; }
+    }
     return p;
+}
+// blocks of a balanced == 2 launch: an upper bound of the units (the host does not know the elements' lengths; surplus blocks exit)
+static unsigned split_grid(const AttnP& p, int owned_max, int streamed_max) {
+    const int ks = (streamed_max + BSTR - 1) / BSTR;
+    const int np = ks > p.sp_kmax ? std::min(p.sp_pmax, (ks + p.sp_kmax - 1) / p.sp_kmax) : 1;
+    return (unsigned)(8 * p.B * ((owned_max + BOWN - 1) / BOWN) * np);
 }
 
 template <typename K> int set_lds(K kern, int bytes) {
@@ -2129,6 +2299,7 @@ template <int DH> int run_fwd_bf16(AttnP p, hipStream_t st) {
             static const int occ = getenv("PA_ATTN_V5_OCC") ? atoi(getenv("PA_ATTN_V5_OCC")) : 3;
             static const int rc4 = set_lds(attn5_fwd_kernel<true, 4, 2>, L5<4>::SHM) | set_lds(attn5_fwd_kernel<false, 4, 2>, L5<4>::SHM);
             if (rc4) return rc4;
+            if (p.balanced && p.sp_tick) { p.balanced = 2; grid = dim3(split_grid(p, p.Lq, p.Lk)); }
             if (occ == 2) {
                 if (p.drop_thr) PA_LAUNCH((attn5_fwd_kernel<true, 4, 2>), grid, dim3(NTH), L5<4>::SHM, st, p);
                 else PA_LAUNCH((attn5_fwd_kernel<false, 4, 2>), grid, dim3(NTH), L5<4>::SHM, st, p);
@@ -2158,9 +2329,10 @@ template <int DH> int run_fwd_bf16(AttnP p, hipStream_t st) {
 }
 template <int DH> int run_bwd_bf16(AttnP p, hipStream_t st) {
     const int shm = BL<DH>::SHM;
-    const dim3 gq(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B), gk(((p.Lk + BOWN - 1) / BOWN) * p.H * p.B);
+    const dim3 gq0(((p.Lq + BOWN - 1) / BOWN) * p.H * p.B), gk0(((p.Lk + BOWN - 1) / BOWN) * p.H * p.B);
     if constexpr (DH == 64) {
         if (use_v4(p, p.Lq > p.Lk ? p.Lq : p.Lk)) {
+            dim3 gq = gq0, gk = gk0;
             // single query tile per (sample, head): dQ and dK/dV blocks in one launch (PA_ATTN_BWD_MERGE=0: two launches)
             static const bool merge_env = !(getenv("PA_ATTN_BWD_MERGE") && atoi(getenv("PA_ATTN_BWD_MERGE")) == 0);
             static const int merge_max = getenv("PA_ATTN_BWD_MERGE_MAX") ? atoi(getenv("PA_ATTN_BWD_MERGE_MAX")) : 128;
@@ -2176,8 +2348,9 @@ template <int DH> int run_bwd_bf16(AttnP p, hipStream_t st) {
                 }
                 return 0;
             }
-            const bool ks = use_ksplit(p, gq.x);
+            bool ks = use_ksplit(p, gq.x);
             constexpr int shm2 = 4 * BL<DH>::BUF + 64;
+            if (p.balanced && p.sp_tick && !ks) { p.balanced = 2; gq = dim3(split_grid(p, p.Lq, p.Lk)); gk = dim3(split_grid(p, p.Lk, p.Lq)); }
             if (ks) {
                 static const int rc_d = set_lds(attn4_bwd_dq_kernel<true, 2>, shm2), rc_n = set_lds(attn4_bwd_dq_kernel<false, 2>, shm2);
                 if (rc_d || rc_n) return rc_d ? rc_d : rc_n;
@@ -2196,6 +2369,7 @@ template <int DH> int run_bwd_bf16(AttnP p, hipStream_t st) {
             return 0;
         }
     }
+    const dim3 gq = gq0, gk = gk0;
     // blocks per CU the register allocation is made for (experiment knob PA_ATTN_OCC="<dq><dkv>", e.g. "43")
     static const int occ_env = getenv("PA_ATTN_OCC") ? atoi(getenv("PA_ATTN_OCC")) : 0;
     const int oq = occ_env ? occ_env / 10 : 3, ok = occ_env ? occ_env % 10 : 2;
@@ -2327,6 +2501,18 @@ extern "C" int64_t pa_attn_split_taken(int32_t reset) {
     const long long v = g_attn_x3_taken.load();
     if (reset) g_attn_x3_taken.store(0);
     return v;
+}
+
+extern "C" int64_t pa_attn_ws_bytes(int32_t rows_total, int32_t B, int32_t H, int32_t L_max) {
+    static const bool sp_env = getenv("PA_ATTN_SPLIT") && atoi(getenv("PA_ATTN_SPLIT")) != 0;     // opt-in: measured slower (profiles/r06_attn_split.txt)
+    if (!sp_env || split_pmax() < 2 || H != 8 || rows_total <= 0 || B <= 0 || B > 64) return 0;
+    if ((L_max + BSTR - 1) / BSTR <= split_kmax()) return 0;
+    const int64_t slots = (int64_t)(rows_total / BOWN + B);             // owned tiles of all elements, an upper bound
+    return slots * 8 * ((int64_t)split_pmax() * SP_BYTES + 64) + 256;
+}
+extern "C" int64_t pa_attn_ws_ticket_bytes(int64_t ws_bytes) {
+    const int64_t per = (int64_t)split_pmax() * SP_BYTES + 64;
+    return (ws_bytes / per / 8 * 8 * 4 + 255) / 256 * 256;
 }
 
 extern "C" int pa_attn_fwd(const pa_attn_args* a, void* stream) {

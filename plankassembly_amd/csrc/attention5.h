@@ -62,7 +62,13 @@ __global__ __launch_bounds__(NTH, OCC) void attn5_fwd_kernel(AttnP pin) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, h, b, off_ = 0, len_ = -1;
-    if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_)) return; }
+    int part = 0, nparts = 1, slot = 0;                                // balanced == 2: this block's range of the key tiles
+    if (pin.balanced == 2) {
+        SplitUnit su;
+        if (!decode_unit_split(pin, pin.cu_q, su)) return;
+        tile_ = su.tile; h = su.h; b = su.b; off_ = su.off; len_ = su.len; part = su.part; nparts = su.nparts; slot = su.slot;
+    }
+    else if (pin.balanced) { if (!decode_block_balanced(pin, pin.cu_q, tile_, h, b, off_, len_)) return; }
     else { decode_block((pin.Lq + BOWN - 1) / BOWN, pin.H, pin.B, tile_, h, b); b = dispatch_batch(pin.order, b); }
     int qoff, koff;
     const AttnP p = batch_view(pin, b, qoff, koff, off_, len_);
@@ -96,6 +102,10 @@ __global__ __launch_bounds__(NTH, OCC) void attn5_fwd_kernel(AttnP pin) {
     int vk0 = tile_voff<DH>(p.ldk, tid), vv0 = tile_voff<DH>(p.ldv, tid);
     int vk1 = vk0 + 32 * p.ldk * 2, vv1 = vv0 + 32 * p.ldv * 2;                       // second 32 rows of a tile
     const int stepK = BSTR * p.ldk * 2, stepV = BSTR * p.ldv * 2;
+    int t_lo = 0, t_hi = (p.Lk + BSTR - 1) / BSTR;                     // key tiles of this block: all of the element's, or its range
+    if (nparts > 1) split_range(t_hi, part, nparts, t_lo, t_hi);
+    const int kbase = t_lo * BSTR;
+    vk0 += t_lo * stepK; vk1 += t_lo * stepK; vv0 += t_lo * stepV; vv1 += t_lo * stepV;
     LdsBase<DH> lb;
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     lb.init(smem_base, lane);
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(NTH, OCC) void attn5_fwd_kernel(AttnP pin) {
     auto issue = [&](int t, int stage, int kfirst_) {
         char* base = smem + stage * STG + wave * 1024;
         char* aux = smem + AUX0 + stage * AUXS;
-        const int k0 = t * BSTR;
+        const int k0 = kbase + t * BSTR;
         const bool tile_masked = k0 + BSTR > kfirst_;                  // block-uniform
         uint8_t mb = 0;
         if (tile_masked && tid < BSTR) {                               // (loaded before the DMA is issued: its wait must not cover the tiles)
@@ -123,14 +133,14 @@ __global__ __launch_bounds__(NTH, OCC) void attn5_fwd_kernel(AttnP pin) {
             if (DROP) reinterpret_cast<uint32_t*>(aux + 64)[key_slot(tid)] = drop_key_hash(p.drop_seed, (uint32_t)(k0 + tid));
         }
     };
-    const int nt_all = (p.Lk + BSTR - 1) / BSTR;
+    const int nt_all = t_hi - t_lo;
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t)
         if (t < nt_all) issue(t, t, 0);
     int kfirst = p.Lk, klast = p.Lk;
     if (mp) scan_key_mask(mp, p.Lk, tid, reinterpret_cast<int*>(smem + AUX0 + NS * AUXS), kfirst, klast);
-    const int ntiles = (klast + BSTR - 1) / BSTR;
-    const int nchunks = (klast + 31) / 32;
+    const int ntiles = min((klast + BSTR - 1) / BSTR, t_hi) - t_lo;
+    const int nchunks = (min(klast, t_hi * BSTR) - kbase + 31) / 32;
 
     f32x16 oacc[2];
 #pragma unroll
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(NTH, OCC) void attn5_fwd_kernel(AttnP pin) {
         constexpr int KNEXT = KT == 0 ? SOFF + 32 * RBN : ((STAGE + 1) % NS) * STG;   // K rows of chunk c + 1
         constexpr int VOFF = SOFF + NAT + KT * 32 * RBN;
         constexpr int HOFF = STAGE * AUXS + 64 + KT * 64;
-        const int k0 = c * 32;
+        const int k0 = kbase + c * 32;
         // ---- every LDS operand of this body, requested up front (in order of first use) ----
         u32x4 kf[4], cq[4], vf[4];
 #pragma unroll
@@ -320,7 +330,33 @@ __global__ __launch_bounds__(NTH, OCC) void attn5_fwd_kernel(AttnP pin) {
         if (t + 2 < ntiles) tile(t + 2, IC<2>{});
         if (NS > 3 && t + 3 < ntiles) tile(t + 3, IC<(NS > 3 ? 3 : 0)>{});
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (nparts > 1) {
+        // range block: publish (O^T, m, l); the last of the tile's range blocks to arrive rescales all of them to the common
+        // reference point and stores (the same merge attn4_fwd_kernel<., 2> does through LDS)
+        char* const pbase = pin.sp_part + (size_t)slot * pin.sp_pmax * SP_BYTES;
+        const SplitOut so(pbase + (size_t)part * SP_BYTES);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) so.put(j, NTH, f32x4{oacc[j >> 2][4 * (j & 3)], oacc[j >> 2][4 * (j & 3) + 1], oacc[j >> 2][4 * (j & 3) + 2], oacc[j >> 2][4 * (j & 3) + 3]});
+        so.put(8, NTH, f32x4{m_run, l_tot, 0.f, 0.f});
+        if (!split_arrive(pin.sp_tick + slot, nparts, reinterpret_cast<int*>(smem + AUX0 + NS * AUXS))) return;
+        for (int pp = 0; pp < nparts; ++pp) {
+            if (pp == part) continue;
+            const char* ob = pbase + (size_t)pp * SP_BYTES;
+            const f32x4 ml = split_get(ob, 8, NTH);
+            const float m_new = fmaxf(m_run, ml[0]);
+            const float ms = (m_new == -INFINITY) ? 0.f : m_new;
+            const float a0 = fast_exp2(m_run - ms), a1 = fast_exp2(ml[0] - ms);
+            l_tot = l_tot * a0 + ml[1] * a1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 x = split_get(ob, j, NTH);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oacc[j >> 2][4 * (j & 3) + e] = oacc[j >> 2][4 * (j & 3) + e] * a0 + x[e] * a1;
+            }
+            m_run = m_new;
+        }
+    }
     const float inv = l_tot > 0.f ? (DROP ? p.drop_scale : 1.0f) / l_tot : 0.f;
     bf16* Op = reinterpret_cast<bf16*>(p.o) + (size_t)qoff * p.ldo + h * DH;
     store_rows<bf16, DH>(Op, p.ldo, qrow, p.Lq, oacc, inv, lane);

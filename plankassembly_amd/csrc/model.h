@@ -55,6 +55,9 @@ struct pa_model {
     void *memory = nullptr, *hid = nullptr; float *mem_m = nullptr, *mem_r = nullptr, *hid_m = nullptr, *hid_r = nullptr;
     float *vlog = nullptr, *plog = nullptr, *sw = nullptr, *row_lse = nullptr; void* pfeat = nullptr; int ldv = 0;
     float* stats = nullptr;
+    // scratch of the packed encoder self-attention's range blocks (pa_attn_args.ws): FIRST region of the train workspace; its ticket
+    // words are zeroed whenever the region moved or changed size (pa_model_train_fwd)
+    void* attn_ws = nullptr; int64_t attn_ws_bytes = 0; void* attn_ws_zeroed = nullptr; int64_t attn_ws_zeroed_bytes = 0;
     const float* upstream = nullptr;      // d(loss) of the caller's autograd (pa_model_set_upstream), or nullptr = stats[3]
     // backward temporaries
     void *gA, *gB, *gC, *gD, *gE, *gF, *gQ3, *gKV, *dmem, *dvlog, *dplog; float *dsw, *delta, *partial, *splitws;

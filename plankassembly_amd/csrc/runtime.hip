@@ -176,6 +176,7 @@ struct Ctx {   // convenience wrapper for kernel calls in the model's dtype
         // packed encoder rows: dispatch the batch elements longest first (pa_pack_rows left that order behind cu_in)
         static const bool use_order = !(getenv("PA_ATTN_ORDER") && atoi(getenv("PA_ATTN_ORDER")) == 0);
         if (use_order && cu_k && cu_k == m->batch.cu_in) a.order = cu_k + m->B + 1;
+        if (cu_q && cu_q == cu_k) { a.ws = m->attn_ws; a.ws_bytes = m->attn_ws_bytes; }      // packed self-attention: range blocks
         const int d = m->cfg.d_model, H = m->cfg.n_head;
         a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.kpm = kpm;
         a.B = m->B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dh = d / H;
@@ -197,6 +198,11 @@ size_t pa_train_layout(pa_model* m, char* base, int B, int S, int T) {
     const size_t BS = (size_t)B * S, BT = (size_t)B * T, R = BS > BT ? BS : BT;
     Arena a{base, 0};
     m->esz = e;
+    {   // (first, so that it only moves with the buffer itself)
+        const int64_t n = c.dtype == PA_BF16 ? pa_attn_ws_bytes(B * S, B, (int32_t)H, S) : 0;
+        m->attn_ws = n > 0 ? a.take((size_t)n) : nullptr;
+        m->attn_ws_bytes = n > 0 ? n : 0;
+    }
     m->X.resize(c.n_enc + 1); m->Y.resize(c.n_dec + 1); m->ea.resize(c.n_enc); m->da.resize(c.n_dec);
     for (int i = 0; i <= c.n_enc; ++i) m->X[i] = a.take(BS * d * e);
     for (int i = 0; i < c.n_enc; ++i) {
@@ -797,6 +803,11 @@ extern "C" int pa_model_train_fwd(pa_model* m, const pa_batch* batch, void* ws, 
     }
     m->seed = seed; m->p_drop = training ? m->cfg.dropout : 0.f;
     m->stats = stats;
+    if (m->attn_ws && (m->attn_ws != m->attn_ws_zeroed || m->attn_ws_bytes != m->attn_ws_zeroed_bytes)) {
+        // contract of pa_attn_args.ws: ticket words zero before the first launch that uses the buffer (launches leave them zero)
+        if (hipMemsetAsync(m->attn_ws, 0, (size_t)pa_attn_ws_ticket_bytes(m->attn_ws_bytes), (hipStream_t)stream) != hipSuccess) return PA_EINVAL;
+        m->attn_ws_zeroed = m->attn_ws; m->attn_ws_zeroed_bytes = m->attn_ws_bytes;
+    }
     m->have_fwd = false;
     int rc = pa_train_forward_impl(m, stream);
     if (rc == 0) m->have_fwd = batch->output_value != nullptr;

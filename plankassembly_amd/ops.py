@@ -393,18 +393,29 @@ def cast(src, dtype):
     return dst
 
 
-def attn_varlen_fwd(q, k, v, H, cu_q, cu_k, B, Lq_max, Lk_max, causal=False, scale=None, drop_p=0.0, drop_seed=0, order=None):
+def attn_split_ws(rows_total, B, H, device, L_max=1 << 20):
+    """Scratch for the range blocks of packed self-attention launches (include/plank_hip.h pa_attn_args.ws), zeroed as its
+    contract asks, or None when the library would not use one."""
+    n = int(L.lib().pa_attn_ws_bytes(int(rows_total), int(B), int(H), int(L_max)))
+    return torch.zeros(n, dtype=torch.uint8, device=device) if n > 0 else None
+
+
+def attn_varlen_fwd(q, k, v, H, cu_q, cu_k, B, Lq_max, Lk_max, causal=False, scale=None, drop_p=0.0, drop_seed=0, order=None, ws=None):
     """Packed ("unpadded") attention: q [Nq, H*dh], k/v [Nk, H*dh] with int32 row offsets cu_q / cu_k [B+1]
-    (either may be None = dense [B*L] rows).  Returns (o [Nq, H*dh], lse [B, H, Lq_max])."""
+    (either may be None = dense [B*L] rows).  Returns (o [Nq, H*dh], lse [B, H, Lq_max]).  ``ws``: attn_split_ws()."""
     o = torch.empty(q.shape[0], q.shape[1], dtype=q.dtype, device=q.device)
     lse = _f32(B, H, Lq_max, device=q.device)
     a = _attn_args(q, k, v, o, lse, None, causal, scale, drop_p, drop_seed, H, cu_q, cu_k, B, Lq_max, Lk_max, order)
+    if ws is not None:
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     L.check(L.lib().pa_attn_fwd(C.byref(a), L.stream()), "pa_attn_fwd")
     return o, lse
 
 
-def attn_varlen_bwd(dout, q, k, v, o, lse, H, cu_q, cu_k, B, Lq_max, Lk_max, causal=False, scale=None, drop_p=0.0, drop_seed=0, order=None):
+def attn_varlen_bwd(dout, q, k, v, o, lse, H, cu_q, cu_k, B, Lq_max, Lk_max, causal=False, scale=None, drop_p=0.0, drop_seed=0, order=None, ws=None):
     a = _attn_args(q, k, v, o, lse, None, causal, scale, drop_p, drop_seed, H, cu_q, cu_k, B, Lq_max, Lk_max, order)
+    if ws is not None:
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
     dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
     dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)

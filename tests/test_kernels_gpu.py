@@ -2,6 +2,7 @@
 GPU only (`-m gpu`).  f32 kernels must agree to 1e-4 (relative to the tensor scale), bf16 kernels
 to bf16 rounding."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -11,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
     from plankassembly_amd import ops
+    from plankassembly_amd import _lib as L
 
 DEV = "cuda"
 
@@ -756,6 +758,61 @@ def test_attention_key_split_blocks_same_dropout_as_dense():
     assert rel_err(dk, dk_d.reshape(B * Lk, dm)[sel]) < 1.5e-2 and rel_err(dv, dv_d.reshape(B * Lk, dm)[sel]) < 1.5e-2
     o0, _ = ops.attn_varlen_fwd(qp, kvp[:, :dm], kvp[:, dm:], H, None, cu_k, B, Lq, Lk)
     assert rel_err(o, o0) > 0.05                                   # (dropout really was on)
+
+
+@pytest.mark.parametrize("lens,drop", [([1021, 33, 700, 577, 960, 64, 129, 513, 1000, 450], 0.2),
+                                        ([1199, 1199, 85, 640, 577], 0.0), ([1021] * 16, 0.2), ([577, 64, 300], 0.2)])
+def test_attention_range_blocks_equal_one_block_per_tile(lens, drop):
+    if os.environ.get("PA_ATTN_SPLIT", "0") == "0":
+        pytest.skip("range blocks are opt-in (PA_ATTN_SPLIT=1, read once per process): run by test_attention_range_blocks_in_a_child_process")
+    _range_blocks_case(lens, drop)
+
+
+def test_attention_range_blocks_in_a_child_process():
+    """The opt-in range-block path stays a tested path: the cases above in a child process with PA_ATTN_SPLIT=1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PA_ATTN_SPLIT="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_kernels_gpu.py", "-k",
+                        "test_attention_range_blocks_equal_one_block_per_tile"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "4 passed" in r.stdout, r.stdout[-2000:]
+
+
+def _range_blocks_case(lens, drop):
+    """Packed bf16 self-attention with scratch (pa_attn_args.ws; csrc/attention.hip decode_unit_split): elements with more than
+    eight 64-row tiles run as several RANGE blocks per owned tile whose partial results (O, m, l resp. dQ / dK, dV sums) meet in
+    HBM and are merged by the last block to arrive.  Same function as one block per tile: same dropout decisions, lse equal to
+    f32 rounding, outputs equal to bf16 rounding; run twice on ONE scratch buffer (tickets must return to zero), in a launch
+    mix that keeps other blocks busy on every CU (uneven lengths), and every ticket word is zero afterwards."""
+    B, H, dh, p, seed = len(lens), 8, 64, drop, 991
+    dm, S = H * dh, max(lens)
+    cu, order = ops.pack_lengths(lens, DEV)
+    n = int(cu[-1])
+    x = rnd(n, 3 * dm, dtype=torch.bfloat16, seed=140).to(DEV)
+    q, k, v = x[:, :dm], x[:, dm:2 * dm], x[:, 2 * dm:]
+    dout = rnd(n, dm, dtype=torch.bfloat16, seed=141).to(DEV)
+    kw = dict(drop_p=p, drop_seed=seed, order=order)
+    o0, lse0 = ops.attn_varlen_fwd(q, k, v, H, cu, cu, B, S, S, **kw)
+    dq0, dk0, dv0 = ops.attn_varlen_bwd(dout, q, k, v, o0, lse0, H, cu, cu, B, S, S, **kw)
+    ws = ops.attn_split_ws(n, B, H, DEV, L_max=S)
+    if S > 512:
+        assert ws is not None
+    rows_ok = (torch.arange(S)[None, :] < torch.tensor(lens)[:, None])[:, None, :].expand(B, H, S).to(DEV)
+    for rep in range(2):
+        o, lse = ops.attn_varlen_fwd(q, k, v, H, cu, cu, B, S, S, ws=ws, **kw)
+        assert rel_err(o, o0) < 4e-3, rel_err(o, o0)
+        assert float((lse[rows_ok] - lse0[rows_ok]).abs().max()) < 2e-5
+        dq, dk, dv = ops.attn_varlen_bwd(dout, q, k, v, o0, lse0, H, cu, cu, B, S, S, ws=ws, **kw)
+        for a, b_ in ((dq, dq0), (dk, dk0), (dv, dv0)):
+            assert rel_err(a, b_) < 4e-3, rel_err(a, b_)
+        if ws is not None:
+            nt = int(L.lib().pa_attn_ws_ticket_bytes(ws.numel()))
+            assert int(ws[:nt].view(torch.int32).abs().sum()) == 0
+    if S > 512:
+        # the split really ran: some row of a long element differs in the last bf16 bit or the f32 sums (different summation order)
+        assert not (torch.equal(o, o0) and torch.equal(dq, dq0) and torch.equal(dk, dk0))
 
 
 @pytest.mark.parametrize("M,N,K,eps,relu", [(256, 512, 512, 1.0, False), (256, 1536, 512, 1.0, False), (256, 1024, 512, 1.0, True),
