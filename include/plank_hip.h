@@ -602,6 +602,15 @@ int pa_decode_buffers(pa_model* m, void** tokens, void** attach, void** first_en
 int pa_dec_cross_mq(void* ctx, const void* qt, const void* mem, const uint8_t* kpm, const int32_t* cu, int32_t B, int32_t S,
                     int32_t H, int32_t d, void* stream);
 /* The same in exact f32 (f32 ctx / qt / mem; v_mfma_f32_16x16x4_f32): the cross-attention of the parity (token-exact) decode. */
+/* pa_dec_cross_mq with scratch for RANGE BLOCKS: below ~256 batch elements one block per element leaves most CUs idle (one CU streams
+ * an element's S x 512 memory rows at ~22 GB/s); with scratch an element's keys are walked by up to 256 / B blocks whose partial
+ * (O, m, l) are merged by the last one to arrive (csrc/decode_mq.h, csrc/split_merge.h).  ws: pa_dec_cross_mq_ws_bytes(B, S) bytes,
+ * 256-byte aligned, its first ceil(4 B / 256) * 256 bytes ZERO before the first launch (launches leave them zero). */
+int64_t pa_dec_cross_mq_ws_bytes(int32_t B, int32_t S);
+int pa_dec_cross_mq_ws(void* ctx, const void* qt, const void* mem, const uint8_t* kpm, const int32_t* cu, int32_t B,
+                       int32_t S, int32_t H, int32_t d, void* ws, int64_t ws_bytes, void* stream);
+int pa_dec_cross_mq32_ws(float* ctx, const float* qt, const float* mem, const uint8_t* kpm, const int32_t* cu, int32_t B,
+                         int32_t S, int32_t H, int32_t d, void* ws, int64_t ws_bytes, void* stream);    /* the exact-f32 form (same scratch size) */
 int pa_dec_cross_mq32(float* ctx, const float* qt, const float* mem, const uint8_t* kpm, const int32_t* cu, int32_t B, int32_t S,
                       int32_t H, int32_t d, void* stream);
 /* The self-attention form of the same launch (exact f32; what the token-exact decode step runs on its cache of layer-input rows):

@@ -183,6 +183,9 @@ def lib():
             "pa_decode_buffers": (I, [P, P, P, P, P]),
             "pa_dec_cross_mq": (I, [P, P, P, P, P, I, I, I, I, P]),
             "pa_dec_cross_mq32": (I, [P, P, P, P, P, I, I, I, I, P]),
+            "pa_dec_cross_mq_ws": (I, [P, P, P, P, P, I, I, I, I, P, I64, P]),
+            "pa_dec_cross_mq_ws_bytes": (I64, [I, I]),
+            "pa_dec_cross_mq32_ws": (I, [P, P, P, P, P, I, I, I, I, P, I64, P]),
             "pa_dec_self_mq32": (I, [P, P, P, P, I, I, I, I, P]),
         }
         for name, (res, args) in sig.items():

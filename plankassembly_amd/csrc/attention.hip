@@ -51,11 +51,6 @@ struct AttnP {
     // the last one to arrive merges the others' partial results (split_publish / split_arrive)
     int* sp_tick; char* sp_part; int sp_slots, sp_pmax, sp_kmax;
 };
-#ifdef PA_SPLIT_FENCE
-constexpr bool SPLIT_FENCE = true;       // probe build: acquire fence + sc1 loads
-#else
-constexpr bool SPLIT_FENCE = false;
-#endif
 constexpr int SP_BYTES = 64 * 1024;               // partial results of one (owned tile, range) block
 
 // Variable-length ("unpadded") batches: with cu_q / cu_k given, batch element b owns rows [cu[b], cu[b+1]) of the
@@ -788,48 +783,7 @@ __device__ __forceinline__ bool decode_unit_split(const AttnP& pin, const int32_
     u.h = x;
     return true;
 }
-// this range block's tiles [lo, hi) of the element's n streamed tiles
-__device__ __forceinline__ void split_range(int n, int part, int nparts, int& lo, int& hi) {
-    const int per = (n + nparts - 1) / nparts;
-    lo = min(n, part * per); hi = min(n, lo + per);
-}
-// Partial results travel through HBM/L2 between blocks that may sit on different XCDs (private, mutually incoherent L2s):
-// cdna_hip_programming.md Guideline 16, form R1 - payload stored WRITE-THROUGH (16-byte sc1 buffer stores), every storing wave
-// drains them (s_waitcnt vmcnt(0)), the block meets, ONE lane takes a ticket (relaxed agent-scope atomic); the block that
-// draws the last ticket does ONE agent-scope acquire (drops its CU's / XCD's stale lines), the block meets again, then plain loads.
-// Tickets are zero between launches: the last arriver puts the word back (the scratch is zeroed once by its owner).
-struct SplitOut {
-    __amdgpu_buffer_rsrc_t rs;
-    __device__ __forceinline__ SplitOut(char* base) : rs(__builtin_amdgcn_make_buffer_rsrc(base, 0, SP_BYTES, 0x00020000)) {}
-    // vector j of this thread ([j][thread] layout: a wave's store covers 1 KB)
-    __device__ __forceinline__ void put(int j, int nthreads, f32x4 v) const {
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(&v), rs, (j * nthreads + (int)threadIdx.x) * 16, 0, 16);   // aux 16 = sc1
-    }
-};
-// (sc1 loads - L1 bypassed, served from the memory side like the sc1 stores that wrote the data: valid WITHOUT an acquire fence
-//  when the producer stored sc1, cdna_hip_programming.md Guideline 16; the fence - buffer_inv sc1 - was measured first and made
-//  every range-block launch slower than the unsplit one: profiles/r06_attn_split.txt)
-__device__ __forceinline__ f32x4 split_get(const char* base, int j, int nthreads) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, SP_BYTES, 0x00020000);
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (j * nthreads + (int)threadIdx.x) * 16, 0, 16);
-    return *reinterpret_cast<const f32x4*>(&v);
-}
-__device__ __forceinline__ bool split_arrive(int* tick, int nparts, int* s_flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave: its write-through stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int old = __hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = old == nparts - 1;
-        if (last) {
-            if (SPLIT_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(tick, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *s_flag = last;
-    }
-    __syncthreads();
-    return *s_flag != 0;
-}
-
+#include "split_merge.h"
 
 
 template <int DH> struct BT {
@@ -2003,14 +1957,14 @@ __device__ __forceinline__ void attn4_dq_body(const AttnP& pin, int bid, char* s
     if (KS == 1 && nparts > 1) {
         // range block: publish the partial dQ^T; the tile's last range block to arrive adds the others to its own and stores
         char* const pbase = pin.sp_part + (size_t)slot * pin.sp_pmax * SP_BYTES;
-        const SplitOut so(pbase + (size_t)part * SP_BYTES);
+        const SplitOut so(pbase + (size_t)part * SP_BYTES, SP_BYTES);
 #pragma unroll
         for (int db = 0; db < 4; ++db) so.put(db, NT4, dqacc[db]);
         if (!split_arrive(pin.sp_tick + slot, nparts, reinterpret_cast<int*>(smem + 2 * BUF))) return;
         for (int pp = 0; pp < nparts; ++pp) {
             if (pp == part) continue;
 #pragma unroll
-            for (int db = 0; db < 4; ++db) dqacc[db] += split_get(pbase + (size_t)pp * SP_BYTES, db, NT4);
+            for (int db = 0; db < 4; ++db) dqacc[db] += split_get(pbase + (size_t)pp * SP_BYTES, db, NT4, SP_BYTES);
         }
     }
     bf16* dQp = reinterpret_cast<bf16*>(p.dq) + (size_t)qoff * p.lddq + h * DH;
@@ -2172,7 +2126,7 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
     if (nparts > 1) {
         // range block: publish the partial dK^T / dV^T; the tile's last range block to arrive adds the others to its own and stores
         char* const pbase = pin.sp_part + (size_t)slot * pin.sp_pmax * SP_BYTES;
-        const SplitOut so(pbase + (size_t)part * SP_BYTES);
+        const SplitOut so(pbase + (size_t)part * SP_BYTES, SP_BYTES);
 #pragma unroll
         for (int db = 0; db < 4; ++db) { so.put(db, NT4, dkacc[db]); so.put(4 + db, NT4, dvacc[db]); }
         if (!split_arrive(pin.sp_tick + slot, nparts, reinterpret_cast<int*>(smem + 2 * BUF))) return;
@@ -2180,8 +2134,8 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
             if (pp == part) continue;
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                dkacc[db] += split_get(pbase + (size_t)pp * SP_BYTES, db, NT4);
-                dvacc[db] += split_get(pbase + (size_t)pp * SP_BYTES, 4 + db, NT4);
+                dkacc[db] += split_get(pbase + (size_t)pp * SP_BYTES, db, NT4, SP_BYTES);
+                dvacc[db] += split_get(pbase + (size_t)pp * SP_BYTES, 4 + db, NT4, SP_BYTES);
             }
         }
     }

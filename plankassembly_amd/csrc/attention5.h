@@ -335,7 +335,7 @@ __global__ __launch_bounds__(NTH, OCC) void attn5_fwd_kernel(AttnP pin) {
         // range block: publish (O^T, m, l); the last of the tile's range blocks to arrive rescales all of them to the common
         // reference point and stores (the same merge attn4_fwd_kernel<., 2> does through LDS)
         char* const pbase = pin.sp_part + (size_t)slot * pin.sp_pmax * SP_BYTES;
-        const SplitOut so(pbase + (size_t)part * SP_BYTES);
+        const SplitOut so(pbase + (size_t)part * SP_BYTES, SP_BYTES);
 #pragma unroll
         for (int j = 0; j < 8; ++j) so.put(j, NTH, f32x4{oacc[j >> 2][4 * (j & 3)], oacc[j >> 2][4 * (j & 3) + 1], oacc[j >> 2][4 * (j & 3) + 2], oacc[j >> 2][4 * (j & 3) + 3]});
         so.put(8, NTH, f32x4{m_run, l_tot, 0.f, 0.f});
@@ -343,14 +343,14 @@ __global__ __launch_bounds__(NTH, OCC) void attn5_fwd_kernel(AttnP pin) {
         for (int pp = 0; pp < nparts; ++pp) {
             if (pp == part) continue;
             const char* ob = pbase + (size_t)pp * SP_BYTES;
-            const f32x4 ml = split_get(ob, 8, NTH);
+            const f32x4 ml = split_get(ob, 8, NTH, SP_BYTES);
             const float m_new = fmaxf(m_run, ml[0]);
             const float ms = (m_new == -INFINITY) ? 0.f : m_new;
             const float a0 = fast_exp2(m_run - ms), a1 = fast_exp2(ml[0] - ms);
             l_tot = l_tot * a0 + ml[1] * a1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const f32x4 x = split_get(ob, j, NTH);
+                const f32x4 x = split_get(ob, j, NTH, SP_BYTES);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) oacc[j >> 2][4 * (j & 3) + e] = oacc[j >> 2][4 * (j & 3) + e] * a0 + x[e] * a1;
             }

@@ -47,12 +47,14 @@ struct DecodeLayout {
     bool mq_contract = false;                  // exact f32, dh 64: W_v as its own launch + the ordinary out-projection instead of wo_t (decode_mq.h)
     void *mem = nullptr, *qt = nullptr, *ctx = nullptr;
     std::vector<void*> wo_t; std::vector<float*> bo_t;
+    void* mq_sp = nullptr; int64_t mq_sp_bytes = 0;   // range blocks of the absorbed cross-attention (decode_mq.h): tickets (zero between launches) + partials
 };
 
 namespace {
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 constexpr float LOG2E_F = 1.4426950408889634f;
+#include "split_merge.h"
 }  // namespace
 #include "decode_mq.h"
 namespace {
@@ -555,6 +557,8 @@ size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tm
         const size_t H = c.n_head;
         L->mem = a.take((size_t)B * S * d * e);
         L->qt = a.take((size_t)B * H * d * e); L->ctx = a.take((size_t)B * H * d * e);
+        L->mq_sp_bytes = mq_split_bytes(B, std::max(mq_parts(B, S), mq_parts(B, Tmax)));      // (cross-attention and the f32 step's self-attention form share it)
+        L->mq_sp = L->mq_sp_bytes > 0 ? a.take((size_t)L->mq_sp_bytes) : nullptr;
         for (int i = 0; i < c.n_dec; ++i) { L->wo_t[i] = a.take(d * H * d * e); L->bo_t[i] = (float*)a.take(d * 4); }
         L->wvt_self.assign(c.n_dec, nullptr);
         if (c.dtype == PA_F32) for (int i = 0; i < c.n_dec; ++i) L->wvt_self[i] = a.take(d * d * e);
@@ -633,9 +637,11 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
         else PA_LAUNCH((mq_expand_q_kernel<0, T>), xg, dim3(512), 0, ss, (T*)L->qt, (const T*)L->q, d, Wk, B, d, H, sl);
         RC(fence_in());
         if constexpr (sizeof(T) == 2)
-            RC(launch_cross_mq((bf16*)L->ctx, (const bf16*)L->qt, (const bf16*)L->mem, L->cu ? nullptr : L->kpm, L->cu, B, S, H, d, ss));
+            RC(launch_cross_mq((bf16*)L->ctx, (const bf16*)L->qt, (const bf16*)L->mem, L->cu ? nullptr : L->kpm, L->cu, B, S, H, d, ss,
+                               L->mq_sp, L->mq_sp_bytes));
         else
-            RC(launch_cross_mq32((float*)L->ctx, (const float*)L->qt, (const float*)L->mem, L->cu ? nullptr : L->kpm, L->cu, B, S, H, d, ss));
+            RC(launch_cross_mq32((float*)L->ctx, (const float*)L->qt, (const float*)L->mem, L->cu ? nullptr : L->kpm, L->cu, B, S, H, d, ss, nullptr,
+                                 L->mq_sp, L->mq_sp_bytes));
         return fence_out();
     };
     // PLANK_DECODE_FUSE_TAIL=1 (default 0): the sampling kernel also writes the next step's input embedding and advances the step
@@ -664,7 +670,8 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
             PA_LAUNCH((mq_expand_q_kernel<64, float>), dim3((B + MQ_XR - 1) / MQ_XR, H), dim3(512), 0, ss, (float*)L->qt, (const float*)L->q, d, Wk, B, d, H, sl,
                       (const float*)xin, (float*)L->self_k[i], (const int32_t*)L->t_dev, Tmax);
             RC(fence_in());
-            RC(launch_cross_mq32((float*)L->ctx, (const float*)L->qt, (const float*)L->self_k[i], nullptr, nullptr, B, Tmax, H, d, ss, L->t_dev));
+            RC(launch_cross_mq32((float*)L->ctx, (const float*)L->qt, (const float*)L->self_k[i], nullptr, nullptr, B, Tmax, H, d, ss, L->t_dev,
+                                 L->mq_sp, L->mq_sp_bytes));
             RC(fence_out());
             PA_LAUNCH(mq_contract_v_kernel<float>, dim3((B + MQ_XR - 1) / MQ_XR, H), dim3(512), 0, ss, (float*)L->ao, d, (const float*)L->ctx,
                       (const float*)L->wvt_self[i], (const float*)mm->pf[pbi + D_SA_IN_B] + 2 * d, B, d, H);
@@ -931,6 +938,10 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
     if (he != hipSuccess) return (int)he;
     he = hipMemsetAsync(L->t_dev, 0, 8, s);                     // step counter and the sampling kernel's ticket
     if (he != hipSuccess) return (int)he;
+    if (L->mq_sp) {                                             // the range blocks' tickets (every launch leaves them zero again)
+        he = hipMemsetAsync(L->mq_sp, 0, ((size_t)B * 4 + 255) / 256 * 256, s);
+        if (he != hipSuccess) return (int)he;
+    }
     he = hipMemsetAsync(L->x, 0, (size_t)B * c.d_model * 4, s);  // input embedding of step 0: zeros (later steps: written by the sampling kernel)
     if (he != hipSuccess) return (int)he;
     he = hipMemsetAsync(L->xb, 0, (size_t)B * c.d_model * 2, s);
@@ -984,11 +995,29 @@ extern "C" int pa_dec_cross_mq(void* ctx, const void* qt, const void* mem, const
     return launch_cross_mq((bf16*)ctx, (const bf16*)qt, (const bf16*)mem, kpm, cu, B, S, H, d, (hipStream_t)stream);
 }
 
+// The same launch with scratch for range blocks (decode_mq.h: at small batches a batch element's keys are walked by several blocks so
+// that the launch uses the whole chip).  ws: pa_dec_cross_mq_ws_bytes(B, S) bytes, 256-byte aligned, its first ceil(4 B / 256) * 256
+// bytes zero before the first launch (launches leave them zero); with ws = NULL or too small it is pa_dec_cross_mq.
+extern "C" int64_t pa_dec_cross_mq_ws_bytes(int32_t B, int32_t S) { return (B > 0 && S > 0) ? mq_split_bytes(B, mq_parts(B, S)) : 0; }
+extern "C" int pa_dec_cross_mq_ws(void* ctx, const void* qt, const void* mem, const uint8_t* kpm, const int32_t* cu, int32_t B,
+                                  int32_t S, int32_t H, int32_t d, void* ws, int64_t ws_bytes, void* stream) {
+    if (!ctx || !qt || !mem) return PA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(mem)) & 15) return PA_EALIGN;
+    return launch_cross_mq((bf16*)ctx, (const bf16*)qt, (const bf16*)mem, kpm, cu, B, S, H, d, (hipStream_t)stream, ws, ws_bytes);
+}
+
 extern "C" int pa_dec_cross_mq32(float* ctx, const float* qt, const float* mem, const uint8_t* kpm, const int32_t* cu, int32_t B,
                                  int32_t S, int32_t H, int32_t d, void* stream) {
     if (!ctx || !qt || !mem) return PA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(mem) | reinterpret_cast<uintptr_t>(ctx)) & 15) return PA_EALIGN;
     return launch_cross_mq32(ctx, qt, mem, kpm, cu, B, S, H, d, (hipStream_t)stream);
+}
+
+extern "C" int pa_dec_cross_mq32_ws(float* ctx, const float* qt, const float* mem, const uint8_t* kpm, const int32_t* cu, int32_t B,
+                                    int32_t S, int32_t H, int32_t d, void* ws, int64_t ws_bytes, void* stream) {
+    if (!ctx || !qt || !mem) return PA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(qt) | reinterpret_cast<uintptr_t>(mem) | reinterpret_cast<uintptr_t>(ctx)) & 15) return PA_EALIGN;
+    return launch_cross_mq32(ctx, qt, mem, kpm, cu, B, S, H, d, (hipStream_t)stream, nullptr, ws, ws_bytes);
 }
 
 extern "C" int pa_dec_self_mq32(float* ctx, const float* qt, const float* xcache, const int32_t* t_dev, int32_t B, int32_t Tmax,

@@ -43,23 +43,31 @@ template <bool SWAP> __device__ __forceinline__ float mq_rows_max(float v) {
     }
 }
 
+// Range blocks (round 6): with nparts > 1 a batch element's key tiles are walked by nparts blocks (blockIdx.x = b * nparts + part),
+// whose partial (O^T, m, l) meet in `sp` - MQ_SP_BYTES per block, behind one ticket word per batch element - and are merged by the
+// last block to arrive (split_merge.h).  One block per element streams its 1 MB of memory rows at what ONE CU's DMA sustains
+// (~22 GB/s: 47 us per launch at S 1024 whatever the batch); at the reference's evaluation batch of 16 that was 16 of 256 CUs
+// busy and 44 % of the decode step (profiles/r06_decode_small_batch.txt).
+constexpr int MQ_SP_BYTES = 40 * 1024;
 template <int AUX, bool SWAP, bool MASK>
 __global__ __launch_bounds__(256, 1) void dec_cross_mq_kernel(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* kpm,
-                                                              const int32_t* cu, int S, int H) {
+                                                              const int32_t* cu, int S, int H, int nparts, char* sp) {
     extern __shared__ __attribute__((aligned(256))) char mq_smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.x / nparts, part = blockIdx.x - b * nparts, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
     const int row0 = cu ? cu[b] : b * S;
     const int Lk = cu ? cu[b + 1] - row0 : S;
     bf16* out = ctx + (size_t)b * H * MQ_D;
     if (Lk <= 0) {                                                      // (block-uniform) no key: zeros, as dec_attn_kernel
-        for (int idx = tid; idx < H * MQ_D; idx += 256) out[idx] = (bf16)0.f;
+        if (part == 0) for (int idx = tid; idx < H * MQ_D; idx += 256) out[idx] = (bf16)0.f;
         return;
     }
     const uint8_t* mk = MASK ? kpm + (size_t)b * S : nullptr;      // (MASK: dense rows with a key-padding mask)
     uint8_t* mlds = reinterpret_cast<uint8_t*>(mq_smem + MQ_NS * MQ_TILE);
     const int ntiles = (Lk + MQ_KT - 1) / MQ_KT;
+    int t0 = 0, t1 = ntiles;                                            // this block's key tiles
+    if (nparts > 1) split_range(ntiles, part, nparts, t0, t1);
     if constexpr (MASK) {
         for (int s = tid; s < ntiles * MQ_KT; s += 256) mlds[s] = s < Lk ? mk[s] : (uint8_t)1;
         __syncthreads();
@@ -173,28 +181,53 @@ __global__ __launch_bounds__(256, 1) void dec_cross_mq_kernel(bf16* ctx, const b
     // the barrier makes that true for every wave's rows and says every wave is through with tile t - 1, whose stage then takes tile
     // t + 7; the score fragments of tile t + 1 are read there, one tile ahead, so their LDS latency hides behind tile t's softmax.
 #pragma unroll
-    for (int t = 0; t < MQ_NS - 1; ++t)
-        if (t < ntiles) issue(t);
-    if (ntiles >= MQ_NS - 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    for (int i = 0; i < MQ_NS - 1; ++i)
+        if (t0 + i < t1) issue(t0 + i);
+    if (t1 - t0 >= MQ_NS - 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    read_scores(0);
-    for (int t = 0; t < ntiles; ++t) {
+    if (t0 < t1) read_scores(t0);
+    for (int t = t0; t < t1; ++t) {
         const f32x4 s4 = scores();
         uint32_t m4 = 0;                                                // mask bytes of this lane's 4 keys (read ahead of the next tile's fragments)
         if constexpr (MASK) m4 = *reinterpret_cast<const uint32_t*>(mlds + t * MQ_KT + 4 * g);
         read_tr(t);
-        if (t + 1 < ntiles) {
-            if (t + MQ_NS - 2 < ntiles) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");      // tiles t + 1 .. t + 6 outstanding
+        if (t + 1 < t1) {
+            if (t + MQ_NS - 2 < t1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");      // tiles t + 1 .. t + 6 outstanding
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (t + MQ_NS - 1 < ntiles) issue(t + MQ_NS - 1);
+            if (t + MQ_NS - 1 < t1) issue(t + MQ_NS - 1);
             read_scores(t + 1);
         }
         finish(t, s4, m4);
     }
     l_run += __shfl_xor(l_run, 16);
     l_run += __shfl_xor(l_run, 32);
+    if (nparts > 1) {
+        // publish (O^T, m, l); the element's last range block to arrive rescales all of them to the common reference point and stores
+        char* const pbase = sp + 256 * (((size_t)gridDim.x / nparts * 4 + 255) / 256) + (size_t)b * nparts * MQ_SP_BYTES;
+        const SplitOut so(pbase + (size_t)part * MQ_SP_BYTES, MQ_SP_BYTES);
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) so.put(nb, 256, acc[nb]);
+        so.put(8, 256, f32x4{m_run, l_run, 0.f, 0.f});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (the ring's last LDS reads are done before its first bytes become the flag)
+        if (!split_arrive(reinterpret_cast<int*>(sp) + b, nparts, reinterpret_cast<int*>(mq_smem))) return;
+        // merged IN RANGE ORDER (own partial re-read like the others): the same sums whichever block arrives last
+        float m_all = -INFINITY;
+        for (int pp = 0; pp < nparts; ++pp) m_all = fmaxf(m_all, split_get(pbase + (size_t)pp * MQ_SP_BYTES, 8, 256, MQ_SP_BYTES)[0]);
+        const float ms = m_all == -INFINITY ? 0.f : m_all;
+        l_run = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pp = 0; pp < nparts; ++pp) {
+            const char* ob = pbase + (size_t)pp * MQ_SP_BYTES;
+            const f32x4 ml = split_get(ob, 8, 256, MQ_SP_BYTES);
+            const float a1 = __builtin_amdgcn_exp2f(ml[0] - ms);
+            l_run += ml[1] * a1;
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) acc[nb] += split_get(ob, nb, 256, MQ_SP_BYTES) * a1;
+        }
+    }
     if (n < H) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         bf16* orow = out + (size_t)n * MQ_D + 128 * wave + 4 * g;
@@ -387,16 +420,16 @@ __global__ __launch_bounds__(256, 1) void dec_cross_mq32_kernel(float* ctx, cons
 constexpr int MQ8_SCR = 2 * 8 * 1024;
 template <bool MASK>
 __global__ __launch_bounds__(512, 1) void dec_cross_mq32w8_kernel(float* ctx, const float* qt, const float* mem, const uint8_t* kpm,
-                                                                  const int32_t* cu, int S, int H, const int32_t* t_dev) {
+                                                                  const int32_t* cu, int S, int H, const int32_t* t_dev, int nparts, char* sp) {
     extern __shared__ __attribute__((aligned(256))) char mq_smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.x / nparts, part = blockIdx.x - b * nparts, tid = threadIdx.x, lane = tid & 63;     // (range blocks: dec_cross_mq_kernel)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
     const int row0 = cu ? cu[b] : b * S;
     const int Lk = t_dev ? *t_dev + 1 : (cu ? cu[b + 1] - row0 : S);
     float* out = ctx + (size_t)b * H * MQ_D;
     if (Lk <= 0) {
-        for (int idx = tid; idx < H * MQ_D; idx += 512) out[idx] = 0.f;
+        if (part == 0) for (int idx = tid; idx < H * MQ_D; idx += 512) out[idx] = 0.f;
         return;
     }
     const uint8_t* mk = MASK ? kpm + (size_t)b * S : nullptr;
@@ -512,18 +545,20 @@ __global__ __launch_bounds__(512, 1) void dec_cross_mq32w8_kernel(float* ctx, co
                 acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[kk][nb], p[kk], acc[nb], 0, 0, 0);
     };
 
-    const int npro = min(ntiles, MQF_NS - 1);
-    for (int t = 0; t < npro; ++t) issue(t);
+    int t0 = 0, t1 = ntiles;                                            // this block's key tiles
+    if (nparts > 1) split_range(ntiles, part, nparts, t0, t1);
+    const int npro = min(t1 - t0, MQF_NS - 1);
+    for (int i = 0; i < npro; ++i) issue(t0 + i);
     wait_vm(npro - 1);
     __builtin_amdgcn_s_barrier();
-    partial_scores(0);
+    if (t0 < t1) partial_scores(t0);
     const bool first_half = wave < 4;                                    // (wave-uniform) which order this wave runs an iteration in
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) wait_vm(t + 2 < ntiles ? 1 : 0);
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) wait_vm(t + 2 < t1 ? 1 : 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + MQF_NS - 1 < ntiles) issue(t + MQF_NS - 1);
+        if (t + MQF_NS - 1 < t1) issue(t + MQF_NS - 1);
         f32x4 s4;
         {
             const char* sb = scr + (t & 1) * 8192 + lane * 16;
@@ -535,15 +570,40 @@ __global__ __launch_bounds__(512, 1) void dec_cross_mq32w8_kernel(float* ctx, co
         uint32_t m4 = 0;
         if constexpr (MASK) m4 = *reinterpret_cast<const uint32_t*>(mlds + t * MQ_KT + 4 * g);
         if (first_half) {
-            if (t + 1 < ntiles) partial_scores(t + 1);
+            if (t + 1 < t1) partial_scores(t + 1);
             finish(t, s4, m4);
         } else {
             finish(t, s4, m4);
-            if (t + 1 < ntiles) partial_scores(t + 1);
+            if (t + 1 < t1) partial_scores(t + 1);
         }
     }
     l_run += __shfl_xor(l_run, 16);
     l_run += __shfl_xor(l_run, 32);
+    if (nparts > 1) {
+        // (as dec_cross_mq_kernel) publish (O^T, m, l); the element's last range block to arrive merges them IN RANGE ORDER - a fixed
+        // summation order whichever block arrives last: the token-exact path stays run-to-run identical
+        char* const pbase = sp + 256 * (((size_t)gridDim.x / nparts * 4 + 255) / 256) + (size_t)b * nparts * MQ_SP_BYTES;
+        const SplitOut so(pbase + (size_t)part * MQ_SP_BYTES, MQ_SP_BYTES);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) so.put(nb, 512, acc[nb]);
+        so.put(4, 512, f32x4{m_run, l_run, 0.f, 0.f});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!split_arrive(reinterpret_cast<int*>(sp) + b, nparts, reinterpret_cast<int*>(mq_smem))) return;
+        float m_all = -INFINITY;
+        for (int pp = 0; pp < nparts; ++pp) m_all = fmaxf(m_all, split_get(pbase + (size_t)pp * MQ_SP_BYTES, 4, 512, MQ_SP_BYTES)[0]);
+        const float ms = m_all == -INFINITY ? 0.f : m_all;
+        l_run = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pp = 0; pp < nparts; ++pp) {
+            const char* ob = pbase + (size_t)pp * MQ_SP_BYTES;
+            const f32x4 ml = split_get(ob, 4, 512, MQ_SP_BYTES);
+            const float a1 = __builtin_amdgcn_exp2f(ml[0] - ms);
+            l_run += ml[1] * a1;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[nb] += split_get(ob, nb, 512, MQ_SP_BYTES) * a1;
+        }
+    }
     if (n < H) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         float* orow = out + (size_t)n * MQ_D + 64 * wave + 16 * g;
@@ -680,8 +740,21 @@ __global__ __launch_bounds__(256) void mq_absorb_o_kernel(T* Wt, float* bt, cons
     }
 }
 
+// range blocks per batch element for a launch of B elements with up to S keys: enough blocks to fill the chip, at least
+// PLANK_DECODE_MQ_MINT (8) key tiles each; PLANK_DECODE_MQ_PARTS=<n> forces, 1 = never
+int mq_parts(int B, int S) {
+    static const int force = getenv("PLANK_DECODE_MQ_PARTS") ? atoi(getenv("PLANK_DECODE_MQ_PARTS")) : 0;
+    static const int mint = getenv("PLANK_DECODE_MQ_MINT") ? atoi(getenv("PLANK_DECODE_MQ_MINT")) : 8;
+    if (force > 0) return force > 64 ? 64 : force;
+    const int ntiles = (S + MQ_KT - 1) / MQ_KT;
+    int p = 256 / (B > 0 ? B : 1);
+    if (p > ntiles / (mint > 0 ? mint : 1)) p = ntiles / (mint > 0 ? mint : 1);
+    return p < 1 ? 1 : (p > 64 ? 64 : p);
+}
+int64_t mq_split_bytes(int B, int nparts) { return nparts > 1 ? (((int64_t)B * 4 + 255) / 256) * 256 + (int64_t)B * nparts * MQ_SP_BYTES : 0; }
+
 int launch_cross_mq(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* kpm, const int32_t* cu, int B, int S, int H, int d,
-                    hipStream_t s) {
+                    hipStream_t s, void* sp = nullptr, int64_t sp_bytes = 0) {
     if (d != MQ_D || H < 1 || H > MQ_MAXH || B <= 0 || S <= 0 || S > MQ_MAXS) return PA_ESHAPE;
     const int lds = MQ_NS * MQ_TILE + ((!cu && kpm) ? (S + 31) / 16 * 16 : 0);
     // PLANK_DECODE_MQ_NT=0: default-policy DMA instead of non-temporal (aux 2; measured in the step, B 256 x 1024: 0.958 vs 0.989 ms); PLANK_DECODE_MQ_SWAP=0: ds_bpermute row reductions instead of v_permlane*_swap
@@ -689,7 +762,7 @@ int launch_cross_mq(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* k
     static const int swap = getenv("PLANK_DECODE_MQ_SWAP") ? atoi(getenv("PLANK_DECODE_MQ_SWAP")) : 1;
     static bool attr_done = false;
     constexpr int MAXLDS = MQ_NS * MQ_TILE + MQ_MAXS + 32;
-    typedef void (*KernT)(bf16*, const bf16*, const bf16*, const uint8_t*, const int32_t*, int, int);
+    typedef void (*KernT)(bf16*, const bf16*, const bf16*, const uint8_t*, const int32_t*, int, int, int, char*);
     static const KernT ks[8] = {dec_cross_mq_kernel<0, false, false>, dec_cross_mq_kernel<0, false, true>, dec_cross_mq_kernel<0, true, false>,
                                 dec_cross_mq_kernel<0, true, true>,   dec_cross_mq_kernel<2, false, false>, dec_cross_mq_kernel<2, false, true>,
                                 dec_cross_mq_kernel<2, true, false>,  dec_cross_mq_kernel<2, true, true>};
@@ -701,12 +774,15 @@ int launch_cross_mq(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* k
         attr_done = true;
     }
     const bool mask = !cu && kpm;
-    PA_LAUNCH(ks[(nt ? 4 : 0) + (swap ? 2 : 0) + (mask ? 1 : 0)], dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H);
+    int nparts = sp ? mq_parts(B, S) : 1;
+    if (nparts > 1 && (mq_split_bytes(B, nparts) > sp_bytes || (reinterpret_cast<uintptr_t>(sp) & 255))) nparts = 1;
+    PA_LAUNCH(ks[(nt ? 4 : 0) + (swap ? 2 : 0) + (mask ? 1 : 0)], dim3(B * nparts), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H, nparts,
+              static_cast<char*>(sp));
     return 0;
 }
 
 int launch_cross_mq32(float* ctx, const float* qt, const float* mem, const uint8_t* kpm, const int32_t* cu, int B, int S, int H, int d,
-                      hipStream_t s, const int32_t* t_dev = nullptr) {
+                      hipStream_t s, const int32_t* t_dev = nullptr, void* sp = nullptr, int64_t sp_bytes = 0) {
     constexpr int MAXS32 = 16000;                 // (ring + partial-score slots + mask bytes within 160 KB)
     if (d != MQ_D || H < 1 || H > MQ_MAXH || B <= 0 || S <= 0 || S > MAXS32) return PA_ESHAPE;
     const bool mask = !cu && kpm;
@@ -726,8 +802,10 @@ int launch_cross_mq32(float* ctx, const float* qt, const float* mem, const uint8
     const int mbytes = mask ? (S + 31) / 16 * 16 : 0;
     if (w8) {
         const int lds = MQF_NS * MQF_TILE + MQ8_SCR + mbytes;
-        if (mask) PA_LAUNCH(dec_cross_mq32w8_kernel<true>, dim3(B), dim3(512), lds, s, ctx, qt, mem, kpm, cu, S, H, t_dev);
-        else PA_LAUNCH(dec_cross_mq32w8_kernel<false>, dim3(B), dim3(512), lds, s, ctx, qt, mem, kpm, cu, S, H, t_dev);
+        int nparts = sp ? mq_parts(B, S) : 1;
+        if (nparts > 1 && (mq_split_bytes(B, nparts) > sp_bytes || (reinterpret_cast<uintptr_t>(sp) & 255))) nparts = 1;
+        if (mask) PA_LAUNCH(dec_cross_mq32w8_kernel<true>, dim3(B * nparts), dim3(512), lds, s, ctx, qt, mem, kpm, cu, S, H, t_dev, nparts, static_cast<char*>(sp));
+        else PA_LAUNCH(dec_cross_mq32w8_kernel<false>, dim3(B * nparts), dim3(512), lds, s, ctx, qt, mem, kpm, cu, S, H, t_dev, nparts, static_cast<char*>(sp));
     } else {
         const int lds = MQF_NS * MQF_TILE + MQF_SCR + mbytes;
         if (mask) PA_LAUNCH(dec_cross_mq32_kernel<true>, dim3(B), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H, t_dev);

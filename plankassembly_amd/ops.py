@@ -426,7 +426,7 @@ def attn_varlen_bwd(dout, q, k, v, o, lse, H, cu_q, cu_k, B, Lq_max, Lk_max, cau
     return dq, dk, dv
 
 
-def dec_cross_mq(qt, mem, *, kpm=None, cu=None, S=None):
+def dec_cross_mq(qt, mem, *, kpm=None, cu=None, S=None, ws=None):
     """Absorbed ("multi-query") cross-attention of one decode step (csrc/decode_mq.h, pa_dec_cross_mq): qt [B, H, 512] bf16 (already
     carrying scale * log2 e), mem dense [B, S, 512] (optional kpm [B, S] uint8, 1 = PAD) or packed [rows, 512] with cu int32 [B + 1].
     Returns ctx [B, H, 512] bf16: per head the softmax-weighted sum of the element's memory rows."""
@@ -435,13 +435,27 @@ def dec_cross_mq(qt, mem, *, kpm=None, cu=None, S=None):
         S = mem.shape[1]
     if qt.dtype == torch.float32:                      # the exact-f32 form (pa_dec_cross_mq32)
         ctx = torch.empty(B, H, d, dtype=torch.float32, device=qt.device)
+        if ws is not None:
+            L.check(L.lib().pa_dec_cross_mq32_ws(L.ptr(ctx), L.ptr(qt), L.ptr(mem), L.ptr(kpm), L.ptr(cu), B, int(S), H, d, L.ptr(ws),
+                                                 C.c_int64(ws.numel()), L.stream()), "pa_dec_cross_mq32_ws")
+            return ctx
         L.check(L.lib().pa_dec_cross_mq32(L.ptr(ctx), L.ptr(qt), L.ptr(mem), L.ptr(kpm), L.ptr(cu), B, int(S), H, d, L.stream()),
                 "pa_dec_cross_mq32")
         return ctx
     ctx = torch.empty(B, H, d, dtype=torch.bfloat16, device=qt.device)
+    if ws is not None:                                 # range blocks (pa_dec_cross_mq_ws); ws = dec_cross_mq_ws(B, S, device)
+        L.check(L.lib().pa_dec_cross_mq_ws(L.ptr(ctx), L.ptr(qt), L.ptr(mem), L.ptr(kpm), L.ptr(cu), B, int(S), H, d, L.ptr(ws),
+                                           C.c_int64(ws.numel()), L.stream()), "pa_dec_cross_mq_ws")
+        return ctx
     L.check(L.lib().pa_dec_cross_mq(L.ptr(ctx), L.ptr(qt), L.ptr(mem), L.ptr(kpm), L.ptr(cu), B, int(S), H, d, L.stream()),
             "pa_dec_cross_mq")
     return ctx
+
+
+def dec_cross_mq_ws(B, S, device):
+    """Zeroed scratch for dec_cross_mq(..., ws=): None when the library would launch one block per element anyway."""
+    n = int(L.lib().pa_dec_cross_mq_ws_bytes(int(B), int(S)))
+    return torch.zeros(n, dtype=torch.uint8, device=device) if n > 0 else None
 
 
 def dec_self_mq32(qt, xcache, t_dev):

@@ -84,6 +84,58 @@ def test_packed_rows(lens):
         _check(ctx[b], _ref(qt[b], m, torch.ones(lens[b], dtype=torch.bool, device="cuda")))
 
 
+@pytest.mark.parametrize("B,S,mode", [(16, 1024, "dense"), (16, 1024, "mask"), (3, 1199, "mask"), (1, 1024, "dense"), (40, 640, "dense"),
+                                      (5, 1024, "packed"), (16, 299, "packed"), (2, 130, "dense")])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_range_blocks_equal_one_block_per_element(B, S, mode, dtype):
+    """pa_dec_cross_mq_ws (csrc/decode_mq.h range blocks: several blocks per batch element, partial (O, m, l) merged by the last to
+    arrive): against float64 and against the one-block launch; twice on one scratch buffer; every ticket word zero afterwards.  Packed
+    lengths include elements shorter than one range (empty range blocks) and the ramp case makes the ranges' reference points differ
+    by tens of log2 units."""
+    from plankassembly_amd import ops
+    from plankassembly_amd import _lib as L
+    torch.manual_seed(B * 7 + S)
+    kpm = cu = None
+    if mode == "packed":
+        lens = [S, 1, 17, S // 2, 333][:B] if B <= 5 else [max(1, (S * (i + 1)) // B) for i in range(B)]
+        cu_h = torch.zeros(B + 1, dtype=torch.int32); cu_h[1:] = torch.tensor(lens).cumsum(0)
+        mem = torch.randn(int(cu_h[-1]), 512, device="cuda")
+        cu = cu_h.cuda()
+    else:
+        lens = [S] * B
+        mem = torch.randn(B, S, 512, device="cuda")
+        if mode == "mask":
+            ln = torch.randint(1, S + 1, (B,)); ln[0] = S
+            kpm = (torch.arange(S)[None, :] >= ln[:, None]).to(torch.uint8).cuda()
+            kpm[1 % B, 0] = 1
+    q = torch.randn(B, 8, 512, device="cuda")
+    q = q / q.norm(dim=-1, keepdim=True)
+    if mode == "dense":                                      # scores of element 0 grow along the keys: later ranges dominate
+        ramp = torch.linspace(-40, 40, S, device="cuda")
+        mem[0] = mem[0] * 0.05 + ramp[:, None] * q[0, 0][None, :]
+    mem = mem.to(dtype)
+    qt = (q * (1.0 if mode == "dense" else 3.0)).to(dtype)
+    ws = ops.dec_cross_mq_ws(B, S, "cuda")
+    if B <= 64 and S >= 256:
+        assert ws is not None
+    one = ops.dec_cross_mq(qt, mem, kpm=kpm, cu=cu, S=S)
+    for rep in range(2):
+        ctx = ops.dec_cross_mq(qt, mem, kpm=kpm, cu=cu, S=S, ws=ws)
+        torch.cuda.synchronize()
+        for b in range(B):
+            if mode == "packed":
+                m = mem[int(cu[b]):int(cu[b + 1])]; valid = torch.ones(lens[b], dtype=torch.bool, device="cuda")
+            else:
+                m = mem[b]; valid = (kpm[b] == 0) if kpm is not None else torch.ones(S, dtype=torch.bool, device="cuda")
+            _check(ctx[b], _ref(qt[b], m, valid), tol=2e-2 if dtype == torch.bfloat16 else 2e-5)
+        assert float((ctx.float() - one.float()).abs().max()) <= (2e-2 if dtype == torch.bfloat16 else 2e-5) * float(one.float().abs().max())
+        if rep == 1:
+            assert torch.equal(ctx, first)                     # merged in range order: run-to-run identical
+        first = ctx
+        if ws is not None:
+            assert int(ws[:(B * 4 + 255) // 256 * 256].view(torch.int32).abs().sum()) == 0
+
+
 def test_large_scores_and_moving_reference_point():
     """Scores spanning +-60 in the log2 domain with the largest key LAST: every tile moves the running reference point (the
     accumulator rescale path) and the early tiles' probabilities underflow - the result must still be the exact softmax."""
