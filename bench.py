@@ -773,6 +773,28 @@ def main():
                 # the same time against the bytes the K/V-cache form moves (what rounds 1-4 quoted hbm_frac on)
                 decode[ddtype]["kv_cache_form_equiv_gbs"] = kv_cache_form_bytes * T_DEC / ddt / 1e9
             log(f"decode {ddtype}: {decode[ddtype]['value']:.0f} tokens/s, {decode[ddtype]['ms_per_step']:.3f} ms/step")
+            # the reference's own evaluation batch (configs/train_complete.yaml BATCH_SIZE 16 -> trainer_complete.py validation_step):
+            # one lane, the same model, max_len steps.  Below ~256 elements the absorbed attention launches run as RANGE BLOCKS
+            # (several blocks per element, csrc/decode_mq.h) - one block per element left 240 of 256 CUs idle.
+            if B_DEC > 16:
+                del dec
+                dec16 = GreedyDecoder(dm, use_graph=True, strict_graph=True, lanes=1)
+                db16 = synth_batch(16, spec_for("decode"), seed=7, device="cuda"); db16.pop("name")
+                db16 = dm.prepare_batch(db16)
+                with torch.no_grad():
+                    dec16.run(db16, max_len=T_DEC, early_stop=False)
+                    fence()
+                    t0 = time.perf_counter()
+                    dec16.run(db16, max_len=T_DEC, early_stop=False)
+                    fence()
+                    d16 = time.perf_counter() - t0
+                decode[ddtype]["b16"] = dict(value=16 * T_DEC / d16, unit="tokens/s", batch=16, ms_per_step=d16 / T_DEC * 1e3,
+                                             us_per_token_row=d16 / T_DEC / 16 * 1e6,
+                                             vs_b256_per_token_row=(d16 / 16) / (ddt / B_DEC),
+                                             note="latency-bound: ~57 dependent launches per step whatever the batch")
+                log(f"decode {ddtype} at batch 16: {decode[ddtype]['b16']['value']:.0f} tokens/s, {decode[ddtype]['b16']['ms_per_step']:.3f} ms/step")
+                dec = dec16
+                del db16
             del dec, dm, db
             torch.cuda.empty_cache()
             mq32 = ddtype == "f32" and D == 512 and H <= 8 and B_DEC <= 512 and os.environ.get("PLANK_DECODE_MQ_F32", "1") != "0" \

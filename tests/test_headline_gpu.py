@@ -114,6 +114,8 @@ def check_grads(name, grads, r64):
     return worst
 
 
+SLACK_CAP = 4.0               # the most the golden-slice comparison is ever relaxed by, in units of the plain bound
+GOLDEN_WORST = {}             # case -> worst golden-slice error in units of the PLAIN bound (tied units excluded)
 GOLDEN_COMPARED = {}          # case -> ReLU ties of the device run whose golden gradient slices were compared (module state)
 TIE_SLACK = 0.5               # per tie, in units of the plain bound (see check_golden_grads); measured on MI355X: every case
                               # is inside the PLAIN bound once the tied units are excluded (worst 0.74 x, headline, one tie)
@@ -133,7 +135,8 @@ def check_golden_grads(name, g, grads, flipped=()):
     for key, unit in flipped:
         skip.setdefault(key + ".weight", set()).add(unit)
         skip.setdefault(key + ".bias", set()).add(unit)
-    slack = 1.0 + TIE_SLACK * len(flipped)
+    # (uncapped, 117 ties would have allowed 59 x the bound; no run needs more than SLACK_CAP)
+    slack = min(1.0 + TIE_SLACK * len(flipped), SLACK_CAP)
     worst = ("", 0.0)
     for k in grads:
         scale = float(g["g64::gmax::" + k])
@@ -152,6 +155,7 @@ def check_golden_grads(name, g, grads, flipped=()):
             n_ref = float(g["g64::gnorm::" + k])
             assert abs(float(got["gnorm::" + k]) - n_ref) <= slack * (1e-6 + 1e-4 * n_ref), (name, k, float(got["gnorm::" + k]), n_ref)
     GOLDEN_COMPARED[name] = len(flipped)
+    GOLDEN_WORST[name] = worst[1]
     return worst
 
 
@@ -668,6 +672,19 @@ def test_x3_train_step_passes_the_f32_gate_unchanged(name):
     nlin = 4 * c["ne"] + 6 * c["nd"]                   # forward Linears of the layers alone; each has a dX and a dW product too
     assert taken >= 5 * nlin // 2 and declined <= taken // 8, (taken, declined)
     f32_gate(name + "-x3", c, sd, batch, m, out, mem, hid, grads, g=g)
+
+
+def test_x3_golden_gradient_slices_were_compared_in_every_case():
+    """the comparison of the x3 step with the reference MODULE's float64 gradient slices is asserted, not printed.
+    All 8 cases compare; the slack is capped (SLACK_CAP) and the measured worst - in units of the PLAIN bound, tied units excluded -
+    stays under 3 (MI355X: 0.05 .. 1.07 in seven cases, 2.58 in sideface with 51 ties); tie counts are bounded like the exact-f32
+    ones (0 .. 51 measured; three cases have none).  Runs after test_x3_train_step_passes_the_f32_gate_unchanged[*] in file order."""
+    cases = [c + "-x3" for c in ["headline", "complete", "visible", "sideface", "live", "eps0", "gelu", "t1024"]]
+    if not all(c in GOLDEN_COMPARED for c in cases):
+        pytest.skip("needs test_x3_train_step_passes_the_f32_gate_unchanged[*] in the same session")
+    assert max(GOLDEN_WORST[c] for c in cases) <= 3.0, {c: GOLDEN_WORST[c] for c in cases}
+    assert sum(1 for c in cases if GOLDEN_COMPARED[c] == 0) >= 3, GOLDEN_COMPARED
+    assert max(GOLDEN_COMPARED[c] for c in cases) <= 96, GOLDEN_COMPARED
 
 
 @pytest.mark.parametrize("which", ["above"])
