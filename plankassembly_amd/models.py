@@ -130,7 +130,7 @@ class PlankModel(nn.Module):
     training step on the bf16 matrix pipe as a three-term hi / lo split - f32-accurate to ~2^-17 per product, see
     include/plank_hip.h pa_gemm_split_config; parameters, activations, LayerNorm, softmax statistics, the loss and the
     greedy decode are exactly the f32 path's)."""
-    _x3_scratch = {}            # device index -> uint8 scratch shared by every 'x3' model of the process
+    _x3_scratch = {}            # (rounds 4-5: one scratch per device shared by every 'x3' model; now each model owns its context and scratch)
 
     def __init__(self, num_model=512, num_head=8, num_feedforward=1024, dropout=0.1, activation="relu",
                  normalize_before=True, num_encoder_layers=6, num_decoder_layers=6, num_view=3, num_type=2,
@@ -297,6 +297,11 @@ class PlankModel(nn.Module):
         if cache is not None:
             L.lib().pa_gemm_split_cache_destroy(cache[0])
         self._x3_cache = None
+        ctx = getattr(self, "_x3_ctx", None)
+        if ctx is not None:                         # this model's bf16x3 context and scratch (include/plank_hip.h pa_split_ctx_*)
+            L.lib().pa_split_ctx_destroy(ctx)
+        self._x3_ctx = None
+        self._x3_ws = None
 
     def __del__(self):
         try:
@@ -363,14 +368,18 @@ class PlankModel(nn.Module):
         return L.PA_BF16 if self.compute_dtype == "bf16" else L.PA_F32
 
     def _split(self, on, retain=False):
-        """'x3': bracket this model's library calls with the process-global bf16x3 GEMM mode (no-op for the other dtypes)."""
+        """'x3': this host thread enters / leaves the model's OWN bf16x3 context around its library calls (no-op for the other
+        dtypes): mode, scratch, retained images and counters belong to the model, not to the process (pa_split_ctx_*)."""
         if not self.split3:
             return
         attn = os.environ.get("PLANK_X3_ATTN", "1") != "0"         # (0: attention stays on the exact-f32 kernels)
         if not on:
-            L.check(L.lib().pa_gemm_split_config(0, None, 0), "pa_gemm_split_config")
-            L.check(L.lib().pa_attn_split_config(0), "pa_attn_split_config")
-            L.check(L.lib().pa_gemm_split_cache_use(None), "pa_gemm_split_cache_use")
+            if getattr(self, "_x3_ctx", None) is not None:
+                L.check(L.lib().pa_split_ctx_enter(self._x3_ctx), "pa_split_ctx_enter")
+                L.check(L.lib().pa_gemm_split_config(0, None, 0), "pa_gemm_split_config")
+                L.check(L.lib().pa_attn_split_config(0), "pa_attn_split_config")
+                L.check(L.lib().pa_gemm_split_cache_use(None), "pa_gemm_split_cache_use")
+            L.check(L.lib().pa_split_ctx_enter(None), "pa_split_ctx_enter")
             return
         try:
             self._split_on(attn, retain)
@@ -384,16 +393,20 @@ class PlankModel(nn.Module):
             raise
 
     def _split_on(self, attn, retain):
+        if getattr(self, "_x3_ctx", None) is None:
+            h = C.c_void_p()
+            L.check(L.lib().pa_split_ctx_create(C.byref(h)), "pa_split_ctx_create")
+            self._x3_ctx = h
+        L.check(L.lib().pa_split_ctx_enter(self._x3_ctx), "pa_split_ctx_enter")
         if attn:
             L.check(L.lib().pa_attn_split_config(1), "pa_attn_split_config")
-        dev = self._flat.device.index or 0
-        ws = PlankModel._x3_scratch.get(dev)
-        if ws is None:
+        ws = getattr(self, "_x3_ws", None)
+        if ws is None or ws.device != self._flat.device:
             # the cut operands of one GEMM at a time, plus (retain modes) the forward's Linear inputs for the backward's weight
-            # gradients: 1.1 GB at the benchmark batch; what does not fit is simply cut again
+            # gradients: 1.1 GB at the benchmark batch; what does not fit is simply cut again.  Owned by the model: released with it.
             mb = int(os.environ.get("PLANK_X3_SCRATCH_MB", "2048"))
             ws = torch.empty(mb * (1 << 20) + 256, dtype=torch.uint8, device=self._flat.device)
-            PlankModel._x3_scratch[dev] = ws
+            self._x3_ws = ws
         base = (ws.data_ptr() + 255) // 256 * 256
         # backward segments: mode 2 keeps the cut dY of every dX GEMM for the segment's grouped weight-gradient launch; the
         # forward: mode 3 keeps the cut input of every Linear for the same launch (include/plank_hip.h pa_gemm_split_config)

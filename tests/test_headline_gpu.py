@@ -687,6 +687,70 @@ def test_x3_golden_gradient_slices_were_compared_in_every_case():
     assert max(GOLDEN_COMPARED[c] for c in cases) <= 96, GOLDEN_COMPARED
 
 
+def test_models_of_different_compute_modes_alternate_and_step_from_two_threads():
+    """the bf16x3 mode is the MODEL's (its own context: mode flags, scratch, retained images - include/plank_hip.h
+    pa_split_ctx_*), not the process's.  (a) An x3 and an exact-f32 model interleaved - x3 forward, f32 forward, x3 backward, f32
+    backward: the f32 model must not see the mode, the x3 model's forward images must survive the other model's step - give the
+    gradients they give alone.  (b) The same two models stepping concurrently from two host threads on two streams (ctypes drops
+    the GIL inside every library call, so the calls interleave freely): same gradients again, several rounds."""
+    import threading
+    c = LC.CASES["live"]
+    sd, batch = LC.case_state_dict(c), LC.case_batch(c)
+
+    def step(m, pb):
+        for p in m.parameters():
+            p.grad = None
+        out = m(pb)
+        out["loss"].backward()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    def close(a, b, rel):
+        for k in a:
+            scale = float(a[k].abs().max())
+            assert float((a[k] - b[k]).abs().max()) <= rel * scale + 1e-12, (k, float((a[k] - b[k]).abs().max()), scale)
+
+    mx, mf = hip_model(c, "x3", sd).train(), hip_model(c, "f32", sd).train()
+    pbx, pbf = mx.prepare_batch(batch), mf.prepare_batch(batch)
+    gx0, gf0 = step(mx, pbx), step(mf, pbf)                       # each alone
+    torch.cuda.synchronize()
+    assert any(float((gx0[k] - gf0[k]).abs().max()) > 0 for k in gx0)          # (the two modes really differ)
+    # (a) interleaved on one thread
+    for p in list(mx.parameters()) + list(mf.parameters()):
+        p.grad = None
+    ox = mx(pbx); of = mf(pbf)
+    ox["loss"].backward(); of["loss"].backward()
+    torch.cuda.synchronize()
+    close(gx0, {k: p.grad for k, p in mx.named_parameters()}, 2e-6)            # (x3: unordered bias / LayerNorm sums)
+    for k, p in mf.named_parameters():
+        assert torch.equal(p.grad, gf0[k]), k                                   # exact f32: ordered sums, bit-identical
+    # (b) two threads, two streams
+    res, err = {}, []
+
+    def worker(name, m, pb, ref, rel):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for it in range(4):
+                    g = step(m, pb)
+                    st.synchronize()
+                    if rel == 0:
+                        for k in g:
+                            assert torch.equal(g[k], ref[k]), (name, it, k)
+                    else:
+                        close(ref, g, rel)
+            res[name] = True
+        except BaseException as e:                                               # surfaces in the main thread below
+            err.append((name, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=("x3", mx, pbx, gx0, 2e-6)), threading.Thread(target=worker, args=("f32", mf, pbf, gf0, 0))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not err and res == {"x3": True, "f32": True}, err
+
+
 @pytest.mark.parametrize("which", ["above"])
 def test_x3_b16_step_matches_oracle(which):
     """Batch 16, S = 1024 packed (the benchmarked dispatch: > 8 192 encoder rows)."""
