@@ -1503,6 +1503,27 @@ template <int OFF> __device__ __forceinline__ void mma_nat4c(f32x4 (&acc)[4], co
         }
     }
 }
+// ... and from a per-ROW constant (dK / dV kernel: a lane's four accumulator values are four consecutive query rows of the tile):
+// c[kb] = the lane's four constants of 16-row block kb, loaded from the tile's aux words straight into the MFMA's C operand
+template <int OFF> __device__ __forceinline__ void mma_nat4v(f32x4 (&acc)[4], const Lds4& lb, const u32x4 (&regs)[2], const u32x4 (&c)[4]) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        u32x4 a[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            PA_DS128(a[2 * j], lb.nat[0], OFF + (2 * h2 + j) * 2048);
+            PA_DS128(a[2 * j + 1], lb.nat[1], OFF + (2 * h2 + j) * 2048);
+        }
+        wait_lds(a);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 z = *reinterpret_cast<const f32x4*>(&c[2 * h2 + j]);
+            mma16(z, a[2 * j], regs[0]);
+            mma16(z, a[2 * j + 1], regs[1]);
+            acc[2 * h2 + j] = z;
+        }
+    }
+}
 // rows held as bf16 fragments *= f (f32 product, one rounding back to bf16)
 __device__ __forceinline__ void scale_row4(u32x4 (&regs)[2], float f) {
 #pragma unroll
@@ -1833,6 +1854,11 @@ __device__ __forceinline__ void attn4_dq_body(const AttnP& pin, int bid, char* s
     u32x4 qreg[2], doreg[2];
     load_row4(qreg, Qp, p.ldq, qrow, p.Lq, lane);
     load_row4(doreg, dOp, p.lddo, qrow, p.Lq, lane);
+    // Instruction diet (round 6; the loop is bound by instruction issue, profiles/r04_attn_issue_bound.txt): the query rows are
+    // pre-multiplied by scale * log2(e) - the forward kernels' own rounding, bf16(q * scale * log2 e) - and both score products start
+    // from a per-row constant (all four values of a lane's 16 x 16 accumulator belong to ONE query row): S^T from -lse, dP^T from
+    // -delta.  The MFMAs then deliver the exponent and dP - delta: no FMA and no subtraction per score (7.5 -> 5.5 VALU per score).
+    scale_row4(qreg, p.scale * LOG2E);
     const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qrow;
     const float lse2 = (qrow < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
     const float keep_p = DROP ? 1.0f / p.drop_scale : 1.0f;
@@ -1893,8 +1919,8 @@ __device__ __forceinline__ void attn4_dq_body(const AttnP& pin, int bid, char* s
     f32x4 dqacc[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) dqacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float sl = p.scale * LOG2E;
-    const float nl = -lse2;
+    const float nl = -lse2, ndlt = -dlt;
+    const f32x4 c_nl = {nl, nl, nl, nl}, c_ndlt = {ndlt, ndlt, ndlt, ndlt};
     const uint32_t arow = DROP ? drop_row_hash(p.drop_seed, (uint32_t)srow) : 0u;
     tile_barrier();
 
@@ -1907,8 +1933,8 @@ __device__ __forceinline__ void attn4_dq_body(const AttnP& pin, int bid, char* s
         const bool key_masked = k0 + BSTR > kfirst;
         const bool need_mask = key_masked || (p.causal && (k0 + BSTR - 1 > qw0));
         f32x4 sacc[4], dpacc[4];
-        mma_nat4<buf * BUF>(sacc, lb, qreg);
-        mma_nat4<buf * BUF + NAT>(dpacc, lb, doreg);
+        mma_nat4c<buf * BUF>(sacc, lb, qreg, c_nl);                    // log2-domain scores - lse: the exponent
+        mma_nat4c<buf * BUF + NAT>(dpacc, lb, doreg, c_ndlt);          // dP - delta
         u32x4 cq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
         if (DROP) PA_DS128(cq[0], cbase, buf * BUF + AUX + 64);
 #pragma unroll
@@ -1926,14 +1952,14 @@ __device__ __forceinline__ void attn4_dq_body(const AttnP& pin, int bid, char* s
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float pe = fast_exp2(__builtin_fmaf(sacc[kb][e], sl, nl));
+                float pe = fast_exp2(sacc[kb][e]);
                 if (need_mask) {
                     const bool masked = ((m4 >> (8 * e)) & 0xffu) || (p.causal && k0 + ko + e > qrow);
                     pe = masked ? 0.f : pe;
                 }
-                float dp = dpacc[kb][e];
-                if (DROP) dp = drop_keep2(arow, cq[kb & 1][e], p.drop_thr) ? dp : 0.f;
-                sacc[kb][e] = pe * (dp - dlt);                         // dS^T / (scale / (1-p))
+                float dp = dpacc[kb][e];                               // dP - delta;  a dropped probability: 0 - delta
+                if (DROP) dp = drop_keep2(arow, cq[kb & 1][e], p.drop_thr) ? dp : ndlt;
+                sacc[kb][e] = pe * dp;                                 // dS^T / (scale / (1-p))
             }
         }
         mma_tr4<buf * BUF>(dqacc, lb, sacc);                           // dQ^T += K^T dS^T
@@ -2011,6 +2037,10 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
     u32x4 kreg[2], vreg[2];
     load_row4(kreg, Kp, p.ldk, krow, p.Lk, lane);
     load_row4(vreg, Vp, p.ldv, krow, p.Lk, lane);
+    // Instruction diet (round 6, as attn4_dq_body): the key rows are pre-multiplied by scale * log2(e) and both score products start
+    // from the tile's per-query-row aux words, stored NEGATED - S from -lse, dP from -delta: the MFMAs deliver the exponent and
+    // dP - delta (8 -> 6 VALU per score with dropout, 4 -> 2 without).
+    scale_row4(kreg, p.scale * LOG2E);
     int nsteps = (p.Lq + BSTR - 1) / BSTR;
     int step0 = CAUSAL ? (key0 / BSTR) : 0;
     if (nparts > 1) split_range(nsteps, part, nparts, step0, nsteps);
@@ -2041,8 +2071,8 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
         glds_tile4(base + NAT, srcO, voffO, r0, wave);
         if (tid < BSTR) {
             float* aux = reinterpret_cast<float*>(base + AUX);
-            aux[tid] = lv;
-            aux[64 + tid] = dv_;
+            aux[tid] = -lv;                                // (negated: accumulator start values of the score products)
+            aux[64 + tid] = -dv_;
             if (DROP) reinterpret_cast<uint32_t*>(aux)[128 + tid] = drop_row_hash(p.drop_seed, (uint32_t)(srow0 + r0 + tid));
         }
     };
@@ -2080,39 +2110,37 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
         if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
         if (!wave_on) { tile_barrier(); return; }      // this wave's 16 keys lie past the element's last key
         const int r0 = step * BSTR;
-        f32x4 sacc[4], dpacc[4];
-        mma_nat4<buf * BUF>(sacc, lb, kreg);                           // S[q][key]: rows q = 16qb + 4g + r, col key = l & 15
-        mma_nat4<buf * BUF + NAT>(dpacc, lb, vreg);                    // dP[q][key]
-        const bool need_causal = CAUSAL && (kw0 + 15 > r0);
-        // per-query-row words of the tile (lse, delta, dropout row hash): without dropout they stream through two register
-        // sets (group qb + 1 requested before qb is consumed); with dropout the third word would push the kernel past 128
-        // registers, so the three words of a group are read when it is processed (the other waves cover the latency)
-        u32x4 lq[2], dq_[2], aq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
         constexpr int AO = buf * BUF + AUX;
-        if (!DROP) { PA_DS128(lq[0], abase, AO); PA_DS128(dq_[0], abase, AO + 256); }
+        u32x4 nl4[4], nd4[4];                                          // -lse * log2 e and -delta * (1 - p) of this lane's query rows
+        // (the two sets one after the other: requested together, the 32 start values pushed the kernel past 128 registers)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) PA_DS128(nl4[qb], abase, AO + qb * 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nl4[0]), "+v"(nl4[1]), "+v"(nl4[2]), "+v"(nl4[3]));
+        f32x4 sacc[4], dpacc[4];
+        mma_nat4v<buf * BUF>(sacc, lb, kreg, nl4);                     // S[q][key] - lse[q] (log2 domain): rows q = 16qb + 4g + r, col key = l & 15
+        __builtin_amdgcn_sched_barrier(0);                             // (keeps hipcc from hoisting the second set above the first product)
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) PA_DS128(nd4[qb], abase, AO + 256 + qb * 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nd4[0]), "+v"(nd4[1]), "+v"(nd4[2]), "+v"(nd4[3]));
+        mma_nat4v<buf * BUF + NAT>(dpacc, lb, vreg, nd4);              // dP[q][key] - delta[q]
+        const bool need_causal = CAUSAL && (kw0 + 15 > r0);
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
             const int qo = 16 * qb + 4 * g;
-            constexpr int dummy = 0; (void)dummy;
-            if (DROP) {
-                PA_DS128(lq[0], abase, AO + qb * 64); PA_DS128(dq_[0], abase, AO + 256 + qb * 64); PA_DS128(aq[0], abase, AO + 512 + qb * 64);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lq[0]), "+v"(dq_[0]), "+v"(aq[0]));
-            } else if (qb + 1 < 4) {
-                PA_DS128(lq[(qb + 1) & 1], abase, AO + (qb + 1) * 64); PA_DS128(dq_[(qb + 1) & 1], abase, AO + 256 + (qb + 1) * 64);
-                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lq[qb & 1]), "+v"(dq_[qb & 1]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lq[qb & 1]), "+v"(dq_[qb & 1]));
-            }
-            const int cur = DROP ? 0 : (qb & 1);
+            u32x4 aq = {0u, 0u, 0u, 0u};
+            if (DROP) { PA_DS128(aq, abase, AO + 512 + qb * 64); asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aq)); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float pe = fast_exp2(__builtin_fmaf(sacc[qb][e], sl, -__uint_as_float(lq[cur][e])));
+                float pe = fast_exp2(sacc[qb][e]);
                 if (CAUSAL && need_causal) pe = (krow > r0 + qo + e) ? 0.f : pe;
-                float pd = pe;
-                if (DROP) pd = drop_keep2(aq[cur][e], ckey, p.drop_thr) ? pe : 0.f;
-                sacc[qb][e] = pd;                                                   // P_drop * (1-p)
-                // dS * (1-p) / scale = P (keep * dP - delta) = P_drop dP - P delta: one select instead of two
-                dpacc[qb][e] = __builtin_fmaf(pd, dpacc[qb][e], -(pe * __uint_as_float(dq_[cur][e])));
+                float pd = pe, x = dpacc[qb][e];
+                if (DROP) {
+                    const bool keep = drop_keep2(aq[e], ckey, p.drop_thr);
+                    pd = keep ? pe : 0.f;                                           // P_drop * (1-p)
+                    x = keep ? x : __uint_as_float(nd4[qb][e]);                     // a dropped probability: 0 - delta
+                }
+                sacc[qb][e] = pd;
+                dpacc[qb][e] = pe * x;                                              // dS * (1-p) / scale = P (keep * dP - delta)
             }
         }
         mma_tr4<buf * BUF + NAT>(dvacc, lb, sacc);                     // dV^T += dO^T P

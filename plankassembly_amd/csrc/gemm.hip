@@ -2932,14 +2932,30 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
                         splitk == 1 && a->K % 64 == 0 && a->M >= big_minm && a->N >= big_minn;
     if (go_big) {
         if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(PA_GEMM_KIND_BIG); if (g_rec && g_rec_group) g_rec_group->push_back(-1); }
-        const bool sq = a->N >= 1024;
+        // tile width: PA_GEMM_BIG=1 (round 4): 256 from N = 1024 on, else 128.  PA_GEMM_BIG=2 (round 6): the width in {256, 192, 128}
+        // that needs the fewest ROUNDS of one block per CU (ties: the wider tile) - 256 x 192 makes N = 1536 one round of 31 x 8 blocks
+        // at 7.9 k rows where 256 x 256 leaves 70 CUs idle and 128-wide tiles take two rounds; PA_GEMM_BIG_TN=<n> forces.
+        static const int force_tn = getenv("PA_GEMM_BIG_TN") ? atoi(getenv("PA_GEMM_BIG_TN")) : 0;
+        int tn = a->N >= 1024 ? 256 : 128;
+        const int tm8 = (a->M + 255) / 256;
+        if (use_big >= 2) {
+            long best = -1;
+            for (int w : {256, 192, 128}) {
+                const long blocks = (long)tm8 * ((a->N + w - 1) / w) * a->batch;
+                const long rounds = (blocks + cus - 1) / cus;
+                const long cost = rounds * w * 1000 + ((a->N + w - 1) / w * w - a->N);       // time ~ rounds x tile width; then least padding
+                if (best < 0 || cost < best) { best = cost; tn = w; }
+            }
+        }
+        if (force_tn == 256 || force_tn == 192 || force_tn == 128) tn = force_tn;
         GemmP pb = pk;
-        pb.tiles_m = (a->M + 255) / 256; pb.tiles_n = (a->N + (sq ? 255 : 127)) / (sq ? 256 : 128);
+        pb.tiles_m = tm8; pb.tiles_n = (a->N + tn - 1) / tn;
         pb.plain_order = pb.tiles_m < 8;
         pb.tiles_m_pad = pb.plain_order ? pb.tiles_m : (pb.tiles_m + 7) / 8 * 8;
         pb.units = pb.tiles_m_pad * pb.tiles_n * a->batch;
         const int gb = pb.units < cus ? pb.units : cus;
-        if (sq) PA_LAUNCH((gemm8_kernel<4, 2, 2, 4, 64, 2>), dim3(gb), dim3(512), 0, st, pb);
+        if (tn == 256) PA_LAUNCH((gemm8_kernel<4, 2, 2, 4, 64, 2>), dim3(gb), dim3(512), 0, st, pb);
+        else if (tn == 192) PA_LAUNCH((gemm8_kernel<4, 2, 2, 3, 64, 2>), dim3(gb), dim3(512), 0, st, pb);
         else PA_LAUNCH((gemm8_kernel<4, 2, 2, 2, 64, 2>), dim3(gb), dim3(512), 0, st, pb);
         return 0;
     }
