@@ -1446,17 +1446,25 @@ constexpr int NT4 = 512;
 __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
 }
+// LDS image of a 64-row tile for the 16-row-wave kernels: row r at r * 128, its 16-byte chunk c at position c ^ key4(r).
+// key4(r) = 2 * ((r >> 1) & 3) (round 6).  The 32-row-wave kernels' key (r >> 1) & 7 is conflict-free for the ds_read_b128 fragment
+// reads but 2-way conflicted for EVERY ds_read_b64_tr_b16 here: a 32-lane group of the transposing read covers rows 8 m .. 8 m + 7 x two
+// neighbouring chunks, and rows r, r + 2 landed on the same bank quads (r >> 1 differs in bit 0 = the chunk pair's own bit).  Measured
+// (profiles/r05_attn_pmc_in_step.txt): 26 % of the dK / dV kernel's LDS cycles were conflict cycles with the LDS 47 % busy.  With bits
+// 1-2 of the row in bits 1-2 of the key both reads are conflict-free (tools: exhaustive search over the GF(2)-linear keys).
+__device__ __forceinline__ int key4(int row) { return ((row >> 1) & 3) << 1; }
+__device__ __forceinline__ int swz4_off(int row, int chunk) { return row * 128 + (((chunk ^ key4(row)) & 7) << 4); }
 struct Lds4 {
     uint32_t nat[2];          // natural rows: row (l & 15), chunk 4s + g               (+ kb * 16 * 128)
     uint32_t tr[4];           // transposing patch of d block db: rows 4g + (L >> 2)    (+ (32kk + 16c) * 128)
     __device__ __forceinline__ void init(uint32_t base, int lane) {
         const int i = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) nat[s] = base + swz_off<128>(i, 4 * s + g);
+        for (int s = 0; s < 2; ++s) nat[s] = base + swz4_off(i, 4 * s + g);
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             const int r = 4 * g + (i >> 2), col = 16 * db + 4 * (i & 3);
-            tr[db] = base + swz_off<128>(r, col >> 3) + (col & 7) * 2;
+            tr[db] = base + swz4_off(r, col >> 3) + (col & 7) * 2;
         }
     }
 };
@@ -1589,7 +1597,7 @@ __device__ __forceinline__ void store_rows4(bf16* base, int ld, int row, int nro
 }
 __device__ __forceinline__ int tile_voff4(int ld, int tid) {
     const int row = tid >> 3;
-    const int ch = ((tid & 7) ^ (row >> 1)) & 7;
+    const int ch = ((tid & 7) ^ key4(row)) & 7;
     return (row * ld + ch * 8) * 2;
 }
 __device__ __forceinline__ void glds_tile4(char* lds, const TileSrc& ts, int voff, int row0, int wave) {
