@@ -1452,7 +1452,11 @@ __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b
 // neighbouring chunks, and rows r, r + 2 landed on the same bank quads (r >> 1 differs in bit 0 = the chunk pair's own bit).  Measured
 // (profiles/r05_attn_pmc_in_step.txt): 26 % of the dK / dV kernel's LDS cycles were conflict cycles with the LDS 47 % busy.  With bits
 // 1-2 of the row in bits 1-2 of the key both reads are conflict-free (tools: exhaustive search over the GF(2)-linear keys).
+#ifdef PA_KEY4_OLD          // A/B build (round 5's key; tools: PLANK_HIP_LIB=<variant>)
+__device__ __forceinline__ int key4(int row) { return (row >> 1) & 7; }
+#else
 __device__ __forceinline__ int key4(int row) { return ((row >> 1) & 3) << 1; }
+#endif
 __device__ __forceinline__ int swz4_off(int row, int chunk) { return row * 128 + (((chunk ^ key4(row)) & 7) << 4); }
 struct Lds4 {
     uint32_t nat[2];          // natural rows: row (l & 15), chunk 4s + g               (+ kb * 16 * 128)

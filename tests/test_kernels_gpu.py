@@ -1074,6 +1074,38 @@ def test_attention_x3_equals_exact_f32_to_split_precision(B, H, Lq, Lk, use_kpm,
         assert err > 0.0 or name == "lse"                           # ... and it is not the exact kernel answering
 
 
+def test_attention_x3_packed_element_without_keys_gets_zero_gradients():
+    """a packed (cu_k) batch element with NO keys - cu_k[b + 1] == cu_k[b] - must come out of the bf16x3 backward with zero dQ
+    rows like the exact-f32 kernels' (the split dQ kernel used to return before its store: uninitialised memory), and must not read
+    before its key range either.  Output buffers are pre-filled with NaN by running on torch.empty storage we poison first."""
+    from plankassembly_amd import _lib as L
+    B, H, Lq, dm = 3, 8, 128, 512
+    lens = [70, 0, 130]
+    cu = torch.tensor([0, 70, 70, 200], dtype=torch.int32, device=DEV)
+    q = rnd(B * Lq, dm, dtype=torch.float32, seed=60).to(DEV)
+    kv = rnd(200, 2 * dm, dtype=torch.float32, seed=61).to(DEV)
+    k, v = kv[:, :dm], kv[:, dm:]
+    dout = rnd(B * Lq, dm, dtype=torch.float32, seed=62).to(DEV)
+
+    def run(split):
+        L.check(L.lib().pa_attn_split_config(1 if split else 0), "pa_attn_split_config")
+        try:
+            poison = torch.full((4 * B * Lq * dm,), float("nan"), device=DEV)      # what the next torch.empty calls will hand out
+            del poison
+            o, lse = ops.attn_varlen_fwd(q, k, v, H, None, cu, B, Lq, max(lens))
+            dq, dk, dv = ops.attn_varlen_bwd(dout, q, k, v, o, lse, H, None, cu, B, Lq, max(lens))
+            torch.cuda.synchronize()
+            return o, dq, dk, dv
+        finally:
+            L.check(L.lib().pa_attn_split_config(0), "pa_attn_split_config")
+
+    exact, x3 = run(False), run(True)
+    for name, a, b in zip(("o", "dq", "dk", "dv"), x3, exact):
+        assert torch.isfinite(a).all(), name
+        assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()) + 1e-6, name
+    assert float(x3[1][Lq:2 * Lq].abs().max()) == 0.0 and float(x3[0][Lq:2 * Lq].abs().max()) == 0.0     # the key-less element's rows
+
+
 def test_attention_mask_order_dispatch_leaves_results_unchanged():
     """ops.mask_order (longest batch element first, pa_attn_args.order on a padded batch with a key-padding mask): a permutation
     of the block -> batch-element mapping only - forward and backward outputs are bit-identical to the plain order, with dropout."""
