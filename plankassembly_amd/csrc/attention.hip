@@ -80,10 +80,22 @@ template <typename T, int DH> struct AT {
     static constexpr int NITEM = (2 * NSB + NTH - 1) / NTH;   // sub-blocks per thread for two tiles
 };
 
+// Swizzle key of an LDS row of RB bytes: its 16-byte chunk c sits at position c ^ tile_key(row).  128-byte rows (bf16 dh = 64 tiles
+// of the 32-row-wave kernels, incl. the bf16x3 images) - round 6: bits (r1, r2, r1 ^ r3) instead of (r >> 1) & 7.  The old key is
+// conflict-free for the ds_read_b128 fragment reads but 2-way conflicted for every ds_read_b64_tr_b16 (a 32-lane group reads rows
+// r0 .. r0 + 3 x four neighbouring chunks: rows r0 and r0 + 2 landed on the same bank quads); the new one is conflict-free for both
+// (exhaustive search over the GF(2)-linear keys, tools/ubench/r06/swizzle_search.py) and keeps the two properties the kernels'
+// address arithmetic relies on: period 16 rows, key(r + 8) = key(r) ^ 4.  -DPA_KEY5_OLD: round 5's key (A/B builds).
+template <int RB> __device__ __forceinline__ int tile_key(int row) {
+    constexpr int RPB = (RB >= 256) ? 1 : 256 / RB;
+#ifndef PA_KEY5_OLD
+    if constexpr (RB == 128) return ((row >> 1) & 3) | ((((row >> 1) ^ (row >> 3)) & 1) << 2);
+#endif
+    return row / RPB;
+}
 template <int RB> __device__ __forceinline__ int swz_off(int row, int chunk) {
     constexpr int NCH = RB / 16;
-    constexpr int RPB = (RB >= 256) ? 1 : 256 / RB;
-    return row * RB + (((chunk ^ (row / RPB)) & (NCH - 1)) << 4);
+    return row * RB + (((chunk ^ tile_key<RB>(row)) & (NCH - 1)) << 4);
 }
 
 // ---- staging: a thread owns 4 consecutive rows x one 16-byte chunk of the streamed tile ----------
@@ -806,7 +818,7 @@ __device__ __forceinline__ void glds_nat(char* lds, const bf16* base, int ld, in
         const int p = tid + i * NTH;
         if (B::NCHUNK % NTH == 0 || p < B::NCHUNK) {
             const int row = p / B::NCHR;
-            const int ch = ((p % B::NCHR) ^ (row / RPB)) & (B::NCHR - 1);       // source chunk that belongs at position p
+            const int ch = ((p % B::NCHR) ^ tile_key<B::RBN>(row)) & (B::NCHR - 1);       // source chunk that belongs at position p
             const int r = min(row0 + row, nrows - 1);                            // clamp: masked rows still read finite data
             const bf16* src = base + (size_t)r * ld + ch * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -840,7 +852,7 @@ template <int DH> __device__ __forceinline__ int tile_voff(int ld, int tid) {
     using B = BT<DH>;
     constexpr int RPB = (B::RBN >= 256) ? 1 : 256 / B::RBN;
     const int row = tid / B::NCHR;
-    const int ch = ((tid % B::NCHR) ^ (row / RPB)) & (B::NCHR - 1);           // source chunk that belongs at position tid
+    const int ch = ((tid % B::NCHR) ^ tile_key<B::RBN>(row)) & (B::NCHR - 1);           // source chunk that belongs at position tid
     return (row * ld + ch * 8) * 2;
 }
 // Round 4: the tile's first row goes into the per-lane offset (one scalar multiply + one vector add per DMA instruction) and the
