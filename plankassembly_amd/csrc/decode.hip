@@ -47,6 +47,10 @@ struct DecodeLayout {
     bool mq_contract = false;                  // exact f32, dh 64: W_v as its own launch + the ordinary out-projection instead of wo_t (decode_mq.h)
     void *mem = nullptr, *qt = nullptr, *ctx = nullptr;
     std::vector<void*> wo_t; std::vector<float*> bo_t;
+    // bf16 step (f32 residual stream), round 6: the SELF-attention absorbed as well - self_k[i] caches the layer-input rows (bf16), the
+    // out-projection runs on the context rows with W~o,self = W_o,h W_v,h (wo_ts / bo_ts); self_v is not read
+    bool mq_self_bf = false;
+    std::vector<void*> wo_ts; std::vector<float*> bo_ts;
     void* mq_sp = nullptr; int64_t mq_sp_bytes = 0;   // range blocks of the absorbed cross-attention (decode_mq.h): tickets (zero between launches) + partials
 };
 
@@ -562,6 +566,8 @@ size_t dec_layout(pa_model* m, DecodeLayout* L, char* base, int B, int S, int Tm
         for (int i = 0; i < c.n_dec; ++i) { L->wo_t[i] = a.take(d * H * d * e); L->bo_t[i] = (float*)a.take(d * 4); }
         L->wvt_self.assign(c.n_dec, nullptr);
         if (c.dtype == PA_F32) for (int i = 0; i < c.n_dec; ++i) L->wvt_self[i] = a.take(d * d * e);
+        L->wo_ts.assign(c.n_dec, nullptr); L->bo_ts.assign(c.n_dec, nullptr);
+        if (c.dtype == PA_BF16) for (int i = 0; i < c.n_dec; ++i) { L->wo_ts[i] = a.take(d * H * d * e); L->bo_ts[i] = (float*)a.take(d * 4); }
     }
     L->kv_tmp = md.mq ? nullptr : a.take((size_t)B * S * 2 * d * e);
     L->hid_cache = a.take((size_t)B * Tmax * d * e);
@@ -729,6 +735,29 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
             return 0;
         }
         const int i = part / 2, pb = m->dec_base(i);
+        if ((part & 1) == 0 && L->mq_self_bf) {
+            // absorbed self-attention: only the query rows are projected (the first d rows of the LayerNorm-folded in_proj); the expand launch
+            // forms q~_h = scale log2e W_k,h^T q_h AND appends this step's layer-input row (f32 residual stream -> bf16) to the row cache
+            if constexpr (sizeof(T) == 2) {
+                if (i > 0) {
+                    const int pp = m->dec_base(i - 1);
+                    RC(linear_norm_a32(m, L->zb, zf, L->fw[0][i], L->fu[0][i], L->fv[0][i], PF(pp + D_N3_W), PF(pp + D_N3_B), c.eps_layer, xf,
+                                       L->q, d, B, d, d, 0, st));
+                } else {
+                    RC(linear(m, L->xb, PL(pb + D_SA_IN_W), PF(pb + D_SA_IN_B), L->q, d, B, d, d, 0, nullptr, -1, st));
+                }
+                const int H = c.n_head;
+                const bf16* Wk = (const bf16*)m->pl[pb + D_SA_IN_W] + (size_t)d * d;
+                const float sl = LOG2E_F / sqrtf((float)(d / H));
+                PA_LAUNCH((mq_expand_q_kernel<64, bf16, float>), dim3((B + MQ_XR - 1) / MQ_XR, H), dim3(512), 0, s, (bf16*)L->qt, (const bf16*)L->q, d, Wk, B, d, H, sl,
+                          (const float*)xf, (bf16*)L->self_k[i], (const int32_t*)L->t_dev, Tmax);
+                RC(fence_in());
+                RC(launch_cross_mq((bf16*)L->ctx, (const bf16*)L->qt, (const bf16*)L->self_k[i], nullptr, nullptr, B, Tmax, H, d, s, L->mq_sp, L->mq_sp_bytes,
+                                   L->t_dev));
+                RC(fence_out());
+            }
+            return 0;
+        }
         if ((part & 1) == 0) {
             if (i > 0) {
                 const int pp = m->dec_base(i - 1);
@@ -742,7 +771,8 @@ int step_part(pa_model* m, int part, void* st, hipEvent_t wait_ev, hipEvent_t re
                               L->t_dev, B, st, nullptr, (const T*)L->qkv));
             RC(fence_out());
         } else {
-            RC(linear_res32(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), xf, z2f, L->z2b, B, d, d, st));
+            if (L->mq_self_bf) RC(linear_res32(m, L->ctx, L->wo_ts[i], L->bo_ts[i], xf, z2f, L->z2b, B, d, c.n_head * d, st));   // W_o,h W_v,h on the context rows
+            else RC(linear_res32(m, L->ao, PL(pb + D_SA_OUT_W), PF(pb + D_SA_OUT_B), xf, z2f, L->z2b, B, d, d, st));
             RC(linear_norm_a32(m, L->z2b, z2f, L->fw[1][i], L->fu[1][i], L->fv[1][i], PF(pb + D_N1_W), PF(pb + D_N1_B), c.eps_layer, yf,
                                L->q, d, B, d, d, 0, st));
             if (L->mq) { RC(cross_mq(m, i, s)); return 0; }
@@ -877,6 +907,14 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
     // then the largest stream of the f32 step), q~ = W_k^T q, W_v behind the softmax (q . b_k cancels, b_v is added once).  PLANK_DECODE_MQ_SELF=0.
     static const int self_env = getenv("PLANK_DECODE_MQ_SELF") ? atoi(getenv("PLANK_DECODE_MQ_SELF")) : 1;
     L->mq_self = L->mq && L->mq_contract && c.dtype == PA_F32 && self_env != 0 && Tmax <= 16000;
+    // bf16 (round 6; needs the f32 residual stream's step form): pays from ~200 batch elements on - measured in one session, B 256 x 1024 steps:
+    // 0.969 -> 0.929 ms / step (264 k -> 276 k tokens/s; half the bytes of the self-attention stream against one more launch and a K = H d
+    // out-projection per layer); B 64: 0.557 -> 0.662, B 16: 0.476 -> 0.609 (profiles/r06_decode_self_absorbed.txt).
+    // PLANK_DECODE_MQ_SELF_BF16: 0 never, 1 always, unset = B >= PLANK_DECODE_MQ_SELF_MINB (200).
+    static const int self_bf_env = getenv("PLANK_DECODE_MQ_SELF_BF16") ? atoi(getenv("PLANK_DECODE_MQ_SELF_BF16")) : -1;
+    static const int self_bf_minb = getenv("PLANK_DECODE_MQ_SELF_MINB") ? atoi(getenv("PLANK_DECODE_MQ_SELF_MINB")) : 200;
+    L->mq_self_bf = L->mq && !L->mq_contract && c.dtype == PA_BF16 && md.f32res && d / c.n_head == 64 && Tmax <= MQ_MAXS &&
+                    (self_bf_env >= 0 ? self_bf_env != 0 : B >= self_bf_minb);
     if (L->mq) {
         // absorbed cross-attention: the step reads the encoder output rows themselves - no K / V projection of the memory at all
         hipError_t hm = hipMemcpyAsync(L->mem, memory, (size_t)m->NE * d * e, hipMemcpyDeviceToDevice, s);
@@ -915,6 +953,9 @@ extern "C" int pa_decode_begin(pa_model* m, void* ws, int64_t ws_bytes, int32_t 
             }
             if (L->mq_self)
                 PA_LAUNCH(mq_transpose_v_kernel<float>, dim3(1024), dim3(256), 0, s, (float*)L->wvt_self[i], (const float*)m->pl[pb + D_SA_IN_W] + (size_t)2 * d * d, d, c.n_head);
+            if (L->mq_self_bf)
+                PA_LAUNCH(mq_absorb_o_kernel<bf16>, dim3(d), dim3(256), 0, s, (bf16*)L->wo_ts[i], L->bo_ts[i], F(pb + D_SA_OUT_W), F(pb + D_SA_OUT_B),
+                          F(pb + D_SA_IN_W), F(pb + D_SA_IN_B), d, c.n_head);
             if (L->mq && !L->mq_contract) {    // W~o = W_o,h W_v,h, b~o = b_o + W_o b_v for the Linear behind the absorbed attention (csrc/decode_mq.h)
                 if (c.dtype == PA_BF16)
                     PA_LAUNCH(mq_absorb_o_kernel<bf16>, dim3(d), dim3(256), 0, s, (bf16*)L->wo_t[i], L->bo_t[i], F(pb + D_CA_OUT_W), F(pb + D_CA_OUT_B),

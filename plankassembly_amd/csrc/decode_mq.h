@@ -51,13 +51,13 @@ template <bool SWAP> __device__ __forceinline__ float mq_rows_max(float v) {
 constexpr int MQ_SP_BYTES = 40 * 1024;
 template <int AUX, bool SWAP, bool MASK>
 __global__ __launch_bounds__(256, 1) void dec_cross_mq_kernel(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* kpm,
-                                                              const int32_t* cu, int S, int H, int nparts, char* sp) {
+                                                              const int32_t* cu, int S, int H, int nparts, char* sp, const int32_t* t_dev) {
     extern __shared__ __attribute__((aligned(256))) char mq_smem[];
     const int b = blockIdx.x / nparts, part = blockIdx.x - b * nparts, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
     const int row0 = cu ? cu[b] : b * S;
-    const int Lk = cu ? cu[b + 1] - row0 : S;
+    const int Lk = t_dev ? *t_dev + 1 : (cu ? cu[b + 1] - row0 : S);     // (t_dev: rows 0 .. t of a [B][S] row cache - the self-attention form)
     bf16* out = ctx + (size_t)b * H * MQ_D;
     if (Lk <= 0) {                                                      // (block-uniform) no key: zeros, as dec_attn_kernel
         if (part == 0) for (int idx = tid; idx < H * MQ_D; idx += 256) out[idx] = (bf16)0.f;
@@ -618,16 +618,16 @@ __global__ __launch_bounds__(512, 1) void dec_cross_mq32w8_kernel(float* ctx, co
 // skinny kernel (four rounds of 1 024 blocks) against 6 + ~4 us for the two launches.  grid (B / 8, H), 512 threads: a thread owns
 // one column j of 8 rows; the weights are read once per block (coalesced over j), the 8 x dh query values come from LDS.
 constexpr int MQ_XR = 8;
-template <int DH, typename T>        // DH = head dim when it is 64 (every weight load of a thread issued before the first use: one round trip), else 0
+template <int DH, typename T, typename XT = T>   // DH = head dim when it is 64 (every weight load of a thread issued before the first use: one round trip), else 0; XT: type of the layer-input rows
 __global__ __launch_bounds__(512) void mq_expand_q_kernel(T* qt, const T* q, int ldq, const T* Wk, int B, int d, int H, float sl,
-                                                          const T* xrow = nullptr, T* xcache = nullptr, const int32_t* t_dev = nullptr, int Tmax = 0) {
+                                                          const XT* xrow = nullptr, T* xcache = nullptr, const int32_t* t_dev = nullptr, int Tmax = 0) {
     __shared__ __attribute__((aligned(16))) float qs[MQ_XR][MQ_D];                 // (dh <= d)
     const int h = blockIdx.y, r0 = blockIdx.x * MQ_XR, dh = DH ? DH : d / H, tid = threadIdx.x;
     if (xcache && h == 0) {                            // self-attention form: this step's layer-input rows join the row cache (row t of [B][Tmax][d])
         const int t = *t_dev;
         for (int e = tid; e < MQ_XR * d; e += 512) {
             const int r = e / d, j = e - r * d;
-            if (r0 + r < B) xcache[((size_t)(r0 + r) * Tmax + t) * d + j] = xrow[(size_t)(r0 + r) * d + j];
+            if (r0 + r < B) xcache[((size_t)(r0 + r) * Tmax + t) * d + j] = (T)(float)xrow[(size_t)(r0 + r) * d + j];
         }
     }
     for (int e = tid; e < MQ_XR * dh; e += 512) {
@@ -754,7 +754,7 @@ int mq_parts(int B, int S) {
 int64_t mq_split_bytes(int B, int nparts) { return nparts > 1 ? (((int64_t)B * 4 + 255) / 256) * 256 + (int64_t)B * nparts * MQ_SP_BYTES : 0; }
 
 int launch_cross_mq(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* kpm, const int32_t* cu, int B, int S, int H, int d,
-                    hipStream_t s, void* sp = nullptr, int64_t sp_bytes = 0) {
+                    hipStream_t s, void* sp = nullptr, int64_t sp_bytes = 0, const int32_t* t_dev = nullptr) {
     if (d != MQ_D || H < 1 || H > MQ_MAXH || B <= 0 || S <= 0 || S > MQ_MAXS) return PA_ESHAPE;
     const int lds = MQ_NS * MQ_TILE + ((!cu && kpm) ? (S + 31) / 16 * 16 : 0);
     // PLANK_DECODE_MQ_NT=0: default-policy DMA instead of non-temporal (aux 2; measured in the step, B 256 x 1024: 0.958 vs 0.989 ms); PLANK_DECODE_MQ_SWAP=0: ds_bpermute row reductions instead of v_permlane*_swap
@@ -762,7 +762,7 @@ int launch_cross_mq(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* k
     static const int swap = getenv("PLANK_DECODE_MQ_SWAP") ? atoi(getenv("PLANK_DECODE_MQ_SWAP")) : 1;
     static bool attr_done = false;
     constexpr int MAXLDS = MQ_NS * MQ_TILE + MQ_MAXS + 32;
-    typedef void (*KernT)(bf16*, const bf16*, const bf16*, const uint8_t*, const int32_t*, int, int, int, char*);
+    typedef void (*KernT)(bf16*, const bf16*, const bf16*, const uint8_t*, const int32_t*, int, int, int, char*, const int32_t*);
     static const KernT ks[8] = {dec_cross_mq_kernel<0, false, false>, dec_cross_mq_kernel<0, false, true>, dec_cross_mq_kernel<0, true, false>,
                                 dec_cross_mq_kernel<0, true, true>,   dec_cross_mq_kernel<2, false, false>, dec_cross_mq_kernel<2, false, true>,
                                 dec_cross_mq_kernel<2, true, false>,  dec_cross_mq_kernel<2, true, true>};
@@ -777,7 +777,7 @@ int launch_cross_mq(bf16* ctx, const bf16* qt, const bf16* mem, const uint8_t* k
     int nparts = sp ? mq_parts(B, S) : 1;
     if (nparts > 1 && (mq_split_bytes(B, nparts) > sp_bytes || (reinterpret_cast<uintptr_t>(sp) & 255))) nparts = 1;
     PA_LAUNCH(ks[(nt ? 4 : 0) + (swap ? 2 : 0) + (mask ? 1 : 0)], dim3(B * nparts), dim3(256), lds, s, ctx, qt, mem, kpm, cu, S, H, nparts,
-              static_cast<char*>(sp));
+              static_cast<char*>(sp), t_dev);
     return 0;
 }
 
