@@ -753,8 +753,13 @@ def main():
             mqf = (ddtype == "f32" and D == 512 and H <= 8 and B_DEC <= 512 and os.environ.get("PLANK_DECODE_MQ_F32", "1") != "0"
                    and os.environ.get("PLANK_DECODE_FOLD_LN", "1") != "0")
             if mq:
-                w_bytes = (ND * ((6 + H) * D * D + 2 * D * FF) + V * D + D * D) * esz
-                kv_bytes = ND * B_DEC * (S_IN + 2 * T_DEC / 2) * D * esz
+                # round 6: from 200 batch elements on the bf16 step absorbs its SELF-attention too (csrc/decode.hip mq_self_bf): the layer-input
+                # rows are cached instead of K and V (one [t][d] stream), q~ from the expand launch, W_o,h W_v,h on the context rows
+                sbf = os.environ.get("PLANK_DECODE_MQ_SELF_BF16")
+                self_abs = (sbf != "0") if sbf is not None else B_DEC >= int(os.environ.get("PLANK_DECODE_MQ_SELF_MINB", "200"))
+                self_abs = self_abs and os.environ.get("PLANK_DECODE_F32_RESID", "1") != "0" and D // H == 64
+                w_bytes = (ND * (((4 + 2 * H) if self_abs else (6 + H)) * D * D + 2 * D * FF) + V * D + D * D) * esz
+                kv_bytes = ND * B_DEC * (S_IN + (1 if self_abs else 2) * T_DEC / 2) * D * esz
             if mqf:        # (f32: W_v as its own launch, the weights are the reference's; the SELF-attention is absorbed too - layer-input rows cached)
                 self_rows = 1 if os.environ.get("PLANK_DECODE_MQ_SELF", "1") != "0" else 2
                 kv_bytes = ND * B_DEC * (S_IN + self_rows * T_DEC / 2) * D * esz
@@ -769,7 +774,9 @@ def main():
                                                      "(no cross-K/V projection, one [S][d] stream per layer and step)")
                 decode[ddtype]["includes"] = "encoder + 1024 decode steps"
                 if mqf and os.environ.get("PLANK_DECODE_MQ_SELF", "1") != "0":
-                    decode[ddtype]["self_attention"] = "absorbed too: the step caches the layer-input rows instead of K and V (exact f32 only)"
+                    decode[ddtype]["self_attention"] = "absorbed too: the step caches the layer-input rows instead of K and V"
+                if mq and self_abs:
+                    decode[ddtype]["self_attention"] = "absorbed too (from 200 batch elements on): the step caches the layer-input rows instead of K and V"
                 # the same time against the bytes the K/V-cache form moves (what rounds 1-4 quoted hbm_frac on)
                 decode[ddtype]["kv_cache_form_equiv_gbs"] = kv_cache_form_bytes * T_DEC / ddt / 1e9
             log(f"decode {ddtype}: {decode[ddtype]['value']:.0f} tokens/s, {decode[ddtype]['ms_per_step']:.3f} ms/step")
