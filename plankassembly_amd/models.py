@@ -256,6 +256,16 @@ class PlankModel(nn.Module):
                     p.uniform_(-bound, bound)
                 else:
                     p.zero_()
+            # torch's nn.TransformerEncoder / nn.TransformerDecoder deep-copy ONE layer (reference models.py:60-69): the 1-D parameters
+            # that _reset_parameters leaves alone - linear1.bias / linear2.bias - start IDENTICAL in every layer of a stack (SURVEY
+            # appendix C).  Same here: layer 0's draw is the stack's.
+            for stack in ("encoder.layers.", "decoder.layers."):
+                for name in ("linear1.bias", "linear2.bias"):
+                    first = self._params.get(stack + "0." + name)
+                    i = 1
+                    while first is not None and (stack + f"{i}." + name) in self._params:
+                        self._params[stack + f"{i}." + name].copy_(first)
+                        i += 1
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)

@@ -49,6 +49,22 @@ def test_default_config_parameter_count():
     assert m.state_dict()["query_pos_embedding.weight"].shape == (22, 512)
 
 
+def test_initial_ffn_biases_are_one_draw_per_stack_like_torchs_deep_copied_layers():
+    """torch's TransformerEncoder / TransformerDecoder deep-copy one layer and the reference re-draws only dim > 1 parameters
+    (/root/reference/plankassembly/models.py:60-69,78-83): linear1.bias / linear2.bias start identical in every
+    layer of a stack, non-zero, and different between the two stacks; the matrices differ per layer."""
+    torch.manual_seed(5)
+    m = PlankModel(64, 4, 128, 0.0, "relu", True, 3, 2, 3, 2, 4, 6, 65, 36, 514, TOKEN)
+    sd = m.state_dict()
+    for name in ("linear1.bias", "linear2.bias"):
+        e0 = sd["encoder.layers.0." + name]
+        assert float(e0.abs().max()) > 0
+        assert torch.equal(sd["encoder.layers.1." + name], e0) and torch.equal(sd["encoder.layers.2." + name], e0)
+        assert torch.equal(sd["decoder.layers.1." + name], sd["decoder.layers.0." + name])
+        assert not torch.equal(sd["decoder.layers.0." + name], e0)
+    assert not torch.equal(sd["encoder.layers.0.linear1.weight"], sd["encoder.layers.1.linear1.weight"])
+
+
 def test_normalize_before_false_has_no_encoder_norm():
     m = PlankModel(64, 4, 128, 0.0, "relu", False, 1, 1, 3, 2, 4, 6, 65, 36, 514, TOKEN)
     assert "encoder.norm.weight" not in m.state_dict() and "decoder.norm.weight" in m.state_dict()
