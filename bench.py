@@ -883,7 +883,7 @@ def main():
                      "small_tt": "gemm3s_kernel (bf16, 64x64x64 tiles, 4-stage LDS ring)",
                      "pair_tt": "gemm_kernel<bf16,64,2,true,true,...> (two blocks per CU)",
                      "wide_tt": "gemm3w_kernel<2,4> (bf16, 128x256x64 tiles, one block per CU, 3-stage LDS ring)",
-                     "attn_enc_self_fwd": "attn4_fwd_kernel<true,1> on the packed encoder rows (self-attention forward)",
+                     "attn_enc_self_fwd": "attn5_fwd_kernel<true,3,3> on the packed encoder rows (self-attention forward)",
                      "attn_enc_self_bwd": "attn4_bwd_dq_kernel + attn4_bwd_dkv_kernel on the packed encoder rows",
                      "attn_cross_fwd": "attn4_fwd_kernel<true,2> (in-block key split), decoder cross-attention forward",
                      "attn_cross_bwd": "attn4_bwd_merged_kernel (dQ and dK/dV blocks in one launch), decoder cross-attention backward",
