@@ -389,7 +389,7 @@ typedef struct {
      * several blocks whose partial results meet in this buffer (csrc/attention.hip decode_unit_split), so that the launch lasts
      * as long as its work instead of as long as its longest element's serial chain.  OPT-IN (PA_ATTN_SPLIT=1): on MI355X every
      * extra block costs ~6 us of slot time (lookup, first tile, publish + merge) and the split launches measured 15-20 % SLOWER
-     * than one block per tile (profiles/r06_attn_split.txt).  Size: pa_attn_ws_bytes() (0 while the split is off).  Contract: its
+     * than one block per tile (profiles/r06_attention_launch_shape.txt).  Size: pa_attn_ws_bytes() (0 while the split is off).  Contract: its
      * first pa_attn_ws_ticket_bytes(ws_bytes) bytes are ZERO before the first launch that uses the buffer; every launch leaves them
      * zero.  Launches that share a buffer must be ordered on one stream.  Results do not depend on it beyond f32 summation order. */
     void* ws; int64_t ws_bytes;

@@ -748,7 +748,7 @@ __device__ __forceinline__ bool decode_block_balanced(const AttnP& pin, const in
 
 
 // ---- balanced == 2: units = (element, owned 128-row tile, range of the streamed side), longest elements first -------------
-// Why (profiles/r05_attention_shape_sweep.txt item 4, profiles/r06_attn_split.txt): every block of the packed launch is resident
+// Why (profiles/r05_attention_shape_sweep.txt item 4, profiles/r06_attention_launch_shape.txt): every block of the packed launch is resident
 // from the start, so the launch lasts as long as the serial chain of its longest block - 15-16 key tiles for a 1 000-row element
 // against ~8 on average - while the CUs that drew short blocks idle.  Cutting the long chains makes the launch's duration its
 // WORK: an element with kt >= sp_kmax + 1 streamed tiles runs as np = min(sp_pmax, ceil(kt / sp_kmax)) blocks per owned tile.
@@ -2237,7 +2237,7 @@ AttnP make_params(const pa_attn_args* a) {
     // range blocks (balanced == 2, set by the launchers whose kernels know it): packed self-attention with scratch from the caller.
     // PA_ATTN_SPLIT=1 enables (default off); PA_ATTN_SPLIT_KMAX (8) longest unsplit chain in 64-row tiles; PA_ATTN_SPLIT_PMAX (2) most ranges.
     p.sp_tick = nullptr; p.sp_part = nullptr; p.sp_slots = 0; p.sp_pmax = split_pmax(); p.sp_kmax = split_kmax();
-    static const bool sp_env = getenv("PA_ATTN_SPLIT") && atoi(getenv("PA_ATTN_SPLIT")) != 0;     // opt-in: measured slower (profiles/r06_attn_split.txt)
+    static const bool sp_env = getenv("PA_ATTN_SPLIT") && atoi(getenv("PA_ATTN_SPLIT")) != 0;     // opt-in: measured slower (profiles/r06_attention_launch_shape.txt)
     if (sp_env && p.balanced && a->ws && a->cu_q == a->cu_k && !a->kpm && !a->causal && a->dtype == PA_BF16 && a->dh == 64 &&
         (reinterpret_cast<uintptr_t>(a->ws) & 255) == 0 && p.sp_pmax > 1) {
         const int64_t per = (int64_t)p.sp_pmax * SP_BYTES + 64;          // one (owned tile, head): its range blocks' partials + ticket
@@ -2511,7 +2511,7 @@ extern "C" int64_t pa_attn_split_taken(int32_t reset) {
 }
 
 extern "C" int64_t pa_attn_ws_bytes(int32_t rows_total, int32_t B, int32_t H, int32_t L_max) {
-    static const bool sp_env = getenv("PA_ATTN_SPLIT") && atoi(getenv("PA_ATTN_SPLIT")) != 0;     // opt-in: measured slower (profiles/r06_attn_split.txt)
+    static const bool sp_env = getenv("PA_ATTN_SPLIT") && atoi(getenv("PA_ATTN_SPLIT")) != 0;     // opt-in: measured slower (profiles/r06_attention_launch_shape.txt)
     if (!sp_env || split_pmax() < 2 || H != 8 || rows_total <= 0 || B <= 0 || B > 64) return 0;
     if ((L_max + BSTR - 1) / BSTR <= split_kmax()) return 0;
     const int64_t slots = (int64_t)(rows_total / BOWN + B);             // owned tiles of all elements, an upper bound

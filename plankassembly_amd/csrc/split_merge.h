@@ -29,7 +29,7 @@ struct SplitOut {
 };
 // (sc1 loads - L1 bypassed, served from the memory side like the sc1 stores that wrote the data: valid WITHOUT an acquire fence
 //  when the producer stored sc1, cdna_hip_programming.md Guideline 16; the fence - buffer_inv sc1 - was measured first and made
-//  every range-block launch slower than the unsplit one: profiles/r06_attn_split.txt)
+//  every range-block launch slower than the unsplit one: profiles/r06_attention_launch_shape.txt)
 __device__ __forceinline__ f32x4 split_get(const char* base, int j, int nthreads, int bytes) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, bytes, 0x00020000);
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (j * nthreads + (int)threadIdx.x) * 16, 0, 16);
