@@ -1553,6 +1553,12 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
                 }
             }
         }
+#ifndef PA_G3S_OLD
+        // every path "uses" the bias: a path that loaded it and stored nothing (a wave past the last row) would leave the load
+        // pending in the COMPILER's scoreboard, and it would guard the K loop's first temporary with `s_waitcnt vmcnt(0)` - the
+        // whole ring - on every item
+        asm volatile("" :: "v"(bias[0]), "v"(bias[1]), "v"(bias[2]), "v"(bias[3]));
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     };
@@ -1659,11 +1665,63 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
                 }
             }
         }
+#ifndef PA_G3S_OLD
+        // a wait the COMPILER sees (vmcnt 0, other counters untouched): without it its scoreboard carries this block's loads into
+        // the K loop (the hand-counted waits there are inline assembly) and it puts its own `s_waitcnt vmcnt(0)` in front of every
+        // item's DMA - every item then waited for the whole ring, one memory round trip per item
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
     }
     wait_items(pending - 1);
     __builtin_amdgcn_s_barrier();
     PA_TR3(2);
     int sc = 0;
+#ifndef PA_G3S_OLD
+    // One item = one 64-deep K tile = four MFMAs per wave.  With ONE wave per SIMD nothing else hides an LDS round trip, so the
+    // fragments are requested a WHOLE item ahead: behind the item's barrier (the next item has landed) the pair of reads of the
+    // next item's k-step s goes out right after the MFMA of this item's k-step s, into the registers that MFMA has just read -
+    // eight reads in flight, each with three MFMAs of lead (round 6; reading one k-step ahead made every k-step wait out most of
+    // an LDS latency: tools/gemm_small_k.py, profiles/r06_gemm_small_tile.txt).  ONE barrier per item: behind it every wave's
+    // reads of the item before have returned (its stage is the one this item's DMA refills) and every wave's share of the next
+    // item has arrived.
+    u32x4 F[8];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) { PA_RD128(F[2 * s_], lds0 + fa_off + xs[s_]); PA_RD128(F[2 * s_ + 1], lds0 + fb_off + xs[s_]); }
+    // (one loop body for every item: a second, specialised body made the compiler COPY the fragment registers between the two
+    //  while their reads were still in flight - the reads are inline assembly, their latency is invisible to it)
+#pragma unroll 1
+    while (true) {
+        const bool has_next = pending >= 2;
+        if (has_next) wait_items(pending - 2);
+        __builtin_amdgcn_s_barrier();
+        if (cd_u < p.units) issue();
+        {   // (the reads go out even behind the last item - into a stage nobody fills any more, never used: the fragment
+            //  registers then have ONE definition per iteration and the compiler keeps them where they are)
+            const uint32_t nst = lds0 + ((sc + 1) & (NSTG - 1)) * STAGE;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(F[2 * s_]), "+v"(F[2 * s_ + 1]));       // (the six younger reads: the three k-steps behind)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&F[2 * s_ + 1]), *reinterpret_cast<const bf16x8*>(&F[2 * s_]), acc, 0, 0, 0);
+                PA_RD128(F[2 * s_], nst + fa_off + xs[s_]); PA_RD128(F[2 * s_ + 1], nst + fb_off + xs[s_]);
+            }
+        }
+        sc = (sc + 1) & (NSTG - 1);
+        if (++cc_t >= nt) {
+            PA_TR3(3);
+            epilogue(cun);
+#ifdef PA_GEMM_TRACE3
+            PA_TR3(5);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            PA_TR3(4);
+            cc_u += ustride; cc_t = 0;
+            if (cc_u < p.units) unit_of(cc_u, cun);
+        }
+        --pending;
+        if (!has_next) break;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]));
+#else
     u32x4 F0[2], F1[2];
     frag(F0, lds0, 0);
     auto item = [&](auto HOT_) -> bool {
@@ -1710,6 +1768,7 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
         for (; hot > 0; --hot) item(std::true_type{});
         if (!item(std::false_type{})) break;
     }
+#endif
 #undef PA_RD128
 }
 
