@@ -1361,26 +1361,39 @@ __global__ __launch_bounds__(NTH, OCC) void attn_bwd_dkv_bf16_kernel(AttnP pin) 
     const uint32_t smem_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     lb.init(smem_base, lane);
     const uint32_t abase = smem_base + half * 16;        // this half-wave's 4 query rows of an 8-row group (aux words)
+    // (the per-row words are requested with the tile's DMA - buffer loads, scalar resource + the lane's word - and only scaled and
+    //  written to LDS at the END of the step that overlaps them, as in attn4_dkv_body: arithmetic next to the loads made hipcc
+    //  wait out a memory round trip in front of every step)
+    const __amdgpu_buffer_rsrc_t rs_lse = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.lse + srow0), 0, p.Lq * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_del = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.delta + srow0), 0, p.Lq * 4, 0x00020000);
+    uint32_t lv_raw = 0u, dv_raw = 0u;
     auto issue = [&](int step, int buf) {
         char* base = smem + buf * BUF;
         const int r0 = step * BSTR;
-        float lv = INFINITY, dv_ = 0.f;                                   // +inf -> p = 0 for rows past Lq
-        if (tid < BSTR && r0 + tid < p.Lq) { lv = p.lse[srow0 + r0 + tid] * LOG2E; dv_ = p.delta[srow0 + r0 + tid] * keep_p; }
+        if (tid < BSTR) {
+            lv_raw = __builtin_amdgcn_raw_buffer_load_b32(rs_lse, tid * 4, r0 * 4, 0);
+            dv_raw = __builtin_amdgcn_raw_buffer_load_b32(rs_del, tid * 4, r0 * 4, 0);
+        }
         glds_tile<DH>(base, srcQ, voffQ, r0, wave);
         glds_tile<DH>(base + B::NAT, srcO, voffO, r0, wave);
+    };
+    auto issue_aux = [&](int step, int buf) {
         if (tid < BSTR) {
-            float* aux = reinterpret_cast<float*>(base + AUX);
-            aux[tid] = lv;
-            aux[64 + tid] = dv_;                                          // delta * (1-p), see the dQ kernel
-            if (DROP) reinterpret_cast<uint32_t*>(aux)[128 + tid] = drop_row_hash(p.drop_seed, (uint32_t)(srow0 + r0 + tid));
+            const int r = step * BSTR + tid;
+            const bool in = r < p.Lq;
+            float* aux = reinterpret_cast<float*>(smem + buf * BUF + AUX);
+            aux[tid] = in ? __uint_as_float(lv_raw) * LOG2E : INFINITY;  // +inf -> p = 0 for rows past Lq
+            aux[64 + tid] = in ? __uint_as_float(dv_raw) * keep_p : 0.f;  // delta * (1-p), see the dQ kernel
+            if (DROP) reinterpret_cast<uint32_t*>(aux)[128 + tid] = drop_row_hash(p.drop_seed, (uint32_t)(srow0 + r));
         }
     };
-    if (step0 < nsteps) issue(step0, 0);
+    if (step0 < nsteps) { issue(step0, 0); issue_aux(step0, 0); }
     tile_barrier();
 
     auto body = [&](int step, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
+        const bool more = step + 1 < nsteps;
+        if (more) issue(step + 1, buf ^ 1);
         const int r0 = step * BSTR;
         auto sub = [&](auto qtc) {
             constexpr int qt = decltype(qtc)::value;
@@ -1428,6 +1441,7 @@ __global__ __launch_bounds__(NTH, OCC) void attn_bwd_dkv_bf16_kernel(AttnP pin) 
         };
         sub(IC<0>{});
         sub(IC<1>{});
+        if (more) issue_aux(step + 1, buf ^ 1);
         tile_barrier();
     };
     for (int step = step0; step < nsteps; step += 2) {
@@ -2083,21 +2097,34 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
     lb.init(smem_base, lane);
     const uint32_t abase = smem_base + g * 16;            // this lane group's 4 query rows of a 16-row block (aux words)
     float* sdelta = reinterpret_cast<float*>(smem + 2 * BUF + 64);       // [Lq] (SELF_DELTA; the merged launch allocates it)
+    // A tile's per-row words (lse, delta) are REQUESTED with the tile's DMA (issue) and only touched - scaled, negated, written to
+    // LDS - at the END of the step that overlaps them (issue_aux, in front of the step's barrier).  Round 6: with the arithmetic next
+    // to the loads hipcc waited for them (`s_waitcnt vmcnt(0)`) before the first wave had even issued its share of the DMA - a
+    // memory round trip in front of every step (tools/isa_loop_waits.py).
+    // (buffer loads: the element's lse / delta rows as a scalar resource + the lane's word offset - no 64-bit lane addresses to
+    //  keep in registers; the kernel sits at its 128-register budget.  Rows past Lq read 0 and are replaced in issue_aux.)
+    const __amdgpu_buffer_rsrc_t rs_lse = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.lse + srow0), 0, p.Lq * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_del = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.delta + srow0), 0, SELF_DELTA ? 0 : p.Lq * 4, 0x00020000);
+    uint32_t lv_raw = 0u, dv_raw = 0u;
     auto issue = [&](int step, int buf) {
         char* base = smem + buf * BUF;
         const int r0 = step * BSTR;
-        float lv = INFINITY, dv_ = 0.f;
-        if (tid < BSTR && r0 + tid < p.Lq) {
-            lv = p.lse[srow0 + r0 + tid] * LOG2E;
-            dv_ = (SELF_DELTA ? sdelta[r0 + tid] : p.delta[srow0 + r0 + tid]) * keep_p;
+        if (tid < BSTR) {
+            lv_raw = __builtin_amdgcn_raw_buffer_load_b32(rs_lse, tid * 4, r0 * 4, 0);
+            if (!SELF_DELTA) dv_raw = __builtin_amdgcn_raw_buffer_load_b32(rs_del, tid * 4, r0 * 4, 0);
         }
         glds_tile4(base, srcQ, voffQ, r0, wave);
         glds_tile4(base + NAT, srcO, voffO, r0, wave);
+    };
+    auto issue_aux = [&](int step, int buf) {
         if (tid < BSTR) {
-            float* aux = reinterpret_cast<float*>(base + AUX);
-            aux[tid] = -lv;                                // (negated: accumulator start values of the score products)
-            aux[64 + tid] = -dv_;
-            if (DROP) reinterpret_cast<uint32_t*>(aux)[128 + tid] = drop_row_hash(p.drop_seed, (uint32_t)(srow0 + r0 + tid));
+            const int r = step * BSTR + tid;
+            const bool in = r < p.Lq;
+            float* aux = reinterpret_cast<float*>(smem + buf * BUF + AUX);
+            const float dlt = SELF_DELTA ? sdelta[min(r, p.Lq - 1)] : __uint_as_float(dv_raw);
+            aux[tid] = in ? -(__uint_as_float(lv_raw) * LOG2E) : -INFINITY;      // (negated: accumulator start values of the score products)
+            aux[64 + tid] = in ? -(dlt * keep_p) : 0.f;
+            if (DROP) reinterpret_cast<uint32_t*>(aux)[128 + tid] = drop_row_hash(p.drop_seed, (uint32_t)(srow0 + r));
         }
     };
     if constexpr (SELF_DELTA) {
@@ -2126,13 +2153,14 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
         }
         __syncthreads();
     }
-    if (step0 < nsteps) issue(step0, 0);
+    if (step0 < nsteps) { issue(step0, 0); issue_aux(step0, 0); }
     tile_barrier();
 
     auto body = [&](int step, auto bufc) {
         constexpr int buf = decltype(bufc)::value;
-        if (step + 1 < nsteps) issue(step + 1, buf ^ 1);
-        if (!wave_on) { tile_barrier(); return; }      // this wave's 16 keys lie past the element's last key
+        const bool more = step + 1 < nsteps;
+        if (more) issue(step + 1, buf ^ 1);
+        if (!wave_on) { if (more) issue_aux(step + 1, buf ^ 1); tile_barrier(); return; }      // this wave's 16 keys lie past the element's last key
         const int r0 = step * BSTR;
         constexpr int AO = buf * BUF + AUX;
         u32x4 nl4[4], nd4[4];                                          // -lse * log2 e and -delta * (1 - p) of this lane's query rows
@@ -2169,6 +2197,7 @@ __device__ __forceinline__ void attn4_dkv_body(const AttnP& pin, int bid, char* 
         }
         mma_tr4<buf * BUF + NAT>(dvacc, lb, sacc);                     // dV^T += dO^T P
         mma_tr4<buf * BUF>(dkacc, lb, dpacc);                          // dK^T += Q^T dS
+        if (more) issue_aux(step + 1, buf ^ 1);
         tile_barrier();
     };
     for (int step = step0; step < nsteps; step += 2) {
