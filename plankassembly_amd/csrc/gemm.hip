@@ -1284,10 +1284,11 @@ __global__ __launch_bounds__(NT, 1) void gemm3_kernel(PT prm) {
             if constexpr (HOT) { DMA(fetch_q(sd, Q3{}); fetch_done()); sd = (sd + 1) & (NSTG - 1); ++cd_t; wait_items(2); }
             else wait_items(pending - 2);
             BAR();
-            step(F1, F0, lds0 + ((sc + 1) & (NSTG - 1)) * STAGE, S0{}, std::true_type{}, NoQ{});
-        } else {
-            step(F1, F0, st, S0{}, std::false_type{}, NoQ{});
         }
+        // (the next stage's first fragments are requested even when no next item exists - from a stage nobody fills any more, never
+        //  used: with the reads on one path only, hipcc resolved the two paths' fragment registers with v_mov copies of registers
+        //  whose reads were still in flight, in FRONT of the hand-written lgkmcnt wait - found by reading the ISA in round 6)
+        step(F1, F0, lds0 + ((sc + 1) & (NSTG - 1)) * STAGE, S0{}, std::true_type{}, NoQ{});
         sc = (sc + 1) & (NSTG - 1);
         if constexpr (HOT) { ++cc_t; return true; }
         else {
@@ -2063,8 +2064,8 @@ __global__ __launch_bounds__(NT, 1) void gemm3w_kernel(GemmP p) {
         if (has_next) {
             if constexpr (HOT) wait_items(1); else wait_items(pending - 2);
             __builtin_amdgcn_s_barrier();       // barrier B: the next item has landed for every wave
-            frag(F0, lds0 + (sc + 1 == NSTG ? 0 : sc + 1) * STAGE, 0);
         }
+        frag(F0, lds0 + (sc + 1 == NSTG ? 0 : sc + 1) * STAGE, 0);      // (unconditional: one definition of F0 on every path, see gemm3_kernel)
         mma_all(F1);
         sc = sc + 1 == NSTG ? 0 : sc + 1;
         if constexpr (HOT) { ++cc_t; return true; }
