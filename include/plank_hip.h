@@ -146,7 +146,7 @@ int pa_gemm_recorded(pa_gemm_args* out, int32_t cap);
  * PA_GEMM_KIND_PAIR = gemm_kernel (two blocks per CU; everything else). */
 #define PA_GEMM_KIND_PAIR 0
 #define PA_GEMM_KIND_RING 1
-#define PA_GEMM_KIND_WIDE 2   /* gemm3w_kernel: 128 x 256 tiles for the large multi-round Linears */
+#define PA_GEMM_KIND_WIDE 2   /* gemm3w_kernel: 128 x 256 tiles for the large multi-round Linears (opt-in); 192 x 128 ("tall") tiles for N <= 512 Linears a few 128 x 128 tiles past one round of the CUs */
 #define PA_GEMM_KIND_SMALL 3  /* gemm3s_kernel: 64 x 64 tiles for launches that cover at most half of the CUs */
 #define PA_GEMM_KIND_SKINNY 4 /* gemm_skinny_kernel: <= 512 rows against a whole weight (greedy decode), 32 x 32 tiles, K resident */
 #define PA_GEMM_KIND_BIG 5    /* gemm8_kernel: eight waves on 256 x 256 / 256 x 128 tiles (plain k-contiguous Linears of many rows) */

@@ -1867,6 +1867,24 @@ __global__ __launch_bounds__(NT, 1) void gemm3w_kernel(GemmP p) {
         const bool out_f32 = p.out_dtype == PA_F32;
         const bool has_bias = p.bias != nullptr, has_aux = p.aux != nullptr, has_res = p.R != nullptr, has_drop = p.drop_thr != 0;
         constexpr int NIT = 4;
+        // bf16 residual / gate rows of ALL of the wave's 32 x 32 tiles are requested before the first tile is staged (round 6: each
+        // of the FM x FN passes used to start with its own loads - one memory round trip per pass, most of this kernel's fixed cost)
+        const bool pre_ok = p.vec_ok && !out_f32 && (has_res || has_aux) && (un.tile_n * TBN + (wn * FN + FN) * 32 <= p.N);
+        u32x2 pres[FN * FM][NIT], paux[FN * FM][NIT];
+        if (pre_ok) {
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int m = min(un.tile_m * TBM + (wm * FM + fm) * 32 + rsub + it * 8, p.M - 1);
+                        const int n = un.tile_n * TBN + (wn * FN + fn) * 32 + chunk * 4;
+                        if (has_res) pres[fn * FM + fm][it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.R) + (size_t)un.b * p.sR + (size_t)m * p.ldr + n);
+                        if (has_aux) paux[fn * FM + fm][it] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(p.aux) + (size_t)un.b * p.sAux + (size_t)m * p.ldaux + n);
+                    }
+        }
+        auto widen2 = [](const u32x2& u) { f32x4 r; r[0] = bf16_lo(u[0]); r[1] = bf16_hi(u[0]); r[2] = bf16_lo(u[1]); r[3] = bf16_hi(u[1]); return r; };
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
             const int nw = un.tile_n * TBN + (wn * FN + fn) * 32;
@@ -1901,19 +1919,27 @@ __global__ __launch_bounds__(NT, 1) void gemm3w_kernel(GemmP p) {
                 }
                 if (fast) {
                     f32x4 res[NIT], gate[NIT];
-                    if (has_res) {
+                    if (pre_ok) {
 #pragma unroll
                         for (int it = 0; it < NIT; ++it) {
-                            const size_t ro = (size_t)un.b * p.sR + (size_t)min(mp + it * 8, p.M - 1) * p.ldr + n;
-                            res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(p.R) + ro)
-                                              : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+                            if (has_res) res[it] = widen2(pres[fn * FM + fm][it]);
+                            if (has_aux) gate[it] = widen2(paux[fn * FM + fm][it]);
                         }
-                    }
-                    if (has_aux) {
+                    } else {
+                        if (has_res) {
 #pragma unroll
-                        for (int it = 0; it < NIT; ++it) {
-                            const size_t ao = (size_t)un.b * p.sAux + (size_t)min(mp + it * 8, p.M - 1) * p.ldaux + n;
-                            gate[it] = ld4<T>(reinterpret_cast<const T*>(p.aux) + ao);
+                            for (int it = 0; it < NIT; ++it) {
+                                const size_t ro = (size_t)un.b * p.sR + (size_t)min(mp + it * 8, p.M - 1) * p.ldr + n;
+                                res[it] = out_f32 ? ld4<float>(reinterpret_cast<const float*>(p.R) + ro)
+                                                  : ld4<bf16>(reinterpret_cast<const bf16*>(p.R) + ro);
+                            }
+                        }
+                        if (has_aux) {
+#pragma unroll
+                            for (int it = 0; it < NIT; ++it) {
+                                const size_t ao = (size_t)un.b * p.sAux + (size_t)min(mp + it * 8, p.M - 1) * p.ldaux + n;
+                                gate[it] = ld4<T>(reinterpret_cast<const T*>(p.aux) + ao);
+                            }
                         }
                     }
                     // one straight-line loop per optional stage behind its own uniform branch; stores with the output type and the
@@ -2968,6 +2994,10 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     const long long wide_tiles = (long long)((a->M + 127) / 128) * ((a->N + 255) / 256) * a->batch;
     const bool go_wide = use_v3 && use_wide && (use_wide == 1 || wide_tiles <= cus) && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds &&
                          is_aligned<bf16>(a) && a->a_kcontig && a->b_kcontig && splitk == 1 && a->K % 64 == 0 && a->N >= 1024 && valid_units > 256;
+    static const int use_tall = getenv("PA_GEMM_TALL") ? atoi(getenv("PA_GEMM_TALL")) : 0;
+    const int tall_units = ((a->M + 191) / 192) * ((a->N + 127) / 128) * a->batch;
+    const bool go_tall = use_v3 && use_tall && !go_wide && a->in_dtype == PA_BF16 && !bk32 && !dbg_noglds && is_aligned<bf16>(a) && a->a_kcontig &&
+                         a->b_kcontig && splitk == 1 && a->K % 64 == 0 && valid_units > 256 && tall_units <= cus;
     // skinny kernel (a few hundred rows against a whole weight: the greedy-decode Linears).  PA_GEMM_SKINNY: 0 never, 1 f32 only,
     // 2 (default) bf16 too.  Measured on MI355X, greedy decode B 256 x 1024 steps: f32 3.65 -> 2.03 ms/step (the f32 Linears were
     // 43 ... 98 us each on 8 blocks), bf16 1.224 -> 1.112 ms/step (32 blocks of the 64 x 64-tile ring kernel before).
@@ -3029,7 +3059,7 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         else PA_LAUNCH((gemm_skinny_kernel<float, false>), gsk, dim3(256), 0, st, ps);
         return 0;
     }
-    if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back(go_wide ? PA_GEMM_KIND_WIDE : (go_small ? PA_GEMM_KIND_SMALL : (go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR))); if (g_rec && g_rec_group) g_rec_group->push_back(-1); }
+    if (g_rec) { std::lock_guard<std::mutex> lk(g_rec_mu); if (g_rec && g_rec_kind) g_rec_kind->push_back((go_wide || go_tall) ? PA_GEMM_KIND_WIDE : (go_small ? PA_GEMM_KIND_SMALL : (go_v3 ? PA_GEMM_KIND_RING : PA_GEMM_KIND_PAIR))); if (g_rec && g_rec_group) g_rec_group->push_back(-1); }
     // wide-tile ring kernel: large multi-round k-contiguous Linears (N >= 1024): 128 x 256 tiles
     if (go_wide) {
         GemmP pw = pk;
@@ -3038,6 +3068,21 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
         pw.units = pw.tiles_m_pad * pw.tiles_n * a->batch;
         const int gw = pw.units < cus ? pw.units : cus;
         PA_LAUNCH((gemm3w_kernel<2, 4>), dim3(gw), dim3(NT), 0, st, pw);
+        return 0;
+    }
+    // "tall" tiles (192 x 128, the same kernel with 3 x 2 MFMA tiles per wave), opt-in (PA_GEMM_TALL=1): a Linear whose 128 x 128
+    // tiling is a few units past one round of the CUs (N = 512 at 8.2 k - 12 k packed encoder rows: 260 - 384 units) becomes ONE
+    // round of at most 256 bigger units (round 6).  Measured LEVEL with the two-blocks-per-CU kernel - 8 704 x
+    // 512 x 512: 16.5 vs 16.2 us, x 1 024: 22.0 vs 22.2; train step 4.56-4.64 either way (profiles/r06_gemm_tile_choice.txt) -
+    // 184 units of 1.5 x the work cost what 272 units on 512 slots do.
+    if (go_tall) {
+        GemmP pw = pk;
+        pw.tiles_m = (a->M + 191) / 192; pw.tiles_n = (a->N + 127) / 128;
+        pw.plain_order = pw.tiles_m < 8;
+        pw.tiles_m_pad = pw.plain_order ? pw.tiles_m : (pw.tiles_m + 7) / 8 * 8;
+        pw.units = pw.tiles_m_pad * pw.tiles_n * a->batch;
+        const int gw = pw.units < cus ? pw.units : cus;
+        PA_LAUNCH((gemm3w_kernel<3, 2>), dim3(gw), dim3(NT), 0, st, pw);
         return 0;
     }
     // small-tile ring kernel: plain k-contiguous Linears whose 128 x 128 tiling covers at most half of the CUs (measured: <= 128 units 7.05 ms/step, <= 64 7.11, <= 256 7.53)

@@ -857,6 +857,51 @@ def test_gemm_wide_tile_bf16():
     assert rel_err(out, a.float() @ b.float().t()) < 1e-2
 
 
+@pytest.mark.parametrize("M", [8704, 8300, 9736, 12288])
+def test_gemm_tall_tile_bf16(M):
+    """N = 512 Linears a few 128 x 128 tiles past one round of the CUs (the packed encoder rows of half the batches) on 192 x 128
+    tiles, one round (gemm3w_kernel<3, 2>; opt-in, PA_GEMM_TALL=1, read once per process: measured level with the two-blocks-per-CU
+    kernel).  Ragged M (rows past M in the last tile), every epilogue incl. the dropout decisions (reference: the float product
+    and, for dropout, the keep pattern of a small-tile launch on the same rows).  Without the switch the same cases run on the
+    default kernel; test_gemm_tall_tile_in_a_child_process runs them with it."""
+    K = 512
+    tall_on = os.environ.get("PA_GEMM_TALL", "0") != "0"
+    for N in (512, 384):
+        a, b = rnd(M, K, dtype=torch.bfloat16, seed=170, scale=0.3), rnd(N, K, dtype=torch.bfloat16, seed=171 + N, scale=0.3)
+        bias, res, aux = rnd(N, seed=172), rnd(M, N, dtype=torch.bfloat16, seed=173), rnd(M, N, dtype=torch.bfloat16, seed=174)
+        acc = a.float() @ b.float().t()
+        ad, bd = a.to(DEV), b.to(DEV)
+        (out, kinds) = _gemm_kinds(lambda: ops.gemm(ad, bd, bias=bias.to(DEV), relu=True))
+        assert rel_err(out, torch.relu(acc + bias)) < 2.5e-2, N
+        if tall_on and ((M + 127) // 128) * ((N + 127) // 128) > 256 and ((M + 191) // 192) * ((N + 127) // 128) <= 256:
+            assert kinds == [_lib_kind("WIDE")], kinds
+        out = ops.gemm(ad, bd, bias=bias.to(DEV), residual=res.to(DEV), out_dtype=torch.bfloat16)
+        assert rel_err(out, acc + bias + res.float()) < 2.5e-2, N
+        out = ops.gemm(ad, bd, aux=aux.to(DEV), aux_scale=1.25, out_dtype=torch.float32)
+        assert rel_err(out, torch.where(aux.float() > 0, acc * 1.25, torch.zeros_like(acc))) < 2.5e-2, N
+        # dropout: the same (row, column) decisions as a launch of the first 2 048 rows alone (64 x 64-tile kernel)
+        out = ops.gemm(ad, bd, drop_p=0.3, drop_seed=11, out_dtype=torch.float32)
+        ref = ops.gemm(ad[:2048].contiguous(), bd, drop_p=0.3, drop_seed=11, out_dtype=torch.float32)
+        assert torch.equal(out[:2048] == 0, ref == 0)
+        kept = out != 0
+        assert abs(float(kept.float().mean()) - 0.7) < 0.01
+        assert rel_err(out[kept], (acc / 0.7).to(DEV)[kept]) < 2.5e-2
+
+
+def test_gemm_tall_tile_in_a_child_process():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_kernels_gpu.py", "-k", "test_gemm_tall_tile_bf16"],
+                       cwd=root, env=dict(os.environ, PA_GEMM_TALL="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "4 passed" in r.stdout, r.stdout[-2000:]
+
+
+def _lib_kind(name):
+    return {"PAIR": 0, "RING": 1, "WIDE": 2, "SMALL": 3, "SKINNY": 4, "BIG": 5}[name]      # include/plank_hip.h PA_GEMM_KIND_*
+
+
 def _gemm_kinds(fn):
     import ctypes as C
     from plankassembly_amd import _lib as L
