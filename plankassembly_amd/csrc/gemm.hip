@@ -1575,7 +1575,8 @@ __global__ __launch_bounds__(NT, 2) void gemm3s_kernel(GemmP p) {
     };
     int cd_u = blockIdx.x, cd_t = 0;            // DMA cursor
     int cc_u = blockIdx.x, cc_t = 0;            // compute cursor
-    if (cc_u >= p.units) return;
+    // (no `cc_u >= p.units` exit: both launch sites size the grid to at most p.units, and the test put a lone dependent kernel-argument
+    //  load in front of every other one - a scalar-memory round trip at the head of each of the step's 71 launches)
     Unit cun, dun;
     unit_of(cc_u, cun);
     {   // prefetch (bf16, vector path), before the first DMA instruction so that the in-order `vmcnt` counts stay exact
@@ -2986,7 +2987,11 @@ extern "C" int pa_gemm(const pa_gemm_args* a, void* stream) {
     // K = 512 it loses to the two-blocks-per-CU kernel (20.4 vs 18.5 us at 7 940 x 1 024) and only wins from K ~ 2 048 on.
     static const int use_small = getenv("PA_GEMM_SMALL") ? atoi(getenv("PA_GEMM_SMALL")) : 1;
     static const int small_max = getenv("PA_GEMM_SMALL_MAX") ? atoi(getenv("PA_GEMM_SMALL_MAX")) : 128;
-    const bool go_small = go_v3 && use_small && a->a_kcontig && a->b_kcontig && splitk == 1 && valid_units <= small_max && a->K % 64 == 0;
+    // (round 6, after the small kernel's K loop was repaired: up to 192 units too while K <= 512 - 2 048 x 1 536 x 512: 12.0 -> 10.8 us;
+    //  from K = 1 024 on the 128 x 128 ring is ahead there, 15.6 vs 16.5 us - profiles/r06_gemm_small_tile.txt)
+    static const int small_max_k512 = getenv("PA_GEMM_SMALL_MAX_K512") ? atoi(getenv("PA_GEMM_SMALL_MAX_K512")) : 192;
+    const bool go_small = go_v3 && use_small && a->a_kcontig && a->b_kcontig && splitk == 1 && a->K % 64 == 0 &&
+                          (valid_units <= small_max || (valid_units <= small_max_k512 && a->K <= 512));
     // PA_GEMM_WIDE: 0 never, 1 every eligible launch, 2 (default) when the 128 x 256 tiling is a single round of blocks
     // (7 940 x 1 024: 248 tiles - measured 15.5 us against 16.8 for the two-blocks-per-CU kernel once the epilogues were
     // restructured; at N = 1 536 the 378 tiles are a round and a half and the two-blocks-per-CU kernel stays ahead)
