@@ -358,8 +358,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(T* y, const T* z, co
                                                             float* mean, float* rstd, int64_t rows, int d, float eps,
                                                             bf16* img, int img_pat) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t row_ = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // (a wave past the last row works on the last row and stores nothing: an early `return` made the row count a lone
+    //  kernel-argument load in front of all others - two scalar-memory round trips before the first row load)
+    const bool live = row_ < rows;
+    const int64_t row = live ? row_ : rows - 1;
     const T* zr = z + row * d;
     // every load of the row (and of gamma / beta) is issued up front, unconditionally (column clamped; lanes past d are
     // masked in the arithmetic)
@@ -384,6 +387,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(T* y, const T* z, co
             for (int j = 0; j < 4; ++j) { const float t = v[i][j] - mu; q += t * t; }
         }
     const float rs = 1.0f / sqrtf(wave_sum(q) / d + eps);
+    if (!live) return;
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     T* yr = y + row * d;
 #pragma unroll
