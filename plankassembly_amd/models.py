@@ -230,6 +230,8 @@ class PlankModel(nn.Module):
         self._shadow = None
         self._shadowT = self._vocabT = self._kvT = None
         self._tr_descs = None
+        self._tr_stream = self._tr_event = None
+        self._tr_pending = False
         self._shadow_version = -1
         self._handle = None
         self._ws = None
@@ -292,6 +294,8 @@ class PlankModel(nn.Module):
         self._gflat = self._gtmp = self._shadow = self._shadowT = self._vocabT = self._kvT = None
         self._tr_descs = None
         self._shadow_version = -1
+        self._tr_stream = self._tr_event = None
+        self._tr_pending = False
         self._drop_handle()
 
     def _drop_handle(self):
@@ -555,15 +559,36 @@ class PlankModel(nn.Module):
                 "pa_model_bind_cross_kv_t")
 
     def refresh_transposed(self):
-        """Re-derive the W^T shadow from the bf16 shadow (one batched transpose launch)."""
+        """Re-derive the W^T shadow from the bf16 shadow (one batched transpose launch) on the current stream.  Only the BACKWARD
+        reads W^T (dX = dY W as a k-contiguous GEMM, csrc/runtime.hip linear_dx); PLANK_TRANSPOSE_STREAM=1 (opt-in) sends the launch
+        to a side stream behind the kernels enqueued so far and lets the backward wait for its event (wait_transposed), so the next
+        forward does not queue behind the 40 us (bf16; f32: 70 us).  MEASURED SLOWER on MI355X / ROCm 7.2: 4.72 ms per step against
+        4.56 (same session, twice; profiles/r06_transpose_stream.txt) - a second active stream costs the main one more than the
+        40 us it hides, as every two-stream arrangement tried since round 4 did."""
         if self._tr_descs is not None:
             d, n, tiles = self._tr_descs
-            L.check(L.lib().pa_transpose_many(L.ptr(d), n, tiles, L.PA_BF16 if self.compute_dtype == "bf16" else L.PA_F32, L.stream()),
-                    "pa_transpose_many")
+            dt = L.PA_BF16 if self.compute_dtype == "bf16" else L.PA_F32
+            if os.environ.get("PLANK_TRANSPOSE_STREAM", "0") == "1":
+                if self._tr_stream is None:
+                    self._tr_stream, self._tr_event = torch.cuda.Stream(device=self._flat.device), torch.cuda.Event()
+                self._tr_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._tr_stream):
+                    L.check(L.lib().pa_transpose_many(L.ptr(d), n, tiles, dt, L.stream()), "pa_transpose_many")
+                    self._tr_event.record(self._tr_stream)
+                self._tr_pending = True
+            else:
+                L.check(L.lib().pa_transpose_many(L.ptr(d), n, tiles, dt, L.stream()), "pa_transpose_many")
         # 'x3': the cut images of the weights (and of their transposes) follow the parameters (pa_gemm_split_cache_refresh)
         cache = getattr(self, "_x3_cache", None)
         if cache is not None:
+            self.wait_transposed()               # (the images of the transposes are cut from W^T)
             L.check(L.lib().pa_gemm_split_cache_refresh(cache[0], L.stream()), "pa_gemm_split_cache_refresh")
+
+    def wait_transposed(self):
+        """The current stream waits for the side-stream transposes (refresh_transposed): called before anything that reads W^T (the
+        backward) or rewrites their source (the optimizer's update of the bf16 shadow / the parameters, _refresh_shadow's cast)."""
+        if self._tr_pending:
+            torch.cuda.current_stream().wait_event(self._tr_event)
 
     def _ensure_grads(self):
         if self._gflat is None:
@@ -585,6 +610,7 @@ class PlankModel(nn.Module):
     def _refresh_shadow(self):
         v = self._param_version()
         if v != self._shadow_version:
+            self.wait_transposed()
             if self.compute_dtype == "bf16":
                 L.check(L.lib().pa_cast(L.ptr(self._shadow), L.PA_BF16, L.ptr(self._flat), L.PA_F32,
                                         C.c_int64(self._numel), L.stream()), "pa_cast")
@@ -769,6 +795,7 @@ class PlankModel(nn.Module):
 
     def _run_backward(self, gloss):
         self._ensure_grads()
+        self.wait_transposed()
         accumulate = any(p.grad is not None for p in self._params.values())
         target = self._gflat
         if accumulate:

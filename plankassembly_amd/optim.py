@@ -41,6 +41,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._step += 1
         grp = self.param_groups[0]
         shadow = m._shadow if m.compute_dtype == "bf16" else None
+        m.wait_transposed()                      # (the side-stream W^T refresh of the step before reads what this kernel rewrites)
         L.check(L.lib().pa_adam_step(L.ptr(flat), L.ptr(g), L.ptr(self._m), L.ptr(self._v), L.ptr(shadow),
                                      C.c_int64(flat.numel()), C.c_float(grp["lr"]), C.c_float(grp["betas"][0]),
                                      C.c_float(grp["betas"][1]), C.c_float(grp["eps"]), self._step,
