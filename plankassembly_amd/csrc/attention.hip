@@ -119,6 +119,31 @@ __device__ __forceinline__ void load_sub(u32x4* regs, const T* base, int ld, int
         regs[i] = in ? v[i] : u32x4{0u, 0u, 0u, 0u};
     }
 }
+// The same loads WITHOUT the zeroing (round 6): a select on a freshly loaded value makes hipcc wait for the load on the spot, so a
+// "prefetch" through load_sub was a synchronous load in front of the step's MFMAs (tools/isa_loop_waits.py-style reading of the bf16x3
+// and exact-f32 attention kernels: loads, s_waitcnt vmcnt(2..0), then the products).  The kernels' gload now takes the raw rows and
+// their lstore - at the END of the overlapped step - zeroes the rows past the end (mask_sub) right before the LDS stores.
+template <typename T, int DH>
+__device__ __forceinline__ void load_sub_raw(u32x4* regs, const T* base, int ld, int row0, int nrows, int sb) {
+    using A = AT<T, DH>;
+    const int cb = sb % A::NCHR, rb = sb / A::NCHR;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + rb * 4 + i;
+        const int rc = r < nrows ? r : nrows - 1;
+        regs[i] = *reinterpret_cast<const u32x4*>(base + (size_t)rc * ld + cb * A::EB);
+    }
+}
+template <typename T, int DH>
+__device__ __forceinline__ void mask_sub(u32x4* regs, int row0, int nrows, int sb) {
+    using A = AT<T, DH>;
+    const int rb = sb / A::NCHR;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool in = row0 + rb * 4 + i < nrows;
+        regs[i] = in ? regs[i] : u32x4{0u, 0u, 0u, 0u};
+    }
+}
 template <typename T, int DH>
 __device__ __forceinline__ void store_nat(const u32x4* regs, char* lds, int sb) {
     using A = AT<T, DH>;
@@ -296,21 +321,20 @@ __global__ __launch_bounds__(NTH) void attn_fwd_kernel(AttnP pin) {
 
     u32x4 st[A::NITEM][4];
     uint8_t mreg = 0;
+    int st_row0 = 0;                             // first row of the tile held in `st` (its rows past Lk are zeroed in lstore)
     auto gload = [&](int step) {
         const int k0 = step * BSTR;
+        st_row0 = k0;
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
             if (item < 2 * A::NSB) {
                 const int sb = item % A::NSB;
-                if (item < A::NSB) load_sub<T, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
-                else load_sub<T, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
+                if (item < A::NSB) load_sub_raw<T, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
+                else load_sub_raw<T, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
             }
         }
-        if (tid < BSTR) {
-            const int key = k0 + tid;
-            mreg = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
-        }
+        if (tid < BSTR && mp) mreg = mp[min(k0 + tid, p.Lk - 1)];          // (raw byte; keys past Lk are set in lstore)
     };
     auto lstore = [&](int buf) {
         char* base = smem + buf * Smem<T, DH>::BUF_FWD;
@@ -319,11 +343,12 @@ __global__ __launch_bounds__(NTH) void attn_fwd_kernel(AttnP pin) {
             const int item = tid + j * NTH;
             if (item < 2 * A::NSB) {
                 const int sb = item % A::NSB;
+                mask_sub<T, DH>(st[j], st_row0, p.Lk, sb);
                 if (item < A::NSB) store_nat<T, DH>(st[j], base, sb);
                 else StoreTr<T, DH>::run(st[j], base + A::NAT_BYTES, sb);
             }
         }
-        if (tid < BSTR) reinterpret_cast<uint8_t*>(base + 2 * A::NAT_BYTES)[tid] = mreg;
+        if (tid < BSTR) reinterpret_cast<uint8_t*>(base + 2 * A::NAT_BYTES)[tid] = (st_row0 + tid >= p.Lk) ? (uint8_t)1 : (mp ? mreg : (uint8_t)0);
     };
 
     if (nsteps > 0) { gload(0); lstore(0); }
@@ -489,21 +514,20 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP pin) {
 
     u32x4 st[A::NITEM][4];
     uint8_t mreg = 0;
+    int st_row0 = 0;                             // first row of the tile held in `st` (its rows past Lk are zeroed in lstore)
     auto gload = [&](int step) {
         const int k0 = step * BSTR;
+        st_row0 = k0;
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
             if (item < 2 * A::NSB) {
                 const int sb = item % A::NSB;
-                if (item < A::NSB) load_sub<T, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
-                else load_sub<T, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
+                if (item < A::NSB) load_sub_raw<T, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
+                else load_sub_raw<T, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
             }
         }
-        if (tid < BSTR) {
-            const int key = k0 + tid;
-            mreg = (key >= p.Lk) ? 1 : (mp ? mp[key] : 0);
-        }
+        if (tid < BSTR && mp) mreg = mp[min(k0 + tid, p.Lk - 1)];          // (raw byte; keys past Lk are set in lstore)
     };
     auto lstore = [&](int buf) {
         char* base = smem + buf * Smem<T, DH>::BUF_DQ;
@@ -512,6 +536,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP pin) {
             const int item = tid + j * NTH;
             if (item < 2 * A::NSB) {
                 const int sb = item % A::NSB;
+                mask_sub<T, DH>(st[j], st_row0, p.Lk, sb);
                 if (item < A::NSB) {
                     store_nat<T, DH>(st[j], base, sb);                              // K natural
                     StoreTr<T, DH>::run(st[j], base + A::NAT_BYTES, sb);            // K transposed
@@ -520,7 +545,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP pin) {
                 }
             }
         }
-        if (tid < BSTR) reinterpret_cast<uint8_t*>(base + 3 * A::NAT_BYTES)[tid] = mreg;
+        if (tid < BSTR) reinterpret_cast<uint8_t*>(base + 3 * A::NAT_BYTES)[tid] = (st_row0 + tid >= p.Lk) ? (uint8_t)1 : (mp ? mreg : (uint8_t)0);
     };
 
     if (nsteps > 0) { gload(0); lstore(0); }
@@ -599,22 +624,23 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP pin) {
 
     u32x4 st[A::NITEM][4];
     float lreg = 0.f, dreg = 0.f;
+    int st_row0 = 0;                             // first row of the tile held in `st` (rows past Lq are zeroed / neutralised in lstore)
     auto gload = [&](int step) {
         const int r0 = step * BSTR;
+        st_row0 = r0;
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
             if (item < 2 * A::NSB) {
                 const int sb = item % A::NSB;
-                if (item < A::NSB) load_sub<T, DH>(st[j], Qp, p.ldq, r0, p.Lq, sb);
-                else load_sub<T, DH>(st[j], dOp, p.lddo, r0, p.Lq, sb);
+                if (item < A::NSB) load_sub_raw<T, DH>(st[j], Qp, p.ldq, r0, p.Lq, sb);
+                else load_sub_raw<T, DH>(st[j], dOp, p.lddo, r0, p.Lq, sb);
             }
         }
         if (tid < BSTR) {
-            const int qr = r0 + tid;
-            const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qr;
-            lreg = (qr < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
-            dreg = (qr < p.Lq) ? p.delta[srow] : 0.f;
+            const size_t srow = ((size_t)b * p.H + h) * pin.Lq + min(r0 + tid, p.Lq - 1);
+            lreg = p.lse[srow];                  // (raw; scaled / replaced for rows past Lq in lstore)
+            dreg = p.delta[srow];
         }
     };
     auto lstore = [&](int buf) {
@@ -625,13 +651,15 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP pin) {
             if (item < 2 * A::NSB) {
                 const int sb = item % A::NSB;
                 char* t0 = base + (item < A::NSB ? 0 : 2 * A::NAT_BYTES);
+                mask_sub<T, DH>(st[j], st_row0, p.Lq, sb);
                 store_nat<T, DH>(st[j], t0, sb);
                 StoreTr<T, DH>::run(st[j], t0 + A::NAT_BYTES, sb);
             }
         }
         if (tid < BSTR) {
             float* aux = reinterpret_cast<float*>(base + 4 * A::NAT_BYTES);
-            aux[tid] = lreg; aux[64 + tid] = dreg;
+            const bool in = st_row0 + tid < p.Lq;
+            aux[tid] = in ? lreg * LOG2E : INFINITY; aux[64 + tid] = in ? dreg : 0.f;
         }
     };
 

@@ -169,21 +169,22 @@ __global__ __launch_bounds__(NTH, 2) void attnx_fwd_kernel(AttnP pin) {
 
     u32x4 st[A::NITEM][4];
     uint8_t mreg = 0;
-    int kreg = 0;
+    int kreg = 0, st_row0 = 0;                   // st_row0: first row of the tile held in `st` (rows past Lk are zeroed in lstore)
     auto gload = [&](int step) {
         const int k0 = step * BSTR;
+        st_row0 = k0;
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
             if (item < 2 * A::NSB) {
                 const int sb = item % A::NSB;
-                if (item < A::NSB) load_sub<float, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
-                else load_sub<float, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
+                if (item < A::NSB) load_sub_raw<float, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
+                else load_sub_raw<float, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
             }
         }
         if (tid < BSTR) {
             kreg = k0 + tid;
-            mreg = (kreg >= p.Lk) ? 1 : (mp ? mp[kreg] : 0);
+            if (mp) mreg = mp[min(kreg, p.Lk - 1)];                  // (raw byte; keys past Lk are set in lstore)
         }
     };
     auto lstore = [&](int buf) {
@@ -191,9 +192,12 @@ __global__ __launch_bounds__(NTH, 2) void attnx_fwd_kernel(AttnP pin) {
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
-            if (item < 2 * A::NSB) x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
+            if (item < 2 * A::NSB) {
+                mask_sub<float, DH>(st[j], st_row0, p.Lk, item % A::NSB);
+                x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
+            }
         }
-        x3_key_aux<DH, DROP>(smem + X::AUX0 + buf * X::AUXS, tid, mreg, p.drop_seed, kreg);
+        x3_key_aux<DH, DROP>(smem + X::AUX0 + buf * X::AUXS, tid, (kreg >= p.Lk) ? (uint8_t)1 : (mp ? mreg : (uint8_t)0), p.drop_seed, kreg);
     };
 
     if (nsteps > 0) { gload(0); lstore(0); }
@@ -327,21 +331,22 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
 
     u32x4 st[A::NITEM][4];
     uint8_t mreg = 0;
-    int kreg = 0;
+    int kreg = 0, st_row0 = 0;                   // st_row0: first row of the tile held in `st` (rows past Lk are zeroed in lstore)
     auto gload = [&](int step) {
         const int k0 = step * BSTR;
+        st_row0 = k0;
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
             if (item < 2 * A::NSB) {
                 const int sb = item % A::NSB;
-                if (item < A::NSB) load_sub<float, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
-                else load_sub<float, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
+                if (item < A::NSB) load_sub_raw<float, DH>(st[j], Kp, p.ldk, k0, p.Lk, sb);
+                else load_sub_raw<float, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
             }
         }
         if (tid < BSTR) {
             kreg = k0 + tid;
-            mreg = (kreg >= p.Lk) ? 1 : (mp ? mp[kreg] : 0);
+            if (mp) mreg = mp[min(kreg, p.Lk - 1)];                  // (raw byte; keys past Lk are set in lstore)
         }
     };
     auto lstore = [&](int buf) {
@@ -349,9 +354,12 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
-            if (item < 2 * A::NSB) x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
+            if (item < 2 * A::NSB) {
+                mask_sub<float, DH>(st[j], st_row0, p.Lk, item % A::NSB);
+                x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
+            }
         }
-        x3_key_aux<DH, DROP>(smem + X::AUX0 + buf * X::AUXS, tid, mreg, p.drop_seed, kreg);
+        x3_key_aux<DH, DROP>(smem + X::AUX0 + buf * X::AUXS, tid, (kreg >= p.Lk) ? (uint8_t)1 : (mp ? mreg : (uint8_t)0), p.drop_seed, kreg);
     };
 
     if (s_lo < nsteps) { gload(s_lo); lstore(0); }                             // (block-uniform)
@@ -447,23 +455,25 @@ __global__ __launch_bounds__(NTH, OCC) void attnx_bwd_dkv_kernel(AttnP pin) {
     u32x4 st[A::NITEM][4];
     float lreg = 0.f, dreg = 0.f;
     uint32_t hreg = 0u;
+    int st_row0 = 0;                             // first row of the tile held in `st` (rows past Lq are zeroed / neutralised in lstore)
     auto gload = [&](int step) {
         const int r0 = step * BSTR;
+        st_row0 = r0;
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
             if (item < 2 * A::NSB) {
                 const int sb = item % A::NSB;
-                if (item < A::NSB) load_sub<float, DH>(st[j], Qp, p.ldq, r0, p.Lq, sb);
-                else load_sub<float, DH>(st[j], dOp, p.lddo, r0, p.Lq, sb);
+                if (item < A::NSB) load_sub_raw<float, DH>(st[j], Qp, p.ldq, r0, p.Lq, sb);
+                else load_sub_raw<float, DH>(st[j], dOp, p.lddo, r0, p.Lq, sb);
             }
         }
         if (tid < BSTR) {
-            const int qr = r0 + tid;
-            const size_t srow = ((size_t)b * p.H + h) * pin.Lq + qr;
-            lreg = (qr < p.Lq) ? p.lse[srow] * LOG2E : INFINITY;
-            dreg = (qr < p.Lq) ? p.delta[srow] : 0.f;
-            if (DROP) hreg = drop_row_hash(p.drop_seed, (uint32_t)srow);
+            const size_t srow0 = ((size_t)b * p.H + h) * pin.Lq;
+            const size_t srow = srow0 + min(r0 + tid, p.Lq - 1);
+            lreg = p.lse[srow];                  // (raw; scaled / replaced for rows past Lq in lstore)
+            dreg = p.delta[srow];
+            if (DROP) hreg = drop_row_hash(p.drop_seed, (uint32_t)(srow0 + r0 + tid));
         }
     };
     auto lstore = [&](int buf) {
@@ -471,11 +481,15 @@ __global__ __launch_bounds__(NTH, OCC) void attnx_bwd_dkv_kernel(AttnP pin) {
 #pragma unroll
         for (int j = 0; j < A::NITEM; ++j) {
             const int item = tid + j * NTH;
-            if (item < 2 * A::NSB) x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
+            if (item < 2 * A::NSB) {
+                mask_sub<float, DH>(st[j], st_row0, p.Lq, item % A::NSB);
+                x3_store<DH>(st[j], base + (item < A::NSB ? 0 : X::TILE), item % A::NSB);
+            }
         }
         if (tid < BSTR) {
             float* aux = reinterpret_cast<float*>(smem + X::AUX0 + buf * X::AUXS);
-            aux[tid] = lreg; aux[64 + tid] = dreg;
+            const bool in = st_row0 + tid < p.Lq;
+            aux[tid] = in ? lreg * LOG2E : INFINITY; aux[64 + tid] = in ? dreg : 0.f;
             if (DROP) reinterpret_cast<uint32_t*>(aux)[128 + tid] = hreg;
         }
     };
