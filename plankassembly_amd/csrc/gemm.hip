@@ -137,6 +137,10 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
     constexpr int NRA = (A_GL || A_TG) ? 1 : (A_KC ? TL::NLD : TL::NTR * EB);
     constexpr int NRB = (B_GL || B_TG) ? 1 : (B_KC ? TL::NLD : TL::NTR * EB);
     u32x4 ra[NRA], rb[NRB];
+    // both operands register-transposed (exact f32, contraction index strided in both - the weight gradients): ONE staging array, the
+    // thread's role selects addresses instead of guarding the loads (a load inside `if (role)` is a masked definition hipcc merges
+    // with v_mov copies of the freshly loaded registers - a wait right behind every load; round 6)
+    constexpr bool BOTH_TR = !A_KC && !B_KC && !TRG;
     const bool a_role = A_KC || (tid < 128);
     const bool b_role = B_KC || (tid >= 128);
     const int t128 = tid & 127;
@@ -201,11 +205,16 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
             for (int i = 0; i < EB; ++i) {
                 const int k = k0 + kb * EB + i;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (blk < TL::NTB && k < p.K) {
+                if constexpr (ALIGNED) {
+                    // unconditional load on a clamped (k, r) - zeroed in store_tr, at the END of the overlapped tile: a load inside
+                    // `if (in range)` (or a select right behind it) makes hipcc wait for it on the spot, and this "prefetch" of the
+                    // next K tile was a synchronous load in front of the tile's MFMAs (round 6, read in the ISA; the exact-f32
+                    // weight-gradient GEMMs run here)
+                    const T* src = reinterpret_cast<const T*>(base) + (size_t)min(k, p.K - 1) * ld + min(r, (nrows - 1) / EB * EB);   // (the last vector may straddle nrows: the stride covers it, is_aligned)
+                    v = *reinterpret_cast<const u32x4*>(src);
+                } else if (blk < TL::NTB && k < p.K) {
                     const T* src = reinterpret_cast<const T*>(base) + (size_t)k * ld + r;
-                    if (ALIGNED) {
-                        if (r < nrows) v = *reinterpret_cast<const u32x4*>(src);
-                    } else {
+                    {
                         T tmp[EB];
 #pragma unroll
                         for (int e = 0; e < EB; ++e) tmp[e] = (r + e < nrows) ? src[e] : (T)0.0f;
@@ -216,15 +225,24 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
             }
         }
     };
-    auto store_tr = [&](const u32x4* regs, char* lds) {
+    int tr_k0 = 0, tr_rA0 = 0, tr_rB0 = 0;      // (k, row) origin of the tile held in ra / rb (set by fetch, used by store_tr's zeroing)
+    auto store_tr = [&](const u32x4* regs_in, char* lds, int r0, int nrows) {
         constexpr int RBLK = BM / EB;
 #pragma unroll
         for (int j = 0; j < TL::NTR; ++j) {
             const int blk = t128 + j * 128;
             if (blk < TL::NTB) {
                 const int rbk = blk % RBLK, kb = blk / RBLK;
+                u32x4 regs_m[EB];
+                const u32x4* regs = regs_in + j * EB;
+                if constexpr (ALIGNED) {
+                    const bool rin = r0 + rbk * EB < nrows;
+#pragma unroll
+                    for (int i = 0; i < EB; ++i) regs_m[i] = (rin && tr_k0 + kb * EB + i < p.K) ? regs[i] : u32x4{0u, 0u, 0u, 0u};
+                    regs = regs_m;
+                }
                 u32x4 tr[EB];
-                transpose_block<T>(regs + j * EB, tr);
+                transpose_block<T>(regs, tr);
 #pragma unroll
                 for (int e = 0; e < EB; ++e)
                     *reinterpret_cast<u32x4*>(lds + lds_off<TL>(rbk * EB + e, kb)) = tr[e];
@@ -235,6 +253,7 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
     // phase 1 of a tile fetch: issue global loads (DMA straight into `buf`, or into registers)
     auto fetch = [&](const Unit& un, int t, int buf) {
         const int k0 = t * TL::BK;
+        tr_k0 = k0; tr_rA0 = un.tile_m * BM; tr_rB0 = un.tile_n * BN;
         char* la = smem + buf * 2 * TL::TILE_BYTES;
         char* lb = la + TL::TILE_BYTES;
         const char* ka = baseA + (size_t)k0 * esz;          // wave-uniform
@@ -270,7 +289,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                     (__attribute__((address_space(3))) void*)(la + (i * NT + wave * 64) * 16), 16, 0, 0);
             }
-        } else { if (a_role) load_tr(ra, baseA, p.lda, un.tile_m * BM, p.M, k0); }
+        } else if constexpr (BOTH_TR) { load_tr(ra, tid < 128 ? baseA : baseB, tid < 128 ? p.lda : p.ldb, tid < 128 ? un.tile_m * BM : un.tile_n * BN, tid < 128 ? p.M : p.N, k0); }
+        else { if (a_role) load_tr(ra, baseA, p.lda, un.tile_m * BM, p.M, k0); }
         if constexpr (B_GL) {
 #pragma unroll
             for (int i = 0; i < TL::NLD; ++i)
@@ -302,7 +322,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                     (__attribute__((address_space(3))) void*)(lb + (i * NT + wave * 64) * 16), 16, 0, 0);
             }
-        } else { if (b_role) load_tr(rb, baseB, p.ldb, un.tile_n * BN, p.N, k0); }
+        } else if constexpr (BOTH_TR) { /* loaded with A above */ }
+        else { if (b_role) load_tr(rb, baseB, p.ldb, un.tile_n * BN, p.N, k0); }
     };
     // phase 2: registers -> LDS (nothing to do for DMA'd operands)
     auto commit = [&](int buf) {
@@ -315,7 +336,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                     const int c = tid + i * NT;
                     *reinterpret_cast<u32x4*>(la + lds_off<TL>(c / TL::NCH, c % TL::NCH)) = ra[i];
                 }
-            } else { if (a_role) store_tr(ra, la); }
+            } else if constexpr (BOTH_TR) { store_tr(ra, tid < 128 ? la : lb, tid < 128 ? tr_rA0 : tr_rB0, tid < 128 ? p.M : p.N); }
+            else { if (a_role) store_tr(ra, la, tr_rA0, p.M); }
         }
         if constexpr (!B_GL && !B_TG) {
             if constexpr (B_KC) {
@@ -324,7 +346,8 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                     const int c = tid + i * NT;
                     *reinterpret_cast<u32x4*>(lb + lds_off<TL>(c / TL::NCH, c % TL::NCH)) = rb[i];
                 }
-            } else { if (b_role) store_tr(rb, lb); }
+            } else if constexpr (BOTH_TR) { /* stored with A above */ }
+            else { if (b_role) store_tr(rb, lb, tr_rB0, p.N); }
         }
     };
 
@@ -684,6 +707,9 @@ __global__ __launch_bounds__(NT, OCC) void gemm_kernel(GemmP p) {
                 epilogue(cur, buf);
                 TR(5);
             }
+            // (register-staged operands: hipcc hoisted these LDS stores - and with them the waits for the next tile's global loads -
+            //  above the tile's MFMAs; the fence keeps the loads in flight under the products.  DMA'd operands have nothing to commit.)
+            if constexpr (!ALL_DMA) __builtin_amdgcn_sched_barrier(0);
             if (has_next) commit(buf ^ 1);
             __syncthreads();
             TR(6);
