@@ -334,7 +334,9 @@ __global__ __launch_bounds__(NTH) void attn_fwd_kernel(AttnP pin) {
                 else load_sub_raw<T, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
             }
         }
-        if (tid < BSTR && mp) mreg = mp[min(k0 + tid, p.Lk - 1)];          // (raw byte; keys past Lk are set in lstore)
+        // (every thread loads a byte - no guard: a load under `if` is a masked definition hipcc merges with a copy of the loaded
+        //  register, i.e. a wait right behind it; without a mask the byte comes from the K rows and is ignored in lstore)
+        mreg = (mp ? mp : reinterpret_cast<const uint8_t*>(Kp))[min(k0 + (tid & (BSTR - 1)), p.Lk - 1)];
     };
     auto lstore = [&](int buf) {
         char* base = smem + buf * Smem<T, DH>::BUF_FWD;
@@ -527,7 +529,9 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_kernel(AttnP pin) {
                 else load_sub_raw<T, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
             }
         }
-        if (tid < BSTR && mp) mreg = mp[min(k0 + tid, p.Lk - 1)];          // (raw byte; keys past Lk are set in lstore)
+        // (every thread loads a byte - no guard: a load under `if` is a masked definition hipcc merges with a copy of the loaded
+        //  register, i.e. a wait right behind it; without a mask the byte comes from the K rows and is ignored in lstore)
+        mreg = (mp ? mp : reinterpret_cast<const uint8_t*>(Kp))[min(k0 + (tid & (BSTR - 1)), p.Lk - 1)];
     };
     auto lstore = [&](int buf) {
         char* base = smem + buf * Smem<T, DH>::BUF_DQ;
@@ -637,8 +641,8 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_kernel(AttnP pin) {
                 else load_sub_raw<T, DH>(st[j], dOp, p.lddo, r0, p.Lq, sb);
             }
         }
-        if (tid < BSTR) {
-            const size_t srow = ((size_t)b * p.H + h) * pin.Lq + min(r0 + tid, p.Lq - 1);
+        {   // (every thread, no guard - see the forward kernel's mask byte)
+            const size_t srow = ((size_t)b * p.H + h) * pin.Lq + min(r0 + (tid & (BSTR - 1)), p.Lq - 1);
             lreg = p.lse[srow];                  // (raw; scaled / replaced for rows past Lq in lstore)
             dreg = p.delta[srow];
         }

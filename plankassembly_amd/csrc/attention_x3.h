@@ -182,10 +182,10 @@ __global__ __launch_bounds__(NTH, 2) void attnx_fwd_kernel(AttnP pin) {
                 else load_sub_raw<float, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
             }
         }
-        if (tid < BSTR) {
-            kreg = k0 + tid;
-            if (mp) mreg = mp[min(kreg, p.Lk - 1)];                  // (raw byte; keys past Lk are set in lstore)
-        }
+        kreg = k0 + (tid & (BSTR - 1));
+        // (every thread loads a byte, no guard: a load under `if` is a masked definition hipcc merges with a copy of the loaded register -
+        //  a wait right behind it; without a mask the byte comes from the K rows and is ignored in lstore)
+        mreg = (mp ? mp : reinterpret_cast<const uint8_t*>(Kp))[min(kreg, p.Lk - 1)];
     };
     auto lstore = [&](int buf) {
         char* base = smem + buf * X::STG;
@@ -344,10 +344,10 @@ __global__ __launch_bounds__(NTH, 2) void attnx_bwd_dq_kernel(AttnP pin) {
                 else load_sub_raw<float, DH>(st[j], Vp, p.ldv, k0, p.Lk, sb);
             }
         }
-        if (tid < BSTR) {
-            kreg = k0 + tid;
-            if (mp) mreg = mp[min(kreg, p.Lk - 1)];                  // (raw byte; keys past Lk are set in lstore)
-        }
+        kreg = k0 + (tid & (BSTR - 1));
+        // (every thread loads a byte, no guard: a load under `if` is a masked definition hipcc merges with a copy of the loaded register -
+        //  a wait right behind it; without a mask the byte comes from the K rows and is ignored in lstore)
+        mreg = (mp ? mp : reinterpret_cast<const uint8_t*>(Kp))[min(kreg, p.Lk - 1)];
     };
     auto lstore = [&](int buf) {
         char* base = smem + buf * X::STG;
@@ -468,12 +468,12 @@ __global__ __launch_bounds__(NTH, OCC) void attnx_bwd_dkv_kernel(AttnP pin) {
                 else load_sub_raw<float, DH>(st[j], dOp, p.lddo, r0, p.Lq, sb);
             }
         }
-        if (tid < BSTR) {
+        {   // (every thread, no guard - see the forward kernel's mask byte)
             const size_t srow0 = ((size_t)b * p.H + h) * pin.Lq;
-            const size_t srow = srow0 + min(r0 + tid, p.Lq - 1);
+            const size_t srow = srow0 + min(r0 + (tid & (BSTR - 1)), p.Lq - 1);
             lreg = p.lse[srow];                  // (raw; scaled / replaced for rows past Lq in lstore)
             dreg = p.delta[srow];
-            if (DROP) hreg = drop_row_hash(p.drop_seed, (uint32_t)(srow0 + r0 + tid));
+            if (DROP) hreg = drop_row_hash(p.drop_seed, (uint32_t)(srow0 + r0 + (tid & (BSTR - 1))));
         }
     };
     auto lstore = [&](int buf) {
